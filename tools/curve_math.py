@@ -1,0 +1,217 @@
+"""Pure-Python big-int model of the BLS12-377 / BLS12-381 fields and curves.
+
+Build-time tooling only (constant generation + small golden vectors); never on the
+product path.  Constants follow SURVEY.md §A.1 and are re-derived / re-checked here.
+"""
+import random
+
+X377 = 0x8508c00000000001
+R377 = X377**4 - X377**2 + 1
+Q377 = ((X377 - 1)**2 * R377) // 3 + X377
+assert R377 == 0x12ab655e9a2ca55660b44d1e5c37b00159aa76fed00000010a11800000000001
+assert Q377 == 0x01ae3a4617c510eac63b05c06ca1493b1a22d9f300f5138f1ef3622fba094800170b5d44300000008508c00000000001
+
+X381 = -0xd201000000010000
+R381 = X381**4 - X381**2 + 1
+Q381 = ((X381 - 1)**2 * R381) // 3 + X381
+assert R381 == 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+assert Q381 == 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+
+G1_377 = (0x008848defe740a67c8fc6225bf87ff5485951e2caa9d41bb188282c8bd37cb5cd5481512ffcd394eeab9b16eb21be9ef,
+          0x01914a69c5102eff1f674f5d30afeec4bd7fb348ca3e52d96d182ad44fb82305c2fe3d3634a9591afd82de55559c8ea6)
+G1_381 = (0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb,
+          0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1)
+assert (G1_377[1]**2 - G1_377[0]**3 - 1) % Q377 == 0
+assert (G1_381[1]**2 - G1_381[0]**3 - 4) % Q381 == 0
+
+
+def two_adicity(p):
+    s, t = 0, p - 1
+    while t % 2 == 0:
+        s += 1
+        t //= 2
+    return s, t
+
+
+def mont_consts(p, nbits):
+    R = (1 << nbits) % p
+    R2 = R * R % p
+    inv64 = (-pow(p, -1, 1 << 64)) % (1 << 64)
+    inv32 = (-pow(p, -1, 1 << 32)) % (1 << 32)
+    return R, R2, inv64, inv32
+
+
+FR = {
+    "377": dict(p=R377, gen=22, bits=253),
+    "381": dict(p=R381, gen=7, bits=255),
+}
+for k, f in FR.items():
+    s, t = two_adicity(f["p"])
+    f["two_adicity"] = s
+    f["root"] = pow(f["gen"], t, f["p"])
+    assert pow(f["root"], 1 << s, f["p"]) == 1 and pow(f["root"], 1 << (s - 1), f["p"]) != 1
+assert FR["377"]["two_adicity"] == 47 and FR["381"]["two_adicity"] == 32
+assert FR["377"]["root"] == 8065159656716812877374967518403273466521432693661810619979959746626482506078
+assert FR["381"]["root"] == 10238227357739495823651030575849232062558860180284477541189508159991286009131
+
+
+# ---------------- generic short-Weierstrass arithmetic over Fp (affine, None = infinity) -------------
+def ec_add(P, Q, p):
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    x1, y1 = P
+    x2, y2 = Q
+    if x1 == x2:
+        if (y1 + y2) % p == 0:
+            return None
+        lam = 3 * x1 * x1 * pow(2 * y1, -1, p) % p
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, -1, p) % p
+    x3 = (lam * lam - x1 - x2) % p
+    return (x3, (lam * (x1 - x3) - y1) % p)
+
+
+def ec_mul(k, P, p):
+    R = None
+    while k:
+        if k & 1:
+            R = ec_add(R, P, p)
+        P = ec_add(P, P, p)
+        k >>= 1
+    return R
+
+
+# ---------------- Fq2 = Fq[u]/(u^2 - NR) -------------
+class Fq2:
+    def __init__(self, p, nr):
+        self.p, self.nr = p, nr % p
+
+    def add(self, a, b):
+        return ((a[0] + b[0]) % self.p, (a[1] + b[1]) % self.p)
+
+    def sub(self, a, b):
+        return ((a[0] - b[0]) % self.p, (a[1] - b[1]) % self.p)
+
+    def mul(self, a, b):
+        p = self.p
+        return ((a[0] * b[0] + self.nr * a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p)
+
+    def inv(self, a):
+        p = self.p
+        n = pow((a[0] * a[0] - self.nr * a[1] * a[1]) % p, -1, p)
+        return (a[0] * n % p, (-a[1]) * n % p)
+
+    def pow(self, a, e):
+        r = (1, 0)
+        while e:
+            if e & 1:
+                r = self.mul(r, a)
+            a = self.mul(a, a)
+            e >>= 1
+        return r
+
+    def sqrt(self, a):
+        """Square root in Fq2 by generic Tonelli-Shanks over the group of order p^2-1 (or None)."""
+        p = self.p
+        if a == (0, 0):
+            return (0, 0)
+        order = p * p - 1
+        if self.pow(a, order // 2) != (1, 0):
+            return None
+        s, t = 0, order
+        while t % 2 == 0:
+            s += 1
+            t //= 2
+        rnd = random.Random(7)
+        while True:
+            z = (rnd.randrange(p), rnd.randrange(p))
+            if z != (0, 0) and self.pow(z, order // 2) != (1, 0):
+                break
+        c = self.pow(z, t)
+        x = self.pow(a, (t + 1) // 2)
+        b = self.pow(a, t)
+        m = s
+        while b != (1, 0):
+            i, bb = 0, b
+            while bb != (1, 0):
+                bb = self.mul(bb, bb)
+                i += 1
+            g = c
+            for _ in range(m - i - 1):
+                g = self.mul(g, g)
+            x = self.mul(x, g)
+            c = self.mul(g, g)
+            b = self.mul(b, c)
+            m = i
+        return x
+
+
+def ec2_add(F, P, Q):
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    x1, y1 = P
+    x2, y2 = Q
+    if x1 == x2:
+        if F.add(y1, y2) == (0, 0):
+            return None
+        lam = F.mul(F.mul((3, 0), F.mul(x1, x1)), F.inv(F.add(y1, y1)))
+    else:
+        lam = F.mul(F.sub(y2, y1), F.inv(F.sub(x2, x1)))
+    x3 = F.sub(F.sub(F.mul(lam, lam), x1), x2)
+    return (x3, F.sub(F.mul(lam, F.sub(x1, x3)), y1))
+
+
+def ec2_mul(F, k, P):
+    R = None
+    while k:
+        if k & 1:
+            R = ec2_add(F, R, P)
+        P = ec2_add(F, P, P)
+        k >>= 1
+    return R
+
+
+def derive_g2_377():
+    """BLS12-377: Fq2 = Fq[u]/(u^2+5); Fq6 = Fq2[v]/(v^3-u); D-type twist E': y^2 = x^3 + 1/u.
+    Returns (b_twist, generator of the order-r subgroup of E'(Fq2), cofactor)."""
+    p, r = Q377, R377
+    F = Fq2(p, -5)
+    bt = F.inv((0, 1))
+    t = X377 + 1                       # trace of Frobenius of E/Fq
+    assert (p + 1 - t) % r == 0
+    t2 = t * t - 2 * p                 # trace over Fq2
+    # 4 p^2 - t2^2 = 3 f^2  (CM discriminant -3)
+    from math import isqrt
+    f2 = isqrt((4 * p * p - t2 * t2) // 3)
+    assert 3 * f2 * f2 == 4 * p * p - t2 * t2
+    cands = [p * p + 1 - (t2 + 3 * f2) // 2, p * p + 1 - (t2 - 3 * f2) // 2,
+             p * p + 1 + (t2 + 3 * f2) // 2, p * p + 1 + (t2 - 3 * f2) // 2]
+    # find a point on E'
+    xi = 1
+    while True:
+        x = (xi, 1)
+        y = F.sqrt(F.add(F.mul(F.mul(x, x), x), bt))
+        if y is not None:
+            break
+        xi += 1
+    P = (x, y)
+    order = None
+    for n in cands:
+        if n % r == 0 and ec2_mul(F, n, P) is None:
+            order = n
+            break
+    assert order is not None
+    cof = order // r
+    G = ec2_mul(F, cof, P)
+    assert G is not None and ec2_mul(F, r, G) is None
+    return bt, G, cof
+
+
+if __name__ == "__main__":
+    bt, G, cof = derive_g2_377()
+    print("twist b =", bt)
+    print("G2 gen =", G)
