@@ -1,0 +1,226 @@
+"""ctypes binding of include/zkaes.h, mirroring the reference's public functions (src/lib.rs:60,116,138)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CIRCUIT_AES, CIRCUIT_OPS_XOR, CIRCUIT_OPS_ADD = 0, 1, 2
+
+
+class ZkAesError(RuntimeError):
+    """The Err(..) side of the reference's anyhow::Result."""
+
+
+def lib_path():
+    return os.path.join(HERE, "libzkaes.so")
+
+
+_lib = None
+
+
+def lib():
+    """Load libzkaes.so (must have been built: python -m aes_zero_knowledge_proof_circuit_amd.build)."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise ZkAesError("libzkaes.so is not built (run: python -m aes_zero_knowledge_proof_circuit_amd.build)")
+        L = C.CDLL(path)
+        L.zkaes_last_error.restype = C.c_char_p
+        for name in ("zkaes_bytes_free", "zkaes_pk_free", "zkaes_vk_free"):
+            getattr(L, name).restype = None
+            getattr(L, name).argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise ZkAesError(lib().zkaes_last_error().decode())
+
+
+def _take(ptr, n):
+    data = C.string_at(ptr, n.value)
+    lib().zkaes_bytes_free(ptr)
+    return data
+
+
+def device_count():
+    return lib().zkaes_device_count()
+
+
+def set_device(ordinal):
+    _check(lib().zkaes_set_device(int(ordinal)))
+
+
+class VerifyingKey:
+    def __init__(self, ptr):
+        self._p = C.c_void_p(ptr)
+
+    def clone(self):  # the reference passes keys by value; callers .clone() them (tests/integration_tests.rs:330)
+        return VerifyingKey.from_bytes(self.to_bytes())
+
+    def to_bytes(self):
+        out, n = C.c_void_p(), C.c_size_t()
+        _check(lib().zkaes_vk_serialize(self._p, C.byref(out), C.byref(n)))
+        return _take(out, n)
+
+    @staticmethod
+    def from_bytes(b):
+        p = C.c_void_p()
+        _check(lib().zkaes_vk_deserialize(bytes(b), C.c_size_t(len(b)), C.byref(p)))
+        return VerifyingKey(p.value)
+
+    @staticmethod
+    def from_trapdoor(info, index_comms, beta_mont, gamma_mont):
+        arr = (C.c_uint64 * 7)(*info)
+        p = C.c_void_p()
+        _check(lib().zkaes_vk_from_trapdoor(arr, bytes(index_comms), bytes(beta_mont), bytes(gamma_mont), C.byref(p)))
+        return VerifyingKey(p.value)
+
+    def verify(self, proof, public_input_bits):
+        acc = C.c_int()
+        bits = bytes(public_input_bits)
+        _check(lib().zkaes_verify(self._p, bytes(proof), C.c_size_t(len(proof)), bits, C.c_size_t(len(bits)), C.byref(acc)))
+        return bool(acc.value)
+
+    def __del__(self):
+        try:
+            if self._p:
+                lib().zkaes_vk_free(self._p)
+                self._p = None
+        except Exception:
+            pass
+
+
+class ProvingKey:
+    def __init__(self, ptr):
+        self._p = C.c_void_p(ptr)
+
+    def clone(self):  # device-resident and immutable: a clone is the same handle (benches/benchmark_encrypt.rs:46 clones per call)
+        return self
+
+    def info(self):
+        out = (C.c_uint64 * 12)()
+        _check(lib().zkaes_pk_info(self._p, out))
+        keys = ["raw_constraints", "raw_instance", "raw_witness", "nnz_a", "nnz_b", "nnz_c", "constraints", "instance", "witness", "joint_nnz", "h", "k"]
+        return dict(zip(keys, out))
+
+    def timings(self):
+        out = (C.c_double * 6)()
+        _check(lib().zkaes_pk_timings(self._p, out))
+        return dict(zip(["witness_ms", "round1_ms", "round2_ms", "round3_ms", "open_ms", "total_ms"], out))
+
+    def debug_fetch(self, name):
+        out, n = C.c_void_p(), C.c_size_t()
+        _check(lib().zkaes_pk_debug_fetch(self._p, name.encode(), C.byref(out), C.byref(n)))
+        return _take(out, n)
+
+    def witness(self, message, secret_key):
+        n = C.c_size_t()
+        _check(lib().zkaes_aes_witness(self._p, bytes(message), C.c_size_t(len(message)), bytes(secret_key), None, C.c_size_t(0), C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        _check(lib().zkaes_aes_witness(self._p, bytes(message), C.c_size_t(len(message)), bytes(secret_key), buf, n, C.byref(n)))
+        return buf.raw
+
+    def prove_ops(self, x, y, zk_seed=None):
+        out, n = C.c_void_p(), C.c_size_t()
+        _check(lib().zkaes_prove_ops(self._p, C.c_uint32(x), C.c_uint32(y), zk_seed, C.byref(out), C.byref(n)))
+        return _take(out, n)
+
+    def encrypt_chunked(self, message, secret_key):
+        chunk = self.info()["raw_instance"] // 8 // 1 and (self.info()["raw_instance"] - 1) // 8
+        n_chunks = len(message) // chunk
+        lens = (C.c_size_t * max(n_chunks, 1))()
+        out, n = C.c_void_p(), C.c_size_t()
+        _check(lib().zkaes_encrypt_chunked(bytes(message), C.c_size_t(len(message)), bytes(secret_key), self._p, C.byref(out), C.byref(n), lens, C.c_size_t(n_chunks)))
+        blob = _take(out, n)
+        proofs, off = [], 0
+        for i in range(n_chunks):
+            proofs.append(blob[off:off + lens[i]])
+            off += lens[i]
+        return proofs
+
+    def __del__(self):
+        try:
+            if self._p:
+                lib().zkaes_pk_free(self._p)
+                self._p = None
+        except Exception:
+            pass
+
+
+def synthesize_keys(plaintext_length, circuit=CIRCUIT_AES, srs=(866_944, 513, 4_062_064)):
+    """zk_aes::synthesize_keys (src/lib.rs:138-174) -> (ProvingKey, VerifyingKey)."""
+    pk, vk = C.c_void_p(), C.c_void_p()
+    _check(lib().zkaes_synthesize_keys_ex(int(circuit), C.c_size_t(plaintext_length), C.c_size_t(srs[0]), C.c_size_t(srs[1]), C.c_size_t(srs[2]), C.byref(pk), C.byref(vk)))
+    return ProvingKey(pk.value), VerifyingKey(vk.value)
+
+
+def encrypt(message, secret_key, proving_key, zk_seed=None):
+    """zk_aes::encrypt (src/lib.rs:60-114) -> serialized MarlinProof bytes."""
+    if len(secret_key) != 16:
+        raise ZkAesError("secret_key must be 16 bytes")
+    out, n = C.c_void_p(), C.c_size_t()
+    _check(lib().zkaes_encrypt_seeded(bytes(message), C.c_size_t(len(message)), bytes(secret_key), proving_key._p, zk_seed, C.byref(out), C.byref(n)))
+    return _take(out, n)
+
+
+def verify_encryption(verifying_key, proof, ciphertext):
+    """zk_aes::verify_encryption (src/lib.rs:116-136) -> bool."""
+    acc = C.c_int()
+    _check(lib().zkaes_verify_encryption(verifying_key._p, bytes(proof), C.c_size_t(len(proof)), bytes(ciphertext), C.c_size_t(len(ciphertext)), C.byref(acc)))
+    return bool(acc.value)
+
+
+def proof_roundtrip(proof):
+    out, n = C.c_void_p(), C.c_size_t()
+    _check(lib().zkaes_proof_roundtrip(bytes(proof), C.c_size_t(len(proof)), C.byref(out), C.byref(n)))
+    return _take(out, n)
+
+
+def circuit_info(circuit, plaintext_length):
+    out = (C.c_uint64 * 12)()
+    _check(lib().zkaes_circuit_info(int(circuit), C.c_size_t(plaintext_length), out))
+    keys = ["raw_constraints", "raw_instance", "raw_witness", "nnz_a", "nnz_b", "nnz_c", "constraints", "instance", "witness", "joint_nnz", "h", "k"]
+    return dict(zip(keys, out))
+
+
+def circuit_matrix(circuit, plaintext_length, which):
+    rows, nnz = C.c_uint64(), C.c_uint64()
+    _check(lib().zkaes_circuit_matrix(int(circuit), C.c_size_t(plaintext_length), which, C.byref(rows), C.byref(nnz), None, None, None))
+    rowptr = np.zeros(rows.value + 1, dtype=np.uint32)
+    col = np.zeros(max(nnz.value, 1), dtype=np.uint32)
+    coeff = np.zeros(max(nnz.value, 1), dtype=np.int64)
+    _check(lib().zkaes_circuit_matrix(int(circuit), C.c_size_t(plaintext_length), which, None, None, rowptr.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p),
+                                      coeff.ctypes.data_as(C.c_void_p)))
+    return rowptr, col[:nnz.value], coeff[:nnz.value]
+
+
+def ntt(field_id, data_mont_bytes, inverse=False):
+    n = len(data_mont_bytes) // 32
+    buf = C.create_string_buffer(bytes(data_mont_bytes), len(data_mont_bytes))
+    _check(lib().zkaes_ntt(int(field_id), buf, C.c_size_t(n), 1 if inverse else 0))
+    return buf.raw
+
+
+def msm(curve_id, bases_bytes, scalars_bytes):
+    n = len(scalars_bytes) // 32
+    out = C.create_string_buffer(96)
+    inf = C.c_int()
+    _check(lib().zkaes_msm(int(curve_id), bytes(bases_bytes), bytes(scalars_bytes), C.c_size_t(n), out, C.byref(inf)))
+    return out.raw, bool(inf.value)
+
+
+def msm_bench(curve_id, bases_bytes, scalars_bytes, reps=3):
+    n = len(scalars_bytes) // 32
+    t, a = C.c_double(), C.c_double()
+    _check(lib().zkaes_msm_bench(int(curve_id), bytes(bases_bytes), bytes(scalars_bytes), C.c_size_t(n), int(reps), C.byref(t), C.byref(a)))
+    return t.value, a.value
+
+
+def msm_stats(reset=False):
+    out = (C.c_double * 4)()
+    _check(lib().zkaes_msm_stats(out, 1 if reset else 0))
+    return dict(accumulate_ms=out[0], total_ms=out[1], points=int(out[2]), launches=int(out[3]))

@@ -1,0 +1,57 @@
+"""Build libzkaes.so (HIP kernels for gfx950 + host library) in-tree with hipcc.
+
+    python -m aes_zero_knowledge_proof_circuit_amd.build [--force]
+
+hipcc cross-compiles gfx950 without a GPU.  Objects are cached under csrc/build/ keyed by source mtime.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libzkaes.so")
+OBJ = os.path.join(CSRC, "build")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HIP_SOURCES = ["runtime.hip", "kernels_ntt.hip", "kernels_msm.hip", "kernels_poly.hip", "kernels_witness.hip", "capi_kernels.hip"]
+CXX_SOURCES = ["circuit.cpp", "marlin.cpp", "capi.cpp"]
+HEADERS = ["ff.cuh", "ec.cuh", "gpu.hpp", "hip_util.hpp", "consts32.h", "trace_layout.h", "circuit.hpp", "marlin.hpp", "pairing.hpp", "transcript.hpp",
+           os.path.join("..", "..", "include", "zkaes.h")]
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-I", CSRC, "-Wno-unused-result"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src):
+    obj = os.path.join(OBJ, src + ".o")
+    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS]
+    if not _newer(obj, deps):
+        return obj
+    if src.endswith(".hip"):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-x", "hip"] + COMMON + ["-c", os.path.join(CSRC, src), "-o", obj]
+    else:
+        cmd = [HIPCC, "-x", "c++"] + COMMON + ["-c", os.path.join(CSRC, src), "-o", obj]
+    subprocess.check_call(cmd)
+    return obj
+
+
+def build(force=False):
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(_compile, HIP_SOURCES + CXX_SOURCES))
+    if force or _newer(OUT, objs):
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,193 @@
+// csrc/capi.cpp -- the extern "C" boundary declared in include/zkaes.h
+#include "../../include/zkaes.h"
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <string>
+#include <vector>
+#include "gpu.hpp"
+#include "marlin.hpp"
+
+struct zkaes_pk { std::unique_ptr<zk::ProvingKey> pk; };
+struct zkaes_vk { zk::VerifyingKey vk; };
+
+namespace {
+thread_local std::string g_err;
+template <class Fn> int guard(Fn &&fn) {
+    try { g_err.clear(); fn(); return 0; }
+    catch (const std::exception &e) { g_err = e.what(); return 1; }
+    catch (...) { g_err = "unknown error"; return 1; }
+}
+uint8_t *give(const std::vector<uint8_t> &v) { uint8_t *p = (uint8_t *)malloc(v.size() ? v.size() : 1); memcpy(p, v.data(), v.size()); return p; }
+void fill_info(const zk::Circuit &c, uint64_t out[12]) {
+    out[0] = c.raw_constraints; out[1] = c.raw_instance; out[2] = c.raw_witness;
+    out[3] = c.A.nnz(); out[4] = c.B.nnz(); out[5] = c.C.nnz();
+    out[6] = c.num_constraints; out[7] = c.num_instance; out[8] = c.num_witness; out[9] = 0; out[10] = 0; out[11] = 0;
+}
+zk::Circuit compile(int kind, size_t len) { return kind == ZKAES_CIRCUIT_AES ? zk::compile_aes_circuit(len) : zk::compile_ops_circuit(kind); }
+size_t next_pow2(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
+
+// ---- VK transport (private layout v1)
+struct W { std::vector<uint8_t> b; void put(const void *p, size_t n) { const uint8_t *q = (const uint8_t *)p; b.insert(b.end(), q, q + n); } template <class T> void pod(const T &v) { put(&v, sizeof v); } };
+struct R { const uint8_t *p; size_t n, off = 0; template <class T> void pod(T &v) { if (off + sizeof v > n) throw std::runtime_error("vk_deserialize: truncated"); memcpy(&v, p + off, sizeof v); off += sizeof v; } };
+}  // namespace
+namespace zk { void capi_set_error(const std::string &m) { g_err = m; } }
+
+extern "C" {
+
+const char *zkaes_last_error(void) { return g_err.c_str(); }
+void zkaes_bytes_free(uint8_t *p) { free(p); }
+void zkaes_pk_free(zkaes_pk *pk) { delete pk; }
+void zkaes_vk_free(zkaes_vk *vk) { delete vk; }
+int zkaes_device_count(void) { return zk::gpu::device_count(); }
+int zkaes_set_device(int ordinal);   // defined in runtime glue below
+
+int zkaes_synthesize_keys_ex(int kind, size_t len, size_t nc, size_t nv, size_t nnz, zkaes_pk **pk, zkaes_vk **vk) {
+    return guard([&] {
+        zk::SrsLiterals srs; srs.num_constraints = nc; srs.num_variables = nv; srs.num_non_zero = nnz;
+        auto k = zk::synthesize_keys(kind, len, srs);
+        zkaes_vk *v = new zkaes_vk{k->vk()};
+        zkaes_pk *p = new zkaes_pk{std::move(k)};
+        if (pk) *pk = p; else delete p;
+        if (vk) *vk = v; else delete v;
+    });
+}
+int zkaes_synthesize_keys(size_t len, zkaes_pk **pk, zkaes_vk **vk) {
+    zk::SrsLiterals d;
+    return zkaes_synthesize_keys_ex(ZKAES_CIRCUIT_AES, len, d.num_constraints, d.num_variables, d.num_non_zero, pk, vk);
+}
+int zkaes_encrypt_seeded(const uint8_t *msg, size_t len, const uint8_t key[16], const zkaes_pk *pk, const uint8_t *seed, uint8_t **proof, size_t *proof_len) {
+    return guard([&] {
+        if (!pk || !proof || !proof_len) throw std::invalid_argument("null argument");
+        zk::Proof p = pk->pk->prove_aes(msg, len, key, seed);
+        auto b = zk::serialize_proof(p);
+        *proof = give(b); *proof_len = b.size();
+    });
+}
+int zkaes_encrypt(const uint8_t *msg, size_t len, const uint8_t key[16], const zkaes_pk *pk, uint8_t **proof, size_t *proof_len) {
+    return zkaes_encrypt_seeded(msg, len, key, pk, nullptr, proof, proof_len);
+}
+int zkaes_encrypt_chunked(const uint8_t *msg, size_t len, const uint8_t key[16], const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens, size_t n_chunks) {
+    return guard([&] {
+        if (!pk || !proofs || !proofs_len) throw std::invalid_argument("null argument");
+        size_t chunk = pk->pk->circuit().n_blocks * 16;
+        if (chunk == 0 || len % chunk || len / chunk != n_chunks) throw std::invalid_argument("message length must be n_chunks * the key's plaintext length");
+        std::vector<uint8_t> all;
+        for (size_t i = 0; i < n_chunks; i++) {
+            auto b = zk::serialize_proof(pk->pk->prove_aes(msg + i * chunk, chunk, key, nullptr));
+            if (proof_lens) proof_lens[i] = b.size();
+            all.insert(all.end(), b.begin(), b.end());
+        }
+        *proofs = give(all); *proofs_len = all.size();
+    });
+}
+int zkaes_prove_ops(const zkaes_pk *pk, uint32_t x, uint32_t y, const uint8_t *seed, uint8_t **proof, size_t *proof_len) {
+    return guard([&] {
+        if (!pk || !proof || !proof_len) throw std::invalid_argument("null argument");
+        auto b = zk::serialize_proof(pk->pk->prove_ops(x, y, seed));
+        *proof = give(b); *proof_len = b.size();
+    });
+}
+int zkaes_verify(const zkaes_vk *vk, const uint8_t *proof, size_t proof_len, const uint8_t *bits, size_t n_bits, int *accepted) {
+    return guard([&] {
+        if (!vk || !proof || !accepted) throw std::invalid_argument("null argument");
+        zk::Proof p = zk::deserialize_proof(proof, proof_len);
+        std::vector<zk::Fr> pub(n_bits);
+        for (size_t i = 0; i < n_bits; i++) pub[i] = bits[i] ? zk::Fr::one() : zk::Fr::zero();
+        *accepted = zk::verify(vk->vk, pub, p) ? 1 : 0;
+    });
+}
+int zkaes_verify_encryption(const zkaes_vk *vk, const uint8_t *proof, size_t proof_len, const uint8_t *ct, size_t ct_len, int *accepted) {
+    return guard([&] {
+        if (!vk || !proof || !accepted) throw std::invalid_argument("null argument");
+        zk::Proof p = zk::deserialize_proof(proof, proof_len);
+        *accepted = zk::verify(vk->vk, zk::ciphertext_to_public_input(ct, ct_len), p) ? 1 : 0;
+    });
+}
+int zkaes_proof_roundtrip(const uint8_t *proof, size_t proof_len, uint8_t **out, size_t *out_len) {
+    return guard([&] { auto b = zk::serialize_proof(zk::deserialize_proof(proof, proof_len)); *out = give(b); *out_len = b.size(); });
+}
+int zkaes_vk_serialize(const zkaes_vk *vk, uint8_t **out, size_t *out_len) {
+    return guard([&] {
+        W w;
+        uint32_t magic = 0x314b565au;   // "ZVK1"
+        w.pod(magic);
+        static_assert(std::is_trivially_copyable<zk::VerifyingKey>::value, "VerifyingKey must be POD for the v1 transport");
+        w.pod(vk->vk);
+        *out = give(w.b); *out_len = w.b.size();
+    });
+}
+int zkaes_vk_deserialize(const uint8_t *bytes, size_t len, zkaes_vk **vk) {
+    return guard([&] {
+        R r{bytes, len};
+        uint32_t magic; r.pod(magic);
+        if (magic != 0x314b565au) throw std::runtime_error("vk_deserialize: bad magic");
+        zkaes_vk *v = new zkaes_vk();
+        try { r.pod(v->vk); } catch (...) { delete v; throw; }
+        if (r.off != len) { delete v; throw std::runtime_error("vk_deserialize: trailing bytes"); }
+        *vk = v;
+    });
+}
+int zkaes_vk_from_trapdoor(const uint64_t info[7], const uint8_t *index_comms, const uint8_t *beta_b, const uint8_t *gamma_b, zkaes_vk **vk) {
+    return guard([&] {
+        zkaes_vk *v = new zkaes_vk();
+        zk::VerifyingKey &k = v->vk;
+        k.num_variables = info[0]; k.num_constraints = info[1]; k.num_non_zero = info[2]; k.num_instance = info[3];
+        k.num_public_inputs = info[4]; k.max_degree = info[5]; k.supported_degree = info[6];
+        for (int i = 0; i < 6; i++) { memcpy(k.index_comms[i].x.l, index_comms + 96 * i, 48); memcpy(k.index_comms[i].y.l, index_comms + 96 * i + 48, 48); }
+        zk::Fr beta, gamma;
+        memcpy(beta.l, beta_b, 32); memcpy(gamma.l, gamma_b, 32);
+        zk::G1A g;
+        for (int i = 0; i < 12; i++) { g.x.l[i] = G1_377_X_MONT[i]; g.y.l[i] = G1_377_Y_MONT[i]; }
+        auto mulg = [&](const zk::Fr &s) { return zk::mul_fr(zk::XYZZ<zk::Fq377>::from_affine(g), s).to_affine(); };
+        k.g = g; k.gamma_g = mulg(gamma);
+        k.h = zk::pairing::g2_generator();
+        uint32_t raw[8]; beta.to_raw(raw);
+        k.beta_h = zk::pairing::g2_mul_raw(k.h, raw, 8);
+        size_t n = next_pow2(k.num_constraints), kk = next_pow2(k.num_non_zero);
+        k.degree_bounds[0] = std::min(n - 2, kk - 2); k.degree_bounds[1] = std::max(n - 2, kk - 2);
+        for (int i = 0; i < 2; i++) k.shift_powers[i] = mulg(beta.pow_u64(k.max_degree - k.degree_bounds[i]));
+        *vk = v;
+    });
+}
+int zkaes_pk_info(const zkaes_pk *pk, uint64_t out[12]) {
+    return guard([&] {
+        fill_info(pk->pk->circuit(), out);
+        out[9] = pk->pk->vk().num_non_zero; out[10] = next_pow2(pk->pk->vk().num_constraints); out[11] = next_pow2(pk->pk->vk().num_non_zero);
+    });
+}
+int zkaes_circuit_info(int kind, size_t len, uint64_t out[12]) { return guard([&] { fill_info(compile(kind, len), out); }); }
+int zkaes_circuit_matrix(int kind, size_t len, int which, uint64_t *n_rows, uint64_t *nnz, uint32_t *rowptr, uint32_t *col, int64_t *coeff) {
+    return guard([&] {
+        zk::Circuit c = compile(kind, len);
+        const zk::CsrMatrix &m = which == 0 ? c.A : which == 1 ? c.B : c.C;
+        if (n_rows) *n_rows = m.rows();
+        if (nnz) *nnz = m.nnz();
+        if (rowptr) memcpy(rowptr, m.rowptr.data(), m.rowptr.size() * 4);
+        if (col) memcpy(col, m.col.data(), m.col.size() * 4);
+        if (coeff) memcpy(coeff, m.coeff.data(), m.coeff.size() * 8);
+    });
+}
+int zkaes_pk_debug_fetch(const zkaes_pk *pk, const char *name, uint8_t **out, size_t *len) {
+    return guard([&] { auto b = pk->pk->debug_fetch(name); *out = give(b); *len = b.size(); });
+}
+int zkaes_aes_witness(const zkaes_pk *pk, const uint8_t *msg, size_t len, const uint8_t key[16], uint8_t *z, size_t z_cap, size_t *z_len) {
+    return guard([&] {
+        auto v = pk->pk->aes_witness(msg, len, key);
+        if (z_len) *z_len = v.size();
+        if (z) { if (z_cap < v.size()) throw std::invalid_argument("z buffer too small"); memcpy(z, v.data(), v.size()); }
+    });
+}
+int zkaes_pk_timings(const zkaes_pk *pk, double out[6]) {
+    return guard([&] { const auto &t = pk->pk->last_timings(); out[0] = t.witness_ms; out[1] = t.round1_ms; out[2] = t.round2_ms; out[3] = t.round3_ms; out[4] = t.open_ms; out[5] = t.total_ms; });
+}
+int zkaes_msm_stats(double out[4], int reset) {
+    return guard([&] {
+        auto &s = zk::gpu::msm_stats();
+        out[0] = s.accumulate_ms; out[1] = s.total_ms; out[2] = (double)s.points; out[3] = (double)s.launches;
+        if (reset) s = zk::gpu::MsmStats();
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// csrc/gpu.hpp -- host-callable launch wrappers around the gfx950 kernels of libzkaes.
+// Everything here takes/returns DEVICE pointers unless a name says host; all launches go to the given stream.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include "ec.cuh"
+
+namespace zk {
+namespace gpu {
+
+struct GpuError : std::runtime_error { using std::runtime_error::runtime_error; };
+typedef void *stream_t;   // hipStream_t
+
+// ---- runtime
+int device_count();                       // 0 when no GPU / driver
+void require_device();                    // throws GpuError("no HIP device ...") -- the product never falls back to the CPU
+void *dmalloc(size_t bytes);
+void dfree(void *p);
+void h2d(void *dst, const void *src, size_t bytes, stream_t s);
+void d2h(void *dst, const void *src, size_t bytes, stream_t s);
+void d2d(void *dst, const void *src, size_t bytes, stream_t s);
+void dzero(void *dst, size_t bytes, stream_t s);
+void sync(stream_t s);
+stream_t stream_create();
+void stream_destroy(stream_t s);
+// event timing on a stream (ms)
+void *event_create();
+void event_record(void *ev, stream_t s);
+float event_elapsed_ms(void *start, void *stop);
+void event_destroy(void *ev);
+
+// ---- NTT (kernels_ntt.hip).  Tables are created lazily per (field, log n) and cached for the life of the process.
+// dst <- NTT(src zero-padded from in_len to 2^lg); dst may equal src only if in_len == 2^lg is NOT required (out of place first pass
+// reads src completely before any tile of dst is written only when dst != src; pass distinct buffers).
+template <class Fr> void ntt(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, stream_t s);
+template <class Fr> const Fr *domain_elements(int lg);   // device table g^i, i < 2^lg  (built lazily)
+
+// ---- MSM (kernels_msm.hip): sum_i scalars[i] * bases[i]; scalars in Montgomery form; result returned to the host (syncs the stream)
+template <class Curve>
+XYZZ<typename Curve::Fq> msm(const Affine<typename Curve::Fq> *bases, const typename Curve::Fr *scalars, size_t n, stream_t s);
+// out[i] = (beta^(from+i)) * base for i < count   (KZG powers; fixed-base windows)   -- device output
+template <class Curve>
+void fixed_base_powers(Affine<typename Curve::Fq> *out, const Affine<typename Curve::Fq> &base, const typename Curve::Fr &beta, size_t from, size_t count, stream_t s);
+// MSM-stage timing hooks for bench.py (accumulated kernel time of the bucket-accumulation kernel, measured with events)
+struct MsmStats { double accumulate_ms = 0; double total_ms = 0; uint64_t points = 0; uint64_t launches = 0; };
+MsmStats &msm_stats();
+
+}  // namespace gpu
+}  // namespace zk
+
+// =====================================================================================================================
+// Marlin-side kernels over the BLS12-377 scalar field (kernels_poly.hip, kernels_witness.hip)
+namespace zk {
+namespace gpu {
+using F = Fr377;
+
+void poly_set_at(F *p, size_t idx, const F &val, stream_t s);                 // p[idx] = val
+void poly_add_at(F *p, size_t idx, const F &val, stream_t s);                 // p[idx] += val
+void poly_axpy(F *acc, const F *p, const F &sc, size_t n, stream_t s);        // acc[i] += sc * p[i]
+void poly_scale(F *p, const F &sc, size_t n, stream_t s);                     // p[i] *= sc
+void poly_lincomb3(F *out, const F *a, const F *b, const F *c, const F &sa, const F &sb, const F &sc, size_t n, stream_t s);
+// q = p / (X^m - 1) (len - m coefficients), rem = remainder (m coefficients); requires len > m
+void divide_by_vanishing(F *q, F *rem, const F *p, size_t len, size_t m, stream_t s);
+// q = p / (X - z) (len - 1 coefficients, remainder dropped); scratch >= 2 * ceil(len/256) + 8 elements
+void divide_by_linear(F *q, const F *p, size_t len, const F &z, F *scratch, stream_t s);
+// p(x) returned to the host (synchronizes); scratch >= ceil(len/64) + 1 elements
+F poly_eval(const F *p, size_t len, const F &x, F *scratch, stream_t s);
+// in-place batch inversion, zeros stay zero; every output optionally multiplied by `post`
+void batch_inverse(F *v, size_t n, const F *post_or_null, stream_t s);
+void sub_from_scalar(F *out, const F *v, const F &sc, size_t n, stream_t s);  // out[i] = sc - v[i]
+// count how many of the first n elements are non-zero (host result; synchronizes)
+size_t count_nonzero(const F *p, size_t n, stream_t s);
+
+// ---- witness generation + sparse products
+void upload_sbox(const uint8_t table[256]);
+// one thread per ECB block (+ the key schedule): fills the trace of `nproofs` chunk-proofs of `nblocks` blocks each
+void aes_trace(uint8_t *trace, size_t trace_stride, const uint8_t *msgs, const uint8_t *keys, uint32_t nproofs, uint32_t nblocks, stream_t s);
+// z[col] (0/1 bytes) for every column, by descriptor
+void witness_expand(uint8_t *z, const uint32_t *desc, uint32_t ncols, const uint8_t *trace, const uint32_t *sbox_in_off, const uint32_t *sbox_tmpl, stream_t s);
+// out[r] = sum_i coeff[i] * z[col[i]] as a field element, rows with no entries give 0 (out has `rows_out` >= rows entries, tail zeroed)
+void spmv_bits(F *out, size_t rows_out, const uint32_t *rowptr, const uint32_t *col, const int64_t *coeff, size_t rows, const uint8_t *z, stream_t s);
+// w evaluations on H (ark-marlin prover_first_round): out[k] = 0 if k % ratio == 0 else w_ext[k - k/ratio - 1] - x_evals[k]
+void w_evals(F *out, const uint8_t *z, const F *x_evals, uint32_t n, uint32_t m, uint32_t num_witness, stream_t s);
+void bits_to_field(F *out, const uint8_t *z, size_t n, stream_t s);
+// t evaluations on H: out[h] = sum over entries (row r, weight w = eta_M * coeff) in column bucket h of  w * r_alpha[r]
+// CSC built by the indexer: colptr[n+1], row[], mat_id[] (0/1/2), coeff[]
+void t_evals(F *out, uint32_t n, const uint32_t *colptr, const uint32_t *row, const uint8_t *mat, const int64_t *coeff, const F *r_alpha, const F &eta_a, const F &eta_b,
+             const F &eta_c, stream_t s);
+// e_ra[i] = e_ra[i] * (eta_a za + eta_b zb + eta_c za zb)[i] - t[i] * z[i]
+void q1_pointwise(F *e_ra, const F *e_za, const F *e_zb, const F *e_t, const F *e_z, const F &eta_a, const F &eta_b, const F &eta_c, size_t n, stream_t s);
+void round3_den(F *den, const F *row, const F *col, const F &alpha, const F &beta, size_t k, stream_t s);     // (beta - row)(alpha - col)
+void mul_pointwise(F *out, const F *a, const F *b, size_t n, stream_t s);                                       // out = a * b
+void mul_sub(F *acc, const F *b, const F *f, size_t n, stream_t s);                                             // acc -= b * f
+// indexer (one-time): row/col/row_col/val_* evaluations on K from the joint matrix entries; tmp = k scratch elements
+void index_evals(F *row, F *col, F *rowcol, F *va, F *vb, F *vc, F *tmp, const uint32_t *ci, const uint32_t *ri, const int64_t *ca, const int64_t *cb, const int64_t *cc, size_t cnt,
+                 size_t k, const F *elems, uint32_t n, stream_t s);
+void z_poly_from_w(F *zp, const F *w, size_t wlen, const F *x_poly, uint32_t m, size_t n, stream_t s);          // w * v_X + x  (n + 1 coefficients)
+
+}  // namespace gpu
+}  // namespace zk

@@ -1,0 +1,250 @@
+// csrc/kernels_msm.hip -- Pippenger multi-scalar multiplication over BLS12-377 / BLS12-381 G1 for gfx950.
+//
+// Replaces ark-ec 0.3.0 VariableBaseMSM::multi_scalar_mul (one rayon task per window, Cargo.lock:118) behind
+// KZG10::commit / open (ark-poly-commit 0.3.0) -- SURVEY.md §8 a17.  GPU shape:
+//   1. k_digits      : scalars Montgomery -> canonical, split into c-bit window digits, emit (window|digit, index) pairs
+//   2. radix sort    : hipcub DeviceRadixSort over all windows at once (plumbing, not the hot op)
+//   3. k_bounds      : bucket [start, end) ranges in the sorted pair list
+//   4. k_accumulate  : ONE LANE PER BUCKET, XYZZ accumulator, mixed adds of affine bases gathered through the sorted
+//                      index list -- the dominant kernel (integer-ALU bound: ~10 Fq products of 12x12 v_mad_u64_u32 each per add)
+//   5. k_reduce_*    : running-sum reduction in 64-bucket segments, then an LDS tree per window
+//   6. host          : Horner over the <= 32 window sums (c doublings each)
+#include <hipcub/hipcub.hpp>
+#include <chrono>
+#include <vector>
+#include "hip_util.hpp"
+
+namespace zk {
+namespace gpu {
+
+static MsmStats g_stats;
+MsmStats &msm_stats() { return g_stats; }
+
+template <class Fr>
+__global__ void k_digits(const Fr *__restrict__ scalars, uint32_t n, int c, int nwin, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t raw[Fr::N + 1];
+    scalars[i].to_raw(raw);
+    raw[Fr::N] = 0;
+    uint32_t mask = (1u << c) - 1;
+    for (int w = 0; w < nwin; w++) {
+        int bit = w * c, limb = bit >> 5, sh = bit & 31;
+        uint64_t two = (uint64_t)raw[limb] | ((uint64_t)raw[limb + 1] << 32);
+        uint32_t d = (uint32_t)(two >> sh) & mask;
+        keys[(size_t)w * n + i] = ((uint32_t)w << c) | d;
+        vals[(size_t)w * n + i] = i;
+    }
+}
+
+__global__ void k_bounds(const uint32_t *__restrict__ keys, size_t total, uint32_t *__restrict__ start, uint32_t *__restrict__ end) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    uint32_t k = keys[i];
+    if (i == 0 || keys[i - 1] != k) start[k] = (uint32_t)i;
+    if (i + 1 == total || keys[i + 1] != k) end[k] = (uint32_t)(i + 1);
+}
+
+template <class Fq>
+__global__ void __launch_bounds__(64) k_accumulate(const Affine<Fq> *__restrict__ bases, const uint32_t *__restrict__ vals,
+                                                    const uint32_t *__restrict__ start, const uint32_t *__restrict__ end,
+                                                    uint32_t nbuckets_total, uint32_t digit_mask, XYZZ<Fq> *__restrict__ buckets) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nbuckets_total) return;
+    XYZZ<Fq> acc = XYZZ<Fq>::inf();
+    if ((k & digit_mask) != 0) {
+        uint32_t s = start[k], e = end[k];
+        for (uint32_t i = s; i < e; i++) {
+            Affine<Fq> p = bases[vals[i]];
+            acc.madd(p);
+        }
+    }
+    buckets[k] = acc;
+}
+
+// segment reduction: thread (w, g) folds digits [g*L, (g+1)*L) of window w into  sum_d d * B_d
+template <class Fq>
+__global__ void __launch_bounds__(64) k_reduce_segments(const XYZZ<Fq> *__restrict__ buckets, int c, int nwin, int L, XYZZ<Fq> *__restrict__ partial) {
+    uint32_t segs = (1u << c) / L;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= segs * (uint32_t)nwin) return;
+    uint32_t w = t / segs, g = t % segs, d0 = g * L;
+    const XYZZ<Fq> *B = buckets + ((size_t)w << c);
+    XYZZ<Fq> run = XYZZ<Fq>::inf(), tot = XYZZ<Fq>::inf();
+    for (int d = (int)d0 + L - 1; d >= (int)d0; d--) {
+        XYZZ<Fq> b = B[d];
+        run.add(b);
+        tot.add(run);
+    }
+    // tot = sum (d - d0 + 1) B_d ; want sum d B_d = tot + (d0 - 1) * run
+    if (d0 == 0) { tot.add(run.neg()); }
+    else {
+        uint32_t m = d0 - 1;
+        XYZZ<Fq> acc = XYZZ<Fq>::inf();
+        for (int bit = 31; bit >= 0; bit--) {
+            acc = acc.dbl();
+            if ((m >> bit) & 1) acc.add(run);
+        }
+        tot.add(acc);
+    }
+    partial[t] = tot;
+}
+
+template <class Fq>
+__global__ void __launch_bounds__(256) k_reduce_window(const XYZZ<Fq> *__restrict__ partial, uint32_t per_window, XYZZ<Fq> *__restrict__ out) {
+    __shared__ XYZZ<Fq> sh[256];
+    uint32_t w = blockIdx.x, t = threadIdx.x;
+    XYZZ<Fq> acc = XYZZ<Fq>::inf();
+    for (uint32_t i = t; i < per_window; i += 256) acc.add(partial[(size_t)w * per_window + i]);
+    sh[t] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)t < s) { XYZZ<Fq> a = sh[t]; a.add(sh[t + s]); sh[t] = a; }
+        __syncthreads();
+    }
+    if (t == 0) out[w] = sh[0];
+}
+
+namespace {
+struct MsmScratch {
+    size_t cap_pairs = 0, cap_buckets = 0, cap_tmp = 0;
+    uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr, *start = nullptr, *end = nullptr;
+    void *buckets = nullptr, *partial = nullptr, *wsum = nullptr, *tmp = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+MsmScratch g_scr;
+void ensure_scratch(size_t pairs, size_t buckets, size_t xyzz_bytes) {
+    MsmScratch &S = g_scr;
+    if (!S.ev0) { HIP_CHECK(hipEventCreate(&S.ev0)); HIP_CHECK(hipEventCreate(&S.ev1)); }
+    if (pairs > S.cap_pairs) {
+        dfree(S.keys_a); dfree(S.keys_b); dfree(S.vals_a); dfree(S.vals_b);
+        S.cap_pairs = pairs;
+        S.keys_a = (uint32_t *)dmalloc(pairs * 4); S.keys_b = (uint32_t *)dmalloc(pairs * 4);
+        S.vals_a = (uint32_t *)dmalloc(pairs * 4); S.vals_b = (uint32_t *)dmalloc(pairs * 4);
+    }
+    if (buckets > S.cap_buckets) {
+        dfree(S.start); dfree(S.end); dfree(S.buckets); dfree(S.partial); dfree(S.wsum);
+        S.cap_buckets = buckets;
+        S.start = (uint32_t *)dmalloc(buckets * 4); S.end = (uint32_t *)dmalloc(buckets * 4);
+        S.buckets = dmalloc(buckets * 192); S.partial = dmalloc(buckets * 192 / 16 + 192 * 64); S.wsum = dmalloc(192 * 64);
+    }
+    (void)xyzz_bytes;
+}
+}  // namespace
+
+template <class Curve>
+XYZZ<typename Curve::Fq> msm(const Affine<typename Curve::Fq> *bases, const typename Curve::Fr *scalars, size_t n, stream_t s_) {
+    using Fq = typename Curve::Fq;
+    using Fr = typename Curve::Fr;
+    static_assert(sizeof(XYZZ<Fq>) == 192, "XYZZ layout");
+    hipStream_t s = (hipStream_t)s_;
+    if (n == 0) return XYZZ<Fq>::inf();
+    if (n >= (1u << 31)) throw GpuError("msm: too many points");
+    auto t_begin = std::chrono::steady_clock::now();
+    int lg = 0;
+    while (((size_t)1 << lg) < n) lg++;
+    int c = lg - 3;
+    if (c < 6) c = 6;
+    if (c > 16) c = 16;
+    const int nwin = (Fr::BITS + c - 1) / c;
+    const int L = 64 < (1 << c) ? 64 : (1 << c);
+    size_t pairs = n * (size_t)nwin, nb = (size_t)nwin << c;
+    ensure_scratch(pairs, nb, sizeof(XYZZ<Fq>));
+    MsmScratch &S = g_scr;
+    hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scalars, (uint32_t)n, c, nwin, S.keys_a, S.vals_a);
+    HIP_LAUNCH_CHECK();
+    int key_bits = c;
+    while ((1 << (key_bits - c)) < nwin) key_bits++;
+    size_t tmp_bytes = 0;
+    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys_a, S.keys_b, S.vals_a, S.vals_b, (int)pairs, 0, key_bits, s));
+    if (tmp_bytes > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tmp_bytes); S.cap_tmp = tmp_bytes; }
+    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp, tmp_bytes, S.keys_a, S.keys_b, S.vals_a, S.vals_b, (int)pairs, 0, key_bits, s));
+    HIP_CHECK(hipMemsetAsync(S.start, 0, nb * 4, s));
+    HIP_CHECK(hipMemsetAsync(S.end, 0, nb * 4, s));
+    hipLaunchKernelGGL(k_bounds, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, S.keys_b, pairs, S.start, S.end);
+    HIP_LAUNCH_CHECK();
+    HIP_CHECK(hipEventRecord(S.ev0, s));
+    hipLaunchKernelGGL((k_accumulate<Fq>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, bases, S.vals_b, S.start, S.end, (uint32_t)nb, (1u << c) - 1,
+                       (XYZZ<Fq> *)S.buckets);
+    HIP_LAUNCH_CHECK();
+    HIP_CHECK(hipEventRecord(S.ev1, s));
+    uint32_t segs = (1u << c) / L;
+    hipLaunchKernelGGL((k_reduce_segments<Fq>), dim3((unsigned)((segs * nwin + 63) / 64)), dim3(64), 0, s, (const XYZZ<Fq> *)S.buckets, c, nwin, L, (XYZZ<Fq> *)S.partial);
+    HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_reduce_window<Fq>), dim3((unsigned)nwin), dim3(256), 0, s, (const XYZZ<Fq> *)S.partial, segs, (XYZZ<Fq> *)S.wsum);
+    HIP_LAUNCH_CHECK();
+    std::vector<XYZZ<Fq>> ws(nwin);
+    HIP_CHECK(hipMemcpyAsync(ws.data(), S.wsum, sizeof(XYZZ<Fq>) * nwin, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, S.ev0, S.ev1));
+    XYZZ<Fq> total = XYZZ<Fq>::inf();
+    for (int w = nwin - 1; w >= 1; w--) {
+        total.add(ws[w]);
+        for (int k = 0; k < c; k++) total = total.dbl();
+    }
+    total.add(ws[0]);
+    g_stats.accumulate_ms += ms;
+    g_stats.points += n;
+    g_stats.launches += 1;
+    g_stats.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return total;
+}
+
+// ---- fixed-base powers: out[i] = beta^(from + i) * base
+template <class Fr>
+__global__ void k_power_scalars(Fr beta, uint64_t from, uint32_t count, Fr *__restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    out[i] = beta.pow_u64(from + i);
+}
+template <class Fq, class Fr>
+__global__ void __launch_bounds__(64) k_fixed_base(const Affine<Fq> *__restrict__ table, const Fr *__restrict__ scalars, uint32_t count, Affine<Fq> *__restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t raw[Fr::N];
+    scalars[i].to_raw(raw);
+    XYZZ<Fq> acc = XYZZ<Fq>::inf();
+    for (int w = 0; w < Fr::N * 4; w++) {
+        uint32_t d = (raw[w >> 2] >> ((w & 3) * 8)) & 0xff;
+        if (d) acc.madd(table[w * 255 + d - 1]);
+    }
+    out[i] = acc.to_affine();
+}
+
+template <class Curve>
+void fixed_base_powers(Affine<typename Curve::Fq> *out, const Affine<typename Curve::Fq> &base, const typename Curve::Fr &beta, size_t from, size_t count, stream_t s_) {
+    using Fq = typename Curve::Fq;
+    using Fr = typename Curve::Fr;
+    hipStream_t s = (hipStream_t)s_;
+    if (!count) return;
+    const int NW = Fr::N * 4;
+    std::vector<Affine<Fq>> table((size_t)NW * 255);
+    XYZZ<Fq> wb = XYZZ<Fq>::from_affine(base);
+    for (int w = 0; w < NW; w++) {
+        XYZZ<Fq> acc = wb;
+        for (int d = 1; d <= 255; d++) { table[(size_t)w * 255 + d - 1] = acc.to_affine(); acc.add(wb); }
+        for (int k = 0; k < 8; k++) wb = wb.dbl();
+    }
+    Affine<Fq> *d_table = (Affine<Fq> *)dmalloc(table.size() * sizeof(Affine<Fq>));
+    HIP_CHECK(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(Affine<Fq>), hipMemcpyHostToDevice, s));
+    const size_t CH = 1 << 20;
+    Fr *d_sc = (Fr *)dmalloc(CH * sizeof(Fr));
+    for (size_t off = 0; off < count; off += CH) {
+        uint32_t m = (uint32_t)((count - off) < CH ? (count - off) : CH);
+        hipLaunchKernelGGL((k_power_scalars<Fr>), dim3((m + 255) / 256), dim3(256), 0, s, beta, (uint64_t)(from + off), m, d_sc);
+        HIP_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_fixed_base<Fq, Fr>), dim3((m + 63) / 64), dim3(64), 0, s, d_table, d_sc, m, out + off);
+        HIP_LAUNCH_CHECK();
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+    dfree(d_table); dfree(d_sc);
+}
+
+template XYZZ<Fq377> msm<Bls377>(const Affine<Fq377> *, const Fr377 *, size_t, stream_t);
+template XYZZ<Fq381> msm<Bls381>(const Affine<Fq381> *, const Fr381 *, size_t, stream_t);
+template void fixed_base_powers<Bls377>(Affine<Fq377> *, const Affine<Fq377> &, const Fr377 &, size_t, size_t, stream_t);
+template void fixed_base_powers<Bls381>(Affine<Fq381> *, const Affine<Fq381> &, const Fr381 &, size_t, size_t, stream_t);
+
+}  // namespace gpu
+}  // namespace zk

@@ -1,0 +1,156 @@
+// csrc/kernels_ntt.hip -- radix-2 NTT over the BLS12-377 / BLS12-381 scalar fields for gfx950.
+//
+// Replaces ark-poly 0.3.0 Radix2EvaluationDomain::{fft, ifft} (Cargo.lock:234) -- SURVEY.md §8 a16.
+// Decimation-in-time with the bit-reversal folded into the first pass's gather, so one transform of 2^lg points is
+// ceil-ish(lg / 10) kernel passes instead of lg: every pass stages a tile of up to 1024 field elements in LDS
+// (limb-major, 8 x u32 planes -> conflict-free unit-stride lanes), runs up to 10 butterfly stages there, and writes
+// the tile back.  Pass 1 reads `src` through bit-reversed addresses (zero-padding short inputs for free) and covers
+// stages 0..S1-1 on contiguous 2^S1 tiles; later passes cover S more stages on tiles made of 2^S strided runs of
+// 2^L contiguous elements (L = 2 -> 128-byte runs) so HBM sees full-sector accesses.  The inverse transform uses the
+// inverse twiddle table and folds the 1/n scaling into the last pass's store.
+#include <map>
+#include <mutex>
+#include <vector>
+#include "hip_util.hpp"
+
+namespace zk {
+namespace gpu {
+
+template <class Fr>
+__global__ void k_fill_powers(Fr w, uint32_t n, Fr *__restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = w.pow_u64(i);
+}
+
+// tile element e = (a << L) | lo ; global index = (hi << (s0+S)) | (a << s0) | (mid << L) | lo
+template <class Fr, int TILE_LG>
+__global__ void __launch_bounds__(256) k_ntt_pass(Fr *dst, const Fr *src, uint32_t in_len, int lg, int s0, int S, int L,
+                                                   const Fr *__restrict__ tw, bool bitrev_load, bool scale, Fr scale_by) {
+    constexpr int N = Fr::N;
+    constexpr uint32_t TILE = 1u << TILE_LG;
+    __shared__ uint32_t lds[N][TILE];
+    const uint32_t tile_elems = 1u << (S + L);
+    const uint32_t tile_id = blockIdx.x;
+    const uint32_t mid_bits = s0 - L;
+    const uint32_t mid = tile_id & ((1u << mid_bits) - 1), hi = tile_id >> mid_bits;
+    const uint32_t base = (hi << (s0 + S)) | (mid << L);
+    for (uint32_t e = threadIdx.x; e < tile_elems; e += 256) {
+        uint32_t a = e >> L, lo = e & ((1u << L) - 1);
+        uint32_t gi = base | (a << s0) | lo;
+        Fr v;
+        if (bitrev_load) {
+            uint32_t sidx = __brev(gi) >> (32 - lg);
+            if (sidx < in_len) v = src[sidx]; else v = Fr::zero();
+        } else {
+            v = src[gi];
+        }
+#pragma unroll
+        for (int k = 0; k < N; k++) lds[k][e] = v.l[k];
+    }
+    __syncthreads();
+    const uint32_t half_tile = tile_elems >> 1;
+    for (int st = 0; st < S; st++) {
+        const int s = s0 + st;                       // butterflies of span 2^s
+        for (uint32_t b = threadIdx.x; b < half_tile; b += 256) {
+            uint32_t lo = b & ((1u << L) - 1), rest = b >> L;
+            uint32_t a_low = rest & ((1u << st) - 1), a_high = rest >> st;
+            uint32_t a0 = (a_high << (st + 1)) | a_low, a1 = a0 | (1u << st);
+            uint32_t e0 = (a0 << L) | lo, e1 = (a1 << L) | lo;
+            uint32_t j = (a_low << s0) | (mid << L) | lo;               // position inside the half-span
+            Fr x, y;
+#pragma unroll
+            for (int k = 0; k < N; k++) { x.l[k] = lds[k][e0]; y.l[k] = lds[k][e1]; }
+            if (j != 0) y = y * tw[(size_t)j << (lg - s - 1)];
+            Fr p = x + y, q = x - y;
+#pragma unroll
+            for (int k = 0; k < N; k++) { lds[k][e0] = p.l[k]; lds[k][e1] = q.l[k]; }
+        }
+        __syncthreads();
+    }
+    for (uint32_t e = threadIdx.x; e < tile_elems; e += 256) {
+        uint32_t a = e >> L, lo = e & ((1u << L) - 1);
+        uint32_t gi = base | (a << s0) | lo;
+        Fr v;
+#pragma unroll
+        for (int k = 0; k < N; k++) v.l[k] = lds[k][e];
+        if (scale) v = v * scale_by;
+        dst[gi] = v;
+    }
+}
+
+namespace {
+template <class Fr> struct RootOf;
+template <> struct RootOf<Fr377> { static constexpr int TWO_ADICITY = FR377_TWO_ADICITY; static Fr377 root() { Fr377 r; for (int i = 0; i < 8; i++) r.l[i] = FR377_ROOT_MONT[i]; return r; } };
+template <> struct RootOf<Fr381> { static constexpr int TWO_ADICITY = FR381_TWO_ADICITY; static Fr381 root() { Fr381 r; for (int i = 0; i < 8; i++) r.l[i] = FR381_ROOT_MONT[i]; return r; } };
+
+template <class Fr>
+struct Tables {
+    std::mutex mu;
+    std::map<int, Fr *> fwd, inv, elems;
+    static Fr gen(int lg) {
+        Fr r = RootOf<Fr>::root();
+        for (int i = lg; i < RootOf<Fr>::TWO_ADICITY; i++) r = r.sqr();
+        return r;
+    }
+    Fr *powers(std::map<int, Fr *> &m, int lg, const Fr &w, uint32_t count) {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = m.find(lg);
+        if (it != m.end()) return it->second;
+        Fr *d = (Fr *)dmalloc((size_t)(count ? count : 1) * sizeof(Fr));
+        if (count) {
+            hipLaunchKernelGGL((k_fill_powers<Fr>), dim3((count + 255) / 256), dim3(256), 0, 0, w, count, d);
+            HIP_LAUNCH_CHECK();
+            HIP_CHECK(hipDeviceSynchronize());
+        }
+        m[lg] = d;
+        return d;
+    }
+};
+template <class Fr> Tables<Fr> &tables() { static Tables<Fr> t; return t; }
+}  // namespace
+
+template <class Fr>
+const Fr *domain_elements(int lg) {
+    if (lg > RootOf<Fr>::TWO_ADICITY) throw GpuError("domain too large for the field's 2-adicity");
+    return tables<Fr>().powers(tables<Fr>().elems, lg, Tables<Fr>::gen(lg), 1u << lg);
+}
+
+template <class Fr>
+void ntt(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, stream_t s_) {
+    hipStream_t s = (hipStream_t)s_;
+    if (lg > RootOf<Fr>::TWO_ADICITY || lg > 30) throw GpuError("ntt: domain too large");
+    const uint32_t n = 1u << lg;
+    if (in_len > n) in_len = n;
+    if (dst == src) throw GpuError("ntt: dst must differ from src (first pass gathers bit-reversed)");
+    if (lg == 0) { HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(Fr) * (in_len ? 1 : 0), hipMemcpyDeviceToDevice, s)); if (!in_len) HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(Fr), s)); return; }
+    Fr w = Tables<Fr>::gen(lg);
+    const Fr *tw = inverse ? tables<Fr>().powers(tables<Fr>().inv, lg, w.inverse(), n / 2) : tables<Fr>().powers(tables<Fr>().fwd, lg, w, n / 2);
+    Fr n_inv = Fr::from_u64(n).inverse();
+    // pass plan
+    int s0 = 0;
+    int S1 = lg < 10 ? lg : 10;
+    int remaining = lg - S1;
+    {
+        bool last = remaining == 0;
+        hipLaunchKernelGGL((k_ntt_pass<Fr, 10>), dim3(n >> S1), dim3(256), 0, s, dst, src, (uint32_t)in_len, lg, 0, S1, 0, tw, true, inverse && last, n_inv);
+        HIP_LAUNCH_CHECK();
+        s0 = S1;
+    }
+    while (remaining > 0) {
+        const int L = 2;
+        int S = remaining < 8 ? remaining : 8;
+        bool last = remaining == S;
+        hipLaunchKernelGGL((k_ntt_pass<Fr, 10>), dim3(n >> (S + L)), dim3(256), 0, s, dst, (const Fr *)dst, n, lg, s0, S, L, tw, false, inverse && last, n_inv);
+        HIP_LAUNCH_CHECK();
+        s0 += S;
+        remaining -= S;
+    }
+}
+
+template void ntt<Fr377>(Fr377 *, const Fr377 *, size_t, int, bool, stream_t);
+template void ntt<Fr381>(Fr381 *, const Fr381 *, size_t, int, bool, stream_t);
+template const Fr377 *domain_elements<Fr377>(int);
+template const Fr381 *domain_elements<Fr381>(int);
+
+}  // namespace gpu
+}  // namespace zk

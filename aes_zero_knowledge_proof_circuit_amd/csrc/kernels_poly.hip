@@ -1,0 +1,247 @@
+// csrc/kernels_poly.hip -- elementwise / scan / reduction kernels over Fr(BLS12-377) used by the Marlin prover rounds.
+//
+// They replace the dense-polynomial plumbing of ark-poly 0.3.0 (DensePolynomial add/mul_by_vanishing/divide_by_vanishing_poly,
+// `p / (X - z)`, evaluate, batch_inversion of ark-ff) that ark-marlin's prover_{first,second,third}_round and
+// KZG10::open call.  All are HBM-streaming: one 32-byte element per lane per access.
+#include "hip_util.hpp"
+
+namespace zk {
+namespace gpu {
+
+#define GRID(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
+
+__global__ void k_set_at(F *p, size_t idx, F val, bool add) { if (threadIdx.x == 0 && blockIdx.x == 0) p[idx] = add ? p[idx] + val : val; }
+void poly_set_at(F *p, size_t idx, const F &val, stream_t s) { hipLaunchKernelGGL(k_set_at, dim3(1), dim3(64), 0, (hipStream_t)s, p, idx, val, false); HIP_LAUNCH_CHECK(); }
+void poly_add_at(F *p, size_t idx, const F &val, stream_t s) { hipLaunchKernelGGL(k_set_at, dim3(1), dim3(64), 0, (hipStream_t)s, p, idx, val, true); HIP_LAUNCH_CHECK(); }
+
+__global__ void k_axpy(F *__restrict__ acc, const F *__restrict__ p, F sc, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] = acc[i] + sc * p[i];
+}
+void poly_axpy(F *acc, const F *p, const F &sc, size_t n, stream_t s) { if (!n) return; hipLaunchKernelGGL(k_axpy, GRID(n), 0, (hipStream_t)s, acc, p, sc, n); HIP_LAUNCH_CHECK(); }
+__global__ void k_scale(F *p, F sc, size_t n) { size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = p[i] * sc; }
+void poly_scale(F *p, const F &sc, size_t n, stream_t s) { if (!n) return; hipLaunchKernelGGL(k_scale, GRID(n), 0, (hipStream_t)s, p, sc, n); HIP_LAUNCH_CHECK(); }
+__global__ void k_lincomb3(F *__restrict__ out, const F *__restrict__ a, const F *__restrict__ b, const F *__restrict__ c, F sa, F sb, F sc, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = sa * a[i] + sb * b[i] + sc * c[i];
+}
+void poly_lincomb3(F *out, const F *a, const F *b, const F *c, const F &sa, const F &sb, const F &sc, size_t n, stream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_lincomb3, GRID(n), 0, (hipStream_t)s, out, a, b, c, sa, sb, sc, n); HIP_LAUNCH_CHECK();
+}
+__global__ void k_sub_from_scalar(F *__restrict__ out, const F *__restrict__ v, F sc, size_t n) { size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = sc - v[i]; }
+void sub_from_scalar(F *out, const F *v, const F &sc, size_t n, stream_t s) { if (!n) return; hipLaunchKernelGGL(k_sub_from_scalar, GRID(n), 0, (hipStream_t)s, out, v, sc, n); HIP_LAUNCH_CHECK(); }
+
+// ---- p / (X^m - 1): residue class j: q_i = p_{i+m} + q_{i+m}; rem_j = p_j + q_j
+__global__ void k_div_vanishing(F *__restrict__ q, F *__restrict__ rem, const F *__restrict__ p, size_t len, size_t m) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    size_t qlen = len - m;
+    F carry = F::zero();
+    // highest index i = j (mod m) with i < qlen
+    if (qlen > j) {
+        size_t top = j + ((qlen - 1 - j) / m) * m;
+        for (size_t i = top;; i -= m) {
+            carry = p[i + m] + carry;
+            q[i] = carry;
+            if (i < m) break;
+        }
+    }
+    if (rem) rem[j] = (j < len ? p[j] : F::zero()) + carry;
+}
+void divide_by_vanishing(F *q, F *rem, const F *p, size_t len, size_t m, stream_t s) {
+    if (len <= m) throw GpuError("divide_by_vanishing: dividend shorter than divisor");
+    hipLaunchKernelGGL(k_div_vanishing, GRID(m), 0, (hipStream_t)s, q, rem, p, len, m); HIP_LAUNCH_CHECK();
+}
+
+// ---- p / (X - z):  q_i = p_{i+1} + z q_{i+1}, computed as a chunked linear-recurrence scan (chunk = 256 coefficients)
+constexpr int DL_CHUNK = 256;
+__global__ void k_divlin_local(F *__restrict__ q, const F *__restrict__ p, size_t qlen, F z, F *__restrict__ chunk_a, F *__restrict__ chunk_m) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t nch = (qlen + DL_CHUNK - 1) / DL_CHUNK;
+    if (t >= nch) return;
+    size_t s0 = t * DL_CHUNK, e = s0 + DL_CHUNK < qlen ? s0 + DL_CHUNK : qlen;
+    F acc = F::zero(), zp = F::one();
+    for (size_t i = e; i-- > s0;) { acc = p[i + 1] + z * acc; q[i] = acc; zp = zp * z; }
+    chunk_a[t] = acc;      // q at chunk start assuming zero carry-in
+    chunk_m[t] = zp;       // z^(chunk length)
+}
+// one wave: carry C_t = true q at the start of chunk t+1 (C_{last} = 0); C_t = A_{t+1} + M_{t+1} C_{t+1}
+__global__ void __launch_bounds__(64) k_divlin_carries(const F *__restrict__ chunk_a, const F *__restrict__ chunk_m, size_t nch, F *__restrict__ carry) {
+    __shared__ F seg_a[64], seg_m[64], seg_c[64];
+    int lane = threadIdx.x;
+    size_t per = (nch + 63) / 64;
+    // lane handles chunks [lo, hi) ; lanes ordered from the TOP of the polynomial: lane 0 = highest chunks
+    size_t hi = nch > (size_t)lane * per ? nch - (size_t)lane * per : 0;
+    size_t lo = hi > per ? hi - per : 0;
+    // compose the affine maps of the segment: carry below the segment = a + m * (carry above the segment)
+    F a = F::zero(), m = F::one();
+    for (size_t t = hi; t-- > lo;) { a = chunk_a[t] + chunk_m[t] * a; m = chunk_m[t] * m; }
+    seg_a[lane] = a; seg_m[lane] = m;
+    __syncthreads();
+    if (lane == 0) {
+        F c = F::zero();
+        for (int l = 0; l < 64; l++) { seg_c[l] = c; c = seg_a[l] + seg_m[l] * c; }
+    }
+    __syncthreads();
+    F c = seg_c[lane];     // true q just above this lane's segment
+    for (size_t t = hi; t-- > lo;) { carry[t] = c; c = chunk_a[t] + chunk_m[t] * c; }
+}
+__global__ void k_divlin_fix(F *__restrict__ q, size_t qlen, F z, const F *__restrict__ carry) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t nch = (qlen + DL_CHUNK - 1) / DL_CHUNK;
+    if (t >= nch) return;
+    F c = carry[t];
+    if (c.is_zero()) return;
+    size_t s0 = t * DL_CHUNK, e = s0 + DL_CHUNK < qlen ? s0 + DL_CHUNK : qlen;
+    F pw = z;
+    for (size_t i = e; i-- > s0;) { q[i] = q[i] + pw * c; pw = pw * z; }
+}
+void divide_by_linear(F *q, const F *p, size_t len, const F &z, F *scratch, stream_t s_) {
+    hipStream_t s = (hipStream_t)s_;
+    if (len < 2) return;
+    size_t qlen = len - 1, nch = (qlen + DL_CHUNK - 1) / DL_CHUNK;
+    F *ca = scratch, *cm = scratch + nch, *cc = scratch + 2 * nch;
+    hipLaunchKernelGGL(k_divlin_local, GRID(nch), 0, s, q, p, qlen, z, ca, cm); HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_divlin_carries, dim3(1), dim3(64), 0, s, ca, cm, nch, cc); HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_divlin_fix, GRID(nch), 0, s, q, qlen, z, cc); HIP_LAUNCH_CHECK();
+}
+
+// ---- evaluation: chunks of 64 coefficients by Horner, then sum_t partial_t * (x^64)^t
+__global__ void k_eval_chunks(const F *__restrict__ p, size_t len, F x, F *__restrict__ partial) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t nch = (len + 63) / 64;
+    if (t >= nch) return;
+    size_t s0 = t * 64, e = s0 + 64 < len ? s0 + 64 : len;
+    F acc = F::zero();
+    for (size_t i = e; i-- > s0;) acc = acc * x + p[i];
+    partial[t] = acc;
+}
+__global__ void __launch_bounds__(256) k_eval_combine(const F *__restrict__ partial, size_t nch, F y, F *__restrict__ out) {
+    __shared__ F sh[256];
+    uint32_t t = threadIdx.x;
+    F y256 = y.pow_u64(256), pw = y.pow_u64(t), acc = F::zero();
+    for (size_t i = t; i < nch; i += 256) { acc = acc + partial[i] * pw; pw = pw * y256; }
+    sh[t] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)t < s) sh[t] = sh[t] + sh[t + s]; __syncthreads(); }
+    if (t == 0) out[0] = sh[0];
+}
+F poly_eval(const F *p, size_t len, const F &x, F *scratch, stream_t s_) {
+    hipStream_t s = (hipStream_t)s_;
+    if (len == 0) return F::zero();
+    size_t nch = (len + 63) / 64;
+    hipLaunchKernelGGL(k_eval_chunks, GRID(nch), 0, s, p, len, x, scratch); HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_eval_combine, dim3(1), dim3(256), 0, s, scratch, nch, x.pow_u64(64), scratch + nch); HIP_LAUNCH_CHECK();
+    F out;
+    HIP_CHECK(hipMemcpyAsync(&out, scratch + nch, sizeof(F), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    return out;
+}
+
+// ---- batch inversion: 16 elements per lane (Montgomery's trick), one Fermat inversion per lane
+constexpr int BI_CHUNK = 16;
+__global__ void k_batch_inverse(F *__restrict__ v, size_t n, bool has_post, F post) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t s0 = t * BI_CHUNK;
+    if (s0 >= n) return;
+    size_t e = s0 + BI_CHUNK < n ? s0 + BI_CHUNK : n;
+    F pre[BI_CHUNK];
+    F acc = F::one();
+    for (size_t i = s0; i < e; i++) { pre[i - s0] = acc; F x = v[i]; if (!x.is_zero()) acc = acc * x; }
+    acc = acc.inverse();
+    if (has_post) acc = acc * post;
+    for (size_t i = e; i-- > s0;) {
+        F x = v[i];
+        if (x.is_zero()) continue;
+        v[i] = acc * pre[i - s0];
+        acc = acc * x;
+    }
+}
+void batch_inverse(F *v, size_t n, const F *post, stream_t s) {
+    if (!n) return;
+    size_t threads = (n + BI_CHUNK - 1) / BI_CHUNK;
+    hipLaunchKernelGGL(k_batch_inverse, GRID(threads), 0, (hipStream_t)s, v, n, post != nullptr, post ? *post : F::one()); HIP_LAUNCH_CHECK();
+}
+
+__global__ void k_count_nonzero(const F *__restrict__ p, size_t n, unsigned long long *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !p[i].is_zero()) atomicAdd(out, 1ull);
+}
+size_t count_nonzero(const F *p, size_t n, stream_t s_) {
+    hipStream_t s = (hipStream_t)s_;
+    unsigned long long *d = (unsigned long long *)dmalloc(8), h = 0;
+    HIP_CHECK(hipMemsetAsync(d, 0, 8, s));
+    if (n) { hipLaunchKernelGGL(k_count_nonzero, GRID(n), 0, s, p, n, d); HIP_LAUNCH_CHECK(); }
+    HIP_CHECK(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    dfree(d);
+    return (size_t)h;
+}
+
+// ---- round 2 / 3 pointwise kernels
+__global__ void k_q1(F *__restrict__ e_ra, const F *__restrict__ za, const F *__restrict__ zb, const F *__restrict__ t, const F *__restrict__ z, F ea, F eb, F ec, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F a = za[i], b = zb[i];
+    F sum = ec * (a * b) + ea * a + eb * b;
+    e_ra[i] = e_ra[i] * sum - t[i] * z[i];
+}
+void q1_pointwise(F *e_ra, const F *e_za, const F *e_zb, const F *e_t, const F *e_z, const F &ea, const F &eb, const F &ec, size_t n, stream_t s) {
+    hipLaunchKernelGGL(k_q1, GRID(n), 0, (hipStream_t)s, e_ra, e_za, e_zb, e_t, e_z, ea, eb, ec, n); HIP_LAUNCH_CHECK();
+}
+__global__ void k_r3_den(F *__restrict__ den, const F *__restrict__ row, const F *__restrict__ col, F alpha, F beta, size_t k) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) den[i] = (beta - row[i]) * (alpha - col[i]);
+}
+void round3_den(F *den, const F *row, const F *col, const F &alpha, const F &beta, size_t k, stream_t s) { hipLaunchKernelGGL(k_r3_den, GRID(k), 0, (hipStream_t)s, den, row, col, alpha, beta, k); HIP_LAUNCH_CHECK(); }
+__global__ void k_mul(F *__restrict__ out, const F *__restrict__ a, const F *__restrict__ b, size_t n) { size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = a[i] * b[i]; }
+void mul_pointwise(F *out, const F *a, const F *b, size_t n, stream_t s) { if (!n) return; hipLaunchKernelGGL(k_mul, GRID(n), 0, (hipStream_t)s, out, a, b, n); HIP_LAUNCH_CHECK(); }
+__global__ void k_mul_sub(F *__restrict__ acc, const F *__restrict__ b, const F *__restrict__ f, size_t n) { size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) acc[i] = acc[i] - b[i] * f[i]; }
+void mul_sub(F *acc, const F *b, const F *f, size_t n, stream_t s) { if (!n) return; hipLaunchKernelGGL(k_mul_sub, GRID(n), 0, (hipStream_t)s, acc, b, f, n); HIP_LAUNCH_CHECK(); }
+// z_poly = w * (X^m - 1) + x_poly : zp[i] = (i >= m ? w[i-m] : 0) - (i < wlen ? w[i] : 0) + (i < m ? x[i] : 0), i <= n
+__global__ void k_z_poly(F *__restrict__ zp, const F *__restrict__ w, size_t wlen, const F *__restrict__ x, uint32_t m, size_t n1) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1) return;
+    F v = F::zero();
+    if (i >= m && i - m < wlen) v = w[i - m];
+    if (i < wlen) v = v - w[i];
+    if (i < m) v = v + x[i];
+    zp[i] = v;
+}
+void z_poly_from_w(F *zp, const F *w, size_t wlen, const F *x_poly, uint32_t m, size_t n, stream_t s) { hipLaunchKernelGGL(k_z_poly, GRID(n + 1), 0, (hipStream_t)s, zp, w, wlen, x_poly, m, n + 1); HIP_LAUNCH_CHECK(); }
+
+// ---- indexer: evaluations of the joint-matrix arithmetization on K (ark-marlin arithmetize_matrix)
+__global__ void k_index_rowcol(F *__restrict__ row, F *__restrict__ col, F *__restrict__ rowcol, F *__restrict__ u, const uint32_t *__restrict__ ci, const uint32_t *__restrict__ ri,
+                               size_t cnt, size_t k, const F *__restrict__ elems, uint32_t n, F n_fe) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    if (i < cnt) {
+        uint32_t c = ci[i], r = ri[i];
+        F rv = elems[c], cv = elems[r];          // transposed: "row" holds the column's domain element
+        row[i] = rv; col[i] = cv; rowcol[i] = rv * cv;
+        u[i] = elems[(n - c) & (n - 1)] * n_fe;   // u_H(x, x) = |H| x^(|H|-1)
+    } else {
+        row[i] = elems[0]; col[i] = elems[0]; rowcol[i] = elems[0]; u[i] = F::zero();
+    }
+}
+__global__ void k_index_vals(F *__restrict__ va, F *__restrict__ vb, F *__restrict__ vc, const F *__restrict__ uinv, const int64_t *__restrict__ ca, const int64_t *__restrict__ cb,
+                             const int64_t *__restrict__ cc, size_t cnt, size_t k) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    if (i < cnt) {
+        F w = uinv[i];
+        va[i] = ca[i] ? F::from_i64(ca[i]) * w : F::zero();
+        vb[i] = cb[i] ? F::from_i64(cb[i]) * w : F::zero();
+        vc[i] = cc[i] ? F::from_i64(cc[i]) * w : F::zero();
+    } else { va[i] = F::zero(); vb[i] = F::zero(); vc[i] = F::zero(); }
+}
+void index_evals(F *row, F *col, F *rowcol, F *va, F *vb, F *vc, F *tmp, const uint32_t *ci, const uint32_t *ri, const int64_t *ca, const int64_t *cb, const int64_t *cc, size_t cnt,
+                 size_t k, const F *elems, uint32_t n, stream_t s) {
+    hipLaunchKernelGGL(k_index_rowcol, GRID(k), 0, (hipStream_t)s, row, col, rowcol, tmp, ci, ri, cnt, k, elems, n, F::from_u64(n)); HIP_LAUNCH_CHECK();
+    batch_inverse(tmp, k, nullptr, s);
+    hipLaunchKernelGGL(k_index_vals, GRID(k), 0, (hipStream_t)s, va, vb, vc, tmp, ca, cb, cc, cnt, k); HIP_LAUNCH_CHECK();
+}
+
+}  // namespace gpu
+}  // namespace zk

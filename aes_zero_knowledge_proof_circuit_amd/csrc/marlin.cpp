@@ -1,0 +1,765 @@
+// csrc/marlin.cpp -- see marlin.hpp.  Host orchestration of the GPU prover + the host verifier.
+#include "marlin.hpp"
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include "gpu.hpp"
+#include "trace_layout.h"
+#include "transcript.hpp"
+
+namespace zk {
+namespace {
+
+using gpu::F;
+using Clock = std::chrono::steady_clock;
+double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+size_t next_pow2(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
+int log2_exact(size_t n) { int l = 0; while (((size_t)1 << l) < n) l++; return l; }
+
+// ------------------------------------------------------------------ host field / domain helpers
+Fr fr_from_limbs(const uint32_t *l) { Fr r; for (int i = 0; i < 8; i++) r.l[i] = l[i]; return r; }
+Fr domain_gen(int lg) { Fr r = fr_from_limbs(FR377_ROOT_MONT); for (int i = lg; i < FR377_TWO_ADICITY; i++) r = r.sqr(); return r; }
+Fr eval_vanishing(size_t size, const Fr &x) { return x.pow_u64(size) - Fr::one(); }
+size_t reindex_by_subdomain(size_t self_size, size_t other_size, size_t index) {   // ark-poly EvaluationDomain::reindex_by_subdomain
+    size_t period = self_size / other_size;
+    if (index < other_size) return index * period;
+    size_t i = index - other_size, x = period - 1;
+    return i + (i / x) + 1;
+}
+size_t ahp_max_degree(size_t nc, size_t nv, size_t nnz) {                        // AHPForR1CS::max_degree, zk_bound = 1
+    size_t h = next_pow2(std::max(nc, nv)), k = next_pow2(nnz);
+    return std::max({2 * h - 1, 3 * h - 1, h, 3 * k - 3});
+}
+G1A g1_generator() { G1A g; for (int i = 0; i < 12; i++) { g.x.l[i] = G1_377_X_MONT[i]; g.y.l[i] = G1_377_Y_MONT[i]; } return g; }
+G1A mul_affine(const G1A &p, const Fr &k) { return mul_fr(XYZZ<Fq377>::from_affine(p), k).to_affine(); }
+
+// ------------------------------------------------------------------ byte encodings (ark-ff ToBytes / ark-serialize)
+struct Bytes {
+    std::vector<uint8_t> b;
+    void put(const void *p, size_t n) { const uint8_t *q = (const uint8_t *)p; b.insert(b.end(), q, q + n); }
+    void u8(uint8_t v) { b.push_back(v); }
+    void u64(uint64_t v) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(v >> (8 * i))); }
+    template <class Fld> void field(const Fld &a) { uint32_t raw[Fld::N]; a.to_raw(raw); for (int i = 0; i < Fld::N; i++) for (int k = 0; k < 4; k++) b.push_back((uint8_t)(raw[i] >> (8 * k))); }
+    void g1_tobytes(const G1A &p) {        // GroupAffine ToBytes: x, y, infinity (zero() = (0, 1, true))
+        if (p.is_inf()) { field(Fq377::zero()); field(Fq377::one()); u8(1); }
+        else { field(p.x); field(p.y); u8(0); }
+    }
+    void commitment_tobytes(const Commitment &c) {   // marlin_pc::Commitment ToBytes
+        g1_tobytes(c.comm); u8(c.has_shifted ? 1 : 0);
+        g1_tobytes(c.has_shifted ? c.shifted : G1A::inf());
+    }
+    void g1_compressed(const G1A &p) {
+        uint8_t buf[48] = {0};
+        if (p.is_inf()) { buf[47] |= 1 << 6; put(buf, 48); return; }
+        uint32_t x[12], y[12], ny[12];
+        p.x.to_raw(x); p.y.to_raw(y); p.y.neg().to_raw(ny);
+        bool y_gt = false;
+        for (int i = 11; i >= 0; i--) if (y[i] != ny[i]) { y_gt = y[i] > ny[i]; break; }
+        for (int i = 0; i < 48; i++) buf[i] = (uint8_t)(x[i / 4] >> (8 * (i % 4)));
+        if (y_gt) buf[47] |= 1 << 7;
+        put(buf, 48);
+    }
+};
+
+// Fq square root (Tonelli-Shanks; q - 1 = 2^46 * t) for point decompression
+bool fq_sqrt(const Fq377 &a, Fq377 &out) {
+    if (a.is_zero()) { out = a; return true; }
+    static bool init = false;
+    static uint32_t t_limbs[12], tp1h_limbs[12], half_limbs[12];
+    static Fq377 z_t;   // nonresidue^t
+    static int S = 0;
+    if (!init) {
+        uint32_t qm1[12];
+        for (int i = 0; i < 12; i++) qm1[i] = FQ377_P[i];
+        qm1[0] -= 1;
+        auto shr1 = [](uint32_t *v) { for (int i = 0; i < 12; i++) v[i] = (v[i] >> 1) | (i < 11 ? v[i + 1] << 31 : 0); };
+        memcpy(half_limbs, qm1, sizeof qm1); shr1(half_limbs);
+        memcpy(t_limbs, qm1, sizeof qm1);
+        while (!(t_limbs[0] & 1)) { shr1(t_limbs); S++; }
+        memcpy(tp1h_limbs, t_limbs, sizeof t_limbs);
+        tp1h_limbs[0] += 1;   // t odd -> no carry beyond limb 0 unless 0xffffffff
+        shr1(tp1h_limbs);
+        Fq377 minus_one = Fq377::one().neg();
+        for (uint64_t c = 2;; c++) { Fq377 cand = Fq377::from_u64(c); if (cand.pow(half_limbs, 12) == minus_one) { z_t = cand.pow(t_limbs, 12); break; } }
+        init = true;
+    }
+    if (!(a.pow(half_limbs, 12) == Fq377::one())) return false;
+    Fq377 c = z_t, x = a.pow(tp1h_limbs, 12), b = a.pow(t_limbs, 12);
+    int m = S;
+    while (!(b == Fq377::one())) {
+        int i = 0;
+        Fq377 bb = b;
+        while (!(bb == Fq377::one())) { bb = bb.sqr(); i++; }
+        Fq377 g = c;
+        for (int k = 0; k < m - i - 1; k++) g = g.sqr();
+        x = x * g; c = g.sqr(); b = b * c; m = i;
+    }
+    out = x;
+    return true;
+}
+
+struct Reader {
+    const uint8_t *p; size_t n, off = 0;
+    void need(size_t k) { if (off + k > n) throw std::runtime_error("deserialize_proof: truncated input"); }
+    uint8_t u8() { need(1); return p[off++]; }
+    uint64_t u64() { need(8); uint64_t v = 0; for (int i = 0; i < 8; i++) v |= (uint64_t)p[off + i] << (8 * i); off += 8; return v; }
+    Fr fr() {
+        need(32);
+        uint32_t raw[8];
+        for (int i = 0; i < 8; i++) raw[i] = (uint32_t)p[off + 4 * i] | (uint32_t)p[off + 4 * i + 1] << 8 | (uint32_t)p[off + 4 * i + 2] << 16 | (uint32_t)p[off + 4 * i + 3] << 24;
+        off += 32;
+        if (Fr::geq_mod(raw)) throw std::runtime_error("deserialize_proof: non-canonical field element");
+        return Fr::from_raw(raw);
+    }
+    G1A g1() {
+        need(48);
+        uint8_t buf[48];
+        memcpy(buf, p + off, 48); off += 48;
+        bool inf = buf[47] & (1 << 6), y_gt = buf[47] & (1 << 7);
+        buf[47] &= 0x3f;
+        if (inf) return G1A::inf();
+        uint32_t raw[12];
+        for (int i = 0; i < 12; i++) raw[i] = (uint32_t)buf[4 * i] | (uint32_t)buf[4 * i + 1] << 8 | (uint32_t)buf[4 * i + 2] << 16 | (uint32_t)buf[4 * i + 3] << 24;
+        if (Fq377::geq_mod(raw)) throw std::runtime_error("deserialize_proof: non-canonical x coordinate");
+        G1A a; a.x = Fq377::from_raw(raw);
+        Fq377 y;
+        if (!fq_sqrt(a.x.sqr() * a.x + Bls377::b(), y)) throw std::runtime_error("deserialize_proof: x is not on the curve");
+        uint32_t yr[12], nyr[12];
+        y.to_raw(yr); y.neg().to_raw(nyr);
+        bool gt = false;
+        for (int i = 11; i >= 0; i--) if (yr[i] != nyr[i]) { gt = yr[i] > nyr[i]; break; }
+        a.y = (gt == y_gt) ? y : y.neg();
+        return a;
+    }
+};
+
+}  // namespace
+
+std::vector<uint8_t> serialize_proof(const Proof &p) {
+    Bytes o;
+    static const int round_len[3] = {4, 3, 2};
+    o.u64(3);
+    int ci = 0;
+    for (int r = 0; r < 3; r++) {
+        o.u64(round_len[r]);
+        for (int i = 0; i < round_len[r]; i++, ci++) {
+            o.g1_compressed(p.comms[ci].comm);
+            o.u8(p.comms[ci].has_shifted ? 1 : 0);
+            if (p.comms[ci].has_shifted) o.g1_compressed(p.comms[ci].shifted);
+        }
+    }
+    o.u64(4);
+    for (int i = 0; i < 4; i++) o.field(p.evals[i]);
+    o.u64(3);
+    for (int i = 0; i < 3; i++) o.u8(0);                 // prover_messages: EmptyMessage -> Option::None
+    o.u64(2);
+    o.g1_compressed(p.w_beta); o.u8(1); o.field(p.random_v_beta);
+    o.g1_compressed(p.w_gamma); o.u8(0);
+    o.u8(0);                                             // pc_proof.evals: None
+    return o.b;
+}
+Proof deserialize_proof(const uint8_t *bytes, size_t len) {
+    Reader r{bytes, len};
+    Proof p;
+    static const uint64_t round_len[3] = {4, 3, 2};
+    if (r.u64() != 3) throw std::runtime_error("deserialize_proof: expected 3 commitment rounds");
+    int ci = 0;
+    for (int rd = 0; rd < 3; rd++) {
+        if (r.u64() != round_len[rd]) throw std::runtime_error("deserialize_proof: unexpected number of commitments");
+        for (uint64_t i = 0; i < round_len[rd]; i++, ci++) {
+            p.comms[ci].comm = r.g1();
+            uint8_t tag = r.u8();
+            if (tag > 1) throw std::runtime_error("deserialize_proof: bad Option tag");
+            p.comms[ci].has_shifted = tag;
+            if (tag) p.comms[ci].shifted = r.g1();
+        }
+    }
+    if (r.u64() != 4) throw std::runtime_error("deserialize_proof: expected 4 evaluations");
+    for (int i = 0; i < 4; i++) p.evals[i] = r.fr();
+    if (r.u64() != 3) throw std::runtime_error("deserialize_proof: expected 3 prover messages");
+    for (int i = 0; i < 3; i++) if (r.u8() != 0) throw std::runtime_error("deserialize_proof: non-empty prover message");
+    if (r.u64() != 2) throw std::runtime_error("deserialize_proof: expected 2 opening proofs");
+    p.w_beta = r.g1();
+    if (r.u8() != 1) throw std::runtime_error("deserialize_proof: opening 0 must carry random_v");
+    p.random_v_beta = r.fr();
+    p.w_gamma = r.g1();
+    if (r.u8() != 0) throw std::runtime_error("deserialize_proof: opening 1 must not carry random_v");
+    if (r.u8() != 0) throw std::runtime_error("deserialize_proof: unexpected pc_proof.evals");
+    if (r.off != len) throw std::runtime_error("deserialize_proof: trailing bytes");
+    return p;
+}
+
+std::vector<Fr> ciphertext_to_public_input(const uint8_t *ct, size_t len) {
+    std::vector<Fr> v;
+    v.reserve(len * 8);
+    for (size_t i = 0; i < len; i++) for (int b = 0; b < 8; b++) v.push_back(((ct[i] >> b) & 1) ? Fr::one() : Fr::zero());
+    return v;
+}
+
+// =====================================================================================================================
+// proving key
+struct DevBuf {
+    F *p = nullptr; size_t n = 0;
+    void alloc(size_t count) { n = count; p = (F *)gpu::dmalloc(count * sizeof(F)); }
+    void release() { gpu::dfree(p); p = nullptr; }
+};
+struct KzgRand { bool hiding = false; Fr b[3]; };
+
+class ProvingKeyImpl {
+  public:
+    VerifyingKey vk;
+    Circuit circuit;
+    gpu::stream_t stream = nullptr;
+    size_t n = 0, k = 0, m = 0;       // |H|, |K|, |X|
+    int lg_n = 0, lg_k = 0, lg_m = 0;
+    size_t max_degree = 0, supported_degree = 0, lowest_shift = 0, bounds[2] = {0, 0};
+    Fr srs_beta;
+    G1A gamma_powers[3];
+    // device: SRS
+    G1A *d_powers = nullptr, *d_shifted = nullptr;
+    // device: circuit
+    uint32_t *d_desc = nullptr, *d_sbox_in = nullptr, *d_sbox_tmpl = nullptr;
+    uint32_t *d_a_rowptr = nullptr, *d_a_col = nullptr, *d_b_rowptr = nullptr, *d_b_col = nullptr;
+    int64_t *d_a_coeff = nullptr, *d_b_coeff = nullptr;
+    uint32_t *d_t_colptr = nullptr, *d_t_row = nullptr; uint8_t *d_t_mat = nullptr; int64_t *d_t_coeff = nullptr;
+    // device: index polynomials (evaluations on K and coefficients); order row col a_val b_val c_val row_col
+    DevBuf ix_ev[6], ix_co[6];
+    // device: per-proof workspace
+    uint8_t *d_trace = nullptr, *d_z = nullptr, *d_msg = nullptr, *d_key = nullptr;
+    DevBuf za_ev, zb_ev, x_poly, x_tmp, x_evals, tmp_n, ra_ev, ra_poly, zpoly;
+    DevBuf poly[9];                    // w z_a z_b mask t g_1 h_1 g_2 h_2 (capacities below)
+    size_t poly_len[9] = {0};
+    DevBuf e[5], big_tmp, f_poly, ab[2], acc, wit, scratch;
+    ProverTimings timings;
+
+    ~ProvingKeyImpl() {
+        gpu::dfree(d_powers); gpu::dfree(d_shifted); gpu::dfree(d_desc); gpu::dfree(d_sbox_in); gpu::dfree(d_sbox_tmpl);
+        gpu::dfree(d_a_rowptr); gpu::dfree(d_a_col); gpu::dfree(d_b_rowptr); gpu::dfree(d_b_col); gpu::dfree(d_a_coeff); gpu::dfree(d_b_coeff);
+        gpu::dfree(d_t_colptr); gpu::dfree(d_t_row); gpu::dfree(d_t_mat); gpu::dfree(d_t_coeff);
+        for (auto &b : ix_ev) b.release();
+        for (auto &b : ix_co) b.release();
+        gpu::dfree(d_trace); gpu::dfree(d_z); gpu::dfree(d_msg); gpu::dfree(d_key);
+        for (DevBuf *b : {&za_ev, &zb_ev, &x_poly, &x_tmp, &x_evals, &tmp_n, &ra_ev, &ra_poly, &zpoly, &big_tmp, &f_poly, &acc, &wit, &scratch}) b->release();
+        for (auto &b : poly) b.release();
+        for (auto &b : e) b.release();
+        for (auto &b : ab) b.release();
+        gpu::stream_destroy(stream);
+    }
+
+    template <class T> static T *upload(const std::vector<T> &v, gpu::stream_t s) {
+        T *d = (T *)gpu::dmalloc(v.size() * sizeof(T));
+        gpu::h2d(d, v.data(), v.size() * sizeof(T), s);
+        return d;
+    }
+
+    // MSM against powers_of_g starting at `off` (plain or shifted table); device scalars
+    XYZZ<Fq377> msm_powers(bool shifted, size_t off, const F *scalars, size_t len) {
+        if (len == 0) return XYZZ<Fq377>::inf();
+        size_t avail = shifted ? (bounds[1] + 1) : (supported_degree + 1);
+        if (off + len > avail) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
+        return gpu::msm<Bls377>((shifted ? d_shifted : d_powers) + off, scalars, len, stream);
+    }
+    // KZG10::commit: MSM(powers, coeffs) [+ MSM(powers_of_gamma_g, blinding) when hiding]
+    G1A kzg_commit(bool shifted, size_t off, const F *coeffs, size_t len, bool hiding, KzgRand &rnd, ChaChaRng &zk) {
+        XYZZ<Fq377> c = msm_powers(shifted, off, coeffs, len);
+        rnd.hiding = hiding;
+        for (auto &x : rnd.b) x = Fr::zero();
+        if (hiding) {
+            for (int i = 0; i < 3; i++) rnd.b[i] = zk.rand_field<Fr>();
+            for (int i = 0; i < 3; i++) c.add(mul_fr(XYZZ<Fq377>::from_affine(gamma_powers[i]), rnd.b[i]));
+        }
+        return c.to_affine();
+    }
+    struct Labeled { int idx; long bound; bool hiding; KzgRand rand, shifted_rand; Commitment comm; };
+    void mpc_commit(Labeled &lp, ChaChaRng &zk) {
+        lp.comm.comm = kzg_commit(false, 0, poly[lp.idx].p, poly_len[lp.idx], lp.hiding, lp.rand, zk);
+        lp.comm.has_shifted = false;
+        if (lp.bound >= 0) {
+            size_t off = (max_degree - (size_t)lp.bound) - lowest_shift;
+            lp.comm.shifted = kzg_commit(true, off, poly[lp.idx].p, poly_len[lp.idx], lp.hiding, lp.shifted_rand, zk);
+            lp.comm.has_shifted = true;
+        }
+    }
+
+    void setup(int kind, size_t message_len, const SrsLiterals &srs);
+    Proof prove(const uint8_t *trace_or_null, const uint8_t *msg, size_t len, const uint8_t *key, const uint8_t *zk_seed);
+};
+
+void ProvingKeyImpl::setup(int kind, size_t message_len, const SrsLiterals &srs) {
+    gpu::require_device();
+    stream = gpu::stream_create();
+    circuit = kind == CIRCUIT_AES ? compile_aes_circuit(message_len) : compile_ops_circuit(kind);
+    const Circuit &c = circuit;
+    // ---- joint matrix (sum_matrices): per-row sorted union of the A, B, C column supports
+    size_t rows = c.num_constraints;
+    std::vector<uint32_t> j_ci, j_ri;
+    std::vector<int64_t> j_a, j_b, j_c;
+    m = c.num_instance; n = next_pow2(c.num_constraints);
+    for (size_t r = 0; r < rows; r++) {
+        uint32_t ia = c.A.rowptr[r], ib = c.B.rowptr[r], ic = c.C.rowptr[r];
+        const uint32_t ea = c.A.rowptr[r + 1], eb = c.B.rowptr[r + 1], ec = c.C.rowptr[r + 1];
+        for (;;) {
+            uint32_t best = 0xffffffffu;
+            if (ia < ea) best = std::min(best, c.A.col[ia]);
+            if (ib < eb) best = std::min(best, c.B.col[ib]);
+            if (ic < ec) best = std::min(best, c.C.col[ic]);
+            if (best == 0xffffffffu) break;
+            j_ci.push_back((uint32_t)reindex_by_subdomain(n, m, best));
+            j_ri.push_back((uint32_t)r);
+            j_a.push_back(ia < ea && c.A.col[ia] == best ? c.A.coeff[ia++] : 0);
+            j_b.push_back(ib < eb && c.B.col[ib] == best ? c.B.coeff[ib++] : 0);
+            j_c.push_back(ic < ec && c.C.col[ic] == best ? c.C.coeff[ic++] : 0);
+        }
+    }
+    size_t nnz = j_ci.size();
+    k = next_pow2(nnz);
+    lg_n = log2_exact(n); lg_k = log2_exact(k); lg_m = log2_exact(m);
+    vk.num_variables = c.num_variables(); vk.num_constraints = c.num_constraints; vk.num_non_zero = nnz; vk.num_instance = c.num_instance;
+    vk.num_public_inputs = c.raw_instance - 1;
+    if (vk.num_variables != vk.num_constraints) throw std::logic_error("index: matrices are not square after padding");
+    // ---- universal SRS sizing + trim
+    max_degree = ahp_max_degree(srs.num_constraints, srs.num_variables, srs.num_non_zero);
+    supported_degree = ahp_max_degree(vk.num_constraints, vk.num_variables, vk.num_non_zero);
+    if (supported_degree > max_degree) throw std::runtime_error("IndexTooLarge: the circuit needs degree " + std::to_string(supported_degree) + " but the universal SRS supports " + std::to_string(max_degree));
+    bounds[0] = std::min(n - 2, k - 2); bounds[1] = std::max(n - 2, k - 2);
+    lowest_shift = max_degree - bounds[1];
+    // KZG10::setup trapdoor from ark_std::test_rng(): beta first (as upstream); g = generator and gamma_g = gamma*g is this
+    // build's documented deviation (upstream samples g, gamma_g, h as random curve points)
+    ChaChaRng setup_rng(ark_test_rng_seed(), 12);
+    srs_beta = setup_rng.rand_field<Fr>();
+    Fr gamma = setup_rng.rand_field<Fr>();
+    G1A g = g1_generator(), gamma_g = mul_affine(g, gamma);
+    d_powers = (G1A *)gpu::dmalloc((supported_degree + 1) * sizeof(G1A));
+    gpu::fixed_base_powers<Bls377>(d_powers, g, srs_beta, 0, supported_degree + 1, stream);
+    d_shifted = (G1A *)gpu::dmalloc((bounds[1] + 1) * sizeof(G1A));
+    gpu::fixed_base_powers<Bls377>(d_shifted, g, srs_beta, lowest_shift, bounds[1] + 1, stream);
+    { Fr bp = Fr::one(); for (int i = 0; i < 3; i++) { gamma_powers[i] = mul_affine(gamma_g, bp); bp = bp * srs_beta; } }
+    vk.g = g; vk.gamma_g = gamma_g;
+    vk.h = pairing::g2_generator();
+    { uint32_t raw[8]; srs_beta.to_raw(raw); vk.beta_h = pairing::g2_mul_raw(vk.h, raw, 8); }
+    vk.degree_bounds[0] = bounds[0]; vk.degree_bounds[1] = bounds[1];
+    for (int i = 0; i < 2; i++) vk.shift_powers[i] = mul_affine(g, srs_beta.pow_u64(max_degree - bounds[i]));
+    vk.supported_degree = supported_degree; vk.max_degree = max_degree;
+    // ---- circuit tables
+    {
+        uint8_t sb[256];
+        // S-box table for the device = the lookup table the circuit was compiled against (level-7 node values of the template)
+        for (int i = 0; i < 256; i++) sb[i] = aes_sbox_value((uint8_t)i);
+        gpu::upload_sbox(sb);
+    }
+    d_desc = upload(c.desc, stream);
+    d_sbox_in = upload(c.sbox_in_off.empty() ? std::vector<uint32_t>{0} : c.sbox_in_off, stream);
+    d_sbox_tmpl = upload(c.sbox_tmpl.empty() ? std::vector<uint32_t>{0} : c.sbox_tmpl, stream);
+    d_a_rowptr = upload(c.A.rowptr, stream); d_a_col = upload(c.A.col.empty() ? std::vector<uint32_t>{0} : c.A.col, stream);
+    d_a_coeff = upload(c.A.coeff.empty() ? std::vector<int64_t>{0} : c.A.coeff, stream);
+    d_b_rowptr = upload(c.B.rowptr, stream); d_b_col = upload(c.B.col.empty() ? std::vector<uint32_t>{0} : c.B.col, stream);
+    d_b_coeff = upload(c.B.coeff.empty() ? std::vector<int64_t>{0} : c.B.coeff, stream);
+    {   // column-bucketed copy of A, B, C for the round-2 t accumulation (calculate_t)
+        std::vector<uint32_t> colptr(n + 1, 0), trow;
+        std::vector<uint8_t> tmat;
+        std::vector<int64_t> tcoef;
+        const CsrMatrix *M[3] = {&c.A, &c.B, &c.C};
+        for (int q = 0; q < 3; q++) for (uint32_t col : M[q]->col) colptr[reindex_by_subdomain(n, m, col) + 1]++;
+        for (size_t i = 0; i < n; i++) colptr[i + 1] += colptr[i];
+        size_t total = colptr[n];
+        trow.resize(total ? total : 1); tmat.resize(total ? total : 1); tcoef.resize(total ? total : 1);
+        std::vector<uint32_t> fill(colptr.begin(), colptr.end() - 1);
+        for (int q = 0; q < 3; q++)
+            for (size_t r = 0; r < rows; r++)
+                for (uint32_t i = M[q]->rowptr[r]; i < M[q]->rowptr[r + 1]; i++) {
+                    uint32_t pos = fill[reindex_by_subdomain(n, m, M[q]->col[i])]++;
+                    trow[pos] = (uint32_t)r; tmat[pos] = (uint8_t)q; tcoef[pos] = M[q]->coeff[i];
+                }
+        d_t_colptr = upload(colptr, stream); d_t_row = upload(trow, stream); d_t_mat = upload(tmat, stream); d_t_coeff = upload(tcoef, stream);
+    }
+    // ---- index polynomials on the GPU
+    for (int i = 0; i < 6; i++) { ix_ev[i].alloc(k); ix_co[i].alloc(k); }
+    {
+        uint32_t *d_ci = upload(j_ci.empty() ? std::vector<uint32_t>{0} : j_ci, stream), *d_ri = upload(j_ri.empty() ? std::vector<uint32_t>{0} : j_ri, stream);
+        int64_t *d_ja = upload(j_a.empty() ? std::vector<int64_t>{0} : j_a, stream), *d_jb = upload(j_b.empty() ? std::vector<int64_t>{0} : j_b, stream), *d_jc = upload(j_c.empty() ? std::vector<int64_t>{0} : j_c, stream);
+        const F *elems = gpu::domain_elements<F>(lg_n);
+        // order: 0 row, 1 col, 2 a_val, 3 b_val, 4 c_val, 5 row_col ; ix_co[0] doubles as the batch-inverse scratch
+        gpu::index_evals(ix_ev[0].p, ix_ev[1].p, ix_ev[5].p, ix_ev[2].p, ix_ev[3].p, ix_ev[4].p, ix_co[0].p, d_ci, d_ri, d_ja, d_jb, d_jc, nnz, k, elems, (uint32_t)n, stream);
+        for (int i = 0; i < 6; i++) gpu::ntt<F>(ix_co[i].p, ix_ev[i].p, k, lg_k, true, stream);
+        gpu::sync(stream);
+        gpu::dfree(d_ci); gpu::dfree(d_ri); gpu::dfree(d_ja); gpu::dfree(d_jb); gpu::dfree(d_jc);
+    }
+    for (int i = 0; i < 6; i++) vk.index_comms[i] = msm_powers(false, 0, ix_co[i].p, k).to_affine();
+    // ---- workspace
+    size_t n4 = next_pow2(3 * n + 1), k2 = 2 * k;
+    d_trace = (uint8_t *)gpu::dmalloc(c.trace_bytes + 64); d_z = (uint8_t *)gpu::dmalloc(c.num_variables() + 64);
+    d_msg = (uint8_t *)gpu::dmalloc(std::max<size_t>(message_len, 16)); d_key = (uint8_t *)gpu::dmalloc(16);
+    za_ev.alloc(n); zb_ev.alloc(n); x_poly.alloc(m); x_tmp.alloc(m); x_evals.alloc(n); tmp_n.alloc(n + 1); ra_ev.alloc(n); ra_poly.alloc(n); zpoly.alloc(n + 1);
+    size_t caps[9] = {n + 1, n + 1, n + 1, 3 * n, n, n, 3 * n, k, k + 1};
+    for (int i = 0; i < 9; i++) poly[i].alloc(caps[i]);
+    size_t big = std::max(n4, k2);
+    for (auto &b : e) b.alloc(big);
+    big_tmp.alloc(big); f_poly.alloc(k); ab[0].alloc(k); ab[1].alloc(k);
+    acc.alloc(std::max(3 * n, k) + 1); wit.alloc(std::max(3 * n, k) + 1); scratch.alloc(std::max(3 * n, k) / 32 + 1024);
+    gpu::sync(stream);
+}
+
+Proof ProvingKeyImpl::prove(const uint8_t *host_trace, const uint8_t *msg, size_t len, const uint8_t *key, const uint8_t *zk_seed) {
+    const Circuit &c = circuit;
+    gpu::stream_t s = stream;
+    auto t_all = Clock::now(), t0 = t_all;
+    ChaChaRng zk(zk_seed ? zk_seed : ark_test_rng_seed(), 12);
+    const size_t n4 = next_pow2(3 * n + 1), k2 = 2 * k;
+    const int lg_n4 = log2_exact(n4), lg_k2 = log2_exact(k2);
+    // ---- witness: trace -> z (bytes) -> z_A, z_B
+    if (host_trace) gpu::h2d(d_trace, host_trace, c.trace_bytes, s);
+    else {
+        gpu::h2d(d_msg, msg, len, s); gpu::h2d(d_key, key, 16, s);
+        gpu::aes_trace(d_trace, c.trace_bytes, d_msg, d_key, 1, (uint32_t)c.n_blocks, s);
+    }
+    gpu::witness_expand(d_z, d_desc, (uint32_t)c.num_variables(), d_trace, d_sbox_in, d_sbox_tmpl, s);
+    gpu::spmv_bits(za_ev.p, n, d_a_rowptr, d_a_col, d_a_coeff, c.num_constraints, d_z, s);
+    gpu::spmv_bits(zb_ev.p, n, d_b_rowptr, d_b_col, d_b_coeff, c.num_constraints, d_z, s);
+    std::vector<uint8_t> inst(m);
+    gpu::d2h(inst.data(), d_z, m, s);
+    timings.witness_ms = ms_since(t0); t0 = Clock::now();
+    // ---- transcript init: "MARLIN-2019" || index_vk || public_input
+    FiatShamirRng fs;
+    {
+        Bytes o;
+        o.put("MARLIN-2019", 11);
+        o.u64(vk.num_variables); o.u64(vk.num_constraints); o.u64(vk.num_non_zero);
+        for (int i = 0; i < 6; i++) { Commitment ic; ic.comm = vk.index_comms[i]; o.commitment_tobytes(ic); }
+        for (size_t i = 1; i < m; i++) o.field(inst[i] ? Fr::one() : Fr::zero());
+        fs.initialize(o.b);
+    }
+    // ---- first round
+    Labeled r1[4] = {{0, -1, true}, {1, -1, true}, {2, -1, true}, {3, -1, false}};
+    gpu::bits_to_field(x_tmp.p, d_z, m, s);
+    gpu::ntt<F>(x_poly.p, x_tmp.p, m, lg_m, true, s);
+    gpu::ntt<F>(x_evals.p, x_poly.p, m, lg_n, false, s);
+    gpu::w_evals(tmp_n.p, d_z, x_evals.p, (uint32_t)n, (uint32_t)m, (uint32_t)c.num_witness, s);
+    gpu::ntt<F>(e[0].p, tmp_n.p, n, lg_n, true, s);                         // interpolate
+    Fr rho = zk.rand_field<Fr>();
+    gpu::poly_add_at(e[0].p, 0, rho.neg(), s); gpu::poly_set_at(e[0].p, n, rho, s);   // + rho * v_H
+    gpu::divide_by_vanishing(poly[0].p, e[1].p, e[0].p, n + 1, m, s);       // / v_X ; remainder must vanish
+    poly_len[0] = n + 1 - m;
+    gpu::ntt<F>(poly[1].p, za_ev.p, n, lg_n, true, s);
+    rho = zk.rand_field<Fr>();
+    gpu::poly_add_at(poly[1].p, 0, rho.neg(), s); gpu::poly_set_at(poly[1].p, n, rho, s); poly_len[1] = n + 1;
+    gpu::ntt<F>(poly[2].p, zb_ev.p, n, lg_n, true, s);
+    rho = zk.rand_field<Fr>();
+    gpu::poly_add_at(poly[2].p, 0, rho.neg(), s); gpu::poly_set_at(poly[2].p, n, rho, s); poly_len[2] = n + 1;
+    {   // mask polynomial: degree 3|H| + 2 zk_bound - 3, sum over H forced to zero
+        std::vector<Fr> mask(3 * n);
+        for (auto &x : mask) x = zk.rand_field<Fr>();
+        Fr sigma = mask[0] + mask[n] + mask[2 * n];
+        mask[0] = mask[0] - sigma;
+        gpu::h2d(poly[3].p, mask.data(), mask.size() * sizeof(Fr), s);
+        gpu::sync(s);
+        poly_len[3] = 3 * n;
+    }
+    for (auto &lp : r1) mpc_commit(lp, zk);
+    { Bytes o; for (auto &lp : r1) o.commitment_tobytes(lp.comm); fs.absorb(o.b); }
+    auto sample_outside_h = [&]() { Fr t; do { t = fs.rng().rand_field<Fr>(); } while (eval_vanishing(n, t).is_zero()); return t; };
+    Fr alpha = sample_outside_h();
+    Fr eta_a = fs.rng().rand_field<Fr>(), eta_b = fs.rng().rand_field<Fr>(), eta_c = fs.rng().rand_field<Fr>();
+    timings.round1_ms = ms_since(t0); t0 = Clock::now();
+    // ---- second round
+    Labeled r2[3] = {{4, -1, false}, {5, (long)(n - 2), true}, {6, -1, false}};
+    Fr vh_alpha = eval_vanishing(n, alpha);
+    const F *elems = gpu::domain_elements<F>(lg_n);
+    gpu::sub_from_scalar(ra_ev.p, elems, alpha, n, s);
+    gpu::batch_inverse(ra_ev.p, n, &vh_alpha, s);                            // r(alpha, h) = v_H(alpha) / (alpha - h)
+    gpu::t_evals(tmp_n.p, (uint32_t)n, d_t_colptr, d_t_row, d_t_mat, d_t_coeff, ra_ev.p, eta_a, eta_b, eta_c, s);
+    gpu::ntt<F>(poly[4].p, tmp_n.p, n, lg_n, true, s); poly_len[4] = n;
+    gpu::ntt<F>(ra_poly.p, ra_ev.p, n, lg_n, true, s);
+    gpu::z_poly_from_w(zpoly.p, poly[0].p, poly_len[0], x_poly.p, (uint32_t)m, n, s);
+    gpu::ntt<F>(e[0].p, poly[1].p, n + 1, lg_n4, false, s);
+    gpu::ntt<F>(e[1].p, poly[2].p, n + 1, lg_n4, false, s);
+    gpu::ntt<F>(e[2].p, ra_poly.p, n, lg_n4, false, s);
+    gpu::ntt<F>(e[3].p, poly[4].p, n, lg_n4, false, s);
+    gpu::ntt<F>(e[4].p, zpoly.p, n + 1, lg_n4, false, s);
+    gpu::q1_pointwise(e[2].p, e[0].p, e[1].p, e[3].p, e[4].p, eta_a, eta_b, eta_c, n4, s);
+    gpu::ntt<F>(big_tmp.p, e[2].p, n4, lg_n4, true, s);
+    gpu::poly_axpy(big_tmp.p, poly[3].p, Fr::one(), 3 * n, s);               // q_1 = mask + rhs  (degree <= 3|H| - 1)
+    gpu::divide_by_vanishing(poly[6].p, e[0].p, big_tmp.p, 3 * n, n, s);     // h_1 (2|H| coeffs), remainder = x * g_1
+    poly_len[6] = 2 * n;
+    gpu::d2d(poly[5].p, e[0].p + 1, (n - 1) * sizeof(F), s); poly_len[5] = n - 1;
+    for (auto &lp : r2) mpc_commit(lp, zk);
+    { Bytes o; for (auto &lp : r2) o.commitment_tobytes(lp.comm); fs.absorb(o.b); }
+    Fr beta = sample_outside_h();
+    timings.round2_ms = ms_since(t0); t0 = Clock::now();
+    // ---- third round
+    Labeled r3[2] = {{7, (long)(k - 2), false}, {8, -1, false}};
+    Fr vh_beta = eval_vanishing(n, beta);
+    Fr vv = vh_alpha * vh_beta, ea_vv = eta_a * vv, eb_vv = eta_b * vv, ec_vv = eta_c * vv, alpha_beta = alpha * beta;
+    gpu::round3_den(e[0].p, ix_ev[0].p, ix_ev[1].p, alpha, beta, k, s);
+    gpu::batch_inverse(e[0].p, k, nullptr, s);
+    gpu::poly_lincomb3(e[1].p, ix_ev[2].p, ix_ev[3].p, ix_ev[4].p, ea_vv, eb_vv, ec_vv, k, s);
+    gpu::mul_pointwise(e[1].p, e[1].p, e[0].p, k, s);                         // f on K
+    gpu::ntt<F>(f_poly.p, e[1].p, k, lg_k, true, s);
+    gpu::d2d(poly[7].p, f_poly.p + 1, (k - 1) * sizeof(F), s); poly_len[7] = k - 1;   // g_2 = (f - f(0)) / X
+    gpu::poly_lincomb3(ab[0].p, ix_co[2].p, ix_co[3].p, ix_co[4].p, ea_vv, eb_vv, ec_vv, k, s);                 // a(X)
+    gpu::poly_lincomb3(ab[1].p, ix_co[5].p, ix_co[0].p, ix_co[1].p, Fr::one(), alpha.neg(), beta.neg(), k, s);   // b(X) - alpha*beta
+    gpu::poly_add_at(ab[1].p, 0, alpha_beta, s);
+    gpu::ntt<F>(e[0].p, ab[0].p, k, lg_k2, false, s);
+    gpu::ntt<F>(e[1].p, ab[1].p, k, lg_k2, false, s);
+    gpu::ntt<F>(e[2].p, f_poly.p, k, lg_k2, false, s);
+    gpu::mul_sub(e[0].p, e[1].p, e[2].p, k2, s);
+    gpu::ntt<F>(big_tmp.p, e[0].p, k2, lg_k2, true, s);
+    gpu::divide_by_vanishing(poly[8].p, e[3].p, big_tmp.p, k2, k, s);          // h_2 ; remainder must vanish
+    poly_len[8] = k - 1;
+    for (auto &lp : r3) mpc_commit(lp, zk);
+    { Bytes o; for (auto &lp : r3) o.commitment_tobytes(lp.comm); fs.absorb(o.b); }
+    Fr gamma = fs.rng().rand_field<Fr>();
+    timings.round3_ms = ms_since(t0); t0 = Clock::now();
+    // ---- evaluations, opening challenge
+    Proof pf;
+    Fr g1_b = gpu::poly_eval(poly[5].p, poly_len[5], beta, scratch.p, s);
+    Fr g2_g = gpu::poly_eval(poly[7].p, poly_len[7], gamma, scratch.p, s);
+    Fr t_b = gpu::poly_eval(poly[4].p, poly_len[4], beta, scratch.p, s);
+    Fr zb_b = gpu::poly_eval(poly[2].p, poly_len[2], beta, scratch.p, s);
+    pf.evals[0] = g1_b; pf.evals[1] = g2_g; pf.evals[2] = t_b; pf.evals[3] = zb_b;
+    { Bytes o; for (auto &v : pf.evals) o.field(v); fs.absorb(o.b); }
+    Fr ch;
+    { uint64_t lo = fs.rng().next_u64(), hi = fs.rng().next_u64(); uint32_t raw[8] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32), 0, 0, 0, 0}; ch = Fr::from_raw(raw); }
+    // ---- linear-combination coefficients (construct_linear_combinations)
+    Fr r_alpha_at_beta = (vh_alpha - vh_beta) * (alpha - beta).inverse();
+    Fr vx_beta = eval_vanishing(m, beta);
+    Fr c_za = r_alpha_at_beta * (eta_a + eta_c * zb_b), c_w = (t_b * vx_beta).neg(), c_h1 = vh_beta.neg();
+    Fr vk_gamma = eval_vanishing(k, gamma);
+    Fr bmul = gamma * g2_g + t_b * Fr::from_u64(k).inverse();
+    Fr c_row = alpha * bmul, c_col = beta * bmul, c_rc = bmul.neg(), c_h2 = vk_gamma.neg();
+    Fr chp[5]; chp[0] = Fr::one(); for (int i = 1; i < 5; i++) chp[i] = chp[i - 1] * ch;
+    auto rand_axpy = [](Fr out[3], const Fr &sc, const KzgRand &r) { if (r.hiding) for (int i = 0; i < 3; i++) out[i] = out[i] + sc * r.b[i]; };
+    auto host_divide_by_linear = [](Fr q[2], const Fr p[3], const Fr &z) { q[1] = p[2]; q[0] = p[1] + z * p[2]; };
+    auto host_eval3 = [](const Fr p[3], const Fr &z) { return p[0] + z * (p[1] + z * p[2]); };
+    {   // open at beta: g_1 (ch^0; shifted ch^1), outer_sumcheck (ch^2), t (ch^3), z_b (ch^4)
+        size_t plen = 3 * n;
+        gpu::dzero(acc.p, plen * sizeof(F), s);
+        Fr rb[3] = {Fr::zero(), Fr::zero(), Fr::zero()};
+        gpu::poly_axpy(acc.p, poly[5].p, chp[0], poly_len[5], s); rand_axpy(rb, chp[0], r2[1].rand);
+        gpu::poly_axpy(acc.p, poly[3].p, chp[2], poly_len[3], s);
+        gpu::poly_axpy(acc.p, poly[1].p, chp[2] * c_za, poly_len[1], s); rand_axpy(rb, chp[2] * c_za, r1[1].rand);
+        gpu::poly_axpy(acc.p, poly[0].p, chp[2] * c_w, poly_len[0], s); rand_axpy(rb, chp[2] * c_w, r1[0].rand);
+        gpu::poly_axpy(acc.p, poly[6].p, chp[2] * c_h1, poly_len[6], s);
+        gpu::poly_axpy(acc.p, poly[4].p, chp[3], poly_len[4], s);
+        gpu::poly_axpy(acc.p, poly[2].p, chp[4], poly_len[2], s); rand_axpy(rb, chp[4], r1[2].rand);
+        gpu::divide_by_linear(wit.p, acc.p, plen, beta, scratch.p, s);
+        XYZZ<Fq377> w = msm_powers(false, 0, wit.p, plen - 1);
+        Fr rq[2]; host_divide_by_linear(rq, rb, beta);
+        for (int i = 0; i < 2; i++) w.add(mul_fr(XYZZ<Fq377>::from_affine(gamma_powers[i]), rq[i]));
+        Fr rv = host_eval3(rb, beta);
+        // shifted part (g_1, degree bound |H| - 2)
+        gpu::divide_by_linear(wit.p, poly[5].p, poly_len[5], beta, scratch.p, s);
+        gpu::poly_scale(wit.p, chp[1], poly_len[5] - 1, s);
+        w.add(msm_powers(true, bounds[1] - (n - 2), wit.p, poly_len[5] - 1));
+        Fr srb[3]; for (int i = 0; i < 3; i++) srb[i] = chp[1] * r2[1].shifted_rand.b[i];
+        host_divide_by_linear(rq, srb, beta);
+        for (int i = 0; i < 2; i++) w.add(mul_fr(XYZZ<Fq377>::from_affine(gamma_powers[i]), rq[i]));
+        rv = rv + host_eval3(srb, beta);
+        pf.w_beta = w.to_affine(); pf.random_v_beta = rv;
+    }
+    {   // open at gamma: g_2 (ch^0; shifted ch^1), inner_sumcheck (ch^2)
+        size_t plen = k;
+        gpu::dzero(acc.p, plen * sizeof(F), s);
+        gpu::poly_axpy(acc.p, poly[7].p, chp[0], poly_len[7], s);
+        gpu::poly_axpy(acc.p, ix_co[2].p, chp[2] * ea_vv, k, s);
+        gpu::poly_axpy(acc.p, ix_co[3].p, chp[2] * eb_vv, k, s);
+        gpu::poly_axpy(acc.p, ix_co[4].p, chp[2] * ec_vv, k, s);
+        gpu::poly_axpy(acc.p, ix_co[0].p, chp[2] * c_row, k, s);
+        gpu::poly_axpy(acc.p, ix_co[1].p, chp[2] * c_col, k, s);
+        gpu::poly_axpy(acc.p, ix_co[5].p, chp[2] * c_rc, k, s);
+        gpu::poly_axpy(acc.p, poly[8].p, chp[2] * c_h2, poly_len[8], s);
+        gpu::divide_by_linear(wit.p, acc.p, plen, gamma, scratch.p, s);
+        XYZZ<Fq377> w = msm_powers(false, 0, wit.p, plen - 1);
+        gpu::divide_by_linear(wit.p, poly[7].p, poly_len[7], gamma, scratch.p, s);
+        gpu::poly_scale(wit.p, chp[1], poly_len[7] - 1, s);
+        w.add(msm_powers(true, bounds[1] - (k - 2), wit.p, poly_len[7] - 1));
+        pf.w_gamma = w.to_affine();
+    }
+    for (int i = 0; i < 4; i++) pf.comms[i] = r1[i].comm;
+    for (int i = 0; i < 3; i++) pf.comms[4 + i] = r2[i].comm;
+    for (int i = 0; i < 2; i++) pf.comms[7 + i] = r3[i].comm;
+    timings.open_ms = ms_since(t0);
+    timings.total_ms = ms_since(t_all);
+    return pf;
+}
+
+ProvingKey::~ProvingKey() { delete impl; }
+const VerifyingKey &ProvingKey::vk() const { return impl->vk; }
+const Circuit &ProvingKey::circuit() const { return impl->circuit; }
+const ProverTimings &ProvingKey::last_timings() const { return impl->timings; }
+Proof ProvingKey::prove_aes(const uint8_t *message, size_t len, const uint8_t key[16], const uint8_t *zk_seed) {
+    if (impl->circuit.kind != CIRCUIT_AES) throw std::invalid_argument("proving key was not synthesized for the AES circuit");
+    if (len % 16) throw std::invalid_argument("Input must be 16 bytes length when adding round key");
+    if (len != impl->circuit.n_blocks * 16) throw std::invalid_argument("InstanceDoesNotMatchIndex: proving key was synthesized for " + std::to_string(impl->circuit.n_blocks * 16) + " bytes");
+    return impl->prove(nullptr, message, len, key, zk_seed);
+}
+std::vector<uint8_t> ProvingKey::aes_witness(const uint8_t *message, size_t len, const uint8_t key[16]) {
+    if (impl->circuit.kind != CIRCUIT_AES) throw std::invalid_argument("proving key was not synthesized for the AES circuit");
+    if (len % 16) throw std::invalid_argument("Input must be 16 bytes length when adding round key");
+    if (len != impl->circuit.n_blocks * 16) throw std::invalid_argument("InstanceDoesNotMatchIndex: proving key was synthesized for " + std::to_string(impl->circuit.n_blocks * 16) + " bytes");
+    const Circuit &c = impl->circuit;
+    gpu::stream_t s = impl->stream;
+    gpu::h2d(impl->d_msg, message, len, s); gpu::h2d(impl->d_key, key, 16, s);
+    gpu::aes_trace(impl->d_trace, c.trace_bytes, impl->d_msg, impl->d_key, 1, (uint32_t)c.n_blocks, s);
+    gpu::witness_expand(impl->d_z, impl->d_desc, (uint32_t)c.num_variables(), impl->d_trace, impl->d_sbox_in, impl->d_sbox_tmpl, s);
+    std::vector<uint8_t> z(c.num_variables());
+    gpu::d2h(z.data(), impl->d_z, z.size(), s);
+    return z;
+}
+Proof ProvingKey::prove_ops(uint32_t x, uint32_t y, const uint8_t *zk_seed) {
+    if (impl->circuit.kind == CIRCUIT_AES) throw std::invalid_argument("proving key was synthesized for the AES circuit");
+    uint8_t trace[16] = {0};
+    uint64_t r = impl->circuit.kind == CIRCUIT_OPS_XOR ? (uint64_t)(x ^ y) : (uint64_t)x + y;
+    for (int i = 0; i < 4; i++) { trace[i] = (uint8_t)(x >> (8 * i)); trace[4 + i] = (uint8_t)(y >> (8 * i)); }
+    for (int i = 0; i < 8; i++) trace[8 + i] = (uint8_t)(r >> (8 * i));
+    return impl->prove(trace, nullptr, 0, nullptr, zk_seed);
+}
+std::vector<uint8_t> ProvingKey::debug_fetch(const std::string &name) const {
+    static const char *pn[9] = {"w", "z_a", "z_b", "mask_poly", "t", "g_1", "h_1", "g_2", "h_2"};
+    static const char *in[6] = {"row", "col", "a_val", "b_val", "c_val", "row_col"};
+    std::vector<uint8_t> out;
+    auto grab = [&](const void *d, size_t bytes) { out.resize(bytes); gpu::d2h(out.data(), d, bytes, impl->stream); };
+    if (name == "z") { grab(impl->d_z, impl->circuit.num_variables()); return out; }
+    if (name == "trace") { grab(impl->d_trace, impl->circuit.trace_bytes); return out; }
+    if (name == "z_a_evals") { grab(impl->za_ev.p, impl->n * sizeof(F)); return out; }
+    if (name == "z_b_evals") { grab(impl->zb_ev.p, impl->n * sizeof(F)); return out; }
+    for (int i = 0; i < 9; i++) if (name == pn[i]) { grab(impl->poly[i].p, impl->poly_len[i] * sizeof(F)); return out; }
+    for (int i = 0; i < 6; i++) {
+        if (name == in[i]) { grab(impl->ix_co[i].p, impl->k * sizeof(F)); return out; }
+        if (name == std::string(in[i]) + "_evals") { grab(impl->ix_ev[i].p, impl->k * sizeof(F)); return out; }
+    }
+    throw std::invalid_argument("debug_fetch: unknown buffer " + name);
+}
+
+std::unique_ptr<ProvingKey> synthesize_keys(int circuit_kind, size_t message_len, const SrsLiterals &srs) {
+    std::unique_ptr<ProvingKey> pk(new ProvingKey());
+    pk->impl = new ProvingKeyImpl();
+    pk->impl->setup(circuit_kind, message_len, srs);
+    return pk;
+}
+
+// =====================================================================================================================
+// verifier (host only)
+bool verify(const VerifyingKey &vk, const std::vector<Fr> &public_input_in, const Proof &proof) {
+    using X = XYZZ<Fq377>;
+    // pad the public input to |X| - 1 (ark-marlin verify)
+    size_t m = next_pow2(public_input_in.size() + 1);
+    std::vector<Fr> pub(public_input_in);
+    pub.resize(std::max(public_input_in.size(), m - 1), Fr::zero());
+    if (m != vk.num_instance) return false;               // InvalidPublicInputLength / instance does not match the index
+    size_t n = next_pow2(vk.num_constraints), k = next_pow2(vk.num_non_zero);
+    FiatShamirRng fs;
+    {
+        Bytes o;
+        o.put("MARLIN-2019", 11);
+        o.u64(vk.num_variables); o.u64(vk.num_constraints); o.u64(vk.num_non_zero);
+        for (int i = 0; i < 6; i++) { Commitment ic; ic.comm = vk.index_comms[i]; o.commitment_tobytes(ic); }
+        for (auto &v : pub) o.field(v);
+        fs.initialize(o.b);
+    }
+    auto absorb_comms = [&](int from, int cnt) { Bytes o; for (int i = 0; i < cnt; i++) o.commitment_tobytes(proof.comms[from + i]); fs.absorb(o.b); };
+    auto sample_outside_h = [&]() { Fr t; do { t = fs.rng().rand_field<Fr>(); } while (eval_vanishing(n, t).is_zero()); return t; };
+    absorb_comms(0, 4);
+    Fr alpha = sample_outside_h();
+    Fr eta_a = fs.rng().rand_field<Fr>(), eta_b = fs.rng().rand_field<Fr>(), eta_c = fs.rng().rand_field<Fr>();
+    absorb_comms(4, 3);
+    Fr beta = sample_outside_h();
+    absorb_comms(7, 2);
+    Fr gamma = fs.rng().rand_field<Fr>();
+    { Bytes o; for (auto &v : proof.evals) o.field(v); fs.absorb(o.b); }
+    Fr ch;
+    { uint64_t lo = fs.rng().next_u64(), hi = fs.rng().next_u64(); uint32_t raw[8] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32), 0, 0, 0, 0}; ch = Fr::from_raw(raw); }
+    // degree-bound shape checks (commitments g_1, g_2 carry shifted parts, the others must not)
+    for (int i = 0; i < 9; i++) if (proof.comms[i].has_shifted != (i == 5 || i == 7)) return false;
+    const Fr g1_b = proof.evals[0], g2_g = proof.evals[1], t_b = proof.evals[2], zb_b = proof.evals[3];
+    // ---- construct_linear_combinations
+    Fr vh_alpha = eval_vanishing(n, alpha), vh_beta = eval_vanishing(n, beta), vx_beta = eval_vanishing(m, beta), vk_gamma = eval_vanishing(k, gamma);
+    Fr r_alpha_at_beta = (vh_alpha - vh_beta) * (alpha - beta).inverse();
+    // x(beta) = sum_i L_i(beta) x_i over the X domain, x = [1, public inputs...]
+    Fr x_at_beta = Fr::zero();
+    {
+        int lg_m = log2_exact(m);
+        Fr gx = domain_gen(lg_m), m_inv = Fr::from_u64(m).inverse();
+        if (vx_beta.is_zero()) {                                   // beta in X: the Lagrange basis is an indicator
+            Fr e = Fr::one();
+            for (size_t i = 0; i < m; i++) { if (e == beta) x_at_beta = i == 0 ? Fr::one() : pub[i - 1]; e = e * gx; }
+        } else {
+            // L_i(beta) = v_X(beta) * g^i / (m * (beta - g^i))
+            std::vector<Fr> den(m);
+            Fr e = Fr::one();
+            for (size_t i = 0; i < m; i++) { den[i] = beta - e; e = e * gx; }
+            // batch inversion
+            std::vector<Fr> pre(m);
+            Fr accp = Fr::one();
+            for (size_t i = 0; i < m; i++) { pre[i] = accp; accp = accp * den[i]; }
+            Fr inv = accp.inverse();
+            for (size_t i = m; i-- > 0;) { Fr d = den[i]; den[i] = inv * pre[i]; inv = inv * d; }
+            e = Fr::one();
+            Fr common = vx_beta * m_inv;
+            for (size_t i = 0; i < m; i++) {
+                const Fr xi = i == 0 ? Fr::one() : pub[i - 1];
+                if (!xi.is_zero()) x_at_beta = x_at_beta + common * e * den[i] * xi;
+                e = e * gx;
+            }
+        }
+    }
+    Fr bmul = gamma * g2_g + t_b * Fr::from_u64(k).inverse();
+    Fr vv = vh_alpha * vh_beta;
+    // commitments by label
+    const G1A &C_w = proof.comms[0].comm, &C_za = proof.comms[1].comm, &C_zb = proof.comms[2].comm, &C_mask = proof.comms[3].comm;
+    const G1A &C_t = proof.comms[4].comm, &C_g1 = proof.comms[5].comm, &C_h1 = proof.comms[6].comm, &C_g2 = proof.comms[7].comm, &C_h2 = proof.comms[8].comm;
+    const G1A *IX = vk.index_comms;   // row col a_val b_val c_val row_col
+    auto add_scaled = [](X &acc, const G1A &c, const Fr &s) { if (s == Fr::one()) acc.madd(c); else acc.add(mul_fr(X::from_affine(c), s)); };
+    // outer_sumcheck: commitment and expected evaluation (constants moved to the evaluation side, check_combinations)
+    X outer = X::inf();
+    add_scaled(outer, C_mask, Fr::one());
+    add_scaled(outer, C_za, r_alpha_at_beta * (eta_a + eta_c * zb_b));
+    add_scaled(outer, C_w, (t_b * vx_beta).neg());
+    add_scaled(outer, C_h1, vh_beta.neg());
+    Fr outer_eval = Fr::zero() - (r_alpha_at_beta * eta_b * zb_b) - ((t_b * x_at_beta).neg()) - ((beta * g1_b).neg());
+    X inner = X::inf();
+    add_scaled(inner, IX[2], eta_a * vv); add_scaled(inner, IX[3], eta_b * vv); add_scaled(inner, IX[4], eta_c * vv);
+    add_scaled(inner, IX[0], alpha * bmul); add_scaled(inner, IX[1], beta * bmul); add_scaled(inner, IX[5], bmul.neg());
+    add_scaled(inner, C_h2, vk_gamma.neg());
+    Fr inner_eval = Fr::zero() - ((alpha * beta * bmul).neg());
+    // ---- combine_and_normalize per query point (labels in BTreeSet order)
+    Fr chp[5]; chp[0] = Fr::one(); for (int i = 1; i < 5; i++) chp[i] = chp[i - 1] * ch;
+    auto shift_power = [&](size_t bound) -> const G1A & { return bound == vk.degree_bounds[0] ? vk.shift_powers[0] : vk.shift_powers[1]; };
+    // beta: g_1 (ch^0, shifted ch^1), outer_sumcheck (ch^2), t (ch^3), z_b (ch^4)
+    X comb_b = X::inf(); Fr val_b = Fr::zero();
+    add_scaled(comb_b, C_g1, chp[0]); val_b = val_b + g1_b * chp[0];
+    { X adj = X::from_affine(proof.comms[5].shifted); adj.add(mul_fr(X::from_affine(shift_power(n - 2)), g1_b).neg()); comb_b.add(mul_fr(adj, chp[1])); }
+    comb_b.add(mul_fr(outer, chp[2])); val_b = val_b + outer_eval * chp[2];
+    add_scaled(comb_b, C_t, chp[3]); val_b = val_b + t_b * chp[3];
+    add_scaled(comb_b, C_zb, chp[4]); val_b = val_b + zb_b * chp[4];
+    // gamma: g_2 (ch^0, shifted ch^1), inner_sumcheck (ch^2)
+    X comb_g = X::inf(); Fr val_g = Fr::zero();
+    add_scaled(comb_g, C_g2, chp[0]); val_g = val_g + g2_g * chp[0];
+    { X adj = X::from_affine(proof.comms[7].shifted); adj.add(mul_fr(X::from_affine(shift_power(k - 2)), g2_g).neg()); comb_g.add(mul_fr(adj, chp[1])); }
+    comb_g.add(mul_fr(inner, chp[2])); val_g = val_g + inner_eval * chp[2];
+    // ---- KZG10::batch_check with 128-bit randomizers from generate_rand()
+    ChaChaRng vrng(ark_test_rng_seed(), 12);
+    X total_c = X::inf(), total_w = X::inf();
+    Fr g_mult = Fr::zero(), gg_mult = Fr::zero(), randomizer = Fr::one();
+    struct Item { X c; Fr z, v; const G1A *w; bool has_rv; Fr rv; } items[2] = {{comb_b, beta, val_b, &proof.w_beta, true, proof.random_v_beta}, {comb_g, gamma, val_g, &proof.w_gamma, false, Fr::zero()}};
+    for (auto &it : items) {
+        X tmp = mul_fr(X::from_affine(*it.w), it.z);
+        tmp.add(it.c);
+        g_mult = g_mult + randomizer * it.v;
+        if (it.has_rv) gg_mult = gg_mult + randomizer * it.rv;
+        total_c.add(mul_fr(tmp, randomizer));
+        total_w.add(mul_fr(X::from_affine(*it.w), randomizer));
+        uint64_t lo = vrng.next_u64(), hi = vrng.next_u64();
+        uint32_t raw[8] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32), 0, 0, 0, 0};
+        randomizer = Fr::from_raw(raw);
+    }
+    total_c.add(mul_fr(X::from_affine(vk.g), g_mult).neg());
+    total_c.add(mul_fr(X::from_affine(vk.gamma_g), gg_mult).neg());
+    G1A Ps[2] = {total_w.neg().to_affine(), total_c.to_affine()};
+    pairing::G2Affine Qs[2] = {vk.beta_h, vk.h};
+    return pairing::pairing_product_is_one(Ps, Qs, 2);
+}
+
+}  // namespace zk
+

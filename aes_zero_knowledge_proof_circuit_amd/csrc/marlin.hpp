@@ -1,0 +1,78 @@
+// csrc/marlin.hpp -- Marlin (AHP for R1CS + MarlinKZG10) keys, GPU prover and CPU verifier of libzkaes.
+//
+// Mirrors what the reference reaches through simpleworks::marlin (not under /root/reference; restated from the published
+// ark-marlin 0.3.0 / ark-poly-commit 0.3.0 algorithms):
+//   synthesize_keys  -> generate_universal_srs + generate_proving_and_verifying_keys   (/root/reference/src/lib.rs:138-174)
+//   prove            -> generate_proof                                                 (src/lib.rs:60-114)
+//   verify           -> verify_proof                                                   (src/lib.rs:116-136)
+// The prover's polynomial work (witness, SpMV, NTTs, MSMs, divisions, evaluations) runs on the GPU; the Fiat-Shamir
+// transcript, the <=3-term hiding MSMs and the final window sums stay on the host.  The verifier is host-only.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+#include "circuit.hpp"
+#include "ec.cuh"
+#include "pairing.hpp"
+
+namespace zk {
+
+using Fr = Fr377;
+using G1A = Affine<Fq377>;
+
+struct Commitment { G1A comm = G1A::inf(); bool has_shifted = false; G1A shifted = G1A::inf(); };
+
+struct Proof {
+    Commitment comms[9];   // w z_a z_b mask_poly | t g_1 h_1 | g_2 h_2
+    Fr evals[4];           // g_1(beta) g_2(gamma) t(beta) z_b(beta)   (sorted by label)
+    G1A w_beta, w_gamma;   // pc_proof.proof[0].w, [1].w
+    Fr random_v_beta;      // pc_proof.proof[0].random_v = Some(..); [1].random_v = None
+};
+// ark-serialize 0.3 compressed layout of ark_marlin::Proof
+std::vector<uint8_t> serialize_proof(const Proof &p);
+// throws std::runtime_error on malformed input
+Proof deserialize_proof(const uint8_t *bytes, size_t len);
+
+struct SrsLiterals { size_t num_constraints = 866944, num_variables = 513, num_non_zero = 4062064; };   // src/lib.rs:141
+
+struct VerifyingKey {
+    uint64_t num_variables = 0, num_constraints = 0, num_non_zero = 0, num_instance = 0;   // IndexInfo (padded)
+    size_t num_public_inputs = 0;     // unpadded instance count minus One (128 per block)
+    G1A index_comms[6];               // row col a_val b_val c_val row_col
+    G1A g, gamma_g;
+    pairing::G2Affine h, beta_h;
+    size_t degree_bounds[2] = {0, 0}; // |H|-2, |K|-2 sorted ascending
+    G1A shift_powers[2];              // powers_of_g[max_degree - bound]
+    size_t supported_degree = 0, max_degree = 0;
+};
+
+struct ProverTimings { double witness_ms = 0, round1_ms = 0, round2_ms = 0, round3_ms = 0, open_ms = 0, total_ms = 0; };
+
+class ProvingKeyImpl;
+class ProvingKey {
+  public:
+    ~ProvingKey();
+    const VerifyingKey &vk() const;
+    const Circuit &circuit() const;
+    // encrypt(): message length must equal the length the key was synthesized for; zk_seed = 32-byte StdRng seed or nullptr for
+    // ark_std::test_rng()'s (what simpleworks::marlin::generate_rand() returns)
+    Proof prove_aes(const uint8_t *message, size_t len, const uint8_t key[16], const uint8_t *zk_seed);
+    Proof prove_ops(uint32_t x, uint32_t y, const uint8_t *zk_seed);
+    // witness generation only (kernels aes_trace + witness_expand): z = padded instance || witness, one byte per variable
+    std::vector<uint8_t> aes_witness(const uint8_t *message, size_t len, const uint8_t key[16]);
+    const ProverTimings &last_timings() const;
+    // test / parity hooks: copy an intermediate of the last proof to the host. names: "z" (bytes), "z_a_evals","z_b_evals",
+    // polys "w","z_a","z_b","mask_poly","t","g_1","h_1","g_2","h_2" (Montgomery Fr), index "row","col","a_val","b_val","c_val","row_col"
+    std::vector<uint8_t> debug_fetch(const std::string &name) const;
+    ProvingKeyImpl *impl;
+};
+
+// universal_setup(literals) + index; GPU required
+std::unique_ptr<ProvingKey> synthesize_keys(int circuit_kind, size_t message_len, const SrsLiterals &srs);
+
+// public_input: the instance values WITHOUT the leading One (0/1 as field elements), e.g. ciphertext bits LSB-first per byte
+bool verify(const VerifyingKey &vk, const std::vector<Fr> &public_input, const Proof &proof);
+std::vector<Fr> ciphertext_to_public_input(const uint8_t *ct, size_t len);   // src/helpers/mod.rs:84-93 per byte
+
+}  // namespace zk

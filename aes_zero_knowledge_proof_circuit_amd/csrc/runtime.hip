@@ -1,0 +1,30 @@
+// csrc/runtime.hip -- thin HIP runtime plumbing (allocation, copies, streams, events)
+#include "hip_util.hpp"
+
+namespace zk {
+namespace gpu {
+
+int device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+void require_device() {
+    if (device_count() <= 0) throw GpuError("no HIP device available: libzkaes proves on an AMD GPU (gfx950) and has no CPU fallback");
+}
+void *dmalloc(size_t bytes) { void *p = nullptr; HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16)); return p; }
+void dfree(void *p) { if (p) (void)hipFree(p); }
+void h2d(void *dst, const void *src, size_t bytes, stream_t s) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)s)); }
+void d2h(void *dst, const void *src, size_t bytes, stream_t s) { if (bytes) { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)s)); HIP_CHECK(hipStreamSynchronize((hipStream_t)s)); } }
+void d2d(void *dst, const void *src, size_t bytes, stream_t s) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s)); }
+void dzero(void *dst, size_t bytes, stream_t s) { if (bytes) HIP_CHECK(hipMemsetAsync(dst, 0, bytes, (hipStream_t)s)); }
+void sync(stream_t s) { HIP_CHECK(hipStreamSynchronize((hipStream_t)s)); }
+stream_t stream_create() { hipStream_t s; HIP_CHECK(hipStreamCreate(&s)); return (stream_t)s; }
+void stream_destroy(stream_t s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
+void *event_create() { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return (void *)e; }
+void event_record(void *ev, stream_t s) { HIP_CHECK(hipEventRecord((hipEvent_t)ev, (hipStream_t)s)); }
+float event_elapsed_ms(void *a, void *b) { float ms = 0; HIP_CHECK(hipEventSynchronize((hipEvent_t)b)); HIP_CHECK(hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b)); return ms; }
+void event_destroy(void *ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+
+}  // namespace gpu
+}  // namespace zk

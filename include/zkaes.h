@@ -1,0 +1,115 @@
+/* include/zkaes.h -- C ABI of libzkaes, the MI355X-native drop-in for the proving hot path of
+ * lambdaclass/AES_zero_knowledge_proof_circuit (crate `zk-aes`).
+ *
+ * The reference has no FFI / plugin interface; its seam is three Rust functions in src/lib.rs (and the crate
+ * forbids `unsafe`, src/lib.rs:2, so the binding lives in a sibling -sys crate: see INTEGRATION.md).  Each entry
+ * point below names the reference item it replaces.  Conventions:
+ *   - return value 0 = Ok, non-zero = Err; the message of the last error on the calling thread is
+ *     zkaes_last_error() (mirrors anyhow::Result, src/lib.rs:45);
+ *   - keys are opaque handles that own device-resident data (SRS powers, index polynomials, circuit tables,
+ *     workspace); a handle is bound to the GPU that was current when it was created;
+ *   - proofs cross the boundary as bytes in the ark-serialize 0.3 compressed layout of ark_marlin::Proof
+ *     (what simpleworks' (de)serialize_proof reads/writes, re-exported at src/lib.rs:52);
+ *   - byte buffers returned through `uint8_t**` are owned by the library: release with zkaes_bytes_free.
+ *   - the library needs a HIP device (gfx950) for key synthesis and proving and FAILS (non-zero + message) when
+ *     none is present -- there is no CPU fallback; zkaes_verify_* runs on the host, as in the reference.
+ */
+#ifndef ZKAES_H
+#define ZKAES_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zkaes_pk zkaes_pk;   /* simpleworks::marlin::ProvingKey   (src/lib.rs:55) */
+typedef struct zkaes_vk zkaes_vk;   /* simpleworks::marlin::VerifyingKey (src/lib.rs:55) */
+
+/* thread-local message of the last failing call ("" if none) */
+const char *zkaes_last_error(void);
+void zkaes_bytes_free(uint8_t *p);
+void zkaes_pk_free(zkaes_pk *pk);
+void zkaes_vk_free(zkaes_vk *vk);
+/* number of visible HIP devices (0 on a host without a GPU) */
+int zkaes_device_count(void);
+/* select the HIP device subsequent key handles are created on (one process per GPU) */
+int zkaes_set_device(int ordinal);
+
+/* ---- the reference's public API ------------------------------------------------------------------------------- */
+/* replaces `pub fn synthesize_keys(plaintext_length: usize) -> Result<(ProvingKey, VerifyingKey)>` (src/lib.rs:138-174):
+ * universal SRS for the literals (866_944, 513, 4_062_064) of src/lib.rs:141 + index of the AES circuit for a message of
+ * `plaintext_length` bytes (multiple of 16). */
+int zkaes_synthesize_keys(size_t plaintext_length, zkaes_pk **pk, zkaes_vk **vk);
+/* replaces `pub fn encrypt(message: &[u8], secret_key: &[u8; 16], proving_key: ProvingKey) -> Result<MarlinProof>`
+ * (src/lib.rs:60-114).  The proving key is borrowed, not consumed (callers of the reference clone it per call,
+ * benches/benchmark_encrypt.rs:46).  Prover randomness = generate_rand() (fixed ark_std::test_rng seed), as src/lib.rs:65. */
+int zkaes_encrypt(const uint8_t *message, size_t message_len, const uint8_t secret_key[16], const zkaes_pk *pk, uint8_t **proof, size_t *proof_len);
+/* replaces `pub fn verify_encryption(verifying_key: VerifyingKey, proof: &MarlinProof, ciphertext: &[u8]) -> Result<bool>`
+ * (src/lib.rs:116-136): ciphertext bytes -> 8 LSB-first field elements each (src/helpers/mod.rs:84-93) -> Marlin verify.
+ * A wrong ciphertext is Ok(false): returns 0 with *accepted = 0 (tests/integration_tests.rs:336). */
+int zkaes_verify_encryption(const zkaes_vk *vk, const uint8_t *proof, size_t proof_len, const uint8_t *ciphertext, size_t ciphertext_len, int *accepted);
+/* replaces the re-export `deserialize_proof` (src/lib.rs:52) as a validity check + canonical re-serialization */
+int zkaes_proof_roundtrip(const uint8_t *proof, size_t proof_len, uint8_t **out, size_t *out_len);
+
+/* ---- extensions ------------------------------------------------------------------------------------------------ */
+#define ZKAES_CIRCUIT_AES 0      /* src/lib.rs:176-293 */
+#define ZKAES_CIRCUIT_OPS_XOR 1  /* src/ops.rs:8-18 (as a BLS12-377 Marlin circuit) */
+#define ZKAES_CIRCUIT_OPS_ADD 2  /* src/ops.rs:20-29 */
+/* as zkaes_synthesize_keys with an explicit circuit kind and universal-SRS literals (generate_universal_srs arguments) */
+int zkaes_synthesize_keys_ex(int circuit_kind, size_t plaintext_length, size_t srs_num_constraints, size_t srs_num_variables, size_t srs_num_non_zero, zkaes_pk **pk,
+                             zkaes_vk **vk);
+/* as zkaes_encrypt with an explicit 32-byte StdRng seed for the prover's zero-knowledge randomness (NULL = test_rng seed) */
+int zkaes_encrypt_seeded(const uint8_t *message, size_t message_len, const uint8_t secret_key[16], const zkaes_pk *pk, const uint8_t *zk_seed32, uint8_t **proof,
+                         size_t *proof_len);
+/* chunked proving of a long ECB message: ceil(message_len / chunk_len) independent proofs with one key for chunk_len bytes
+ * (the last chunk must be full).  proofs = concatenation, proof_lens[i] = length of proof i (caller array of n_chunks). */
+int zkaes_encrypt_chunked(const uint8_t *message, size_t message_len, const uint8_t secret_key[16], const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len,
+                          size_t *proof_lens, size_t n_chunks);
+/* src/ops.rs toy gates proven with Marlin (public input: none) */
+int zkaes_prove_ops(const zkaes_pk *pk, uint32_t x, uint32_t y, const uint8_t *zk_seed32, uint8_t **proof, size_t *proof_len);
+/* generic verify: public_input_bits = instance assignment without the leading One, one byte (0/1) per variable */
+int zkaes_verify(const zkaes_vk *vk, const uint8_t *proof, size_t proof_len, const uint8_t *public_input_bits, size_t n_bits, int *accepted);
+/* verifying-key transport (library-private layout, versioned; NOT the ark-serialize layout yet -- SURVEY.md §8f item 1) */
+int zkaes_vk_serialize(const zkaes_vk *vk, uint8_t **out, size_t *out_len);
+int zkaes_vk_deserialize(const uint8_t *bytes, size_t len, zkaes_vk **vk);
+
+/* host-only: assemble a verifying key from an index made elsewhere with the SAME (public, test_rng-derived) KZG trapdoor:
+ * info = {num_variables, num_constraints, num_non_zero, num_instance (padded), num_public_inputs, max_degree, supported_degree};
+ * index_comms = 6 x 96 B affine Montgomery (row col a_val b_val c_val row_col); beta, gamma = 32 B Montgomery Fr.
+ * g = G1 generator, gamma_g = gamma*g, h = G2 generator, beta_h = beta*h, shift powers = beta^(max_degree - bound) * g. */
+int zkaes_vk_from_trapdoor(const uint64_t info[7], const uint8_t *index_comms, const uint8_t *beta, const uint8_t *gamma, zkaes_vk **vk);
+
+/* ---- introspection used by tests / bench ----------------------------------------------------------------------- */
+/* counters the reference logs through debug_constraint_system_status (src/helpers/mod.rs:73-81) and the Marlin index sizes:
+ * out[0..11] = raw constraints, raw instance, raw witness, nnz A, nnz B, nnz C, padded constraints, padded instance,
+ *              padded witness, joint nnz, |H|, |K| */
+int zkaes_pk_info(const zkaes_pk *pk, uint64_t out[12]);
+/* host-only circuit compilation (no GPU): same counters (joint nnz, |H|, |K| = 0) */
+int zkaes_circuit_info(int circuit_kind, size_t plaintext_length, uint64_t out[12]);
+/* host-only: CSR of matrix which (0 A, 1 B, 2 C) after padding.  Call with NULL arrays to get sizes. */
+int zkaes_circuit_matrix(int circuit_kind, size_t plaintext_length, int which, uint64_t *n_rows, uint64_t *nnz, uint32_t *rowptr, uint32_t *col, int64_t *coeff);
+/* copy an intermediate buffer of the LAST proof made with this key to the host ("z", "trace", "z_a_evals", "z_b_evals", "w", "z_a", "z_b",
+ * "mask_poly", "t", "g_1", "h_1", "g_2", "h_2", index polys "row", "col", "a_val", "b_val", "c_val", "row_col" (+"_evals")).
+ * Field elements are raw little-endian Montgomery limbs (32 B).  Returns the byte count in *len. */
+int zkaes_pk_debug_fetch(const zkaes_pk *pk, const char *name, uint8_t **out, size_t *len);
+/* per-phase wall times of the last proof: witness, round1, round2, round3, open, total (ms) */
+int zkaes_pk_timings(const zkaes_pk *pk, double out[6]);
+/* accumulated MSM statistics since the last reset: bucket-accumulation kernel ms (HIP events), total MSM wall ms, points, launches */
+int zkaes_msm_stats(double out[4], int reset);
+
+/* ---- kernel-level entry points (parity tests + roofline measurement) -------------------------------------------- */
+/* field_id: 377 or 381 (BLS12-377 / BLS12-381 scalar field).  data: n x 32 B Montgomery limbs, host memory, transformed in place.
+ * n must be a power of two.  inverse != 0 -> IFFT (scaled by 1/n).  Natural order in and out. */
+int zkaes_ntt(int field_id, uint8_t *data, size_t n, int inverse);
+/* curve_id 377 / 381.  bases: n x 96 B affine (x||y Montgomery), scalars: n x 32 B Montgomery Fr; out_xy 96 B, *out_inf = 1 if infinity */
+int zkaes_msm(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, uint8_t *out_xy, int *out_inf);
+/* device-resident variant for benchmarking: repeats the MSM `reps` times over device copies, returns ms per MSM of the whole pipeline and of
+ * the bucket-accumulation kernel alone */
+int zkaes_msm_bench(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, int reps, double *ms_total, double *ms_accumulate);
+/* AES witness only: fills z (padded instance + witness, one byte per variable) for a message under the key's circuit */
+int zkaes_aes_witness(const zkaes_pk *pk, const uint8_t *message, size_t message_len, const uint8_t secret_key[16], uint8_t *z, size_t z_cap, size_t *z_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
