@@ -1,0 +1,42 @@
+"""CPU tests of the C-ABI boundary: every symbol include/zkaes.h declares is exported, and the product refuses to work without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "zkaes.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(zkaes_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(api):
+    L = api.lib()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), n
+
+
+def test_no_cpu_fallback(api):
+    if api.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.ZkAesError, match="no HIP device"):
+        api.synthesize_keys(16)
+    with pytest.raises(api.ZkAesError, match="no HIP device"):
+        api.ntt(377, bytes(64))
+    with pytest.raises(api.ZkAesError, match="no HIP device"):
+        api.msm(377, bytes(96), bytes(32))
+
+
+def test_product_does_not_reference_the_oracle():
+    pkg = os.path.join(ROOT, "aes_zero_knowledge_proof_circuit_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".cuh", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle/" not in text and "import oracle" not in text and "from oracle" not in text and "zko" not in text, os.path.join(dirpath, f)

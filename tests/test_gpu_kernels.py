@@ -1,0 +1,104 @@
+"""GPU parity tests of the individual HIP kernels, through the C ABI, against the CPU oracle (bit-exact)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import mt_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_fr_mont(n, p, seed):
+    """n pseudo-random Montgomery-form field elements as bytes (any value < p is a valid Montgomery representative)"""
+    rs = np.random.RandomState(seed)
+    out = bytearray()
+    for _ in range(n):
+        v = int.from_bytes(rs.bytes(32), "little") % p
+        out += v.to_bytes(32, "little")
+    return bytes(out)
+
+
+@pytest.mark.parametrize("cid", [377, 381])
+@pytest.mark.parametrize("lg", [0, 1, 2, 5, 9, 10, 11, 13, 16, 18])
+def test_ntt_matches_oracle(zko, api, cid, lg):
+    n = 1 << lg
+    data = rand_fr_mont(n, zko.FR[cid], 1000 + lg)
+    for kind, inverse in ((0, False), (1, True)):
+        ref = C.create_string_buffer(data, len(data))
+        assert zko.lib().zko_api_ntt(cid, ref, C.c_size_t(n), kind) == 0
+        assert api.ntt(cid, data, inverse=inverse) == ref.raw
+
+
+def test_ntt_full_size_roundtrip_and_linearity(zko, api):
+    # BASELINE sizes: |K| = 2^20 and the 2^22 product domain; size-independent properties instead of an oracle run
+    p = zko.R377
+    for lg in (20, 22):
+        n = 1 << lg
+        a = rand_fr_mont(n, p, lg)
+        fa = api.ntt(377, a)
+        assert api.ntt(377, fa, inverse=True) == a
+        # a delta at position 1 transforms to the domain elements g^i: check a few against the oracle's generator
+        delta = bytearray(32 * n)
+        delta[32:64] = zko.fr_pack([1])
+        fd = api.ntt(377, bytes(delta))
+        g = C.create_string_buffer(32)
+        zko.lib().zko_api_domain_gen(377, C.c_size_t(n), g)
+        gv = zko.fr_unpack(g.raw)[0]
+        for i in (0, 1, 2, 12345, n - 1):
+            assert zko.fr_unpack(fd[32 * i:32 * i + 32])[0] == pow(gv, i, p)
+
+
+def oracle_points(zko, cid, n, seed):
+    rs = np.random.RandomState(seed)
+    sc = b"".join((int.from_bytes(rs.bytes(32), "little") % zko.FR[cid]).to_bytes(32, "little") for _ in range(n))
+    out = C.create_string_buffer(96 * n)
+    zko.lib().zko_api_fixed_base(cid, sc, C.c_size_t(n), out)
+    return out.raw
+
+
+@pytest.mark.parametrize("cid", [377, 381])
+@pytest.mark.parametrize("n", [1, 2, 33, 1000, 1 << 12, (1 << 14) + 7])
+def test_msm_matches_oracle(zko, api, cid, n):
+    bases = oracle_points(zko, cid, n, 7 * n)
+    scalars = bytearray(rand_fr_mont(n, zko.FR[cid], 13 * n))
+    # edge scalars: zero, one (Montgomery one), p - 1
+    if n >= 33:
+        scalars[0:32] = bytes(32)
+        scalars[32:64] = zko.fr_pack([1], cid)
+        scalars[64:96] = zko.fr_pack([zko.FR[cid] - 1], cid)
+    ref = C.create_string_buffer(96)
+    ref_inf = zko.lib().zko_api_msm(cid, bases, bytes(scalars), C.c_size_t(n), ref)
+    got, inf = api.msm(cid, bases, bytes(scalars))
+    assert inf == bool(ref_inf)
+    if not inf:
+        assert got == ref.raw
+
+
+def test_msm_degenerate_inputs(zko, api):
+    n = 64
+    bases = oracle_points(zko, 377, 1, 5) * n                    # all bases equal: buckets hit the doubling branch
+    scalars = zko.fr_pack([3] * n)
+    ref = C.create_string_buffer(96)
+    zko.lib().zko_api_msm(377, bases, scalars, C.c_size_t(n), ref)
+    got, inf = api.msm(377, bases, scalars)
+    assert not inf and got == ref.raw
+    got, inf = api.msm(377, bases, bytes(32 * n))                # all-zero scalars -> infinity
+    assert inf
+    # P and -P cancel
+    pts = zko.pt_unpack(bases[:96])
+    neg = zko.pt_pack([(pts[0][0], (-pts[0][1]) % zko.Q377)])
+    got, inf = api.msm(377, bases[:96] + neg, zko.fr_pack([5, 5]))
+    assert inf
+
+
+def test_msm_2_16_matches_oracle(zko, api):
+    n = 1 << 16
+    bases = oracle_points(zko, 377, n, 99)
+    scalars = rand_fr_mont(n, zko.R377, 98)
+    ref = C.create_string_buffer(96)
+    zko.lib().zko_api_msm(377, bases, scalars, C.c_size_t(n), ref)
+    got, inf = api.msm(377, bases, scalars)
+    assert not inf and got == ref.raw
