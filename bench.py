@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py -- AES-ECB blocks proven per second (Marlin) on N x MI355X.
+
+A "step" proves one synthetic ECB message of --blocks 16-byte blocks on every rank: ceil(blocks / chunk) independent
+chunk-proofs (chunk = blocks per proof) with one proving key, witness generation -> serialized proof, SRS / index / circuit
+tables resident in HBM beforehand (the region criterion times in the reference: benches/benchmark_encrypt.rs:45-47).
+Every timed proof is verified afterwards on the host (accept rate must be 100 %) together with the reference's negative
+case (a wrong ciphertext must be rejected).  Multi-GPU = independent messages per rank (weak scaling, no data-path collective).
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def synthetic(nbytes, seed):
+    return np.random.RandomState(seed & 0xFFFFFFFF).randint(0, 256, size=nbytes, dtype=np.uint8).tobytes()
+
+
+def cpu_baseline(sample_blocks=1):
+    """Time the CPU oracle (oracle/, a C restatement of the same algorithm; NOT arkworks) on the host cores: one chunk-proof."""
+    from oracle import zko
+    nthreads = zko.lib().zko_api_num_threads()
+    cs, _ = zko.synth_aes(bytes(16 * sample_blocks), bytes(16))
+    ix = zko.Index(cs)                       # setup (SRS + index), outside the timed region like the GPU side
+    msg, key = synthetic(16 * sample_blocks, 0x5EED + 1), synthetic(16, 0x5EED)
+    t0 = time.perf_counter()
+    cs, ct = zko.synth_aes(msg, key)
+    proof = ix.prove(cs)
+    dt = time.perf_counter() - t0
+    return dict(value=sample_blocks / dt, unit="blocks/s", cores=int(nthreads), kind="port",
+                sample="1 chunk-proof of %d block(s), |H|=%d |K|=%d, SRS+index prebuilt; %.1f s" % (sample_blocks, ix.info()["h"], ix.info()["k"], dt)), proof.to_bytes(), ct
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--blocks", type=int, default=64, help="ECB blocks per message (per rank)")
+    ap.add_argument("--chunk", type=int, default=4, help="blocks per chunk-proof")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from aes_zero_knowledge_proof_circuit_amd import api
+    if api.device_count() <= 0:
+        raise SystemExit("bench.py needs a HIP device: libzkaes has no CPU fallback")
+    api.set_device(local_rank)
+
+    chunk_bytes = 16 * args.chunk
+    n_chunks = (args.blocks + args.chunk - 1) // args.chunk
+    blocks = n_chunks * args.chunk                      # the last chunk must be full: round the message up
+    key = synthetic(16, 0x5EED)
+    msg = synthetic(16 * blocks, 0x5EED + 1 + rank)
+    t_setup = time.perf_counter()
+    pk, vk = api.synthesize_keys(chunk_bytes)
+    setup_s = time.perf_counter() - t_setup
+    info = pk.info()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        return pk.encrypt_chunked(msg, key)
+
+    for _ in range(args.warmup):
+        step()
+    api.msm_stats(reset=True)
+    phase = dict(witness_ms=0.0, round1_ms=0.0, round2_ms=0.0, round3_ms=0.0, open_ms=0.0, total_ms=0.0)
+    barrier()
+    t0 = time.perf_counter()
+    all_proofs = []
+    for _ in range(args.steps):
+        all_proofs.append(step())
+        for k, v in pk.timings().items():
+            phase[k] += v                                 # timings of the last chunk-proof of the step (sampled, not summed over chunks)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stats = api.msm_stats()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- acceptance: every timed proof must verify (host), the wrong-ciphertext negative must be rejected
+    from oracle import zko   # checker only: byte-level AES for the expected ciphertext
+    ct = zko.aes_encrypt(msg, key)
+    accepted = total = 0
+    for proofs in all_proofs:
+        for i, p in enumerate(proofs):
+            total += 1
+            accepted += bool(api.verify_encryption(vk, p, ct[i * chunk_bytes:(i + 1) * chunk_bytes]))
+    bad = bytearray(ct[:chunk_bytes]); bad[1] ^= 1; bad[-1] ^= 1
+    rejected_wrong = not api.verify_encryption(vk, all_proofs[0][0], bytes(bad))
+    ok = torch.tensor([accepted, total, int(rejected_wrong)], dtype=torch.int64)
+    if world > 1:
+        ok = ok.cuda()
+        dist.all_reduce(ok, op=dist.ReduceOp.SUM)
+        ok = ok.cpu()
+
+    if rank == 0:
+        value = world * blocks * args.steps / elapsed
+        # roofline of the dominant kernel (MSM bucket accumulation, kernels_msm.hip k_accumulate): algorithmic bytes per launch =
+        # 128 B per point (96 B affine base + 32 B scalar) x points in the launch; duration from HIP events on the
+        # kernel's own stream, accumulated over every launch of the timed region.
+        acc_ms, pts, launches = stats["accumulate_ms"], stats["points"], stats["launches"]
+        achieved = (128.0 * pts / 1e9) / (acc_ms / 1e3) if acc_ms > 0 else 0.0
+        out = {
+            "metric": "AES-ECB blocks proven/sec (Marlin), proof verifies", "value": round(value, 4), "unit": "blocks/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (253-bit Fr / 377-bit Fq modular integers)",
+            "data": "synthetic (numpy MT19937 bytes, seed 0x5EED; key fixed, message per rank)",
+            "config": {"workload": "%d-block (%d B) ECB message per GPU as %d chunk-proofs of %d block(s); BLS12-377 Marlin, |H|=%d |K|=%d, universal SRS literals (866944,513,4062064)"
+                                   % (blocks, 16 * blocks, n_chunks, args.chunk, info["h"], info["k"]),
+                       "blocks_per_gpu": blocks, "chunk_blocks": args.chunk, "proofs_per_step": n_chunks * world, "parallelism": "independent chunk-proofs per rank, no collective"},
+            "proofs_verified": "%d/%d" % (int(ok[0]), int(ok[1])), "wrong_ciphertext_rejected": bool(int(ok[2]) == world),
+            "setup_s": round(setup_s, 2),
+            "phase_ms_last_proof_avg": {k: round(v / args.steps, 2) for k, v in phase.items()},
+            "roofline": {"bound": "hbm", "kernel": "k_accumulate (Pippenger bucket accumulation)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "launches": launches, "avg_launch_ms": round(acc_ms / max(launches, 1), 4), "algorithmic_bytes_per_launch": round(128.0 * pts / max(launches, 1)),
+                         "note": "integer-ALU bound (12x12 v_mad_u64_u32 Montgomery products); HBM fraction of O(1%) is the expected regime (BASELINE.md §3)"},
+        }
+        if int(ok[0]) != int(ok[1]) or int(ok[2]) != world:
+            out["error"] = "verification failure"
+        if world == 1 and not args.no_cpu_baseline:
+            cb, ref_proof, ref_ct = cpu_baseline(1)
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_baseline"] = round(value / cb["value"], 2)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
