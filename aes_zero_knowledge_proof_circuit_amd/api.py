@@ -130,7 +130,7 @@ class ProvingKey:
         return _take(out, n)
 
     def encrypt_chunked(self, message, secret_key):
-        chunk = self.info()["raw_instance"] // 8 // 1 and (self.info()["raw_instance"] - 1) // 8
+        chunk = (self.info()["raw_instance"] - 1) // 8          # 8 public-input bits per ciphertext byte
         n_chunks = len(message) // chunk
         lens = (C.c_size_t * max(n_chunks, 1))()
         out, n = C.c_void_p(), C.c_size_t()

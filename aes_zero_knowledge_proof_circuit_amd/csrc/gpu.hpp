@@ -84,10 +84,12 @@ void spmv_bits(F *out, size_t rows_out, const uint32_t *rowptr, const uint32_t *
 // w evaluations on H (ark-marlin prover_first_round): out[k] = 0 if k % ratio == 0 else w_ext[k - k/ratio - 1] - x_evals[k]
 void w_evals(F *out, const uint8_t *z, const F *x_evals, uint32_t n, uint32_t m, uint32_t num_witness, stream_t s);
 void bits_to_field(F *out, const uint8_t *z, size_t n, stream_t s);
-// t evaluations on H: out[h] = sum over entries (row r, weight w = eta_M * coeff) in column bucket h of  w * r_alpha[r]
-// CSC built by the indexer: colptr[n+1], row[], mat_id[] (0/1/2), coeff[]
-void t_evals(F *out, uint32_t n, const uint32_t *colptr, const uint32_t *row, const uint8_t *mat, const int64_t *coeff, const F *r_alpha, const F &eta_a, const F &eta_b,
-             const F &eta_c, stream_t s);
+// t evaluations on H: out[h] = sum over entries (row r, weight w = eta_M * coeff) in column bucket h of  w * r_alpha[r].
+// The indexer buckets A, B, C by (re-indexed) column and cuts every bucket into segments of <= T_SEG entries:
+// seg_start/seg_end[nseg] (entry ranges), col_seg_ptr[n+1] (segments of column h), row[], mat[] (0/1/2), coeff[]; partial = nseg scratch elements
+constexpr uint32_t T_SEG = 32;
+void t_evals(F *out, uint32_t n, F *partial, uint32_t nseg, const uint32_t *col_seg_ptr, const uint32_t *seg_start, const uint32_t *seg_end, const uint32_t *row, const uint8_t *mat,
+             const int64_t *coeff, const F *r_alpha, const F &eta_a, const F &eta_b, const F &eta_c, stream_t s);
 // e_ra[i] = e_ra[i] * (eta_a za + eta_b zb + eta_c za zb)[i] - t[i] * z[i]
 void q1_pointwise(F *e_ra, const F *e_za, const F *e_zb, const F *e_t, const F *e_z, const F &eta_a, const F &eta_b, const F &eta_c, size_t n, stream_t s);
 void round3_den(F *den, const F *row, const F *col, const F &alpha, const F &beta, size_t k, stream_t s);     // (beta - row)(alpha - col)

@@ -140,12 +140,14 @@ void w_evals(F *out, const uint8_t *z, const F *x_evals, uint32_t n, uint32_t m,
 __global__ void k_bits_to_field(F *__restrict__ out, const uint8_t *__restrict__ z, size_t n) { size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = z[i] ? F::one() : F::zero(); }
 void bits_to_field(F *out, const uint8_t *z, size_t n, stream_t s) { if (!n) return; hipLaunchKernelGGL(k_bits_to_field, GRID(n), 0, (hipStream_t)s, out, z, n); HIP_LAUNCH_CHECK(); }
 
-__global__ void k_t_evals(F *__restrict__ out, uint32_t n, const uint32_t *__restrict__ colptr, const uint32_t *__restrict__ row, const uint8_t *__restrict__ mat,
-                          const int64_t *__restrict__ coeff, const F *__restrict__ r_alpha, F eta_a, F eta_b, F eta_c) {
-    uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= n) return;
+// Two passes so that heavy columns (the constant One, key bits) do not serialize on one lane: pass 1 = one lane per SEGMENT of at most
+// T_SEG entries of one column, pass 2 = one lane per column adding its segments' partial sums.
+__global__ void k_t_partials(F *__restrict__ partial, uint32_t nseg, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end, const uint32_t *__restrict__ row,
+                             const uint8_t *__restrict__ mat, const int64_t *__restrict__ coeff, const F *__restrict__ r_alpha, F eta_a, F eta_b, F eta_c) {
+    uint32_t sgi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sgi >= nseg) return;
     F acc = F::zero();
-    for (uint32_t i = colptr[h]; i < colptr[h + 1]; i++) {
+    for (uint32_t i = seg_start[sgi]; i < seg_end[sgi]; i++) {
         F eta = mat[i] == 0 ? eta_a : (mat[i] == 1 ? eta_b : eta_c);
         long long c = coeff[i];
         F term = eta * r_alpha[row[i]];
@@ -153,11 +155,19 @@ __global__ void k_t_evals(F *__restrict__ out, uint32_t n, const uint32_t *__res
         else if (c == -1) acc = acc - term;
         else acc = acc + term * small_to_field(c);
     }
+    partial[sgi] = acc;
+}
+__global__ void k_t_columns(F *__restrict__ out, uint32_t n, const uint32_t *__restrict__ col_seg_ptr, const F *__restrict__ partial) {
+    uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n) return;
+    F acc = F::zero();
+    for (uint32_t i = col_seg_ptr[h]; i < col_seg_ptr[h + 1]; i++) acc = acc + partial[i];
     out[h] = acc;
 }
-void t_evals(F *out, uint32_t n, const uint32_t *colptr, const uint32_t *row, const uint8_t *mat, const int64_t *coeff, const F *r_alpha, const F &eta_a, const F &eta_b,
-             const F &eta_c, stream_t s) {
-    hipLaunchKernelGGL(k_t_evals, GRID(n), 0, (hipStream_t)s, out, n, colptr, row, mat, coeff, r_alpha, eta_a, eta_b, eta_c); HIP_LAUNCH_CHECK();
+void t_evals(F *out, uint32_t n, F *partial, uint32_t nseg, const uint32_t *col_seg_ptr, const uint32_t *seg_start, const uint32_t *seg_end, const uint32_t *row, const uint8_t *mat,
+             const int64_t *coeff, const F *r_alpha, const F &eta_a, const F &eta_b, const F &eta_c, stream_t s) {
+    if (nseg) { hipLaunchKernelGGL(k_t_partials, GRID(nseg), 0, (hipStream_t)s, partial, nseg, seg_start, seg_end, row, mat, coeff, r_alpha, eta_a, eta_b, eta_c); HIP_LAUNCH_CHECK(); }
+    hipLaunchKernelGGL(k_t_columns, GRID(n), 0, (hipStream_t)s, out, n, col_seg_ptr, partial); HIP_LAUNCH_CHECK();
 }
 
 }  // namespace gpu

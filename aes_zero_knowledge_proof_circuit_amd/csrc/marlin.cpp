@@ -223,7 +223,9 @@ class ProvingKeyImpl {
     uint32_t *d_desc = nullptr, *d_sbox_in = nullptr, *d_sbox_tmpl = nullptr;
     uint32_t *d_a_rowptr = nullptr, *d_a_col = nullptr, *d_b_rowptr = nullptr, *d_b_col = nullptr;
     int64_t *d_a_coeff = nullptr, *d_b_coeff = nullptr;
-    uint32_t *d_t_colptr = nullptr, *d_t_row = nullptr; uint8_t *d_t_mat = nullptr; int64_t *d_t_coeff = nullptr;
+    uint32_t *d_t_colptr = nullptr, *d_t_seg_start = nullptr, *d_t_seg_end = nullptr, *d_t_row = nullptr; uint8_t *d_t_mat = nullptr; int64_t *d_t_coeff = nullptr;
+    uint32_t t_nseg = 0;
+    DevBuf t_partial;
     // device: index polynomials (evaluations on K and coefficients); order row col a_val b_val c_val row_col
     DevBuf ix_ev[6], ix_co[6];
     // device: per-proof workspace
@@ -237,7 +239,7 @@ class ProvingKeyImpl {
     ~ProvingKeyImpl() {
         gpu::dfree(d_powers); gpu::dfree(d_shifted); gpu::dfree(d_desc); gpu::dfree(d_sbox_in); gpu::dfree(d_sbox_tmpl);
         gpu::dfree(d_a_rowptr); gpu::dfree(d_a_col); gpu::dfree(d_b_rowptr); gpu::dfree(d_b_col); gpu::dfree(d_a_coeff); gpu::dfree(d_b_coeff);
-        gpu::dfree(d_t_colptr); gpu::dfree(d_t_row); gpu::dfree(d_t_mat); gpu::dfree(d_t_coeff);
+        gpu::dfree(d_t_colptr); gpu::dfree(d_t_seg_start); gpu::dfree(d_t_seg_end); t_partial.release(); gpu::dfree(d_t_row); gpu::dfree(d_t_mat); gpu::dfree(d_t_coeff);
         for (auto &b : ix_ev) b.release();
         for (auto &b : ix_co) b.release();
         gpu::dfree(d_trace); gpu::dfree(d_z); gpu::dfree(d_msg); gpu::dfree(d_key);
@@ -372,7 +374,16 @@ void ProvingKeyImpl::setup(int kind, size_t message_len, const SrsLiterals &srs)
                     uint32_t pos = fill[reindex_by_subdomain(n, m, M[q]->col[i])]++;
                     trow[pos] = (uint32_t)r; tmat[pos] = (uint8_t)q; tcoef[pos] = M[q]->coeff[i];
                 }
-        d_t_colptr = upload(colptr, stream); d_t_row = upload(trow, stream); d_t_mat = upload(tmat, stream); d_t_coeff = upload(tcoef, stream);
+        std::vector<uint32_t> col_seg_ptr(n + 1, 0), seg_start, seg_end;
+        for (size_t h = 0; h < n; h++) {
+            for (uint32_t st = colptr[h]; st < colptr[h + 1]; st += gpu::T_SEG) { seg_start.push_back(st); seg_end.push_back(std::min(st + gpu::T_SEG, colptr[h + 1])); }
+            col_seg_ptr[h + 1] = (uint32_t)seg_start.size();
+        }
+        t_nseg = (uint32_t)seg_start.size();
+        if (seg_start.empty()) { seg_start.push_back(0); seg_end.push_back(0); }
+        d_t_colptr = upload(col_seg_ptr, stream); d_t_seg_start = upload(seg_start, stream); d_t_seg_end = upload(seg_end, stream);
+        d_t_row = upload(trow, stream); d_t_mat = upload(tmat, stream); d_t_coeff = upload(tcoef, stream);
+        t_partial.alloc(t_nseg + 1);
     }
     // ---- index polynomials on the GPU
     for (int i = 0; i < 6; i++) { ix_ev[i].alloc(k); ix_co[i].alloc(k); }
@@ -468,7 +479,7 @@ Proof ProvingKeyImpl::prove(const uint8_t *host_trace, const uint8_t *msg, size_
     const F *elems = gpu::domain_elements<F>(lg_n);
     gpu::sub_from_scalar(ra_ev.p, elems, alpha, n, s);
     gpu::batch_inverse(ra_ev.p, n, &vh_alpha, s);                            // r(alpha, h) = v_H(alpha) / (alpha - h)
-    gpu::t_evals(tmp_n.p, (uint32_t)n, d_t_colptr, d_t_row, d_t_mat, d_t_coeff, ra_ev.p, eta_a, eta_b, eta_c, s);
+    gpu::t_evals(tmp_n.p, (uint32_t)n, t_partial.p, t_nseg, d_t_colptr, d_t_seg_start, d_t_seg_end, d_t_row, d_t_mat, d_t_coeff, ra_ev.p, eta_a, eta_b, eta_c, s);
     gpu::ntt<F>(poly[4].p, tmp_n.p, n, lg_n, true, s); poly_len[4] = n;
     gpu::ntt<F>(ra_poly.p, ra_ev.p, n, lg_n, true, s);
     gpu::z_poly_from_w(zpoly.p, poly[0].p, poly_len[0], x_poly.p, (uint32_t)m, n, s);

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Summarize a rocprofv3 --kernel-trace --stats rocpd database (…_results.db) into a small markdown table.
+
+    python tools/rocprof_summary.py gpurun_out/prof1/r01_results.db profiles/r01_kernel_stats.md "command line that was profiled"
+"""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"<.*", "", name.replace("void ", ""))
+    if "rocprim" in name:
+        m = re.search(r"radix_sort_\w+", name)
+        return "rocprim::" + (m.group(0) if m else "kernel")
+    return name.split("(")[0]
+
+
+def main():
+    db, out = sys.argv[1], sys.argv[2]
+    cmd = sys.argv[3] if len(sys.argv) > 3 else ""
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
+    agg = {}
+    for name, calls, total, avg, pct in rows:
+        k = short(name)
+        a = agg.setdefault(k, [0, 0.0, 0.0])
+        a[0] += calls; a[1] += total; a[2] += pct
+    lines = ["# rocprofv3 --kernel-trace --stats summary", "", "command: `%s`" % cmd, "", "| kernel | calls | total ms | avg us | % of GPU time |", "|---|---:|---:|---:|---:|"]
+    for k, (calls, total, pct) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        lines.append("| %s | %d | %.2f | %.1f | %.2f |" % (k, calls, total / 1e6, total / calls / 1e3, pct))
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:14]))
+
+
+if __name__ == "__main__":
+    main()
