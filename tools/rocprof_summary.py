@@ -28,7 +28,7 @@ def main():
         a[0] += calls; a[1] += total; a[2] += pct
     lines = ["# rocprofv3 --kernel-trace --stats summary", "", "command: `%s`" % cmd, "", "| kernel | calls | total ms | avg us | % of GPU time |", "|---|---:|---:|---:|---:|"]
     for k, (calls, total, pct) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        lines.append("| %s | %d | %.2f | %.1f | %.2f |" % (k, calls, total / 1e6, total / calls / 1e3, pct))
+        lines.append("| %s | %d | %.2f | %.1f | %.2f |" % (k, calls, total / 1e3, total / calls, pct))   # rocpd top_kernels durations are in microseconds
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:14]))
 
