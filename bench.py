@@ -25,8 +25,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def synthetic(nbytes, seed):
-    return np.random.RandomState(seed & 0xFFFFFFFF).randint(0, 256, size=nbytes, dtype=np.uint8).tobytes()
+from aes_zero_knowledge_proof_circuit_amd import sharding  # noqa: E402
+
+synthetic = sharding.synthetic_bytes
 
 
 def cpu_baseline(sample_blocks=1):
@@ -68,10 +69,8 @@ def main():
     api.set_device(local_rank)
 
     chunk_bytes = 16 * args.chunk
-    n_chunks = (args.blocks + args.chunk - 1) // args.chunk
-    blocks = n_chunks * args.chunk                      # the last chunk must be full: round the message up
-    key = synthetic(16, 0x5EED)
-    msg = synthetic(16 * blocks, 0x5EED + 1 + rank)
+    n_chunks, blocks = sharding.plan(args.blocks, args.chunk)      # the last chunk must be full: the message is rounded up
+    key, msg = sharding.rank_message(rank, blocks)
     t_setup = time.perf_counter()
     pk, vk = api.synthesize_keys(chunk_bytes)
     setup_s = time.perf_counter() - t_setup
@@ -99,10 +98,6 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     stats = api.msm_stats()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     # ---- acceptance: every timed proof must verify (host), the wrong-ciphertext negative must be rejected
     from oracle import zko   # checker only: byte-level AES for the expected ciphertext
@@ -114,14 +109,11 @@ def main():
             accepted += bool(api.verify_encryption(vk, p, ct[i * chunk_bytes:(i + 1) * chunk_bytes]))
     bad = bytearray(ct[:chunk_bytes]); bad[1] ^= 1; bad[-1] ^= 1
     rejected_wrong = not api.verify_encryption(vk, all_proofs[0][0], bytes(bad))
-    ok = torch.tensor([accepted, total, int(rejected_wrong)], dtype=torch.int64)
-    if world > 1:
-        ok = ok.cuda()
-        dist.all_reduce(ok, op=dist.ReduceOp.SUM)
-        ok = ok.cpu()
+    elapsed, acc_sum, tot_sum, neg_sum = sharding.reduce_report(elapsed, accepted, total, int(rejected_wrong), device="cuda" if world > 1 else None)
+    ok = [acc_sum, tot_sum, neg_sum]
 
     if rank == 0:
-        value = world * blocks * args.steps / elapsed
+        value = sharding.aggregate_value(world, blocks, args.steps, elapsed)
         # roofline of the dominant kernel (MSM bucket accumulation, kernels_msm.hip k_accumulate): algorithmic bytes per launch =
         # 128 B per point (96 B affine base + 32 B scalar) x points in the launch; duration from HIP events on the
         # kernel's own stream, accumulated over every launch of the timed region.
