@@ -74,8 +74,11 @@ int zkaes_encrypt_chunked(const uint8_t *msg, size_t len, const uint8_t key[16],
         size_t chunk = pk->pk->circuit().n_blocks * 16;
         if (chunk == 0 || len % chunk || len / chunk != n_chunks) throw std::invalid_argument("message length must be n_chunks * the key's plaintext length");
         std::vector<uint8_t> all;
+        size_t n_ctx = 4;
+        if (const char *e = getenv("ZKAES_CONTEXTS")) n_ctx = (size_t)std::max(1, atoi(e));
+        auto ps = pk->pk->prove_aes_chunked(msg, len, key, n_ctx);
         for (size_t i = 0; i < n_chunks; i++) {
-            auto b = zk::serialize_proof(pk->pk->prove_aes(msg + i * chunk, chunk, key, nullptr));
+            auto b = zk::serialize_proof(ps[i]);
             if (proof_lens) proof_lens[i] = b.size();
             all.insert(all.end(), b.begin(), b.end());
         }
@@ -184,9 +187,8 @@ int zkaes_pk_timings(const zkaes_pk *pk, double out[6]) {
 }
 int zkaes_msm_stats(double out[4], int reset) {
     return guard([&] {
-        auto &s = zk::gpu::msm_stats();
+        auto s = zk::gpu::msm_stats(reset != 0);
         out[0] = s.accumulate_ms; out[1] = s.total_ms; out[2] = (double)s.points; out[3] = (double)s.launches;
-        if (reset) s = zk::gpu::MsmStats();
     });
 }
 

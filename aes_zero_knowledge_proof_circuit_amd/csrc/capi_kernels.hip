@@ -36,15 +36,16 @@ template <class Curve> void run_msm(const uint8_t *bases, const uint8_t *scalars
     Fr *ds = (Fr *)zk::gpu::dmalloc(n * 32);
     zk::gpu::h2d(db, bases, n * 96, s); zk::gpu::h2d(ds, scalars, n * 32, s);
     zk::gpu::sync(s);
-    zk::XYZZ<Fq> r = zk::gpu::msm<Curve>(db, ds, n, s);   // warm-up / result
+    zk::gpu::MsmWorkspace *ws = zk::gpu::msm_workspace_create();
+    zk::XYZZ<Fq> r = zk::gpu::msm<Curve>(ws, db, ds, n, s);   // warm-up / result
     if (reps > 0) {
-        zk::gpu::MsmStats before = zk::gpu::msm_stats();
+        zk::gpu::MsmStats before = zk::gpu::msm_stats(false);
         void *e0 = zk::gpu::event_create(), *e1 = zk::gpu::event_create();
         zk::gpu::event_record(e0, s);
-        for (int i = 0; i < reps; i++) r = zk::gpu::msm<Curve>(db, ds, n, s);
+        for (int i = 0; i < reps; i++) r = zk::gpu::msm<Curve>(ws, db, ds, n, s);
         zk::gpu::event_record(e1, s);
         float ms = zk::gpu::event_elapsed_ms(e0, e1);
-        zk::gpu::MsmStats after = zk::gpu::msm_stats();
+        zk::gpu::MsmStats after = zk::gpu::msm_stats(false);
         if (ms_total) *ms_total = ms / reps;
         if (ms_acc) *ms_acc = (after.accumulate_ms - before.accumulate_ms) / reps;
         zk::gpu::event_destroy(e0); zk::gpu::event_destroy(e1);
@@ -52,6 +53,7 @@ template <class Curve> void run_msm(const uint8_t *bases, const uint8_t *scalars
     zk::Affine<Fq> a = r.to_affine();
     if (out_inf) *out_inf = a.is_inf() ? 1 : 0;
     if (out_xy) { memcpy(out_xy, a.x.l, 48); memcpy(out_xy + 48, a.y.l, 48); }
+    zk::gpu::msm_workspace_destroy(ws);
     zk::gpu::dfree(db); zk::gpu::dfree(ds); zk::gpu::stream_destroy(s);
 }
 }  // namespace

@@ -15,7 +15,9 @@ typedef void *stream_t;   // hipStream_t
 
 // ---- runtime
 int device_count();                       // 0 when no GPU / driver
-void require_device();                    // throws GpuError("no HIP device ...") -- the product never falls back to the CPU
+void require_device();
+int current_device();
+void set_device(int ordinal);                    // throws GpuError("no HIP device ...") -- the product never falls back to the CPU
 void *dmalloc(size_t bytes);
 void dfree(void *p);
 void h2d(void *dst, const void *src, size_t bytes, stream_t s);
@@ -38,14 +40,18 @@ template <class Fr> void ntt(Fr *dst, const Fr *src, size_t in_len, int lg, bool
 template <class Fr> const Fr *domain_elements(int lg);   // device table g^i, i < 2^lg  (built lazily)
 
 // ---- MSM (kernels_msm.hip): sum_i scalars[i] * bases[i]; scalars in Montgomery form; result returned to the host (syncs the stream)
+// `ws` holds the sort / bucket scratch of one in-flight MSM: use one workspace per stream (per prover context)
+struct MsmWorkspace;
+MsmWorkspace *msm_workspace_create();
+void msm_workspace_destroy(MsmWorkspace *ws);
 template <class Curve>
-XYZZ<typename Curve::Fq> msm(const Affine<typename Curve::Fq> *bases, const typename Curve::Fr *scalars, size_t n, stream_t s);
+XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws, const Affine<typename Curve::Fq> *bases, const typename Curve::Fr *scalars, size_t n, stream_t s);
 // out[i] = (beta^(from+i)) * base for i < count   (KZG powers; fixed-base windows)   -- device output
 template <class Curve>
 void fixed_base_powers(Affine<typename Curve::Fq> *out, const Affine<typename Curve::Fq> &base, const typename Curve::Fr &beta, size_t from, size_t count, stream_t s);
 // MSM-stage timing hooks for bench.py (accumulated kernel time of the bucket-accumulation kernel, measured with events)
 struct MsmStats { double accumulate_ms = 0; double total_ms = 0; uint64_t points = 0; uint64_t launches = 0; };
-MsmStats &msm_stats();
+MsmStats msm_stats(bool reset);   // process-wide totals (thread-safe)
 
 }  // namespace gpu
 }  // namespace zk

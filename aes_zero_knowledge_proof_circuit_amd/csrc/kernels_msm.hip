@@ -11,6 +11,7 @@
 //   6. host          : Horner over the <= 32 window sums (c doublings each)
 #include <hipcub/hipcub.hpp>
 #include <chrono>
+#include <mutex>
 #include <vector>
 #include "hip_util.hpp"
 
@@ -18,7 +19,13 @@ namespace zk {
 namespace gpu {
 
 static MsmStats g_stats;
-MsmStats &msm_stats() { return g_stats; }
+static std::mutex g_stats_mu;
+MsmStats msm_stats(bool reset) {
+    std::lock_guard<std::mutex> g(g_stats_mu);
+    MsmStats s = g_stats;
+    if (reset) g_stats = MsmStats();
+    return s;
+}
 
 template <class Fr>
 __global__ void k_digits(const Fr *__restrict__ scalars, uint32_t n, int c, int nwin, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
@@ -45,49 +52,128 @@ __global__ void k_bounds(const uint32_t *__restrict__ keys, size_t total, uint32
     if (i + 1 == total || keys[i + 1] != k) end[k] = (uint32_t)(i + 1);
 }
 
+// mixed add with every Fq product inlined (hot path of k_accumulate).  Returns false when the generic formula does not apply
+// (accumulator at infinity, or P == +-Q): the caller then takes the out-of-line XYZZ::madd.
 template <class Fq>
-__global__ void __launch_bounds__(64) k_accumulate(const Affine<Fq> *__restrict__ bases, const uint32_t *__restrict__ vals,
-                                                    const uint32_t *__restrict__ start, const uint32_t *__restrict__ end,
-                                                    uint32_t nbuckets_total, uint32_t digit_mask, XYZZ<Fq> *__restrict__ buckets) {
+__device__ __forceinline__ bool madd_fast(XYZZ<Fq> &a, const Affine<Fq> &q) {
+    Fq u2 = q.x * a.zz, s2 = q.y * a.zzz;
+    Fq p = u2 - a.x, r = s2 - a.y;
+    if (p.is_zero()) return false;
+    Fq pp = p.sqr(), ppp = p * pp, qq = a.x * pp;
+    Fq x3 = r.sqr() - ppp - qq.dbl();
+    a.y = r * (qq - x3) - a.y * ppp;
+    a.x = x3;
+    a.zz = a.zz * pp;
+    a.zzz = a.zzz * ppp;
+    return true;
+}
+
+__global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, uint32_t nb, uint32_t *__restrict__ size_key, uint32_t *__restrict__ ids) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nbuckets_total) return;
+    if (k >= nb) return;
+    uint32_t sz = end[k] - start[k];
+    size_key[k] = 0xffffffffu - sz;       // ascending sort on this key = descending bucket size
+    ids[k] = k;
+}
+
+// ONE LANE PER BUCKET, buckets visited in descending-size order so the 64 lanes of a wave run the same trip count.
+// The loop body has no function call: the (cryptographically negligible, but reachable with repeated bases) P == +-Q case is
+// appended to a deferred list and replayed by k_accumulate_fixup with the complete addition law.
+template <class Fq>
+__global__ void __launch_bounds__(64, 2) k_accumulate(const Affine<Fq> *__restrict__ bases, const uint32_t *__restrict__ vals,
+                                                    const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, const uint32_t *__restrict__ order,
+                                                    uint32_t nbuckets_total, uint32_t digit_mask, XYZZ<Fq> *__restrict__ buckets,
+                                                    uint32_t *__restrict__ deferred, uint32_t deferred_cap, uint32_t *__restrict__ deferred_count) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nbuckets_total) return;
+    uint32_t k = order[t];
     XYZZ<Fq> acc = XYZZ<Fq>::inf();
     if ((k & digit_mask) != 0) {
         uint32_t s = start[k], e = end[k];
-        for (uint32_t i = s; i < e; i++) {
-            Affine<Fq> p = bases[vals[i]];
-            acc.madd(p);
+        if (s < e) {
+            uint32_t idx = vals[s];
+            Affine<Fq> nxt = bases[idx];
+            for (uint32_t i = s; i < e; i++) {
+                Affine<Fq> p = nxt;
+                uint32_t cur = idx;
+                if (i + 1 < e) { idx = vals[i + 1]; nxt = bases[idx]; }   // prefetch the next gather under this add's ALU work
+                if (p.is_inf()) continue;
+                if (acc.zz.is_zero()) { acc.x = p.x; acc.y = p.y; acc.zz = Fq::one(); acc.zzz = Fq::one(); continue; }
+                if (!madd_fast(acc, p)) {
+                    uint32_t slot = atomicAdd(deferred_count, 1u);
+                    if (slot < deferred_cap) { deferred[2 * slot] = k; deferred[2 * slot + 1] = cur; }
+                }
+            }
         }
     }
     buckets[k] = acc;
 }
-
-// segment reduction: thread (w, g) folds digits [g*L, (g+1)*L) of window w into  sum_d d * B_d
+// replay of the deferred (bucket, point) pairs with the complete formulas; one lane, sequential (the list is empty in practice)
 template <class Fq>
-__global__ void __launch_bounds__(64) k_reduce_segments(const XYZZ<Fq> *__restrict__ buckets, int c, int nwin, int L, XYZZ<Fq> *__restrict__ partial) {
-    uint32_t segs = (1u << c) / L;
+__global__ void k_accumulate_fixup(const Affine<Fq> *__restrict__ bases, XYZZ<Fq> *__restrict__ buckets, const uint32_t *__restrict__ deferred, uint32_t deferred_cap,
+                                   const uint32_t *__restrict__ deferred_count) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t n = *deferred_count;
+    if (n > deferred_cap) n = deferred_cap;
+    for (uint32_t i = 0; i < n; i++) {
+        XYZZ<Fq> b = buckets[deferred[2 * i]];
+        b.madd(bases[deferred[2 * i + 1]]);
+        buckets[deferred[2 * i]] = b;
+    }
+}
+
+// Bucket reduction  sum_d d * B_d  per window, in three fully parallel levels:
+//   k_reduce_l1: lane (w, g) over the 16 buckets d0 = 16 g ..: S_g = sum B_d, W_g = sum (d - d0 + 1) B_d          (running sums only)
+//   k_reduce_l2: lane (w, h) over 32 segments: sum_g [W_g + (d0_g - 1) S_g] via a second running sum + ONE small scalar product
+//   k_reduce_window: LDS tree over the (2^c / 512) group partials of a window
+constexpr int RED_L1 = 8, RED_L2 = 8;
+template <class Fq>
+__global__ void __launch_bounds__(64) k_reduce_l1(const XYZZ<Fq> *__restrict__ buckets, int c, int nwin, XYZZ<Fq> *__restrict__ seg_s, XYZZ<Fq> *__restrict__ seg_w) {
+    uint32_t segs = (1u << c) / RED_L1;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= segs * (uint32_t)nwin) return;
-    uint32_t w = t / segs, g = t % segs, d0 = g * L;
-    const XYZZ<Fq> *B = buckets + ((size_t)w << c);
+    uint32_t w = t / segs, g = t % segs;
+    const XYZZ<Fq> *B = buckets + ((size_t)w << c) + (size_t)g * RED_L1;
     XYZZ<Fq> run = XYZZ<Fq>::inf(), tot = XYZZ<Fq>::inf();
-    for (int d = (int)d0 + L - 1; d >= (int)d0; d--) {
+    for (int d = RED_L1 - 1; d >= 0; d--) {
         XYZZ<Fq> b = B[d];
         run.add(b);
         tot.add(run);
     }
-    // tot = sum (d - d0 + 1) B_d ; want sum d B_d = tot + (d0 - 1) * run
-    if (d0 == 0) { tot.add(run.neg()); }
+    seg_s[t] = run;
+    seg_w[t] = tot;
+}
+template <class Fq>
+__global__ void __launch_bounds__(64) k_reduce_l2(const XYZZ<Fq> *__restrict__ seg_s, const XYZZ<Fq> *__restrict__ seg_w, int c, int nwin, XYZZ<Fq> *__restrict__ partial) {
+    uint32_t segs = (1u << c) / RED_L1, groups = (segs + RED_L2 - 1) / RED_L2;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= groups * (uint32_t)nwin) return;
+    uint32_t w = t / groups, h = t % groups;
+    uint32_t g0 = h * RED_L2, g1 = g0 + RED_L2 < segs ? g0 + RED_L2 : segs;
+    const XYZZ<Fq> *S = seg_s + (size_t)w * segs, *W = seg_w + (size_t)w * segs;
+    XYZZ<Fq> run = XYZZ<Fq>::inf(), tot2 = XYZZ<Fq>::inf(), sw = XYZZ<Fq>::inf();
+    for (int g = (int)g1 - 1; g >= (int)g0; g--) {
+        run.add(S[g]);
+        tot2.add(run);           // tot2 = sum (g - g0 + 1) S_g
+        sw.add(W[g]);
+    }
+    // sum_g [W_g + (L1 g - 1) S_g] = sw + L1 (tot2 - run) + (L1 g0 - 1) run     (run = sum S_g, L1 = 8)
+    XYZZ<Fq> a = tot2;
+    a.add(run.neg());
+    for (int i = 0; i < 3; i++) a = a.dbl();      // * RED_L1
+    sw.add(a);
+    if (g0 == 0) sw.add(run.neg());
     else {
-        uint32_t m = d0 - 1;
+        uint32_t m = RED_L1 * g0 - 1;
         XYZZ<Fq> acc = XYZZ<Fq>::inf();
-        for (int bit = 31; bit >= 0; bit--) {
+        int top = 31 - __clz(m);
+        for (int bit = top; bit >= 0; bit--) {
             acc = acc.dbl();
             if ((m >> bit) & 1) acc.add(run);
         }
-        tot.add(acc);
+        sw.add(acc);
     }
-    partial[t] = tot;
+    partial[t] = sw;
 }
 
 template <class Fq>
@@ -105,17 +191,20 @@ __global__ void __launch_bounds__(256) k_reduce_window(const XYZZ<Fq> *__restric
     if (t == 0) out[w] = sh[0];
 }
 
-namespace {
-struct MsmScratch {
+constexpr uint32_t DEFERRED_CAP = 1u << 20;
+struct MsmWorkspace {
     size_t cap_pairs = 0, cap_buckets = 0, cap_tmp = 0;
     uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr, *start = nullptr, *end = nullptr;
-    void *buckets = nullptr, *partial = nullptr, *wsum = nullptr, *tmp = nullptr;
+    uint32_t *size_key = nullptr, *size_key2 = nullptr, *ids = nullptr, *order = nullptr;
+    uint32_t *deferred = nullptr, *deferred_count = nullptr;
+    void *buckets = nullptr, *seg_s = nullptr, *seg_w = nullptr, *partial = nullptr, *wsum = nullptr, *tmp = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
-MsmScratch g_scr;
-void ensure_scratch(size_t pairs, size_t buckets, size_t xyzz_bytes) {
-    MsmScratch &S = g_scr;
-    if (!S.ev0) { HIP_CHECK(hipEventCreate(&S.ev0)); HIP_CHECK(hipEventCreate(&S.ev1)); }
+static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t xyzz_bytes) {
+    if (!S.ev0) {
+        HIP_CHECK(hipEventCreate(&S.ev0)); HIP_CHECK(hipEventCreate(&S.ev1));
+        S.deferred = (uint32_t *)dmalloc(2 * DEFERRED_CAP * 4); S.deferred_count = (uint32_t *)dmalloc(4);
+    }
     if (pairs > S.cap_pairs) {
         dfree(S.keys_a); dfree(S.keys_b); dfree(S.vals_a); dfree(S.vals_b);
         S.cap_pairs = pairs;
@@ -123,17 +212,28 @@ void ensure_scratch(size_t pairs, size_t buckets, size_t xyzz_bytes) {
         S.vals_a = (uint32_t *)dmalloc(pairs * 4); S.vals_b = (uint32_t *)dmalloc(pairs * 4);
     }
     if (buckets > S.cap_buckets) {
-        dfree(S.start); dfree(S.end); dfree(S.buckets); dfree(S.partial); dfree(S.wsum);
+        dfree(S.start); dfree(S.end); dfree(S.buckets); dfree(S.partial); dfree(S.wsum); dfree(S.seg_s); dfree(S.seg_w);
+        dfree(S.size_key); dfree(S.size_key2); dfree(S.ids); dfree(S.order);
         S.cap_buckets = buckets;
         S.start = (uint32_t *)dmalloc(buckets * 4); S.end = (uint32_t *)dmalloc(buckets * 4);
-        S.buckets = dmalloc(buckets * 192); S.partial = dmalloc(buckets * 192 / 16 + 192 * 64); S.wsum = dmalloc(192 * 64);
+        S.size_key = (uint32_t *)dmalloc(buckets * 4); S.size_key2 = (uint32_t *)dmalloc(buckets * 4); S.ids = (uint32_t *)dmalloc(buckets * 4); S.order = (uint32_t *)dmalloc(buckets * 4);
+        S.buckets = dmalloc(buckets * 192);
+        S.seg_s = dmalloc((buckets / RED_L1 + 64) * 192); S.seg_w = dmalloc((buckets / RED_L1 + 64) * 192);
+        S.partial = dmalloc((buckets / (RED_L1 * RED_L2) + 64 * 64) * 192); S.wsum = dmalloc(192 * 64);
     }
     (void)xyzz_bytes;
 }
-}  // namespace
+MsmWorkspace *msm_workspace_create() { return new MsmWorkspace(); }
+void msm_workspace_destroy(MsmWorkspace *w) {
+    if (!w) return;
+    for (void *p : {(void *)w->keys_a, (void *)w->keys_b, (void *)w->vals_a, (void *)w->vals_b, (void *)w->start, (void *)w->end, (void *)w->size_key, (void *)w->size_key2, (void *)w->ids,
+                    (void *)w->order, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->wsum, w->tmp}) dfree(p);
+    if (w->ev0) { (void)hipEventDestroy(w->ev0); (void)hipEventDestroy(w->ev1); }
+    delete w;
+}
 
 template <class Curve>
-XYZZ<typename Curve::Fq> msm(const Affine<typename Curve::Fq> *bases, const typename Curve::Fr *scalars, size_t n, stream_t s_) {
+XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws_, const Affine<typename Curve::Fq> *bases, const typename Curve::Fr *scalars, size_t n, stream_t s_) {
     using Fq = typename Curve::Fq;
     using Fr = typename Curve::Fr;
     static_assert(sizeof(XYZZ<Fq>) == 192, "XYZZ layout");
@@ -147,10 +247,10 @@ XYZZ<typename Curve::Fq> msm(const Affine<typename Curve::Fq> *bases, const type
     if (c < 6) c = 6;
     if (c > 16) c = 16;
     const int nwin = (Fr::BITS + c - 1) / c;
-    const int L = 64 < (1 << c) ? 64 : (1 << c);
     size_t pairs = n * (size_t)nwin, nb = (size_t)nwin << c;
-    ensure_scratch(pairs, nb, sizeof(XYZZ<Fq>));
-    MsmScratch &S = g_scr;
+    if (!ws_) throw GpuError("msm: null workspace");
+    MsmWorkspace &S = *ws_;
+    ensure_scratch(S, pairs, nb, sizeof(XYZZ<Fq>));
     hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scalars, (uint32_t)n, c, nwin, S.keys_a, S.vals_a);
     HIP_LAUNCH_CHECK();
     int key_bits = c;
@@ -163,19 +263,39 @@ XYZZ<typename Curve::Fq> msm(const Affine<typename Curve::Fq> *bases, const type
     HIP_CHECK(hipMemsetAsync(S.end, 0, nb * 4, s));
     hipLaunchKernelGGL(k_bounds, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, S.keys_b, pairs, S.start, S.end);
     HIP_LAUNCH_CHECK();
+    // size-balanced visiting order of the buckets
+    hipLaunchKernelGGL(k_bucket_sizes, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, S.start, S.end, (uint32_t)nb, S.size_key, S.ids);
+    HIP_LAUNCH_CHECK();
+    {
+        int size_bits = 1;
+        while (((size_t)1 << size_bits) <= n && size_bits < 32) size_bits++;
+        size_t tb = 0;
+        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, S.size_key, S.size_key2, S.ids, S.order, (int)nb, 0, 32, s));
+        if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
+        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp, tb, S.size_key, S.size_key2, S.ids, S.order, (int)nb, 0, 32, s));
+        (void)size_bits;
+    }
+    HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 4, s));
     HIP_CHECK(hipEventRecord(S.ev0, s));
-    hipLaunchKernelGGL((k_accumulate<Fq>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, bases, S.vals_b, S.start, S.end, (uint32_t)nb, (1u << c) - 1,
-                       (XYZZ<Fq> *)S.buckets);
+    hipLaunchKernelGGL((k_accumulate<Fq>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, bases, S.vals_b, S.start, S.end, S.order, (uint32_t)nb, (1u << c) - 1,
+                       (XYZZ<Fq> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
     HIP_CHECK(hipEventRecord(S.ev1, s));
-    uint32_t segs = (1u << c) / L;
-    hipLaunchKernelGGL((k_reduce_segments<Fq>), dim3((unsigned)((segs * nwin + 63) / 64)), dim3(64), 0, s, (const XYZZ<Fq> *)S.buckets, c, nwin, L, (XYZZ<Fq> *)S.partial);
+    hipLaunchKernelGGL((k_accumulate_fixup<Fq>), dim3(1), dim3(64), 0, s, bases, (XYZZ<Fq> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_reduce_window<Fq>), dim3((unsigned)nwin), dim3(256), 0, s, (const XYZZ<Fq> *)S.partial, segs, (XYZZ<Fq> *)S.wsum);
+    uint32_t segs = (1u << c) / RED_L1, groups = (segs + RED_L2 - 1) / RED_L2;
+    hipLaunchKernelGGL((k_reduce_l1<Fq>), dim3((unsigned)((segs * nwin + 63) / 64)), dim3(64), 0, s, (const XYZZ<Fq> *)S.buckets, c, nwin, (XYZZ<Fq> *)S.seg_s, (XYZZ<Fq> *)S.seg_w);
+    HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_reduce_l2<Fq>), dim3((unsigned)((groups * nwin + 63) / 64)), dim3(64), 0, s, (const XYZZ<Fq> *)S.seg_s, (const XYZZ<Fq> *)S.seg_w, c, nwin, (XYZZ<Fq> *)S.partial);
+    HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_reduce_window<Fq>), dim3((unsigned)nwin), dim3(256), 0, s, (const XYZZ<Fq> *)S.partial, groups, (XYZZ<Fq> *)S.wsum);
     HIP_LAUNCH_CHECK();
     std::vector<XYZZ<Fq>> ws(nwin);
+    uint32_t n_deferred = 0;
     HIP_CHECK(hipMemcpyAsync(ws.data(), S.wsum, sizeof(XYZZ<Fq>) * nwin, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(&n_deferred, S.deferred_count, 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
+    if (n_deferred > DEFERRED_CAP) throw GpuError("msm: more than 2^20 degenerate additions (repeated base points); refusing to return a wrong sum");
     float ms = 0;
     HIP_CHECK(hipEventElapsedTime(&ms, S.ev0, S.ev1));
     XYZZ<Fq> total = XYZZ<Fq>::inf();
@@ -184,10 +304,13 @@ XYZZ<typename Curve::Fq> msm(const Affine<typename Curve::Fq> *bases, const type
         for (int k = 0; k < c; k++) total = total.dbl();
     }
     total.add(ws[0]);
-    g_stats.accumulate_ms += ms;
-    g_stats.points += n;
-    g_stats.launches += 1;
-    g_stats.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    {
+        std::lock_guard<std::mutex> g(g_stats_mu);
+        g_stats.accumulate_ms += ms;
+        g_stats.points += n;
+        g_stats.launches += 1;
+        g_stats.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    }
     return total;
 }
 
@@ -241,8 +364,8 @@ void fixed_base_powers(Affine<typename Curve::Fq> *out, const Affine<typename Cu
     dfree(d_table); dfree(d_sc);
 }
 
-template XYZZ<Fq377> msm<Bls377>(const Affine<Fq377> *, const Fr377 *, size_t, stream_t);
-template XYZZ<Fq381> msm<Bls381>(const Affine<Fq381> *, const Fr381 *, size_t, stream_t);
+template XYZZ<Fq377> msm<Bls377>(MsmWorkspace *, const Affine<Fq377> *, const Fr377 *, size_t, stream_t);
+template XYZZ<Fq381> msm<Bls381>(MsmWorkspace *, const Affine<Fq381> *, const Fr381 *, size_t, stream_t);
 template void fixed_base_powers<Bls377>(Affine<Fq377> *, const Affine<Fq377> &, const Fr377 &, size_t, size_t, stream_t);
 template void fixed_base_powers<Bls381>(Affine<Fq381> *, const Affine<Fq381> &, const Fr381 &, size_t, size_t, stream_t);
 

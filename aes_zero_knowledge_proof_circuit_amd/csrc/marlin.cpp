@@ -3,7 +3,10 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <stdexcept>
 #include "gpu.hpp"
 #include "trace_layout.h"
@@ -207,11 +210,37 @@ struct DevBuf {
 };
 struct KzgRand { bool hiding = false; Fr b[3]; };
 
+// Everything one in-flight proof needs: its own stream, MSM scratch and polynomial workspace.  Several contexts prove different
+// chunk-proofs concurrently (zkaes_encrypt_chunked): the latency-bound phases of one proof (bucket reductions, scans, host
+// transcript work) overlap with the throughput-bound kernels of the others.
+struct ProverContext {
+    gpu::stream_t stream = nullptr;
+    gpu::MsmWorkspace *msm_ws = nullptr;
+    uint8_t *d_trace = nullptr, *d_z = nullptr, *d_msg = nullptr, *d_key = nullptr;
+    DevBuf za_ev, zb_ev, x_poly, x_tmp, x_evals, tmp_n, ra_ev, ra_poly, zpoly, t_partial;
+    DevBuf poly[9];                    // w z_a z_b mask t g_1 h_1 g_2 h_2
+    size_t poly_len[9] = {0};
+    DevBuf e[5], big_tmp, f_poly, ab[2], acc, wit, scratch;
+    ProverTimings timings;
+    ProverContext() { stream = gpu::stream_create(); msm_ws = gpu::msm_workspace_create(); }
+    ~ProverContext() {
+        gpu::dfree(d_trace); gpu::dfree(d_z); gpu::dfree(d_msg); gpu::dfree(d_key);
+        for (DevBuf *b : {&za_ev, &zb_ev, &x_poly, &x_tmp, &x_evals, &tmp_n, &ra_ev, &ra_poly, &zpoly, &t_partial, &big_tmp, &f_poly, &acc, &wit, &scratch}) b->release();
+        for (auto &b : poly) b.release();
+        for (auto &b : e) b.release();
+        for (auto &b : ab) b.release();
+        gpu::msm_workspace_destroy(msm_ws);
+        gpu::stream_destroy(stream);
+    }
+};
+
 class ProvingKeyImpl {
   public:
     VerifyingKey vk;
     Circuit circuit;
-    gpu::stream_t stream = nullptr;
+    std::vector<std::unique_ptr<ProverContext>> ctxs;
+    std::mutex ctx_mu;
+    size_t message_len = 0;
     size_t n = 0, k = 0, m = 0;       // |H|, |K|, |X|
     int lg_n = 0, lg_k = 0, lg_m = 0;
     size_t max_degree = 0, supported_degree = 0, lowest_shift = 0, bounds[2] = {0, 0};
@@ -225,29 +254,41 @@ class ProvingKeyImpl {
     int64_t *d_a_coeff = nullptr, *d_b_coeff = nullptr;
     uint32_t *d_t_colptr = nullptr, *d_t_seg_start = nullptr, *d_t_seg_end = nullptr, *d_t_row = nullptr; uint8_t *d_t_mat = nullptr; int64_t *d_t_coeff = nullptr;
     uint32_t t_nseg = 0;
-    DevBuf t_partial;
     // device: index polynomials (evaluations on K and coefficients); order row col a_val b_val c_val row_col
     DevBuf ix_ev[6], ix_co[6];
-    // device: per-proof workspace
-    uint8_t *d_trace = nullptr, *d_z = nullptr, *d_msg = nullptr, *d_key = nullptr;
-    DevBuf za_ev, zb_ev, x_poly, x_tmp, x_evals, tmp_n, ra_ev, ra_poly, zpoly;
-    DevBuf poly[9];                    // w z_a z_b mask t g_1 h_1 g_2 h_2 (capacities below)
-    size_t poly_len[9] = {0};
-    DevBuf e[5], big_tmp, f_poly, ab[2], acc, wit, scratch;
-    ProverTimings timings;
+    ProverTimings last_timings;
 
     ~ProvingKeyImpl() {
         gpu::dfree(d_powers); gpu::dfree(d_shifted); gpu::dfree(d_desc); gpu::dfree(d_sbox_in); gpu::dfree(d_sbox_tmpl);
         gpu::dfree(d_a_rowptr); gpu::dfree(d_a_col); gpu::dfree(d_b_rowptr); gpu::dfree(d_b_col); gpu::dfree(d_a_coeff); gpu::dfree(d_b_coeff);
-        gpu::dfree(d_t_colptr); gpu::dfree(d_t_seg_start); gpu::dfree(d_t_seg_end); t_partial.release(); gpu::dfree(d_t_row); gpu::dfree(d_t_mat); gpu::dfree(d_t_coeff);
+        gpu::dfree(d_t_colptr); gpu::dfree(d_t_seg_start); gpu::dfree(d_t_seg_end); gpu::dfree(d_t_row); gpu::dfree(d_t_mat); gpu::dfree(d_t_coeff);
         for (auto &b : ix_ev) b.release();
         for (auto &b : ix_co) b.release();
-        gpu::dfree(d_trace); gpu::dfree(d_z); gpu::dfree(d_msg); gpu::dfree(d_key);
-        for (DevBuf *b : {&za_ev, &zb_ev, &x_poly, &x_tmp, &x_evals, &tmp_n, &ra_ev, &ra_poly, &zpoly, &big_tmp, &f_poly, &acc, &wit, &scratch}) b->release();
-        for (auto &b : poly) b.release();
-        for (auto &b : e) b.release();
-        for (auto &b : ab) b.release();
-        gpu::stream_destroy(stream);
+        ctxs.clear();
+    }
+    // context i, created on first use (workspace allocation happens outside any timed region when callers warm up)
+    ProverContext &context(size_t i) {
+        std::lock_guard<std::mutex> g(ctx_mu);
+        while (ctxs.size() <= i) {
+            std::unique_ptr<ProverContext> c(new ProverContext());
+            alloc_workspace(*c);
+            ctxs.push_back(std::move(c));
+        }
+        return *ctxs[i];
+    }
+    void alloc_workspace(ProverContext &cx) {
+        const Circuit &c = circuit;
+        size_t n4 = next_pow2(3 * n + 1), k2 = 2 * k;
+        cx.d_trace = (uint8_t *)gpu::dmalloc(c.trace_bytes + 64); cx.d_z = (uint8_t *)gpu::dmalloc(c.num_variables() + 64);
+        cx.d_msg = (uint8_t *)gpu::dmalloc(std::max<size_t>(message_len, 16)); cx.d_key = (uint8_t *)gpu::dmalloc(16);
+        cx.za_ev.alloc(n); cx.zb_ev.alloc(n); cx.x_poly.alloc(m); cx.x_tmp.alloc(m); cx.x_evals.alloc(n); cx.tmp_n.alloc(n + 1); cx.ra_ev.alloc(n); cx.ra_poly.alloc(n);
+        cx.zpoly.alloc(n + 1); cx.t_partial.alloc(t_nseg + 1);
+        size_t caps[9] = {n + 1, n + 1, n + 1, 3 * n, n, n, 3 * n, k, k + 1};
+        for (int i = 0; i < 9; i++) cx.poly[i].alloc(caps[i]);
+        size_t big = std::max(n4, k2);
+        for (auto &b : cx.e) b.alloc(big);
+        cx.big_tmp.alloc(big); cx.f_poly.alloc(k); cx.ab[0].alloc(k); cx.ab[1].alloc(k);
+        cx.acc.alloc(std::max(3 * n, k) + 1); cx.wit.alloc(std::max(3 * n, k) + 1); cx.scratch.alloc(std::max(3 * n, k) / 32 + 1024);
     }
 
     template <class T> static T *upload(const std::vector<T> &v, gpu::stream_t s) {
@@ -257,15 +298,15 @@ class ProvingKeyImpl {
     }
 
     // MSM against powers_of_g starting at `off` (plain or shifted table); device scalars
-    XYZZ<Fq377> msm_powers(bool shifted, size_t off, const F *scalars, size_t len) {
+    XYZZ<Fq377> msm_powers(ProverContext &cx, bool shifted, size_t off, const F *scalars, size_t len) {
         if (len == 0) return XYZZ<Fq377>::inf();
         size_t avail = shifted ? (bounds[1] + 1) : (supported_degree + 1);
         if (off + len > avail) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
-        return gpu::msm<Bls377>((shifted ? d_shifted : d_powers) + off, scalars, len, stream);
+        return gpu::msm<Bls377>(cx.msm_ws, (shifted ? d_shifted : d_powers) + off, scalars, len, cx.stream);
     }
     // KZG10::commit: MSM(powers, coeffs) [+ MSM(powers_of_gamma_g, blinding) when hiding]
-    G1A kzg_commit(bool shifted, size_t off, const F *coeffs, size_t len, bool hiding, KzgRand &rnd, ChaChaRng &zk) {
-        XYZZ<Fq377> c = msm_powers(shifted, off, coeffs, len);
+    G1A kzg_commit(ProverContext &cx, bool shifted, size_t off, const F *coeffs, size_t len, bool hiding, KzgRand &rnd, ChaChaRng &zk) {
+        XYZZ<Fq377> c = msm_powers(cx, shifted, off, coeffs, len);
         rnd.hiding = hiding;
         for (auto &x : rnd.b) x = Fr::zero();
         if (hiding) {
@@ -275,23 +316,25 @@ class ProvingKeyImpl {
         return c.to_affine();
     }
     struct Labeled { int idx; long bound; bool hiding; KzgRand rand, shifted_rand; Commitment comm; };
-    void mpc_commit(Labeled &lp, ChaChaRng &zk) {
-        lp.comm.comm = kzg_commit(false, 0, poly[lp.idx].p, poly_len[lp.idx], lp.hiding, lp.rand, zk);
+    void mpc_commit(ProverContext &cx, Labeled &lp, ChaChaRng &zk) {
+        lp.comm.comm = kzg_commit(cx, false, 0, cx.poly[lp.idx].p, cx.poly_len[lp.idx], lp.hiding, lp.rand, zk);
         lp.comm.has_shifted = false;
         if (lp.bound >= 0) {
             size_t off = (max_degree - (size_t)lp.bound) - lowest_shift;
-            lp.comm.shifted = kzg_commit(true, off, poly[lp.idx].p, poly_len[lp.idx], lp.hiding, lp.shifted_rand, zk);
+            lp.comm.shifted = kzg_commit(cx, true, off, cx.poly[lp.idx].p, cx.poly_len[lp.idx], lp.hiding, lp.shifted_rand, zk);
             lp.comm.has_shifted = true;
         }
     }
 
     void setup(int kind, size_t message_len, const SrsLiterals &srs);
-    Proof prove(const uint8_t *trace_or_null, const uint8_t *msg, size_t len, const uint8_t *key, const uint8_t *zk_seed);
+    Proof prove(ProverContext &cx, const uint8_t *trace_or_null, const uint8_t *msg, size_t len, const uint8_t *key, const uint8_t *zk_seed);
 };
 
-void ProvingKeyImpl::setup(int kind, size_t message_len, const SrsLiterals &srs) {
+void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs) {
     gpu::require_device();
-    stream = gpu::stream_create();
+    message_len = message_len_;
+    std::unique_ptr<ProverContext> cx0(new ProverContext());
+    gpu::stream_t stream = cx0->stream;
     circuit = kind == CIRCUIT_AES ? compile_aes_circuit(message_len) : compile_ops_circuit(kind);
     const Circuit &c = circuit;
     // ---- joint matrix (sum_matrices): per-row sorted union of the A, B, C column supports
@@ -383,7 +426,7 @@ void ProvingKeyImpl::setup(int kind, size_t message_len, const SrsLiterals &srs)
         if (seg_start.empty()) { seg_start.push_back(0); seg_end.push_back(0); }
         d_t_colptr = upload(col_seg_ptr, stream); d_t_seg_start = upload(seg_start, stream); d_t_seg_end = upload(seg_end, stream);
         d_t_row = upload(trow, stream); d_t_mat = upload(tmat, stream); d_t_coeff = upload(tcoef, stream);
-        t_partial.alloc(t_nseg + 1);
+
     }
     // ---- index polynomials on the GPU
     for (int i = 0; i < 6; i++) { ix_ev[i].alloc(k); ix_co[i].alloc(k); }
@@ -397,24 +440,21 @@ void ProvingKeyImpl::setup(int kind, size_t message_len, const SrsLiterals &srs)
         gpu::sync(stream);
         gpu::dfree(d_ci); gpu::dfree(d_ri); gpu::dfree(d_ja); gpu::dfree(d_jb); gpu::dfree(d_jc);
     }
-    for (int i = 0; i < 6; i++) vk.index_comms[i] = msm_powers(false, 0, ix_co[i].p, k).to_affine();
-    // ---- workspace
-    size_t n4 = next_pow2(3 * n + 1), k2 = 2 * k;
-    d_trace = (uint8_t *)gpu::dmalloc(c.trace_bytes + 64); d_z = (uint8_t *)gpu::dmalloc(c.num_variables() + 64);
-    d_msg = (uint8_t *)gpu::dmalloc(std::max<size_t>(message_len, 16)); d_key = (uint8_t *)gpu::dmalloc(16);
-    za_ev.alloc(n); zb_ev.alloc(n); x_poly.alloc(m); x_tmp.alloc(m); x_evals.alloc(n); tmp_n.alloc(n + 1); ra_ev.alloc(n); ra_poly.alloc(n); zpoly.alloc(n + 1);
-    size_t caps[9] = {n + 1, n + 1, n + 1, 3 * n, n, n, 3 * n, k, k + 1};
-    for (int i = 0; i < 9; i++) poly[i].alloc(caps[i]);
-    size_t big = std::max(n4, k2);
-    for (auto &b : e) b.alloc(big);
-    big_tmp.alloc(big); f_poly.alloc(k); ab[0].alloc(k); ab[1].alloc(k);
-    acc.alloc(std::max(3 * n, k) + 1); wit.alloc(std::max(3 * n, k) + 1); scratch.alloc(std::max(3 * n, k) / 32 + 1024);
+    for (int i = 0; i < 6; i++) vk.index_comms[i] = msm_powers(*cx0, false, 0, ix_co[i].p, k).to_affine();
+    // ---- workspace of context 0 (further contexts are created on demand)
+    alloc_workspace(*cx0);
+    ctxs.push_back(std::move(cx0));
     gpu::sync(stream);
 }
 
-Proof ProvingKeyImpl::prove(const uint8_t *host_trace, const uint8_t *msg, size_t len, const uint8_t *key, const uint8_t *zk_seed) {
+Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const uint8_t *msg, size_t len, const uint8_t *key, const uint8_t *zk_seed) {
     const Circuit &c = circuit;
-    gpu::stream_t s = stream;
+    gpu::stream_t s = cx.stream;
+    auto &d_trace = cx.d_trace; auto &d_z = cx.d_z; auto &d_msg = cx.d_msg; auto &d_key = cx.d_key;
+    auto &za_ev = cx.za_ev; auto &zb_ev = cx.zb_ev; auto &x_poly = cx.x_poly; auto &x_tmp = cx.x_tmp; auto &x_evals = cx.x_evals; auto &tmp_n = cx.tmp_n;
+    auto &ra_ev = cx.ra_ev; auto &ra_poly = cx.ra_poly; auto &zpoly = cx.zpoly; auto &t_partial = cx.t_partial;
+    auto &poly = cx.poly; auto &poly_len = cx.poly_len; auto &e = cx.e; auto &big_tmp = cx.big_tmp; auto &f_poly = cx.f_poly; auto &ab = cx.ab;
+    auto &acc = cx.acc; auto &wit = cx.wit; auto &scratch = cx.scratch; auto &timings = cx.timings;
     auto t_all = Clock::now(), t0 = t_all;
     ChaChaRng zk(zk_seed ? zk_seed : ark_test_rng_seed(), 12);
     const size_t n4 = next_pow2(3 * n + 1), k2 = 2 * k;
@@ -467,7 +507,7 @@ Proof ProvingKeyImpl::prove(const uint8_t *host_trace, const uint8_t *msg, size_
         gpu::sync(s);
         poly_len[3] = 3 * n;
     }
-    for (auto &lp : r1) mpc_commit(lp, zk);
+    for (auto &lp : r1) mpc_commit(cx, lp, zk);
     { Bytes o; for (auto &lp : r1) o.commitment_tobytes(lp.comm); fs.absorb(o.b); }
     auto sample_outside_h = [&]() { Fr t; do { t = fs.rng().rand_field<Fr>(); } while (eval_vanishing(n, t).is_zero()); return t; };
     Fr alpha = sample_outside_h();
@@ -494,7 +534,7 @@ Proof ProvingKeyImpl::prove(const uint8_t *host_trace, const uint8_t *msg, size_
     gpu::divide_by_vanishing(poly[6].p, e[0].p, big_tmp.p, 3 * n, n, s);     // h_1 (2|H| coeffs), remainder = x * g_1
     poly_len[6] = 2 * n;
     gpu::d2d(poly[5].p, e[0].p + 1, (n - 1) * sizeof(F), s); poly_len[5] = n - 1;
-    for (auto &lp : r2) mpc_commit(lp, zk);
+    for (auto &lp : r2) mpc_commit(cx, lp, zk);
     { Bytes o; for (auto &lp : r2) o.commitment_tobytes(lp.comm); fs.absorb(o.b); }
     Fr beta = sample_outside_h();
     timings.round2_ms = ms_since(t0); t0 = Clock::now();
@@ -518,7 +558,7 @@ Proof ProvingKeyImpl::prove(const uint8_t *host_trace, const uint8_t *msg, size_
     gpu::ntt<F>(big_tmp.p, e[0].p, k2, lg_k2, true, s);
     gpu::divide_by_vanishing(poly[8].p, e[3].p, big_tmp.p, k2, k, s);          // h_2 ; remainder must vanish
     poly_len[8] = k - 1;
-    for (auto &lp : r3) mpc_commit(lp, zk);
+    for (auto &lp : r3) mpc_commit(cx, lp, zk);
     { Bytes o; for (auto &lp : r3) o.commitment_tobytes(lp.comm); fs.absorb(o.b); }
     Fr gamma = fs.rng().rand_field<Fr>();
     timings.round3_ms = ms_since(t0); t0 = Clock::now();
@@ -555,14 +595,14 @@ Proof ProvingKeyImpl::prove(const uint8_t *host_trace, const uint8_t *msg, size_
         gpu::poly_axpy(acc.p, poly[4].p, chp[3], poly_len[4], s);
         gpu::poly_axpy(acc.p, poly[2].p, chp[4], poly_len[2], s); rand_axpy(rb, chp[4], r1[2].rand);
         gpu::divide_by_linear(wit.p, acc.p, plen, beta, scratch.p, s);
-        XYZZ<Fq377> w = msm_powers(false, 0, wit.p, plen - 1);
+        XYZZ<Fq377> w = msm_powers(cx, false, 0, wit.p, plen - 1);
         Fr rq[2]; host_divide_by_linear(rq, rb, beta);
         for (int i = 0; i < 2; i++) w.add(mul_fr(XYZZ<Fq377>::from_affine(gamma_powers[i]), rq[i]));
         Fr rv = host_eval3(rb, beta);
         // shifted part (g_1, degree bound |H| - 2)
         gpu::divide_by_linear(wit.p, poly[5].p, poly_len[5], beta, scratch.p, s);
         gpu::poly_scale(wit.p, chp[1], poly_len[5] - 1, s);
-        w.add(msm_powers(true, bounds[1] - (n - 2), wit.p, poly_len[5] - 1));
+        w.add(msm_powers(cx, true, bounds[1] - (n - 2), wit.p, poly_len[5] - 1));
         Fr srb[3]; for (int i = 0; i < 3; i++) srb[i] = chp[1] * r2[1].shifted_rand.b[i];
         host_divide_by_linear(rq, srb, beta);
         for (int i = 0; i < 2; i++) w.add(mul_fr(XYZZ<Fq377>::from_affine(gamma_powers[i]), rq[i]));
@@ -581,10 +621,10 @@ Proof ProvingKeyImpl::prove(const uint8_t *host_trace, const uint8_t *msg, size_
         gpu::poly_axpy(acc.p, ix_co[5].p, chp[2] * c_rc, k, s);
         gpu::poly_axpy(acc.p, poly[8].p, chp[2] * c_h2, poly_len[8], s);
         gpu::divide_by_linear(wit.p, acc.p, plen, gamma, scratch.p, s);
-        XYZZ<Fq377> w = msm_powers(false, 0, wit.p, plen - 1);
+        XYZZ<Fq377> w = msm_powers(cx, false, 0, wit.p, plen - 1);
         gpu::divide_by_linear(wit.p, poly[7].p, poly_len[7], gamma, scratch.p, s);
         gpu::poly_scale(wit.p, chp[1], poly_len[7] - 1, s);
-        w.add(msm_powers(true, bounds[1] - (k - 2), wit.p, poly_len[7] - 1));
+        w.add(msm_powers(cx, true, bounds[1] - (k - 2), wit.p, poly_len[7] - 1));
         pf.w_gamma = w.to_affine();
     }
     for (int i = 0; i < 4; i++) pf.comms[i] = r1[i].comm;
@@ -592,31 +632,63 @@ Proof ProvingKeyImpl::prove(const uint8_t *host_trace, const uint8_t *msg, size_
     for (int i = 0; i < 2; i++) pf.comms[7 + i] = r3[i].comm;
     timings.open_ms = ms_since(t0);
     timings.total_ms = ms_since(t_all);
+    { std::lock_guard<std::mutex> g(ctx_mu); last_timings = timings; }
     return pf;
 }
 
 ProvingKey::~ProvingKey() { delete impl; }
 const VerifyingKey &ProvingKey::vk() const { return impl->vk; }
 const Circuit &ProvingKey::circuit() const { return impl->circuit; }
-const ProverTimings &ProvingKey::last_timings() const { return impl->timings; }
+const ProverTimings &ProvingKey::last_timings() const { return impl->last_timings; }
 Proof ProvingKey::prove_aes(const uint8_t *message, size_t len, const uint8_t key[16], const uint8_t *zk_seed) {
     if (impl->circuit.kind != CIRCUIT_AES) throw std::invalid_argument("proving key was not synthesized for the AES circuit");
     if (len % 16) throw std::invalid_argument("Input must be 16 bytes length when adding round key");
     if (len != impl->circuit.n_blocks * 16) throw std::invalid_argument("InstanceDoesNotMatchIndex: proving key was synthesized for " + std::to_string(impl->circuit.n_blocks * 16) + " bytes");
-    return impl->prove(nullptr, message, len, key, zk_seed);
+    return impl->prove(impl->context(0), nullptr, message, len, key, zk_seed);
 }
 std::vector<uint8_t> ProvingKey::aes_witness(const uint8_t *message, size_t len, const uint8_t key[16]) {
     if (impl->circuit.kind != CIRCUIT_AES) throw std::invalid_argument("proving key was not synthesized for the AES circuit");
     if (len % 16) throw std::invalid_argument("Input must be 16 bytes length when adding round key");
     if (len != impl->circuit.n_blocks * 16) throw std::invalid_argument("InstanceDoesNotMatchIndex: proving key was synthesized for " + std::to_string(impl->circuit.n_blocks * 16) + " bytes");
     const Circuit &c = impl->circuit;
-    gpu::stream_t s = impl->stream;
-    gpu::h2d(impl->d_msg, message, len, s); gpu::h2d(impl->d_key, key, 16, s);
-    gpu::aes_trace(impl->d_trace, c.trace_bytes, impl->d_msg, impl->d_key, 1, (uint32_t)c.n_blocks, s);
-    gpu::witness_expand(impl->d_z, impl->d_desc, (uint32_t)c.num_variables(), impl->d_trace, impl->d_sbox_in, impl->d_sbox_tmpl, s);
+    ProverContext &cx = impl->context(0);
+    gpu::stream_t s = cx.stream;
+    gpu::h2d(cx.d_msg, message, len, s); gpu::h2d(cx.d_key, key, 16, s);
+    gpu::aes_trace(cx.d_trace, c.trace_bytes, cx.d_msg, cx.d_key, 1, (uint32_t)c.n_blocks, s);
+    gpu::witness_expand(cx.d_z, impl->d_desc, (uint32_t)c.num_variables(), cx.d_trace, impl->d_sbox_in, impl->d_sbox_tmpl, s);
     std::vector<uint8_t> z(c.num_variables());
-    gpu::d2h(z.data(), impl->d_z, z.size(), s);
+    gpu::d2h(z.data(), cx.d_z, z.size(), s);
     return z;
+}
+std::vector<Proof> ProvingKey::prove_aes_chunked(const uint8_t *message, size_t len, const uint8_t key[16], size_t n_contexts) {
+    if (impl->circuit.kind != CIRCUIT_AES) throw std::invalid_argument("proving key was not synthesized for the AES circuit");
+    size_t chunk = impl->circuit.n_blocks * 16;
+    if (chunk == 0 || len % chunk) throw std::invalid_argument("message length must be a multiple of the key's plaintext length (" + std::to_string(chunk) + " bytes)");
+    size_t n_chunks = len / chunk;
+    if (n_contexts == 0) n_contexts = 1;
+    n_contexts = std::min(n_contexts, std::max<size_t>(n_chunks, 1));
+    std::vector<Proof> proofs(n_chunks);
+    for (size_t i = 0; i < n_contexts; i++) impl->context(i);           // allocate outside the worker threads
+    std::atomic<size_t> next{0};
+    std::vector<std::string> errors(n_contexts);
+    int device = gpu::current_device();
+    auto worker = [&](size_t ci) {
+        try {
+            gpu::set_device(device);
+            ProverContext &cx = impl->context(ci);
+            for (;;) {
+                size_t i = next.fetch_add(1);
+                if (i >= n_chunks) break;
+                proofs[i] = impl->prove(cx, nullptr, message + i * chunk, chunk, key, nullptr);
+            }
+        } catch (const std::exception &e) { errors[ci] = e.what(); }
+    };
+    std::vector<std::thread> threads;
+    for (size_t ci = 1; ci < n_contexts; ci++) threads.emplace_back(worker, ci);
+    worker(0);
+    for (auto &t : threads) t.join();
+    for (auto &e : errors) if (!e.empty()) throw std::runtime_error(e);
+    return proofs;
 }
 Proof ProvingKey::prove_ops(uint32_t x, uint32_t y, const uint8_t *zk_seed) {
     if (impl->circuit.kind == CIRCUIT_AES) throw std::invalid_argument("proving key was synthesized for the AES circuit");
@@ -624,18 +696,19 @@ Proof ProvingKey::prove_ops(uint32_t x, uint32_t y, const uint8_t *zk_seed) {
     uint64_t r = impl->circuit.kind == CIRCUIT_OPS_XOR ? (uint64_t)(x ^ y) : (uint64_t)x + y;
     for (int i = 0; i < 4; i++) { trace[i] = (uint8_t)(x >> (8 * i)); trace[4 + i] = (uint8_t)(y >> (8 * i)); }
     for (int i = 0; i < 8; i++) trace[8 + i] = (uint8_t)(r >> (8 * i));
-    return impl->prove(trace, nullptr, 0, nullptr, zk_seed);
+    return impl->prove(impl->context(0), trace, nullptr, 0, nullptr, zk_seed);
 }
 std::vector<uint8_t> ProvingKey::debug_fetch(const std::string &name) const {
     static const char *pn[9] = {"w", "z_a", "z_b", "mask_poly", "t", "g_1", "h_1", "g_2", "h_2"};
     static const char *in[6] = {"row", "col", "a_val", "b_val", "c_val", "row_col"};
     std::vector<uint8_t> out;
-    auto grab = [&](const void *d, size_t bytes) { out.resize(bytes); gpu::d2h(out.data(), d, bytes, impl->stream); };
-    if (name == "z") { grab(impl->d_z, impl->circuit.num_variables()); return out; }
-    if (name == "trace") { grab(impl->d_trace, impl->circuit.trace_bytes); return out; }
-    if (name == "z_a_evals") { grab(impl->za_ev.p, impl->n * sizeof(F)); return out; }
-    if (name == "z_b_evals") { grab(impl->zb_ev.p, impl->n * sizeof(F)); return out; }
-    for (int i = 0; i < 9; i++) if (name == pn[i]) { grab(impl->poly[i].p, impl->poly_len[i] * sizeof(F)); return out; }
+    ProverContext &cx = impl->context(0);
+    auto grab = [&](const void *d, size_t bytes) { out.resize(bytes); gpu::d2h(out.data(), d, bytes, cx.stream); };
+    if (name == "z") { grab(cx.d_z, impl->circuit.num_variables()); return out; }
+    if (name == "trace") { grab(cx.d_trace, impl->circuit.trace_bytes); return out; }
+    if (name == "z_a_evals") { grab(cx.za_ev.p, impl->n * sizeof(F)); return out; }
+    if (name == "z_b_evals") { grab(cx.zb_ev.p, impl->n * sizeof(F)); return out; }
+    for (int i = 0; i < 9; i++) if (name == pn[i]) { grab(cx.poly[i].p, cx.poly_len[i] * sizeof(F)); return out; }
     for (int i = 0; i < 6; i++) {
         if (name == in[i]) { grab(impl->ix_co[i].p, impl->k * sizeof(F)); return out; }
         if (name == std::string(in[i]) + "_evals") { grab(impl->ix_ev[i].p, impl->k * sizeof(F)); return out; }

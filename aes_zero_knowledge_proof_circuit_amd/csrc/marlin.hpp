@@ -58,6 +58,8 @@ class ProvingKey {
     // encrypt(): message length must equal the length the key was synthesized for; zk_seed = 32-byte StdRng seed or nullptr for
     // ark_std::test_rng()'s (what simpleworks::marlin::generate_rand() returns)
     Proof prove_aes(const uint8_t *message, size_t len, const uint8_t key[16], const uint8_t *zk_seed);
+    // ceil(len / chunk) independent chunk-proofs of a long ECB message, `n_contexts` proofs in flight on separate HIP streams
+    std::vector<Proof> prove_aes_chunked(const uint8_t *message, size_t len, const uint8_t key[16], size_t n_contexts);
     Proof prove_ops(uint32_t x, uint32_t y, const uint8_t *zk_seed);
     // witness generation only (kernels aes_trace + witness_expand): z = padded instance || witness, one byte per variable
     std::vector<uint8_t> aes_witness(const uint8_t *message, size_t len, const uint8_t key[16]);

@@ -12,6 +12,8 @@ int device_count() {
 void require_device() {
     if (device_count() <= 0) throw GpuError("no HIP device available: libzkaes proves on an AMD GPU (gfx950) and has no CPU fallback");
 }
+int current_device() { int d = 0; HIP_CHECK(hipGetDevice(&d)); return d; }
+void set_device(int ordinal) { HIP_CHECK(hipSetDevice(ordinal)); }
 void *dmalloc(size_t bytes) { void *p = nullptr; HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16)); return p; }
 void dfree(void *p) { if (p) (void)hipFree(p); }
 void h2d(void *dst, const void *src, size_t bytes, stream_t s) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)s)); }
