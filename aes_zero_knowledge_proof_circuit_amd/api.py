@@ -213,10 +213,24 @@ def msm(curve_id, bases_bytes, scalars_bytes):
     return out.raw, bool(inf.value)
 
 
+def msm_table(curve_id, bases_bytes, scalars_bytes, window_bits):
+    n = len(scalars_bytes) // 32
+    out = C.create_string_buffer(96)
+    inf = C.c_int()
+    _check(lib().zkaes_msm_table(int(curve_id), bytes(bases_bytes), bytes(scalars_bytes), C.c_size_t(n), int(window_bits), out, C.byref(inf)))
+    return out.raw, bool(inf.value)
+
+
 def msm_bench(curve_id, bases_bytes, scalars_bytes, reps=3):
     n = len(scalars_bytes) // 32
     t, a = C.c_double(), C.c_double()
     _check(lib().zkaes_msm_bench(int(curve_id), bytes(bases_bytes), bytes(scalars_bytes), C.c_size_t(n), int(reps), C.byref(t), C.byref(a)))
+    return t.value, a.value
+
+
+def msm_bench_synth(n, window_bits=0, reps=3):
+    t, a = C.c_double(), C.c_double()
+    _check(lib().zkaes_msm_bench_synth(C.c_size_t(n), int(window_bits), int(reps), C.byref(t), C.byref(a)))
     return t.value, a.value
 
 

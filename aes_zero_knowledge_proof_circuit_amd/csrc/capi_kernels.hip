@@ -35,14 +35,16 @@ template <class Curve> void run_msm(const uint8_t *bases, const uint8_t *scalars
     zk::Affine<Fq> *db = (zk::Affine<Fq> *)zk::gpu::dmalloc(n * 96);
     Fr *ds = (Fr *)zk::gpu::dmalloc(n * 32);
     zk::gpu::h2d(db, bases, n * 96, s); zk::gpu::h2d(ds, scalars, n * 32, s);
+    zk::Affine28<typename Curve::FqP> *db28 = (zk::Affine28<typename Curve::FqP> *)zk::gpu::dmalloc(n * sizeof(zk::Affine28<typename Curve::FqP>));
+    zk::gpu::convert_bases<Curve>(db28, db, n, s);
     zk::gpu::sync(s);
     zk::gpu::MsmWorkspace *ws = zk::gpu::msm_workspace_create();
-    zk::XYZZ<Fq> r = zk::gpu::msm<Curve>(ws, db, ds, n, s);   // warm-up / result
+    zk::XYZZ<Fq> r = zk::gpu::msm<Curve>(ws, db28, ds, n, s);   // warm-up / result
     if (reps > 0) {
         zk::gpu::MsmStats before = zk::gpu::msm_stats(false);
         void *e0 = zk::gpu::event_create(), *e1 = zk::gpu::event_create();
         zk::gpu::event_record(e0, s);
-        for (int i = 0; i < reps; i++) r = zk::gpu::msm<Curve>(ws, db, ds, n, s);
+        for (int i = 0; i < reps; i++) r = zk::gpu::msm<Curve>(ws, db28, ds, n, s);
         zk::gpu::event_record(e1, s);
         float ms = zk::gpu::event_elapsed_ms(e0, e1);
         zk::gpu::MsmStats after = zk::gpu::msm_stats(false);
@@ -54,11 +56,35 @@ template <class Curve> void run_msm(const uint8_t *bases, const uint8_t *scalars
     if (out_inf) *out_inf = a.is_inf() ? 1 : 0;
     if (out_xy) { memcpy(out_xy, a.x.l, 48); memcpy(out_xy + 48, a.y.l, 48); }
     zk::gpu::msm_workspace_destroy(ws);
+    zk::gpu::dfree(db28);
     zk::gpu::dfree(db); zk::gpu::dfree(ds); zk::gpu::stream_destroy(s);
+}
+template <class Curve> void run_msm_table(const uint8_t *bases, const uint8_t *scalars, size_t n, int c, uint8_t *out_xy, int *out_inf) {
+    using Fq = typename Curve::Fq; using Fr = typename Curve::Fr;
+    zk::gpu::require_device();
+    if (c < 2 || c > 22) throw std::invalid_argument("window bits must be in [2, 22]");
+    zk::gpu::stream_t s = zk::gpu::stream_create();
+    const size_t nt = (size_t)zk::gpu::table_windows<Curve>(c);
+    zk::Affine<Fq> *tab = (zk::Affine<Fq> *)zk::gpu::dmalloc(nt * n * 96);
+    Fr *ds = (Fr *)zk::gpu::dmalloc(n * 32);
+    zk::gpu::h2d(tab, bases, n * 96, s); zk::gpu::h2d(ds, scalars, n * 32, s);
+    zk::gpu::build_window_tables<Curve>(tab, n, c, s);
+    zk::Affine28<typename Curve::FqP> *tab28 = (zk::Affine28<typename Curve::FqP> *)zk::gpu::dmalloc(nt * n * sizeof(zk::Affine28<typename Curve::FqP>));
+    zk::gpu::convert_bases<Curve>(tab28, tab, nt * n, s);
+    zk::gpu::MsmWorkspace *ws = zk::gpu::msm_workspace_create();
+    zk::Affine<Fq> a = zk::gpu::msm_table<Curve>(ws, tab28, n, 0, c, ds, n, s).to_affine();
+    zk::gpu::dfree(tab28);
+    if (out_inf) *out_inf = a.is_inf() ? 1 : 0;
+    if (out_xy) { memcpy(out_xy, a.x.l, 48); memcpy(out_xy + 48, a.y.l, 48); }
+    zk::gpu::msm_workspace_destroy(ws);
+    zk::gpu::dfree(tab); zk::gpu::dfree(ds); zk::gpu::stream_destroy(s);
 }
 }  // namespace
 
 extern "C" {
+int zkaes_msm_table(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, int window_bits, uint8_t *out_xy, int *out_inf) {
+    return guardk([&] { if (curve_id == 381) run_msm_table<zk::Bls381>(bases, scalars, n, window_bits, out_xy, out_inf); else if (curve_id == 377) run_msm_table<zk::Bls377>(bases, scalars, n, window_bits, out_xy, out_inf); else throw std::invalid_argument("curve_id must be 377 or 381"); });
+}
 int zkaes_set_device(int ordinal) { return guardk([&] { HIP_CHECK(hipSetDevice(ordinal)); }); }
 int zkaes_ntt(int field_id, uint8_t *data, size_t n, int inverse) {
     return guardk([&] { if (field_id == 381) run_ntt<zk::Fr381>(data, n, inverse); else if (field_id == 377) run_ntt<zk::Fr377>(data, n, inverse); else throw std::invalid_argument("field_id must be 377 or 381"); });
@@ -68,5 +94,43 @@ int zkaes_msm(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t
 }
 int zkaes_msm_bench(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, int reps, double *ms_total, double *ms_accumulate) {
     return guardk([&] { if (curve_id == 381) run_msm<zk::Bls381>(bases, scalars, n, nullptr, nullptr, reps, ms_total, ms_accumulate); else run_msm<zk::Bls377>(bases, scalars, n, nullptr, nullptr, reps, ms_total, ms_accumulate); });
+}
+// BLS12-377 only: n_points synthetic bases (powers of a fixed scalar times the generator, made on the device) and pseudo-random scalars;
+// window_bits = 0 -> classic per-window buckets, else the precomputed-table path.  Returns ms per MSM (whole pipeline / accumulate kernel).
+int zkaes_msm_bench_synth(size_t n, int window_bits, int reps, double *ms_total, double *ms_accumulate) {
+    return guardk([&] {
+        using Fq = zk::Fq377; using Fr = zk::Fr377;
+        zk::gpu::require_device();
+        zk::gpu::stream_t s = zk::gpu::stream_create();
+        const size_t nt = window_bits ? (size_t)zk::gpu::table_windows<zk::Bls377>(window_bits) : 1;
+        zk::Affine<Fq> *tab = (zk::Affine<Fq> *)zk::gpu::dmalloc(nt * n * 96);
+        zk::Affine<Fq> g; for (int i = 0; i < 12; i++) { g.x.l[i] = G1_377_X_MONT[i]; g.y.l[i] = G1_377_Y_MONT[i]; }
+        Fr beta = Fr::from_u64(0x9e3779b97f4a7c15ull) * Fr::from_u64(0xc2b2ae3d27d4eb4full);
+        zk::gpu::fixed_base_powers<zk::Bls377>(tab, g, beta, 1, n, s);
+        if (window_bits) zk::gpu::build_window_tables<zk::Bls377>(tab, n, window_bits, s);
+        zk::Affine28<zk::Fq377P> *tab28 = (zk::Affine28<zk::Fq377P> *)zk::gpu::dmalloc(nt * n * sizeof(zk::Affine28<zk::Fq377P>));
+        zk::gpu::convert_bases<zk::Bls377>(tab28, tab, nt * n, s);
+        std::vector<Fr> sc(n);
+        uint64_t x = 88172645463325252ull;
+        for (size_t i = 0; i < n; i++) { for (int k = 0; k < 8; k += 2) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; sc[i].l[k] = (uint32_t)x; sc[i].l[k + 1] = (uint32_t)(x >> 32); } sc[i].l[7] &= 0x0fffffffu; }
+        Fr *ds = (Fr *)zk::gpu::dmalloc(n * 32);
+        zk::gpu::h2d(ds, sc.data(), n * 32, s);
+        zk::gpu::sync(s);
+        zk::gpu::MsmWorkspace *ws = zk::gpu::msm_workspace_create();
+        auto run = [&] { return window_bits ? zk::gpu::msm_table<zk::Bls377>(ws, tab28, n, 0, window_bits, ds, n, s) : zk::gpu::msm<zk::Bls377>(ws, tab28, ds, n, s); };
+        run();
+        zk::gpu::MsmStats before = zk::gpu::msm_stats(false);
+        void *e0 = zk::gpu::event_create(), *e1 = zk::gpu::event_create();
+        zk::gpu::event_record(e0, s);
+        for (int i = 0; i < reps; i++) run();
+        zk::gpu::event_record(e1, s);
+        float ms = zk::gpu::event_elapsed_ms(e0, e1);
+        zk::gpu::MsmStats after = zk::gpu::msm_stats(false);
+        *ms_total = ms / reps; *ms_accumulate = (after.accumulate_ms - before.accumulate_ms) / reps;
+        zk::gpu::event_destroy(e0); zk::gpu::event_destroy(e1);
+        zk::gpu::msm_workspace_destroy(ws);
+        zk::gpu::dfree(tab28);
+        zk::gpu::dfree(tab); zk::gpu::dfree(ds); zk::gpu::stream_destroy(s);
+    });
 }
 }

@@ -7,6 +7,7 @@
 // (Cargo.lock:118) for this path.
 #pragma once
 #include "ff.cuh"
+#include "ff28.cuh"
 
 // The group operations are deliberately NOT inlined on the device: each is 9-14 Fq products (~300 VALU instructions
 // apiece), so a call costs <1% while keeping kernels (and hipcc's compile time) bounded.
@@ -116,14 +117,23 @@ ZK_HD bool on_curve(const Affine<Fq> &a, const Fq &b) {
     return a.y.sqr() == a.x.sqr() * a.x + b;
 }
 
+// affine point in the reduced-radix form the MSM accumulate kernel consumes (ff28.cuh): 2 x 14 x 28-bit limbs = 112 B, (0,0) = infinity
+template <class P>
+struct Affine28 {
+    Fp28<P> x, y;
+    ZK_HD bool is_inf() const { return x.limbs_zero() && y.limbs_zero(); }
+    ZK_HD static Affine28 from_std(const Affine<Fp<P>> &a) { Affine28 r; r.x = Fp28<P>::from_std(a.x); r.y = Fp28<P>::from_std(a.y); return r; }
+    ZK_HD Affine<Fp<P>> to_std() const { Affine<Fp<P>> r; r.x = x.to_std(); r.y = y.to_std(); return r; }
+};
+
 // per-curve bundles
 struct Bls377 {
-    using Fr = Fr377; using Fq = Fq377;
+    using Fr = Fr377; using Fq = Fq377; using FqP = Fq377P;
     static constexpr int ID = 377;
     ZK_HD static Fq b() { Fq v; constexpr uint32_t t[12] = FQ377_ONE_INIT; for (int i = 0; i < 12; i++) v.l[i] = t[i]; return v; }   // b = 1
 };
 struct Bls381 {
-    using Fr = Fr381; using Fq = Fq381;
+    using Fr = Fr381; using Fq = Fq381; using FqP = Fq381P;
     static constexpr int ID = 381;
     ZK_HD static Fq b() { Fq v = Fq::one(); v = v.dbl().dbl(); return v; }   // b = 4
 };

@@ -1,0 +1,167 @@
+// csrc/ff28.cuh -- reduced-radix ("lazy carry") Montgomery arithmetic for the 377/381-bit base fields on gfx950.
+//
+// Why: a 12x32-bit CIOS product compiles to 276 v_mad_u64_u32 + ~1000 full-rate fix-up instructions (64-bit adds and
+// register-pair moves that only propagate carries); on MI355X v_mad_u64_u32 issues at ~0.4x the simple-VALU rate, so the
+// fix-ups cost more than the multiplies (tools/ubench/rates.hip).  With 14 limbs of 28 bits a limb product is < 2^56 and a 64-bit
+// accumulator absorbs all 28 products of a column, so the whole product is v_mad_u64_u32 with the accumulator as the addend:
+// 2 * 14^2 = 392 multiply-accumulates and ~100 shifts/masks, no carry chain.
+//
+// Representation: value = sum l[i] 2^(28 i), limbs normalized to < 2^28 after every operation, Montgomery radix R' = 2^392.
+// "Almost Montgomery": R' > 2^13 p, so for inputs < 64 p the product is < 1.2 p and NO conditional subtraction is needed; additions and
+// subtractions let values grow (sub adds a multiple of p) and callers bound them statically (see madd28 in kernels_msm.hip).
+// Conversion from the library-wide 12x32 form (R = 2^384): split limbs, multiply by 2^8 R' mod p; back: multiply by R mod p... (to_std).
+#pragma once
+#include "ff.cuh"
+
+namespace zk {
+
+template <class P>   // P = Fq377P / Fq381P (12 x 32-bit parameter pack)
+struct Fp28 {
+    static constexpr int N = 14;
+    static constexpr uint32_t MASK = (1u << 28) - 1;
+    uint32_t l[N];
+
+    // ---- constants derived at compile time from the 32-bit parameter pack
+    ZK_HD static constexpr uint32_t mod28(int i) {           // limb i of p in radix 2^28
+        int bit = 28 * i, w = bit >> 5, sh = bit & 31;
+        uint64_t two = (w < P::N ? (uint64_t)P::mod(w) : 0) | ((w + 1 < P::N ? (uint64_t)P::mod(w + 1) : 0) << 32);
+        return (uint32_t)(two >> sh) & MASK;
+    }
+    static constexpr uint32_t PINV = P::INV & MASK;   // -p^-1 mod 2^28 = the low 28 bits of -p^-1 mod 2^32
+
+    ZK_HD static Fp28 zero() { Fp28 r; for (int i = 0; i < N; i++) r.l[i] = 0; return r; }
+    ZK_HD bool limbs_zero() const { uint32_t o = 0; for (int i = 0; i < N; i++) o |= l[i]; return o == 0; }
+
+    // split a 12x32 little-endian integer into 28-bit limbs (no arithmetic)
+    ZK_HD static Fp28 split(const uint32_t *w) {
+        Fp28 r;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            int bit = 28 * i, k = bit >> 5, sh = bit & 31;
+            uint64_t two = (k < P::N ? (uint64_t)w[k] : 0) | ((k + 1 < P::N ? (uint64_t)w[k + 1] : 0) << 32);
+            r.l[i] = (uint32_t)(two >> sh) & MASK;
+        }
+        return r;
+    }
+    // pack normalized limbs (value < 2^384) back into 12x32
+    ZK_HD void pack(uint32_t *w) const {
+#pragma unroll
+        for (int k = 0; k < P::N; k++) {
+            int bit = 32 * k, i = bit / 28, sh = bit % 28;     // word k = bits [32k, 32k+32)
+            uint64_t v = (uint64_t)l[i] >> sh;
+            int have = 28 - sh;
+            if (i + 1 < N) v |= (uint64_t)l[i + 1] << have;
+            if (have + 28 < 32 && i + 2 < N) v |= (uint64_t)l[i + 2] << (have + 28);
+            w[k] = (uint32_t)v;
+        }
+    }
+    // carry-propagate signed 64-bit limb values into normalized limbs (top limb keeps the excess)
+    ZK_HD static Fp28 normalize(const int64_t *t) {
+        Fp28 r;
+        int64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < N - 1; i++) { int64_t v = t[i] + c; r.l[i] = (uint32_t)v & MASK; c = v >> 28; }
+        r.l[N - 1] = (uint32_t)(t[N - 1] + c);
+        return r;
+    }
+    // a + b (no modular reduction; value grows)
+    ZK_HD Fp28 operator+(const Fp28 &b) const {
+        Fp28 r;
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < N - 1; i++) { uint32_t v = l[i] + b.l[i] + c; r.l[i] = v & MASK; c = v >> 28; }
+        r.l[N - 1] = l[N - 1] + b.l[N - 1] + c;
+        return r;
+    }
+    ZK_HD Fp28 dbl() const { return *this + *this; }
+    // a - b + K p, K chosen by the caller so that K p >= b (keeps the result non-negative)
+    template <int K>
+    ZK_HD Fp28 sub(const Fp28 &b) const {
+        Fp28 r;
+        int32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < N - 1; i++) {
+            int64_t v = (int64_t)l[i] - b.l[i] + (int64_t)K * mod28(i) + c;
+            r.l[i] = (uint32_t)v & MASK; c = (int32_t)(v >> 28);
+        }
+        r.l[N - 1] = (uint32_t)((int64_t)l[N - 1] - b.l[N - 1] + (int64_t)K * mod28(N - 1) + c);
+        return r;
+    }
+
+    // almost-Montgomery product: row-wise operand scanning, 64-bit column accumulators, no carry chain
+    ZK_HD Fp28 operator*(const Fp28 &b) const {
+        uint64_t t[2 * N];
+#pragma unroll
+        for (int i = 0; i < 2 * N; i++) t[i] = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+#pragma unroll
+            for (int j = 0; j < N; j++) t[i + j] += (uint64_t)l[j] * b.l[i];
+            uint32_t m = (((uint32_t)t[i] & MASK) * PINV) & MASK;
+#pragma unroll
+            for (int j = 0; j < N; j++) t[i + j] += (uint64_t)m * mod28(j);
+            t[i + 1] += t[i] >> 28;
+        }
+        Fp28 r;
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < N - 1; i++) { uint64_t v = t[N + i] + c; r.l[i] = (uint32_t)v & MASK; c = v >> 28; }
+        r.l[N - 1] = (uint32_t)(t[2 * N - 1] + c);
+        return r;
+    }
+    ZK_HD Fp28 sqr() const { return *this * *this; }
+
+    // fully reduce a value < 64 p to the canonical range [0, p) (used only at conversions and for zero tests)
+    ZK_HD Fp28 canonical() const {
+        Fp28 v = *this;
+        // subtract p while v >= p: at most 64 rounds would be wasteful; peel powers of two: 32p, 16p, ... p
+#pragma unroll
+        for (int k = 5; k >= 0; k--) {
+            // t = v - (2^k) p
+            int64_t c = 0;
+            uint32_t tl[N];
+#pragma unroll
+            for (int i = 0; i < N - 1; i++) { int64_t x = (int64_t)v.l[i] - ((int64_t)mod28(i) << k) + c; tl[i] = (uint32_t)x & MASK; c = x >> 28; }
+            int64_t top = (int64_t)v.l[N - 1] - ((int64_t)mod28(N - 1) << k) + c;
+            if (top >= 0) {
+#pragma unroll
+                for (int i = 0; i < N - 1; i++) v.l[i] = tl[i];
+                v.l[N - 1] = (uint32_t)top;
+            }
+        }
+        return v;
+    }
+    ZK_HD bool is_zero_mod_p() const { return canonical().limbs_zero(); }
+
+    // constants: 2^8 R' mod p ... obtained at run time from the 32-bit field (host + device) to avoid a second generated table
+    ZK_HD static Fp28 from_std(const Fp<P> &a) {
+        // a = x R (R = 2^384).  want x R' (R' = 2^392) = a 2^8.  mul28(split(a), c) = a c / R'  with c = 2^8 R'^1 ... = 2^400 mod p
+        Fp28 s = split(a.l);
+        return s * k_2_400();
+    }
+    ZK_HD Fp<P> to_std() const {
+        // w = x R'.  mul28(w, 2^384 mod p) = x 2^384 = standard Montgomery form; then canonicalize and repack
+        Fp28 y = (*this * k_2_384()).canonical();
+        Fp<P> r;
+        y.pack(r.l);
+        return r;
+    }
+    // 2^400 mod p and 2^384 mod p as 28-bit limb integers, computed from Fp<P> (R = 2^384: one() = 2^384 mod p)
+    ZK_HD static Fp28 k_2_384() { Fp<P> o = Fp<P>::one(); return split(o.l); }
+    ZK_HD static Fp28 k_2_392() {               // the Montgomery one of this representation (R' mod p)
+        Fp<P> v = Fp<P>::one();
+        for (int i = 0; i < 8; i++) v = v.dbl();
+        return split(v.l);
+    }
+    ZK_HD static Fp28 k_2_400() {
+        // 2^400 mod p = (2^384 mod p) * 2^16 mod p : in Montgomery form of Fp<P>: from_u64(2^16) * one ... compute raw integer:
+        Fp<P> v = Fp<P>::one();                 // raw limbs = 2^384 mod p  (as an integer)
+        for (int i = 0; i < 16; i++) v = v.dbl();   // integer doubling mod p of the raw limbs (Fp add is plain modular add on the limbs)
+        return split(v.l);
+    }
+};
+
+using Fq377x28 = Fp28<Fq377P>;
+using Fq381x28 = Fp28<Fq381P>;
+
+}  // namespace zk

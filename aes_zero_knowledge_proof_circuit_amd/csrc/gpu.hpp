@@ -44,8 +44,17 @@ template <class Fr> const Fr *domain_elements(int lg);   // device table g^i, i 
 struct MsmWorkspace;
 MsmWorkspace *msm_workspace_create();
 void msm_workspace_destroy(MsmWorkspace *ws);
+// Bases are consumed in the reduced-radix form (Affine28, ff28.cuh): convert once with convert_bases (the SRS at key synthesis).
+template <class Curve> void convert_bases(Affine28<typename Curve::FqP> *dst, const Affine<typename Curve::Fq> *src, size_t n, stream_t s);
 template <class Curve>
-XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws, const Affine<typename Curve::Fq> *bases, const typename Curve::Fr *scalars, size_t n, stream_t s);
+XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws, const Affine28<typename Curve::FqP> *bases, const typename Curve::Fr *scalars, size_t n, stream_t s);
+// Precomputed-window variant for FIXED bases (the SRS): tables[j * stride + i] = 2^(c j) * P_i for j < table_windows(c); with one
+// table copy per window all windows share ONE bucket set, so bucket reduction is paid once and c can grow (fewer windows = fewer adds).
+// build_window_tables fills copies 1.. from copy 0 (already in tables[0..stride)); msm_table sums scalars[i] * P_{off+i}, i < n.
+template <class Curve> int table_windows(int c);
+template <class Curve> void build_window_tables(Affine<typename Curve::Fq> *tables, size_t stride, int c, stream_t s);
+template <class Curve>
+XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws, const Affine28<typename Curve::FqP> *tables, size_t stride, size_t off, int c, const typename Curve::Fr *scalars, size_t n, stream_t s);
 // out[i] = (beta^(from+i)) * base for i < count   (KZG powers; fixed-base windows)   -- device output
 template <class Curve>
 void fixed_base_powers(Affine<typename Curve::Fq> *out, const Affine<typename Curve::Fq> &base, const typename Curve::Fr &beta, size_t from, size_t count, stream_t s);

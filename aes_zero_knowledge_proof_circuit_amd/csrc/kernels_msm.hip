@@ -44,6 +44,52 @@ __global__ void k_digits(const Fr *__restrict__ scalars, uint32_t n, int c, int 
     }
 }
 
+// table mode: every window j reads its own precomputed copy T_j[i] = 2^(c j) * P_i, so all windows share ONE bucket set:
+// key = digit, value = absolute index j * stride + base_off + i into the table array
+template <class Fr>
+__global__ void k_digits_table(const Fr *__restrict__ scalars, uint32_t n, int c, int nwin, uint32_t stride, uint32_t base_off, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t raw[Fr::N + 1];
+    scalars[i].to_raw(raw);
+    raw[Fr::N] = 0;
+    uint32_t mask = (1u << c) - 1;
+    for (int w = 0; w < nwin; w++) {
+        int bit = w * c, limb = bit >> 5, sh = bit & 31;
+        uint64_t two = (uint64_t)raw[limb] | ((uint64_t)raw[limb + 1] << 32);
+        keys[(size_t)w * n + i] = (uint32_t)(two >> sh) & mask;
+        vals[(size_t)w * n + i] = (uint32_t)w * stride + base_off + i;
+    }
+}
+// T_j = 2^c * T_{j-1}: 8 points per lane, c doublings each, ONE field inversion per lane (Montgomery's trick) back to affine
+template <class Fq>
+__global__ void __launch_bounds__(64) k_table_next(const Affine<Fq> *__restrict__ prev, Affine<Fq> *__restrict__ next, uint32_t count, int c) {
+    constexpr int B = 8;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s0 = t * B;
+    if (s0 >= count) return;
+    uint32_t e = s0 + B < count ? s0 + B : count;
+    Fq xs[B], ys[B], zz[B], zzz[B], pre[B];
+    Fq acc = Fq::one();
+    for (uint32_t i = s0; i < e; i++) {
+        XYZZ<Fq> p = XYZZ<Fq>::from_affine(prev[i]);
+        for (int k = 0; k < c; k++) p = p.dbl();
+        xs[i - s0] = p.x; ys[i - s0] = p.y; zz[i - s0] = p.zz; zzz[i - s0] = p.zzz;
+        pre[i - s0] = acc;
+        if (!p.zzz.is_zero()) acc = acc * p.zzz;
+    }
+    acc = acc.inverse();
+    for (uint32_t i = e; i-- > s0;) {
+        uint32_t q = i - s0;
+        if (zzz[q].is_zero()) { next[i] = Affine<Fq>::inf(); continue; }
+        Fq zi3 = acc * pre[q];          // 1 / ZZZ_i
+        acc = acc * zzz[q];
+        Fq zi2 = (zi3 * zz[q]).sqr();   // 1 / ZZ_i
+        Affine<Fq> a; a.x = xs[q] * zi2; a.y = ys[q] * zi3;
+        next[i] = a;
+    }
+}
+
 __global__ void k_bounds(const uint32_t *__restrict__ keys, size_t total, uint32_t *__restrict__ start, uint32_t *__restrict__ end) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -52,20 +98,39 @@ __global__ void k_bounds(const uint32_t *__restrict__ keys, size_t total, uint32
     if (i + 1 == total || keys[i + 1] != k) end[k] = (uint32_t)(i + 1);
 }
 
-// mixed add with every Fq product inlined (hot path of k_accumulate).  Returns false when the generic formula does not apply
-// (accumulator at infinity, or P == +-Q): the caller then takes the out-of-line XYZZ::madd.
-template <class Fq>
-__device__ __forceinline__ bool madd_fast(XYZZ<Fq> &a, const Affine<Fq> &q) {
-    Fq u2 = q.x * a.zz, s2 = q.y * a.zzz;
-    Fq p = u2 - a.x, r = s2 - a.y;
-    if (p.is_zero()) return false;
-    Fq pp = p.sqr(), ppp = p * pp, qq = a.x * pp;
-    Fq x3 = r.sqr() - ppp - qq.dbl();
-    a.y = r * (qq - x3) - a.y * ppp;
-    a.x = x3;
+// Bucket accumulator in the reduced-radix form (ff28.cuh).  Values are NOT kept below p: the bounds are tracked statically --
+//   x < 6.2 p, y < 3.2 p, zz, zzz < 1.2 p (products) -- and every subtraction adds the multiple of p that keeps it non-negative.
+template <class P>
+struct Acc28 { Fp28<P> x, y, zz, zzz; };
+
+// mixed add, every product inlined, no carry chains (hot path of k_accumulate).  Returns false for P == +-Q (left to the fix-up pass).
+template <class P>
+__device__ __forceinline__ bool madd28(Acc28<P> &a, const Affine28<P> &q) {
+    using G = Fp28<P>;
+    G u2 = q.x * a.zz, s2 = q.y * a.zzz;                        // < 1.2 p
+    G pd = u2.template sub<7>(a.x), r = s2.template sub<4>(a.y); // < 8.2 p, < 5.2 p
+    G pp = pd.sqr();                                            // < 1.2 p ; pd == 0 (mod p)  <=>  pp in {0, p}
+    {
+        uint32_t z0 = 0, zp = 0;
+#pragma unroll
+        for (int i = 0; i < G::N; i++) { z0 |= pp.l[i]; zp |= pp.l[i] ^ G::mod28(i); }
+        if (z0 == 0 || zp == 0) return false;
+    }
+    G ppp = pd * pp, qq = a.x * pp;
+    G x3 = (r.sqr().template sub<2>(ppp)).template sub<3>(qq.dbl());   // r^2 - ppp - 2 qq + 5p  < 6.2 p
+    G t = qq.template sub<7>(x3);                                      // < 8.2 p
+    G y3 = (r * t).template sub<2>(a.y * ppp);                         // < 3.2 p
+    a.x = x3; a.y = y3;
     a.zz = a.zz * pp;
     a.zzz = a.zzz * ppp;
     return true;
+}
+
+// standard (12 x 32, R = 2^384) bases -> reduced-radix copies; done once per SRS at key synthesis, or per call for ad-hoc bases
+template <class P>
+__global__ void k_convert_bases(const Affine<Fp<P>> *__restrict__ src, Affine28<P> *__restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = Affine28<P>::from_std(src[i]);
 }
 
 __global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, uint32_t nb, uint32_t *__restrict__ size_key, uint32_t *__restrict__ ids) {
@@ -78,46 +143,52 @@ __global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_
 
 // ONE LANE PER BUCKET, buckets visited in descending-size order so the 64 lanes of a wave run the same trip count.
 // The loop body has no function call: the (cryptographically negligible, but reachable with repeated bases) P == +-Q case is
-// appended to a deferred list and replayed by k_accumulate_fixup with the complete addition law.
-template <class Fq>
-__global__ void __launch_bounds__(64, 2) k_accumulate(const Affine<Fq> *__restrict__ bases, const uint32_t *__restrict__ vals,
-                                                    const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, const uint32_t *__restrict__ order,
-                                                    uint32_t nbuckets_total, uint32_t digit_mask, XYZZ<Fq> *__restrict__ buckets,
-                                                    uint32_t *__restrict__ deferred, uint32_t deferred_cap, uint32_t *__restrict__ deferred_count) {
+// appended to a deferred list and replayed by k_accumulate_fixup with the complete addition law.  The accumulator lives in the
+// reduced-radix form for the whole loop and is converted to the library-wide XYZZ form once, at the store.
+template <class P>
+__global__ void __launch_bounds__(64, 2) k_accumulate(const Affine28<P> *__restrict__ bases, const uint32_t *__restrict__ vals,
+                                                       const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, const uint32_t *__restrict__ order,
+                                                       uint32_t nbuckets_total, uint32_t digit_mask, XYZZ<Fp<P>> *__restrict__ buckets,
+                                                       uint32_t *__restrict__ deferred, uint32_t deferred_cap, uint32_t *__restrict__ deferred_count) {
+    using G = Fp28<P>;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nbuckets_total) return;
     uint32_t k = order[t];
-    XYZZ<Fq> acc = XYZZ<Fq>::inf();
+    Acc28<P> acc;
+    bool acc_inf = true;
     if ((k & digit_mask) != 0) {
         uint32_t s = start[k], e = end[k];
         if (s < e) {
             uint32_t idx = vals[s];
-            Affine<Fq> nxt = bases[idx];
+            Affine28<P> nxt = bases[idx];
             for (uint32_t i = s; i < e; i++) {
-                Affine<Fq> p = nxt;
+                Affine28<P> p = nxt;
                 uint32_t cur = idx;
                 if (i + 1 < e) { idx = vals[i + 1]; nxt = bases[idx]; }   // prefetch the next gather under this add's ALU work
                 if (p.is_inf()) continue;
-                if (acc.zz.is_zero()) { acc.x = p.x; acc.y = p.y; acc.zz = Fq::one(); acc.zzz = Fq::one(); continue; }
-                if (!madd_fast(acc, p)) {
+                if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_2_392(); acc.zzz = acc.zz; acc_inf = false; continue; }
+                if (!madd28(acc, p)) {
                     uint32_t slot = atomicAdd(deferred_count, 1u);
                     if (slot < deferred_cap) { deferred[2 * slot] = k; deferred[2 * slot + 1] = cur; }
                 }
             }
         }
     }
-    buckets[k] = acc;
+    XYZZ<Fp<P>> out;
+    if (acc_inf) out = XYZZ<Fp<P>>::inf();
+    else { out.x = acc.x.to_std(); out.y = acc.y.to_std(); out.zz = acc.zz.to_std(); out.zzz = acc.zzz.to_std(); }
+    buckets[k] = out;
 }
 // replay of the deferred (bucket, point) pairs with the complete formulas; one lane, sequential (the list is empty in practice)
-template <class Fq>
-__global__ void k_accumulate_fixup(const Affine<Fq> *__restrict__ bases, XYZZ<Fq> *__restrict__ buckets, const uint32_t *__restrict__ deferred, uint32_t deferred_cap,
+template <class P>
+__global__ void k_accumulate_fixup(const Affine28<P> *__restrict__ bases, XYZZ<Fp<P>> *__restrict__ buckets, const uint32_t *__restrict__ deferred, uint32_t deferred_cap,
                                    const uint32_t *__restrict__ deferred_count) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     uint32_t n = *deferred_count;
     if (n > deferred_cap) n = deferred_cap;
     for (uint32_t i = 0; i < n; i++) {
-        XYZZ<Fq> b = buckets[deferred[2 * i]];
-        b.madd(bases[deferred[2 * i + 1]]);
+        XYZZ<Fp<P>> b = buckets[deferred[2 * i]];
+        b.madd(bases[deferred[2 * i + 1]].to_std());
         buckets[deferred[2 * i]] = b;
     }
 }
@@ -220,6 +291,7 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
         S.buckets = dmalloc(buckets * 192);
         S.seg_s = dmalloc((buckets / RED_L1 + 64) * 192); S.seg_w = dmalloc((buckets / RED_L1 + 64) * 192);
         S.partial = dmalloc((buckets / (RED_L1 * RED_L2) + 64 * 64) * 192); S.wsum = dmalloc(192 * 64);
+        // (window sums: at most 64 sets)
     }
     (void)xyzz_bytes;
 }
@@ -232,29 +304,14 @@ void msm_workspace_destroy(MsmWorkspace *w) {
     delete w;
 }
 
-template <class Curve>
-XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws_, const Affine<typename Curve::Fq> *bases, const typename Curve::Fr *scalars, size_t n, stream_t s_) {
-    using Fq = typename Curve::Fq;
-    using Fr = typename Curve::Fr;
-    static_assert(sizeof(XYZZ<Fq>) == 192, "XYZZ layout");
-    hipStream_t s = (hipStream_t)s_;
-    if (n == 0) return XYZZ<Fq>::inf();
-    if (n >= (1u << 31)) throw GpuError("msm: too many points");
-    auto t_begin = std::chrono::steady_clock::now();
-    int lg = 0;
-    while (((size_t)1 << lg) < n) lg++;
-    int c = lg - 3;
-    if (c < 6) c = 6;
-    if (c > 16) c = 16;
-    const int nwin = (Fr::BITS + c - 1) / c;
-    size_t pairs = n * (size_t)nwin, nb = (size_t)nwin << c;
-    if (!ws_) throw GpuError("msm: null workspace");
-    MsmWorkspace &S = *ws_;
-    ensure_scratch(S, pairs, nb, sizeof(XYZZ<Fq>));
-    hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scalars, (uint32_t)n, c, nwin, S.keys_a, S.vals_a);
-    HIP_LAUNCH_CHECK();
+// shared tail: sort the (key, value) pairs, find bucket ranges, visit buckets by descending size, accumulate, reduce.
+// nsets bucket sets of 2^c buckets each (keys < nsets << c); returns the nsets window sums.
+template <class P>
+static std::vector<XYZZ<Fp<P>>> run_buckets(MsmWorkspace &S, const Affine28<P> *bases, size_t pairs, int c, int nsets, size_t n_points, hipStream_t s, float *acc_ms) {
+    using Fq = Fp<P>;
+    size_t nb = (size_t)nsets << c;
     int key_bits = c;
-    while ((1 << (key_bits - c)) < nwin) key_bits++;
+    while ((1 << (key_bits - c)) < nsets) key_bits++;
     size_t tmp_bytes = 0;
     HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys_a, S.keys_b, S.vals_a, S.vals_b, (int)pairs, 0, key_bits, s));
     if (tmp_bytes > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tmp_bytes); S.cap_tmp = tmp_bytes; }
@@ -267,51 +324,120 @@ XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws_, const Affine<typename Curve::Fq>
     hipLaunchKernelGGL(k_bucket_sizes, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, S.start, S.end, (uint32_t)nb, S.size_key, S.ids);
     HIP_LAUNCH_CHECK();
     {
-        int size_bits = 1;
-        while (((size_t)1 << size_bits) <= n && size_bits < 32) size_bits++;
         size_t tb = 0;
         HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, S.size_key, S.size_key2, S.ids, S.order, (int)nb, 0, 32, s));
         if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
         HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp, tb, S.size_key, S.size_key2, S.ids, S.order, (int)nb, 0, 32, s));
-        (void)size_bits;
     }
     HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 4, s));
     HIP_CHECK(hipEventRecord(S.ev0, s));
-    hipLaunchKernelGGL((k_accumulate<Fq>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, bases, S.vals_b, S.start, S.end, S.order, (uint32_t)nb, (1u << c) - 1,
+    hipLaunchKernelGGL((k_accumulate<P>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, bases, S.vals_b, S.start, S.end, S.order, (uint32_t)nb, (1u << c) - 1,
                        (XYZZ<Fq> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
     HIP_CHECK(hipEventRecord(S.ev1, s));
-    hipLaunchKernelGGL((k_accumulate_fixup<Fq>), dim3(1), dim3(64), 0, s, bases, (XYZZ<Fq> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
+    hipLaunchKernelGGL((k_accumulate_fixup<P>), dim3(1), dim3(64), 0, s, bases, (XYZZ<Fq> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
     uint32_t segs = (1u << c) / RED_L1, groups = (segs + RED_L2 - 1) / RED_L2;
-    hipLaunchKernelGGL((k_reduce_l1<Fq>), dim3((unsigned)((segs * nwin + 63) / 64)), dim3(64), 0, s, (const XYZZ<Fq> *)S.buckets, c, nwin, (XYZZ<Fq> *)S.seg_s, (XYZZ<Fq> *)S.seg_w);
+    hipLaunchKernelGGL((k_reduce_l1<Fq>), dim3((unsigned)((segs * nsets + 63) / 64)), dim3(64), 0, s, (const XYZZ<Fq> *)S.buckets, c, nsets, (XYZZ<Fq> *)S.seg_s, (XYZZ<Fq> *)S.seg_w);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_reduce_l2<Fq>), dim3((unsigned)((groups * nwin + 63) / 64)), dim3(64), 0, s, (const XYZZ<Fq> *)S.seg_s, (const XYZZ<Fq> *)S.seg_w, c, nwin, (XYZZ<Fq> *)S.partial);
+    hipLaunchKernelGGL((k_reduce_l2<Fq>), dim3((unsigned)((groups * nsets + 63) / 64)), dim3(64), 0, s, (const XYZZ<Fq> *)S.seg_s, (const XYZZ<Fq> *)S.seg_w, c, nsets, (XYZZ<Fq> *)S.partial);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_reduce_window<Fq>), dim3((unsigned)nwin), dim3(256), 0, s, (const XYZZ<Fq> *)S.partial, groups, (XYZZ<Fq> *)S.wsum);
+    hipLaunchKernelGGL((k_reduce_window<Fq>), dim3((unsigned)nsets), dim3(256), 0, s, (const XYZZ<Fq> *)S.partial, groups, (XYZZ<Fq> *)S.wsum);
     HIP_LAUNCH_CHECK();
-    std::vector<XYZZ<Fq>> ws(nwin);
+    std::vector<XYZZ<Fq>> ws(nsets);
     uint32_t n_deferred = 0;
-    HIP_CHECK(hipMemcpyAsync(ws.data(), S.wsum, sizeof(XYZZ<Fq>) * nwin, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(ws.data(), S.wsum, sizeof(XYZZ<Fq>) * nsets, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(&n_deferred, S.deferred_count, 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     if (n_deferred > DEFERRED_CAP) throw GpuError("msm: more than 2^20 degenerate additions (repeated base points); refusing to return a wrong sum");
+    HIP_CHECK(hipEventElapsedTime(acc_ms, S.ev0, S.ev1));
+    (void)n_points;
+    return ws;
+}
+static void add_stats(float acc_ms, size_t n, std::chrono::steady_clock::time_point t_begin) {
+    std::lock_guard<std::mutex> g(g_stats_mu);
+    g_stats.accumulate_ms += acc_ms;
+    g_stats.points += n;
+    g_stats.launches += 1;
+    g_stats.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+}
+
+template <class Curve>
+void convert_bases(Affine28<typename Curve::FqP> *dst, const Affine<typename Curve::Fq> *src, size_t n, stream_t s_) {
+    if (!n) return;
+    hipLaunchKernelGGL((k_convert_bases<typename Curve::FqP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s_, src, dst, n);
+    HIP_LAUNCH_CHECK();
+}
+
+template <class Curve>
+XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *bases, const typename Curve::Fr *scalars, size_t n, stream_t s_) {
+    using Fq = typename Curve::Fq;
+    using Fr = typename Curve::Fr;
+    static_assert(sizeof(XYZZ<Fq>) == 192, "XYZZ layout");
+    hipStream_t s = (hipStream_t)s_;
+    if (n == 0) return XYZZ<Fq>::inf();
+    if (n >= (1u << 31)) throw GpuError("msm: too many points");
+    if (!ws_) throw GpuError("msm: null workspace");
+    auto t_begin = std::chrono::steady_clock::now();
+    int lg = 0;
+    while (((size_t)1 << lg) < n) lg++;
+    int c = lg - 3;
+    if (c < 6) c = 6;
+    if (c > 16) c = 16;
+    const int nwin = (Fr::BITS + c - 1) / c;
+    size_t pairs = n * (size_t)nwin;
+    MsmWorkspace &S = *ws_;
+    ensure_scratch(S, pairs, (size_t)nwin << c, sizeof(XYZZ<Fq>));
+    hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scalars, (uint32_t)n, c, nwin, S.keys_a, S.vals_a);
+    HIP_LAUNCH_CHECK();
     float ms = 0;
-    HIP_CHECK(hipEventElapsedTime(&ms, S.ev0, S.ev1));
+    std::vector<XYZZ<Fq>> ws = run_buckets<typename Curve::FqP>(S, bases, pairs, c, nwin, n, s, &ms);
     XYZZ<Fq> total = XYZZ<Fq>::inf();
     for (int w = nwin - 1; w >= 1; w--) {
         total.add(ws[w]);
         for (int k = 0; k < c; k++) total = total.dbl();
     }
     total.add(ws[0]);
-    {
-        std::lock_guard<std::mutex> g(g_stats_mu);
-        g_stats.accumulate_ms += ms;
-        g_stats.points += n;
-        g_stats.launches += 1;
-        g_stats.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-    }
+    add_stats(ms, n, t_begin);
     return total;
+}
+
+template <class Curve>
+int table_windows(int c) { return (Curve::Fr::BITS + c - 1) / c; }
+
+template <class Curve>
+void build_window_tables(Affine<typename Curve::Fq> *tables, size_t stride, int c, stream_t s_) {
+    using Fq = typename Curve::Fq;
+    hipStream_t s = (hipStream_t)s_;
+    const int nwin = table_windows<Curve>(c);
+    for (int j = 1; j < nwin; j++) {
+        uint32_t lanes = (uint32_t)((stride + 7) / 8);
+        hipLaunchKernelGGL((k_table_next<Fq>), dim3((lanes + 63) / 64), dim3(64), 0, s, tables + (size_t)(j - 1) * stride, tables + (size_t)j * stride, (uint32_t)stride, c);
+        HIP_LAUNCH_CHECK();
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
+template <class Curve>
+XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *tables, size_t stride, size_t off, int c, const typename Curve::Fr *scalars, size_t n, stream_t s_) {
+    using Fq = typename Curve::Fq;
+    using Fr = typename Curve::Fr;
+    hipStream_t s = (hipStream_t)s_;
+    if (n == 0) return XYZZ<Fq>::inf();
+    if (!ws_) throw GpuError("msm: null workspace");
+    const int nwin = table_windows<Curve>(c);
+    if (off + n > stride) throw GpuError("msm_table: range exceeds the table");
+    if ((uint64_t)nwin * stride >= (1ull << 32) || (uint64_t)n * nwin >= (1ull << 31)) throw GpuError("msm_table: index range too large");
+    auto t_begin = std::chrono::steady_clock::now();
+    size_t pairs = n * (size_t)nwin;
+    MsmWorkspace &S = *ws_;
+    ensure_scratch(S, pairs, (size_t)1 << c, sizeof(XYZZ<Fq>));
+    hipLaunchKernelGGL((k_digits_table<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scalars, (uint32_t)n, c, nwin, (uint32_t)stride, (uint32_t)off, S.keys_a, S.vals_a);
+    HIP_LAUNCH_CHECK();
+    float ms = 0;
+    std::vector<XYZZ<Fq>> ws = run_buckets<typename Curve::FqP>(S, tables, pairs, c, 1, n, s, &ms);
+    add_stats(ms, n, t_begin);
+    return ws[0];
 }
 
 // ---- fixed-base powers: out[i] = beta^(from + i) * base
@@ -364,8 +490,16 @@ void fixed_base_powers(Affine<typename Curve::Fq> *out, const Affine<typename Cu
     dfree(d_table); dfree(d_sc);
 }
 
-template XYZZ<Fq377> msm<Bls377>(MsmWorkspace *, const Affine<Fq377> *, const Fr377 *, size_t, stream_t);
-template XYZZ<Fq381> msm<Bls381>(MsmWorkspace *, const Affine<Fq381> *, const Fr381 *, size_t, stream_t);
+template XYZZ<Fq377> msm_table<Bls377>(MsmWorkspace *, const Affine28<Fq377P> *, size_t, size_t, int, const Fr377 *, size_t, stream_t);
+template XYZZ<Fq381> msm_table<Bls381>(MsmWorkspace *, const Affine28<Fq381P> *, size_t, size_t, int, const Fr381 *, size_t, stream_t);
+template void convert_bases<Bls377>(Affine28<Fq377P> *, const Affine<Fq377> *, size_t, stream_t);
+template void convert_bases<Bls381>(Affine28<Fq381P> *, const Affine<Fq381> *, size_t, stream_t);
+template void build_window_tables<Bls377>(Affine<Fq377> *, size_t, int, stream_t);
+template void build_window_tables<Bls381>(Affine<Fq381> *, size_t, int, stream_t);
+template int table_windows<Bls377>(int);
+template int table_windows<Bls381>(int);
+template XYZZ<Fq377> msm<Bls377>(MsmWorkspace *, const Affine28<Fq377P> *, const Fr377 *, size_t, stream_t);
+template XYZZ<Fq381> msm<Bls381>(MsmWorkspace *, const Affine28<Fq381P> *, const Fr381 *, size_t, stream_t);
 template void fixed_base_powers<Bls377>(Affine<Fq377> *, const Affine<Fq377> &, const Fr377 &, size_t, size_t, stream_t);
 template void fixed_base_powers<Bls381>(Affine<Fq381> *, const Affine<Fq381> &, const Fr381 &, size_t, size_t, stream_t);
 

@@ -2,6 +2,7 @@
 #include "marlin.hpp"
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <atomic>
 #include <map>
@@ -246,8 +247,10 @@ class ProvingKeyImpl {
     size_t max_degree = 0, supported_degree = 0, lowest_shift = 0, bounds[2] = {0, 0};
     Fr srs_beta;
     G1A gamma_powers[3];
-    // device: SRS
-    G1A *d_powers = nullptr, *d_shifted = nullptr;
+    // device: SRS as precomputed window tables: copy j holds 2^(table_c * j) * powers_of_g[i] (gpu.hpp msm_table)
+    Affine28<Fq377P> *d_powers = nullptr, *d_shifted = nullptr;   // reduced-radix copies (ff28.cuh) -- what k_accumulate gathers
+    int table_c = 16;
+    bool use_tables = false;   // ZKAES_MSM_TABLES=1: precomputed-window path (measured slower than per-window buckets on MI355X today: DESIGN.md §3)
     // device: circuit
     uint32_t *d_desc = nullptr, *d_sbox_in = nullptr, *d_sbox_tmpl = nullptr;
     uint32_t *d_a_rowptr = nullptr, *d_a_col = nullptr, *d_b_rowptr = nullptr, *d_b_col = nullptr;
@@ -302,6 +305,7 @@ class ProvingKeyImpl {
         if (len == 0) return XYZZ<Fq377>::inf();
         size_t avail = shifted ? (bounds[1] + 1) : (supported_degree + 1);
         if (off + len > avail) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
+        if (use_tables) return gpu::msm_table<Bls377>(cx.msm_ws, shifted ? d_shifted : d_powers, shifted ? bounds[1] + 1 : supported_degree + 1, off, table_c, scalars, len, cx.stream);
         return gpu::msm<Bls377>(cx.msm_ws, (shifted ? d_shifted : d_powers) + off, scalars, len, cx.stream);
     }
     // KZG10::commit: MSM(powers, coeffs) [+ MSM(powers_of_gamma_g, blinding) when hiding]
@@ -376,10 +380,22 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
     srs_beta = setup_rng.rand_field<Fr>();
     Fr gamma = setup_rng.rand_field<Fr>();
     G1A g = g1_generator(), gamma_g = mul_affine(g, gamma);
-    d_powers = (G1A *)gpu::dmalloc((supported_degree + 1) * sizeof(G1A));
-    gpu::fixed_base_powers<Bls377>(d_powers, g, srs_beta, 0, supported_degree + 1, stream);
-    d_shifted = (G1A *)gpu::dmalloc((bounds[1] + 1) * sizeof(G1A));
-    gpu::fixed_base_powers<Bls377>(d_shifted, g, srs_beta, lowest_shift, bounds[1] + 1, stream);
+    if (const char *e = getenv("ZKAES_MSM_TABLES")) use_tables = atoi(e) != 0;
+    // window bits of the table path: the top window must keep enough significant bits or a handful of buckets receive most points
+    table_c = lg_k >= 22 ? 20 : (lg_k >= 19 ? 17 : 8);
+    const size_t n_tab = use_tables ? (size_t)gpu::table_windows<Bls377>(table_c) : 1;
+    auto make_srs = [&](size_t from, size_t count) {
+        G1A *tmp = (G1A *)gpu::dmalloc(n_tab * count * sizeof(G1A));
+        gpu::fixed_base_powers<Bls377>(tmp, g, srs_beta, from, count, stream);
+        if (use_tables) gpu::build_window_tables<Bls377>(tmp, count, table_c, stream);
+        Affine28<Fq377P> *dst = (Affine28<Fq377P> *)gpu::dmalloc(n_tab * count * sizeof(Affine28<Fq377P>));
+        gpu::convert_bases<Bls377>(dst, tmp, n_tab * count, stream);
+        gpu::sync(stream);
+        gpu::dfree(tmp);
+        return dst;
+    };
+    d_powers = make_srs(0, supported_degree + 1);
+    d_shifted = make_srs(lowest_shift, bounds[1] + 1);
     { Fr bp = Fr::one(); for (int i = 0; i < 3; i++) { gamma_powers[i] = mul_affine(gamma_g, bp); bp = bp * srs_beta; } }
     vk.g = g; vk.gamma_g = gamma_g;
     vk.h = pairing::g2_generator();

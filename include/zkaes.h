@@ -103,9 +103,13 @@ int zkaes_msm_stats(double out[4], int reset);
 int zkaes_ntt(int field_id, uint8_t *data, size_t n, int inverse);
 /* curve_id 377 / 381.  bases: n x 96 B affine (x||y Montgomery), scalars: n x 32 B Montgomery Fr; out_xy 96 B, *out_inf = 1 if infinity */
 int zkaes_msm(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, uint8_t *out_xy, int *out_inf);
+/* same sum through the precomputed-window path the prover uses for the SRS (tables 2^(c j) P_i built on the fly here; one bucket set) */
+int zkaes_msm_table(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, int window_bits, uint8_t *out_xy, int *out_inf);
 /* device-resident variant for benchmarking: repeats the MSM `reps` times over device copies, returns ms per MSM of the whole pipeline and of
  * the bucket-accumulation kernel alone */
 int zkaes_msm_bench(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, int reps, double *ms_total, double *ms_accumulate);
+/* BLS12-377, synthetic device-made bases and scalars: window_bits = 0 classic per-window buckets, else the precomputed-table path */
+int zkaes_msm_bench_synth(size_t n, int window_bits, int reps, double *ms_total, double *ms_accumulate);
 /* AES witness only: fills z (padded instance + witness, one byte per variable) for a message under the key's circuit */
 int zkaes_aes_witness(const zkaes_pk *pk, const uint8_t *message, size_t message_len, const uint8_t secret_key[16], uint8_t *z, size_t z_cap, size_t *z_len);
 

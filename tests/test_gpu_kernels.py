@@ -102,3 +102,21 @@ def test_msm_2_16_matches_oracle(zko, api):
     zko.lib().zko_api_msm(377, bases, scalars, C.c_size_t(n), ref)
     got, inf = api.msm(377, bases, scalars)
     assert not inf and got == ref.raw
+
+
+@pytest.mark.parametrize("cid", [377, 381])
+@pytest.mark.parametrize("n,c", [(1, 8), (33, 5), (1000, 11), (1 << 12, 13), ((1 << 13) + 3, 20)])
+def test_msm_precomputed_window_tables_match_oracle(zko, api, cid, n, c):
+    """the prover's SRS path: tables 2^(c j) P_i, one shared bucket set (kernels_msm.hip msm_table)"""
+    bases = oracle_points(zko, cid, n, 3 * n + c)
+    scalars = bytearray(rand_fr_mont(n, zko.FR[cid], 5 * n + c))
+    if n >= 33:
+        scalars[0:32] = bytes(32)
+        scalars[32:64] = zko.fr_pack([1], cid)
+        scalars[64:96] = zko.fr_pack([zko.FR[cid] - 1], cid)
+    ref = C.create_string_buffer(96)
+    ref_inf = zko.lib().zko_api_msm(cid, bases, bytes(scalars), C.c_size_t(n), ref)
+    got, inf = api.msm_table(cid, bases, bytes(scalars), c)
+    assert inf == bool(ref_inf)
+    if not inf:
+        assert got == ref.raw
