@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--blocks", type=int, default=64, help="ECB blocks per message (per rank)")
     ap.add_argument("--chunk", type=int, default=6, help="blocks per chunk-proof (6 = the most that fits |H|=2^20, |K|=2^22 and the reference's SRS literal)")
-    ap.add_argument("--contexts", type=int, default=6, help="chunk-proofs in flight per GPU (separate HIP streams)")
+    ap.add_argument("--contexts", type=int, default=8, help="chunk-proofs in flight per GPU (separate HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
