@@ -126,6 +126,63 @@ __device__ __forceinline__ bool madd28(Acc28<P> &a, const Affine28<P> &q) {
     return true;
 }
 
+// ---- complete group law on reduced-radix XYZZ points (bucket reduction kernels).  Infinity <=> zz limbs all zero.
+// Coordinate bounds maintained by every routine: x < 6.2 p, y < 4 p, zz, zzz < 1.2 p.
+template <class P>
+__device__ __forceinline__ bool is_zero_product(const Fp28<P> &v) {     // v is a product (< 1.2 p): v == 0 (mod p)  <=>  v in {0, p}
+    uint32_t z0 = 0, zp = 0;
+#pragma unroll
+    for (int i = 0; i < Fp28<P>::N; i++) { z0 |= v.l[i]; zp |= v.l[i] ^ Fp28<P>::mod28(i); }
+    return z0 == 0 || zp == 0;
+}
+template <class P>
+__device__ __noinline__ void dbl28(Acc28<P> &a) {                        // dbl-2008-s-1
+    using G = Fp28<P>;
+    if (a.zz.limbs_zero()) return;
+    G u = a.y.dbl(), v = u.sqr(), w = u * v, s = a.x * v;                // u < 8 p
+    G xx = a.x.sqr(), m = xx.dbl() + xx;                                 // m < 3.6 p
+    G x3 = m.sqr().template sub<3>(s.dbl());                             // < 4.2 p
+    G y3 = (m * s.template sub<5>(x3)).template sub<2>(w * a.y);         // < 3.2 p
+    a.x = x3; a.y = y3; a.zz = v * a.zz; a.zzz = w * a.zzz;
+}
+template <class P>
+__device__ __noinline__ void add28(Acc28<P> &a, const Acc28<P> &b) {     // add-2008-s, complete
+    using G = Fp28<P>;
+    if (b.zz.limbs_zero()) return;
+    if (a.zz.limbs_zero()) { a = b; return; }
+    G u1 = a.x * b.zz, u2 = b.x * a.zz, s1 = a.y * b.zzz, s2 = b.y * a.zzz;
+    G pd = u2.template sub<2>(u1), r = s2.template sub<2>(s1);           // < 3.2 p
+    G pp = pd.sqr();
+    if (is_zero_product<P>(pp)) {
+        if (is_zero_product<P>(r.sqr())) dbl28<P>(a);
+        else { a.x = G::zero(); a.y = G::zero(); a.zz = G::zero(); a.zzz = G::zero(); }
+        return;
+    }
+    G ppp = pd * pp, qq = u1 * pp;
+    G x3 = (r.sqr().template sub<2>(ppp)).template sub<3>(qq.dbl());     // < 6.2 p
+    G y3 = (r * qq.template sub<7>(x3)).template sub<2>(s1 * ppp);       // < 3.2 p
+    a.x = x3; a.y = y3;
+    a.zz = a.zz * b.zz * pp;
+    a.zzz = a.zzz * b.zzz * ppp;
+}
+template <class P>
+__device__ __forceinline__ Acc28<P> neg28(const Acc28<P> &a) { Acc28<P> r = a; r.y = Fp28<P>::zero().template sub<4>(a.y); return r; }
+template <class P>
+__device__ __forceinline__ Acc28<P> inf28() { Acc28<P> r; r.x = Fp28<P>::zero(); r.y = r.x; r.zz = r.x; r.zzz = r.x; return r; }
+template <class P>
+__device__ __forceinline__ XYZZ<Fp<P>> to_std_point(const Acc28<P> &a) {
+    XYZZ<Fp<P>> o;
+    if (a.zz.limbs_zero()) return XYZZ<Fp<P>>::inf();
+    o.x = a.x.to_std(); o.y = a.y.to_std(); o.zz = a.zz.to_std(); o.zzz = a.zzz.to_std();
+    return o;
+}
+template <class P>
+__device__ __forceinline__ Acc28<P> from_std_point(const XYZZ<Fp<P>> &a) {
+    if (a.is_inf()) return inf28<P>();
+    Acc28<P> o; o.x = Fp28<P>::from_std(a.x); o.y = Fp28<P>::from_std(a.y); o.zz = Fp28<P>::from_std(a.zz); o.zzz = Fp28<P>::from_std(a.zzz);
+    return o;
+}
+
 // standard (12 x 32, R = 2^384) bases -> reduced-radix copies; done once per SRS at key synthesis, or per call for ad-hoc bases
 template <class P>
 __global__ void k_convert_bases(const Affine<Fp<P>> *__restrict__ src, Affine28<P> *__restrict__ dst, size_t n) {
@@ -137,18 +194,19 @@ __global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nb) return;
     uint32_t sz = end[k] - start[k];
-    size_key[k] = 0xffffffffu - sz;       // ascending sort on this key = descending bucket size
+    if (sz > 8191u) sz = 8191u;
+    size_key[k] = 8191u - sz;             // ascending sort on this 13-bit key = descending bucket size (sizes above 8191 tie)
     ids[k] = k;
 }
 
 // ONE LANE PER BUCKET, buckets visited in descending-size order so the 64 lanes of a wave run the same trip count.
 // The loop body has no function call: the (cryptographically negligible, but reachable with repeated bases) P == +-Q case is
-// appended to a deferred list and replayed by k_accumulate_fixup with the complete addition law.  The accumulator lives in the
-// reduced-radix form for the whole loop and is converted to the library-wide XYZZ form once, at the store.
+// appended to a deferred list and replayed by k_accumulate_fixup with the complete addition law.  Buckets stay in the
+// reduced-radix form through the reduction kernels; only the per-window sums are converted back for the host.
 template <class P>
 __global__ void __launch_bounds__(64, 2) k_accumulate(const Affine28<P> *__restrict__ bases, const uint32_t *__restrict__ vals,
                                                        const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, const uint32_t *__restrict__ order,
-                                                       uint32_t nbuckets_total, uint32_t digit_mask, XYZZ<Fp<P>> *__restrict__ buckets,
+                                                       uint32_t nbuckets_total, uint32_t digit_mask, Acc28<P> *__restrict__ buckets,
                                                        uint32_t *__restrict__ deferred, uint32_t deferred_cap, uint32_t *__restrict__ deferred_count) {
     using G = Fp28<P>;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -174,22 +232,20 @@ __global__ void __launch_bounds__(64, 2) k_accumulate(const Affine28<P> *__restr
             }
         }
     }
-    XYZZ<Fp<P>> out;
-    if (acc_inf) out = XYZZ<Fp<P>>::inf();
-    else { out.x = acc.x.to_std(); out.y = acc.y.to_std(); out.zz = acc.zz.to_std(); out.zzz = acc.zzz.to_std(); }
-    buckets[k] = out;
+    if (acc_inf) acc = inf28<P>();
+    buckets[k] = acc;
 }
 // replay of the deferred (bucket, point) pairs with the complete formulas; one lane, sequential (the list is empty in practice)
 template <class P>
-__global__ void k_accumulate_fixup(const Affine28<P> *__restrict__ bases, XYZZ<Fp<P>> *__restrict__ buckets, const uint32_t *__restrict__ deferred, uint32_t deferred_cap,
+__global__ void k_accumulate_fixup(const Affine28<P> *__restrict__ bases, Acc28<P> *__restrict__ buckets, const uint32_t *__restrict__ deferred, uint32_t deferred_cap,
                                    const uint32_t *__restrict__ deferred_count) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     uint32_t n = *deferred_count;
     if (n > deferred_cap) n = deferred_cap;
     for (uint32_t i = 0; i < n; i++) {
-        XYZZ<Fp<P>> b = buckets[deferred[2 * i]];
+        XYZZ<Fp<P>> b = to_std_point<P>(buckets[deferred[2 * i]]);
         b.madd(bases[deferred[2 * i + 1]].to_std());
-        buckets[deferred[2 * i]] = b;
+        buckets[deferred[2 * i]] = from_std_point<P>(b);
     }
 }
 
@@ -198,68 +254,68 @@ __global__ void k_accumulate_fixup(const Affine28<P> *__restrict__ bases, XYZZ<F
 //   k_reduce_l2: lane (w, h) over 32 segments: sum_g [W_g + (d0_g - 1) S_g] via a second running sum + ONE small scalar product
 //   k_reduce_window: LDS tree over the (2^c / 512) group partials of a window
 constexpr int RED_L1 = 8, RED_L2 = 8;
-template <class Fq>
-__global__ void __launch_bounds__(64) k_reduce_l1(const XYZZ<Fq> *__restrict__ buckets, int c, int nwin, XYZZ<Fq> *__restrict__ seg_s, XYZZ<Fq> *__restrict__ seg_w) {
+template <class P>
+__global__ void __launch_bounds__(64) k_reduce_l1(const Acc28<P> *__restrict__ buckets, int c, int nwin, Acc28<P> *__restrict__ seg_s, Acc28<P> *__restrict__ seg_w) {
     uint32_t segs = (1u << c) / RED_L1;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= segs * (uint32_t)nwin) return;
     uint32_t w = t / segs, g = t % segs;
-    const XYZZ<Fq> *B = buckets + ((size_t)w << c) + (size_t)g * RED_L1;
-    XYZZ<Fq> run = XYZZ<Fq>::inf(), tot = XYZZ<Fq>::inf();
+    const Acc28<P> *B = buckets + ((size_t)w << c) + (size_t)g * RED_L1;
+    Acc28<P> run = inf28<P>(), tot = inf28<P>();
     for (int d = RED_L1 - 1; d >= 0; d--) {
-        XYZZ<Fq> b = B[d];
-        run.add(b);
-        tot.add(run);
+        Acc28<P> b = B[d];
+        add28<P>(run, b);
+        add28<P>(tot, run);
     }
     seg_s[t] = run;
     seg_w[t] = tot;
 }
-template <class Fq>
-__global__ void __launch_bounds__(64) k_reduce_l2(const XYZZ<Fq> *__restrict__ seg_s, const XYZZ<Fq> *__restrict__ seg_w, int c, int nwin, XYZZ<Fq> *__restrict__ partial) {
+template <class P>
+__global__ void __launch_bounds__(64) k_reduce_l2(const Acc28<P> *__restrict__ seg_s, const Acc28<P> *__restrict__ seg_w, int c, int nwin, Acc28<P> *__restrict__ partial) {
     uint32_t segs = (1u << c) / RED_L1, groups = (segs + RED_L2 - 1) / RED_L2;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= groups * (uint32_t)nwin) return;
     uint32_t w = t / groups, h = t % groups;
     uint32_t g0 = h * RED_L2, g1 = g0 + RED_L2 < segs ? g0 + RED_L2 : segs;
-    const XYZZ<Fq> *S = seg_s + (size_t)w * segs, *W = seg_w + (size_t)w * segs;
-    XYZZ<Fq> run = XYZZ<Fq>::inf(), tot2 = XYZZ<Fq>::inf(), sw = XYZZ<Fq>::inf();
+    const Acc28<P> *S = seg_s + (size_t)w * segs, *W = seg_w + (size_t)w * segs;
+    Acc28<P> run = inf28<P>(), tot2 = inf28<P>(), sw = inf28<P>();
     for (int g = (int)g1 - 1; g >= (int)g0; g--) {
-        run.add(S[g]);
-        tot2.add(run);           // tot2 = sum (g - g0 + 1) S_g
-        sw.add(W[g]);
+        add28<P>(run, S[g]);
+        add28<P>(tot2, run);           // tot2 = sum (g - g0 + 1) S_g
+        add28<P>(sw, W[g]);
     }
     // sum_g [W_g + (L1 g - 1) S_g] = sw + L1 (tot2 - run) + (L1 g0 - 1) run     (run = sum S_g, L1 = 8)
-    XYZZ<Fq> a = tot2;
-    a.add(run.neg());
-    for (int i = 0; i < 3; i++) a = a.dbl();      // * RED_L1
-    sw.add(a);
-    if (g0 == 0) sw.add(run.neg());
+    Acc28<P> a = tot2;
+    add28<P>(a, neg28<P>(run));
+    for (int i = 0; i < 3; i++) dbl28<P>(a);      // * RED_L1
+    add28<P>(sw, a);
+    if (g0 == 0) add28<P>(sw, neg28<P>(run));
     else {
         uint32_t m = RED_L1 * g0 - 1;
-        XYZZ<Fq> acc = XYZZ<Fq>::inf();
+        Acc28<P> acc = inf28<P>();
         int top = 31 - __clz(m);
         for (int bit = top; bit >= 0; bit--) {
-            acc = acc.dbl();
-            if ((m >> bit) & 1) acc.add(run);
+            dbl28<P>(acc);
+            if ((m >> bit) & 1) add28<P>(acc, run);
         }
-        sw.add(acc);
+        add28<P>(sw, acc);
     }
     partial[t] = sw;
 }
 
-template <class Fq>
-__global__ void __launch_bounds__(256) k_reduce_window(const XYZZ<Fq> *__restrict__ partial, uint32_t per_window, XYZZ<Fq> *__restrict__ out) {
-    __shared__ XYZZ<Fq> sh[256];
+template <class P>
+__global__ void __launch_bounds__(256) k_reduce_window(const Acc28<P> *__restrict__ partial, uint32_t per_window, XYZZ<Fp<P>> *__restrict__ out) {
+    __shared__ Acc28<P> sh[256];
     uint32_t w = blockIdx.x, t = threadIdx.x;
-    XYZZ<Fq> acc = XYZZ<Fq>::inf();
-    for (uint32_t i = t; i < per_window; i += 256) acc.add(partial[(size_t)w * per_window + i]);
+    Acc28<P> acc = inf28<P>();
+    for (uint32_t i = t; i < per_window; i += 256) add28<P>(acc, partial[(size_t)w * per_window + i]);
     sh[t] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if ((int)t < s) { XYZZ<Fq> a = sh[t]; a.add(sh[t + s]); sh[t] = a; }
+        if ((int)t < s) { Acc28<P> a = sh[t]; add28<P>(a, sh[t + s]); sh[t] = a; }
         __syncthreads();
     }
-    if (t == 0) out[w] = sh[0];
+    if (t == 0) out[w] = to_std_point<P>(sh[0]);
 }
 
 constexpr uint32_t DEFERRED_CAP = 1u << 20;
@@ -288,9 +344,9 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
         S.cap_buckets = buckets;
         S.start = (uint32_t *)dmalloc(buckets * 4); S.end = (uint32_t *)dmalloc(buckets * 4);
         S.size_key = (uint32_t *)dmalloc(buckets * 4); S.size_key2 = (uint32_t *)dmalloc(buckets * 4); S.ids = (uint32_t *)dmalloc(buckets * 4); S.order = (uint32_t *)dmalloc(buckets * 4);
-        S.buckets = dmalloc(buckets * 192);
-        S.seg_s = dmalloc((buckets / RED_L1 + 64) * 192); S.seg_w = dmalloc((buckets / RED_L1 + 64) * 192);
-        S.partial = dmalloc((buckets / (RED_L1 * RED_L2) + 64 * 64) * 192); S.wsum = dmalloc(192 * 64);
+        S.buckets = dmalloc(buckets * 224);
+        S.seg_s = dmalloc((buckets / RED_L1 + 64) * 224); S.seg_w = dmalloc((buckets / RED_L1 + 64) * 224);
+        S.partial = dmalloc((buckets / (RED_L1 * RED_L2) + 64 * 64) * 224); S.wsum = dmalloc(192 * 64);
         // (window sums: at most 64 sets)
     }
     (void)xyzz_bytes;
@@ -325,24 +381,24 @@ static std::vector<XYZZ<Fp<P>>> run_buckets(MsmWorkspace &S, const Affine28<P> *
     HIP_LAUNCH_CHECK();
     {
         size_t tb = 0;
-        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, S.size_key, S.size_key2, S.ids, S.order, (int)nb, 0, 32, s));
+        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, S.size_key, S.size_key2, S.ids, S.order, (int)nb, 0, 13, s));
         if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
-        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp, tb, S.size_key, S.size_key2, S.ids, S.order, (int)nb, 0, 32, s));
+        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp, tb, S.size_key, S.size_key2, S.ids, S.order, (int)nb, 0, 13, s));
     }
     HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 4, s));
     HIP_CHECK(hipEventRecord(S.ev0, s));
     hipLaunchKernelGGL((k_accumulate<P>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, bases, S.vals_b, S.start, S.end, S.order, (uint32_t)nb, (1u << c) - 1,
-                       (XYZZ<Fq> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
+                       (Acc28<P> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
     HIP_CHECK(hipEventRecord(S.ev1, s));
-    hipLaunchKernelGGL((k_accumulate_fixup<P>), dim3(1), dim3(64), 0, s, bases, (XYZZ<Fq> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
+    hipLaunchKernelGGL((k_accumulate_fixup<P>), dim3(1), dim3(64), 0, s, bases, (Acc28<P> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
     uint32_t segs = (1u << c) / RED_L1, groups = (segs + RED_L2 - 1) / RED_L2;
-    hipLaunchKernelGGL((k_reduce_l1<Fq>), dim3((unsigned)((segs * nsets + 63) / 64)), dim3(64), 0, s, (const XYZZ<Fq> *)S.buckets, c, nsets, (XYZZ<Fq> *)S.seg_s, (XYZZ<Fq> *)S.seg_w);
+    hipLaunchKernelGGL((k_reduce_l1<P>), dim3((unsigned)((segs * nsets + 63) / 64)), dim3(64), 0, s, (const Acc28<P> *)S.buckets, c, nsets, (Acc28<P> *)S.seg_s, (Acc28<P> *)S.seg_w);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_reduce_l2<Fq>), dim3((unsigned)((groups * nsets + 63) / 64)), dim3(64), 0, s, (const XYZZ<Fq> *)S.seg_s, (const XYZZ<Fq> *)S.seg_w, c, nsets, (XYZZ<Fq> *)S.partial);
+    hipLaunchKernelGGL((k_reduce_l2<P>), dim3((unsigned)((groups * nsets + 63) / 64)), dim3(64), 0, s, (const Acc28<P> *)S.seg_s, (const Acc28<P> *)S.seg_w, c, nsets, (Acc28<P> *)S.partial);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_reduce_window<Fq>), dim3((unsigned)nsets), dim3(256), 0, s, (const XYZZ<Fq> *)S.partial, groups, (XYZZ<Fq> *)S.wsum);
+    hipLaunchKernelGGL((k_reduce_window<P>), dim3((unsigned)nsets), dim3(256), 0, s, (const Acc28<P> *)S.partial, groups, (XYZZ<Fq> *)S.wsum);
     HIP_LAUNCH_CHECK();
     std::vector<XYZZ<Fq>> ws(nsets);
     uint32_t n_deferred = 0;
