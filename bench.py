@@ -148,7 +148,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_accumulate (Pippenger bucket accumulation)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "launches": launches, "avg_launch_ms": round(acc_ms / max(launches, 1), 4), "algorithmic_bytes_per_launch": round(128.0 * pts / max(launches, 1)),
-                         "note": "integer-ALU bound (12x12 v_mad_u64_u32 Montgomery products); HBM fraction of O(1%) is the expected regime (BASELINE.md §3)"},
+                         "note": "integer-ALU bound (10 Fq products of 392 v_mad_u64_u32 per mixed add); HBM fraction of O(1%) is the expected regime (BASELINE.md §3)"},
         }
         if int(ok[0]) != int(ok[1]) or int(ok[2]) != world:
             out["error"] = "verification failure"
