@@ -142,6 +142,19 @@ class ProvingKey:
             off += lens[i]
         return proofs
 
+    def encrypt_batch(self, messages, secret_keys):
+        """n independent proofs: messages = list of equal-length byte strings, secret_keys = list of 16-byte keys"""
+        n = len(messages)
+        lens = (C.c_size_t * max(n, 1))()
+        out, total = C.c_void_p(), C.c_size_t()
+        _check(lib().zkaes_encrypt_batch(C.c_size_t(n), b"".join(bytes(m) for m in messages), b"".join(bytes(k) for k in secret_keys), self._p, C.byref(out), C.byref(total), lens))
+        blob = _take(out, total)
+        proofs, off = [], 0
+        for i in range(n):
+            proofs.append(blob[off:off + lens[i]])
+            off += lens[i]
+        return proofs
+
     def __del__(self):
         try:
             if self._p:
@@ -235,6 +248,6 @@ def msm_bench_synth(n, window_bits=0, reps=3):
 
 
 def msm_stats(reset=False):
-    out = (C.c_double * 4)()
+    out = (C.c_double * 5)()
     _check(lib().zkaes_msm_stats(out, 1 if reset else 0))
-    return dict(accumulate_ms=out[0], total_ms=out[1], points=int(out[2]), launches=int(out[3]))
+    return dict(accumulate_ms=out[0], total_ms=out[1], points=int(out[2]), launches=int(out[3]), pairs=int(out[4]))

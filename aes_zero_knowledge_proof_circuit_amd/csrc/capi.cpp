@@ -85,6 +85,21 @@ int zkaes_encrypt_chunked(const uint8_t *msg, size_t len, const uint8_t key[16],
         *proofs = give(all); *proofs_len = all.size();
     });
 }
+int zkaes_encrypt_batch(size_t n, const uint8_t *messages, const uint8_t *secret_keys, const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens) {
+    return guard([&] {
+        if (!pk || !proofs || !proofs_len) throw std::invalid_argument("null argument");
+        size_t n_ctx = 4;
+        if (const char *e = getenv("ZKAES_CONTEXTS")) n_ctx = (size_t)std::max(1, atoi(e));
+        auto ps = pk->pk->prove_aes_batch(messages, secret_keys, n, n_ctx);
+        std::vector<uint8_t> all;
+        for (size_t i = 0; i < n; i++) {
+            auto b = zk::serialize_proof(ps[i]);
+            if (proof_lens) proof_lens[i] = b.size();
+            all.insert(all.end(), b.begin(), b.end());
+        }
+        *proofs = give(all); *proofs_len = all.size();
+    });
+}
 int zkaes_prove_ops(const zkaes_pk *pk, uint32_t x, uint32_t y, const uint8_t *seed, uint8_t **proof, size_t *proof_len) {
     return guard([&] {
         if (!pk || !proof || !proof_len) throw std::invalid_argument("null argument");
@@ -185,10 +200,10 @@ int zkaes_aes_witness(const zkaes_pk *pk, const uint8_t *msg, size_t len, const 
 int zkaes_pk_timings(const zkaes_pk *pk, double out[6]) {
     return guard([&] { const auto &t = pk->pk->last_timings(); out[0] = t.witness_ms; out[1] = t.round1_ms; out[2] = t.round2_ms; out[3] = t.round3_ms; out[4] = t.open_ms; out[5] = t.total_ms; });
 }
-int zkaes_msm_stats(double out[4], int reset) {
+int zkaes_msm_stats(double out[5], int reset) {
     return guard([&] {
         auto s = zk::gpu::msm_stats(reset != 0);
-        out[0] = s.accumulate_ms; out[1] = s.total_ms; out[2] = (double)s.points; out[3] = (double)s.launches;
+        out[0] = s.accumulate_ms; out[1] = s.total_ms; out[2] = (double)s.points; out[3] = (double)s.launches; out[4] = (double)s.pairs;
     });
 }
 

@@ -109,7 +109,34 @@ struct Fp28 {
         r.l[N - 1] = (uint32_t)(t[2 * N - 1] + c);
         return r;
     }
-    ZK_HD Fp28 sqr() const { return *this * *this; }
+    // squaring: the 105 distinct limb products (cross terms doubled by pre-doubling one operand) instead of 196; same reduction
+    ZK_HD Fp28 sqr() const {
+        uint64_t t[2 * N];
+#pragma unroll
+        for (int i = 0; i < 2 * N; i++) t[i] = 0;
+        uint32_t d[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) d[i] = l[i] << 1;                      // < 2^29 (top limb of a bounded value stays far below 2^31)
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            t[2 * i] += (uint64_t)l[i] * l[i];
+#pragma unroll
+            for (int j = i + 1; j < N; j++) t[i + j] += (uint64_t)d[i] * l[j];
+        }
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            uint32_t m = (((uint32_t)t[i] & MASK) * PINV) & MASK;
+#pragma unroll
+            for (int j = 0; j < N; j++) t[i + j] += (uint64_t)m * mod28(j);
+            t[i + 1] += t[i] >> 28;
+        }
+        Fp28 r;
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < N - 1; i++) { uint64_t v = t[N + i] + c; r.l[i] = (uint32_t)v & MASK; c = v >> 28; }
+        r.l[N - 1] = (uint32_t)(t[2 * N - 1] + c);
+        return r;
+    }
 
     // fully reduce a value < 64 p to the canonical range [0, p) (used only at conversions and for zero tests)
     ZK_HD Fp28 canonical() const {

@@ -59,7 +59,7 @@ XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws, const Affine28<typename Cur
 template <class Curve>
 void fixed_base_powers(Affine<typename Curve::Fq> *out, const Affine<typename Curve::Fq> &base, const typename Curve::Fr &beta, size_t from, size_t count, stream_t s);
 // MSM-stage timing hooks for bench.py (accumulated kernel time of the bucket-accumulation kernel, measured with events)
-struct MsmStats { double accumulate_ms = 0; double total_ms = 0; uint64_t points = 0; uint64_t launches = 0; };
+struct MsmStats { double accumulate_ms = 0; double total_ms = 0; uint64_t points = 0; uint64_t launches = 0; uint64_t pairs = 0; };   // pairs = sum of points x windows
 MsmStats msm_stats(bool reset);   // process-wide totals (thread-safe)
 
 }  // namespace gpu

@@ -190,10 +190,16 @@ __global__ void k_convert_bases(const Affine<Fp<P>> *__restrict__ src, Affine28<
     if (i < n) dst[i] = Affine28<P>::from_std(src[i]);
 }
 
-__global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, uint32_t nb, uint32_t *__restrict__ size_key, uint32_t *__restrict__ ids) {
+// A bucket lane adds at most BUCKET_CAP points; the rest of an oversized bucket (skewed scalars: many equal digits) is cut into
+// BUCKET_CAP-point overflow segments that k_accumulate_overflow sums in parallel and k_combine_overflow folds back -- so no input can
+// serialise the whole MSM on one lane.
+constexpr uint32_t BUCKET_CAP = 2048;
+__global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, uint32_t nb, uint32_t digit_mask, uint32_t *__restrict__ size_key,
+                               uint32_t *__restrict__ ids, uint32_t *__restrict__ extra) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nb) return;
     uint32_t sz = end[k] - start[k];
+    extra[k] = ((k & digit_mask) != 0 && sz > BUCKET_CAP) ? (sz - 1) / BUCKET_CAP : 0;
     if (sz > 8191u) sz = 8191u;
     size_key[k] = 8191u - sz;             // ascending sort on this 13-bit key = descending bucket size (sizes above 8191 tie)
     ids[k] = k;
@@ -216,6 +222,7 @@ __global__ void __launch_bounds__(64, 2) k_accumulate(const Affine28<P> *__restr
     bool acc_inf = true;
     if ((k & digit_mask) != 0) {
         uint32_t s = start[k], e = end[k];
+        if (e - s > BUCKET_CAP) e = s + BUCKET_CAP;                        // the remainder goes through the overflow kernels
         if (s < e) {
             uint32_t idx = vals[s];
             Affine28<P> nxt = bases[idx];
@@ -247,6 +254,49 @@ __global__ void k_accumulate_fixup(const Affine28<P> *__restrict__ bases, Acc28<
         b.madd(bases[deferred[2 * i + 1]].to_std());
         buckets[deferred[2 * i]] = from_std_point<P>(b);
     }
+}
+
+// overflow segment t of bucket k covers sorted positions [start[k] + (j+1) CAP, min(start[k] + (j+2) CAP, end[k])), j = t - extra_off[k]
+template <class P>
+__global__ void __launch_bounds__(64, 2) k_accumulate_overflow(const Affine28<P> *__restrict__ bases, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ start,
+                                                                const uint32_t *__restrict__ end, const uint32_t *__restrict__ extra_off, uint32_t nb, uint32_t max_segments,
+                                                                Acc28<P> *__restrict__ partial, uint32_t *__restrict__ deferred, uint32_t deferred_cap,
+                                                                uint32_t *__restrict__ deferred_count) {
+    using G = Fp28<P>;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t total = extra_off[nb];                   // exclusive scan has nb + 1 entries
+    if (total > max_segments) total = max_segments;
+    if (t >= total) return;
+    uint32_t lo = 0, hi = nb;                         // largest k with extra_off[k] <= t
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (extra_off[mid] <= t) lo = mid; else hi = mid; }
+    uint32_t k = lo, j = t - extra_off[k];
+    uint32_t s = start[k] + (j + 1) * BUCKET_CAP, e = s + BUCKET_CAP < end[k] ? s + BUCKET_CAP : end[k];
+    Acc28<P> acc;
+    bool acc_inf = true;
+    for (uint32_t i = s; i < e; i++) {
+        uint32_t cur = vals[i];
+        Affine28<P> p = bases[cur];
+        if (p.is_inf()) continue;
+        if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_2_392(); acc.zzz = acc.zz; acc_inf = false; continue; }
+        if (!madd28(acc, p)) {
+            uint32_t slot = atomicAdd(deferred_count, 1u);
+            if (slot < deferred_cap) { deferred[2 * slot] = k; deferred[2 * slot + 1] = cur; }
+        }
+    }
+    if (acc_inf) acc = inf28<P>();
+    partial[t] = acc;
+}
+template <class P>
+__global__ void __launch_bounds__(64) k_combine_overflow(Acc28<P> *__restrict__ buckets, const uint32_t *__restrict__ extra_off, uint32_t nb, uint32_t max_segments,
+                                                          const Acc28<P> *__restrict__ partial) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nb) return;
+    uint32_t a = extra_off[k], b = extra_off[k + 1];
+    if (a == b) return;
+    if (b > max_segments) b = max_segments;
+    Acc28<P> acc = buckets[k];
+    for (uint32_t i = a; i < b; i++) add28<P>(acc, partial[i]);
+    buckets[k] = acc;
 }
 
 // Bucket reduction  sum_d d * B_d  per window, in three fully parallel levels:
@@ -322,7 +372,8 @@ constexpr uint32_t DEFERRED_CAP = 1u << 20;
 struct MsmWorkspace {
     size_t cap_pairs = 0, cap_buckets = 0, cap_tmp = 0;
     uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr, *start = nullptr, *end = nullptr;
-    uint32_t *size_key = nullptr, *size_key2 = nullptr, *ids = nullptr, *order = nullptr;
+    uint32_t *size_key = nullptr, *size_key2 = nullptr, *ids = nullptr, *order = nullptr, *extra = nullptr, *extra_off = nullptr;
+    void *ovf_partial = nullptr; size_t cap_ovf = 0;
     uint32_t *deferred = nullptr, *deferred_count = nullptr;
     void *buckets = nullptr, *seg_s = nullptr, *seg_w = nullptr, *partial = nullptr, *wsum = nullptr, *tmp = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -332,6 +383,7 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
         HIP_CHECK(hipEventCreate(&S.ev0)); HIP_CHECK(hipEventCreate(&S.ev1));
         S.deferred = (uint32_t *)dmalloc(2 * DEFERRED_CAP * 4); S.deferred_count = (uint32_t *)dmalloc(4);
     }
+    if (pairs / BUCKET_CAP + 64 > S.cap_ovf) { dfree(S.ovf_partial); S.cap_ovf = pairs / BUCKET_CAP + 64; S.ovf_partial = dmalloc(S.cap_ovf * 224); }
     if (pairs > S.cap_pairs) {
         dfree(S.keys_a); dfree(S.keys_b); dfree(S.vals_a); dfree(S.vals_b);
         S.cap_pairs = pairs;
@@ -340,7 +392,8 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
     }
     if (buckets > S.cap_buckets) {
         dfree(S.start); dfree(S.end); dfree(S.buckets); dfree(S.partial); dfree(S.wsum); dfree(S.seg_s); dfree(S.seg_w);
-        dfree(S.size_key); dfree(S.size_key2); dfree(S.ids); dfree(S.order);
+        dfree(S.size_key); dfree(S.size_key2); dfree(S.ids); dfree(S.order); dfree(S.extra); dfree(S.extra_off);
+        S.extra = (uint32_t *)dmalloc((buckets + 1) * 4); S.extra_off = (uint32_t *)dmalloc((buckets + 1) * 4);
         S.cap_buckets = buckets;
         S.start = (uint32_t *)dmalloc(buckets * 4); S.end = (uint32_t *)dmalloc(buckets * 4);
         S.size_key = (uint32_t *)dmalloc(buckets * 4); S.size_key2 = (uint32_t *)dmalloc(buckets * 4); S.ids = (uint32_t *)dmalloc(buckets * 4); S.order = (uint32_t *)dmalloc(buckets * 4);
@@ -355,7 +408,7 @@ MsmWorkspace *msm_workspace_create() { return new MsmWorkspace(); }
 void msm_workspace_destroy(MsmWorkspace *w) {
     if (!w) return;
     for (void *p : {(void *)w->keys_a, (void *)w->keys_b, (void *)w->vals_a, (void *)w->vals_b, (void *)w->start, (void *)w->end, (void *)w->size_key, (void *)w->size_key2, (void *)w->ids,
-                    (void *)w->order, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->wsum, w->tmp}) dfree(p);
+                    (void *)w->order, (void *)w->extra, (void *)w->extra_off, w->ovf_partial, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->wsum, w->tmp}) dfree(p);
     if (w->ev0) { (void)hipEventDestroy(w->ev0); (void)hipEventDestroy(w->ev1); }
     delete w;
 }
@@ -377,8 +430,15 @@ static std::vector<XYZZ<Fp<P>>> run_buckets(MsmWorkspace &S, const Affine28<P> *
     hipLaunchKernelGGL(k_bounds, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, S.keys_b, pairs, S.start, S.end);
     HIP_LAUNCH_CHECK();
     // size-balanced visiting order of the buckets
-    hipLaunchKernelGGL(k_bucket_sizes, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, S.start, S.end, (uint32_t)nb, S.size_key, S.ids);
+    HIP_CHECK(hipMemsetAsync(S.extra + nb, 0, 4, s));
+    hipLaunchKernelGGL(k_bucket_sizes, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, S.start, S.end, (uint32_t)nb, (1u << c) - 1, S.size_key, S.ids, S.extra);
     HIP_LAUNCH_CHECK();
+    {
+        size_t tb = 0;
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, S.extra, S.extra_off, (int)(nb + 1), s));
+        if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(S.tmp, tb, S.extra, S.extra_off, (int)(nb + 1), s));
+    }
     {
         size_t tb = 0;
         HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, S.size_key, S.size_key2, S.ids, S.order, (int)nb, 0, 13, s));
@@ -391,6 +451,14 @@ static std::vector<XYZZ<Fp<P>>> run_buckets(MsmWorkspace &S, const Affine28<P> *
                        (Acc28<P> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
     HIP_CHECK(hipEventRecord(S.ev1, s));
+    {   // oversized buckets (none for uniformly distributed digits: both kernels exit at once)
+        uint32_t max_seg = (uint32_t)(pairs / BUCKET_CAP + 1);
+        hipLaunchKernelGGL((k_accumulate_overflow<P>), dim3((max_seg + 63) / 64), dim3(64), 0, s, bases, S.vals_b, S.start, S.end, S.extra_off, (uint32_t)nb, max_seg,
+                           (Acc28<P> *)S.ovf_partial, S.deferred, DEFERRED_CAP, S.deferred_count);
+        HIP_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_combine_overflow<P>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, (Acc28<P> *)S.buckets, S.extra_off, (uint32_t)nb, max_seg, (const Acc28<P> *)S.ovf_partial);
+        HIP_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL((k_accumulate_fixup<P>), dim3(1), dim3(64), 0, s, bases, (Acc28<P> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
     uint32_t segs = (1u << c) / RED_L1, groups = (segs + RED_L2 - 1) / RED_L2;
@@ -410,10 +478,11 @@ static std::vector<XYZZ<Fp<P>>> run_buckets(MsmWorkspace &S, const Affine28<P> *
     (void)n_points;
     return ws;
 }
-static void add_stats(float acc_ms, size_t n, std::chrono::steady_clock::time_point t_begin) {
+static void add_stats(float acc_ms, size_t n, size_t pairs, std::chrono::steady_clock::time_point t_begin) {
     std::lock_guard<std::mutex> g(g_stats_mu);
     g_stats.accumulate_ms += acc_ms;
     g_stats.points += n;
+    g_stats.pairs += pairs;
     g_stats.launches += 1;
     g_stats.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 }
@@ -454,7 +523,7 @@ XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws_, const Affine28<typename Curve::F
         for (int k = 0; k < c; k++) total = total.dbl();
     }
     total.add(ws[0]);
-    add_stats(ms, n, t_begin);
+    add_stats(ms, n, pairs, t_begin);
     return total;
 }
 
@@ -492,7 +561,7 @@ XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws_, const Affine28<typename Cu
     HIP_LAUNCH_CHECK();
     float ms = 0;
     std::vector<XYZZ<Fq>> ws = run_buckets<typename Curve::FqP>(S, tables, pairs, c, 1, n, s, &ms);
-    add_stats(ms, n, t_begin);
+    add_stats(ms, n, pairs, t_begin);
     return ws[0];
 }
 

@@ -676,11 +676,8 @@ std::vector<uint8_t> ProvingKey::aes_witness(const uint8_t *message, size_t len,
     gpu::d2h(z.data(), cx.d_z, z.size(), s);
     return z;
 }
-std::vector<Proof> ProvingKey::prove_aes_chunked(const uint8_t *message, size_t len, const uint8_t key[16], size_t n_contexts) {
-    if (impl->circuit.kind != CIRCUIT_AES) throw std::invalid_argument("proving key was not synthesized for the AES circuit");
+static std::vector<Proof> prove_many(ProvingKeyImpl *impl, const uint8_t *messages, const uint8_t *keys, size_t key_stride, size_t n_chunks, size_t n_contexts) {
     size_t chunk = impl->circuit.n_blocks * 16;
-    if (chunk == 0 || len % chunk) throw std::invalid_argument("message length must be a multiple of the key's plaintext length (" + std::to_string(chunk) + " bytes)");
-    size_t n_chunks = len / chunk;
     if (n_contexts == 0) n_contexts = 1;
     n_contexts = std::min(n_contexts, std::max<size_t>(n_chunks, 1));
     std::vector<Proof> proofs(n_chunks);
@@ -695,7 +692,7 @@ std::vector<Proof> ProvingKey::prove_aes_chunked(const uint8_t *message, size_t 
             for (;;) {
                 size_t i = next.fetch_add(1);
                 if (i >= n_chunks) break;
-                proofs[i] = impl->prove(cx, nullptr, message + i * chunk, chunk, key, nullptr);
+                proofs[i] = impl->prove(cx, nullptr, messages + i * chunk, chunk, keys + i * key_stride, nullptr);
             }
         } catch (const std::exception &e) { errors[ci] = e.what(); }
     };
@@ -705,6 +702,17 @@ std::vector<Proof> ProvingKey::prove_aes_chunked(const uint8_t *message, size_t 
     for (auto &t : threads) t.join();
     for (auto &e : errors) if (!e.empty()) throw std::runtime_error(e);
     return proofs;
+}
+std::vector<Proof> ProvingKey::prove_aes_chunked(const uint8_t *message, size_t len, const uint8_t key[16], size_t n_contexts) {
+    if (impl->circuit.kind != CIRCUIT_AES) throw std::invalid_argument("proving key was not synthesized for the AES circuit");
+    size_t chunk = impl->circuit.n_blocks * 16;
+    if (chunk == 0 || len % chunk) throw std::invalid_argument("message length must be a multiple of the key's plaintext length (" + std::to_string(chunk) + " bytes)");
+    return prove_many(impl, message, key, 0, len / chunk, n_contexts);
+}
+std::vector<Proof> ProvingKey::prove_aes_batch(const uint8_t *messages, const uint8_t *keys, size_t n, size_t n_contexts) {
+    if (impl->circuit.kind != CIRCUIT_AES) throw std::invalid_argument("proving key was not synthesized for the AES circuit");
+    if (impl->circuit.n_blocks == 0) throw std::invalid_argument("proving key has an empty plaintext");
+    return prove_many(impl, messages, keys, 16, n, n_contexts);
 }
 Proof ProvingKey::prove_ops(uint32_t x, uint32_t y, const uint8_t *zk_seed) {
     if (impl->circuit.kind == CIRCUIT_AES) throw std::invalid_argument("proving key was synthesized for the AES circuit");

@@ -60,6 +60,8 @@ class ProvingKey {
     Proof prove_aes(const uint8_t *message, size_t len, const uint8_t key[16], const uint8_t *zk_seed);
     // ceil(len / chunk) independent chunk-proofs of a long ECB message, `n_contexts` proofs in flight on separate HIP streams
     std::vector<Proof> prove_aes_chunked(const uint8_t *message, size_t len, const uint8_t key[16], size_t n_contexts);
+    // n independent (message_i, key_i) pairs, each message of the key's plaintext length; keys = n x 16 bytes
+    std::vector<Proof> prove_aes_batch(const uint8_t *messages, const uint8_t *keys, size_t n, size_t n_contexts);
     Proof prove_ops(uint32_t x, uint32_t y, const uint8_t *zk_seed);
     // witness generation only (kernels aes_trace + witness_expand): z = padded instance || witness, one byte per variable
     std::vector<uint8_t> aes_witness(const uint8_t *message, size_t len, const uint8_t key[16]);

@@ -144,6 +144,15 @@ def main():
         # kernel's own stream, accumulated over every launch of the timed region.
         acc_ms, pts, launches = stats["accumulate_ms"], stats["points"], stats["launches"]
         achieved = (128.0 * pts / 1e9) / (acc_ms / 1e3) if acc_ms > 0 else 0.0
+        # HBM traffic per launch: the PMC pass of the same kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, calibrated on a
+        # known byte count of the same access pattern -- profiles/r01_pmc_k_accumulate_v4.json) gives bytes per (point, window) gather;
+        # scaled by the (point, window) pairs this run's launches actually processed.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_k_accumulate_v4.json")))
+            traffic = round(pmc["hbm_bytes_per_point_window"] * stats["pairs"] / max(launches, 1))
+        except Exception:
+            pass
         out = {
             "metric": "AES-ECB blocks proven/sec (Marlin), proof verifies", "value": round(value, 4), "unit": "blocks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
@@ -157,7 +166,8 @@ def main():
             "setup_s": round(setup_s, 2),
             "phase_ms_last_proof_avg": {k: round(v / args.steps, 2) for k, v in phase.items()},
             "roofline": {"bound": "hbm", "kernel": "k_accumulate (Pippenger bucket accumulation)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "traffic_source": "profiles/r01_pmc_k_accumulate_v4.json (PMC bytes per point-window x pairs of this run)",
                          "launches": launches, "avg_launch_ms": round(acc_ms / max(launches, 1), 4), "algorithmic_bytes_per_launch": round(128.0 * pts / max(launches, 1)),
                          "note": "integer-ALU bound (10 Fq products of 392 v_mad_u64_u32 per mixed add); HBM fraction of O(1%) is the expected regime (BASELINE.md §3)"},
         }

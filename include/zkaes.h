@@ -65,6 +65,9 @@ int zkaes_encrypt_seeded(const uint8_t *message, size_t message_len, const uint8
  * (the last chunk must be full).  proofs = concatenation, proof_lens[i] = length of proof i (caller array of n_chunks). */
 int zkaes_encrypt_chunked(const uint8_t *message, size_t message_len, const uint8_t secret_key[16], const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len,
                           size_t *proof_lens, size_t n_chunks);
+/* n independent (message_i, secret_key_i) pairs on one key / one SRS (BASELINE config 5: many small proofs): messages = n x plaintext
+ * length bytes, secret_keys = n x 16 bytes.  Up to ZKAES_CONTEXTS (default 4) proofs are in flight on separate HIP streams. */
+int zkaes_encrypt_batch(size_t n, const uint8_t *messages, const uint8_t *secret_keys, const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens);
 /* src/ops.rs toy gates proven with Marlin (public input: none) */
 int zkaes_prove_ops(const zkaes_pk *pk, uint32_t x, uint32_t y, const uint8_t *zk_seed32, uint8_t **proof, size_t *proof_len);
 /* generic verify: public_input_bits = instance assignment without the leading One, one byte (0/1) per variable */
@@ -94,8 +97,9 @@ int zkaes_circuit_matrix(int circuit_kind, size_t plaintext_length, int which, u
 int zkaes_pk_debug_fetch(const zkaes_pk *pk, const char *name, uint8_t **out, size_t *len);
 /* per-phase wall times of the last proof: witness, round1, round2, round3, open, total (ms) */
 int zkaes_pk_timings(const zkaes_pk *pk, double out[6]);
-/* accumulated MSM statistics since the last reset: bucket-accumulation kernel ms (HIP events), total MSM wall ms, points, launches */
-int zkaes_msm_stats(double out[4], int reset);
+/* accumulated MSM statistics since the last reset: bucket-accumulation kernel ms (HIP events), total MSM wall ms, points, launches,
+ * (point, window) pairs */
+int zkaes_msm_stats(double out[5], int reset);
 
 /* ---- kernel-level entry points (parity tests + roofline measurement) -------------------------------------------- */
 /* field_id: 377 or 381 (BLS12-377 / BLS12-381 scalar field).  data: n x 32 B Montgomery limbs, host memory, transformed in place.

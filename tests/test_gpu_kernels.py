@@ -120,3 +120,16 @@ def test_msm_precomputed_window_tables_match_oracle(zko, api, cid, n, c):
     assert inf == bool(ref_inf)
     if not inf:
         assert got == ref.raw
+
+
+@pytest.mark.parametrize("distinct", [1, 3])
+def test_msm_skewed_scalars_use_the_overflow_path(zko, api, distinct):
+    """few distinct scalars => every window has buckets far above BUCKET_CAP: must stay correct (and not serialise on one lane)"""
+    n = 10_000
+    bases = oracle_points(zko, 377, n, 4242)
+    vals = [int.from_bytes(np.random.RandomState(77 + i).bytes(31), "little") for i in range(distinct)]
+    scalars = zko.fr_pack([vals[i % distinct] for i in range(n)])
+    ref = C.create_string_buffer(96)
+    ref_inf = zko.lib().zko_api_msm(377, bases, scalars, C.c_size_t(n), ref)
+    got, inf = api.msm(377, bases, scalars)
+    assert not inf and not ref_inf and got == ref.raw

@@ -102,3 +102,24 @@ def test_aes16_proof_bytes_identical_to_oracle(zko, api, aes16, vectors):
     for poly in zko.POLY_NAMES:
         assert pk.debug_fetch(poly) == ref.poly(poly), poly
     assert proof == ref.to_bytes()
+
+
+def test_batch_of_independent_single_block_proofs(zko, api, aes16):
+    """BASELINE config 5 shape (many small proofs on one SRS), reduced to 12 proofs: each (message, key) pair gets its own proof."""
+    pk, vk = aes16
+    msgs = [mt_bytes(16, 300 + i) for i in range(12)]
+    keys = [mt_bytes(16, 400 + i) for i in range(12)]
+    proofs = pk.encrypt_batch(msgs, keys)
+    assert len(proofs) == 12
+    for i, (m, k, p) in enumerate(zip(msgs, keys, proofs)):
+        assert api.verify_encryption(vk, p, zko.aes_encrypt(m, k))
+        assert not api.verify_encryption(vk, p, zko.aes_encrypt(m, keys[(i + 1) % 12]))
+    # the concurrent contexts produce exactly what the single-proof entry point does
+    assert proofs[3] == api.encrypt(msgs[3], keys[3], pk)
+
+
+def test_chunked_message_equals_individual_proofs(api, aes16):
+    pk, vk = aes16
+    key, msg = mt_bytes(16, 500), mt_bytes(16 * 5, 501)
+    proofs = pk.encrypt_chunked(msg, key)
+    assert proofs == [api.encrypt(msg[16 * i:16 * i + 16], key, pk) for i in range(5)]
