@@ -11,9 +11,12 @@
 //   6. host          : Horner over the <= 32 window sums (c doublings each)
 #include <hipcub/hipcub.hpp>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 #include "hip_util.hpp"
+#include "ec28.cuh"
 
 namespace zk {
 namespace gpu {
@@ -27,20 +30,26 @@ MsmStats msm_stats(bool reset) {
     return s;
 }
 
+// Signed window digits d in [-2^(c-1), 2^(c-1)] (carry recoding): bucket index = |d| - 1 in a window of 2^(c-1) buckets, the sign rides
+// in bit 31 of the value (the accumulate kernel negates y).  Zero digits get the out-of-range key `nb` and sort past every bucket.
 template <class Fr>
-__global__ void k_digits(const Fr *__restrict__ scalars, uint32_t n, int c, int nwin, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+__global__ void k_digits(const Fr *__restrict__ scalars, uint32_t n, int c, int nwin, uint32_t nb, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t raw[Fr::N + 1];
     scalars[i].to_raw(raw);
     raw[Fr::N] = 0;
-    uint32_t mask = (1u << c) - 1;
+    const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
+    uint32_t carry = 0;
     for (int w = 0; w < nwin; w++) {
         int bit = w * c, limb = bit >> 5, sh = bit & 31;
-        uint64_t two = (uint64_t)raw[limb] | ((uint64_t)raw[limb + 1] << 32);
-        uint32_t d = (uint32_t)(two >> sh) & mask;
-        keys[(size_t)w * n + i] = ((uint32_t)w << c) | d;
-        vals[(size_t)w * n + i] = i;
+        uint64_t two = limb <= Fr::N - 1 ? ((uint64_t)raw[limb] | ((uint64_t)raw[limb + 1] << 32)) : 0;
+        uint32_t v = ((uint32_t)(two >> sh) & mask) + carry;
+        uint32_t neg = 0;
+        carry = 0;
+        if (v > half) { v = (1u << c) - v; neg = 1u << 31; carry = 1; }
+        keys[(size_t)w * n + i] = v ? (((uint32_t)w << (c - 1)) | (v - 1)) : nb;
+        vals[(size_t)w * n + i] = i | neg;
     }
 }
 
@@ -57,7 +66,8 @@ __global__ void k_digits_table(const Fr *__restrict__ scalars, uint32_t n, int c
     for (int w = 0; w < nwin; w++) {
         int bit = w * c, limb = bit >> 5, sh = bit & 31;
         uint64_t two = (uint64_t)raw[limb] | ((uint64_t)raw[limb + 1] << 32);
-        keys[(size_t)w * n + i] = (uint32_t)(two >> sh) & mask;
+        uint32_t d = (uint32_t)(two >> sh) & mask;
+        keys[(size_t)w * n + i] = d ? d - 1 : (1u << c);                       // bucket index = digit - 1; zero digits sort past the buckets
         vals[(size_t)w * n + i] = (uint32_t)w * stride + base_off + i;
     }
 }
@@ -90,97 +100,13 @@ __global__ void __launch_bounds__(64) k_table_next(const Affine<Fq> *__restrict_
     }
 }
 
-__global__ void k_bounds(const uint32_t *__restrict__ keys, size_t total, uint32_t *__restrict__ start, uint32_t *__restrict__ end) {
+__global__ void k_bounds(const uint32_t *__restrict__ keys, size_t total, uint32_t nb, uint32_t *__restrict__ start, uint32_t *__restrict__ end) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     uint32_t k = keys[i];
+    if (k >= nb) return;                       // zero digits
     if (i == 0 || keys[i - 1] != k) start[k] = (uint32_t)i;
     if (i + 1 == total || keys[i + 1] != k) end[k] = (uint32_t)(i + 1);
-}
-
-// Bucket accumulator in the reduced-radix form (ff28.cuh).  Values are NOT kept below p: the bounds are tracked statically --
-//   x < 6.2 p, y < 3.2 p, zz, zzz < 1.2 p (products) -- and every subtraction adds the multiple of p that keeps it non-negative.
-template <class P>
-struct Acc28 { Fp28<P> x, y, zz, zzz; };
-
-// mixed add, every product inlined, no carry chains (hot path of k_accumulate).  Returns false for P == +-Q (left to the fix-up pass).
-template <class P>
-__device__ __forceinline__ bool madd28(Acc28<P> &a, const Affine28<P> &q) {
-    using G = Fp28<P>;
-    G u2 = q.x * a.zz, s2 = q.y * a.zzz;                        // < 1.2 p
-    G pd = u2.template sub<7>(a.x), r = s2.template sub<4>(a.y); // < 8.2 p, < 5.2 p
-    G pp = pd.sqr();                                            // < 1.2 p ; pd == 0 (mod p)  <=>  pp in {0, p}
-    {
-        uint32_t z0 = 0, zp = 0;
-#pragma unroll
-        for (int i = 0; i < G::N; i++) { z0 |= pp.l[i]; zp |= pp.l[i] ^ G::mod28(i); }
-        if (z0 == 0 || zp == 0) return false;
-    }
-    G ppp = pd * pp, qq = a.x * pp;
-    G x3 = (r.sqr().template sub<2>(ppp)).template sub<3>(qq.dbl());   // r^2 - ppp - 2 qq + 5p  < 6.2 p
-    G t = qq.template sub<7>(x3);                                      // < 8.2 p
-    G y3 = (r * t).template sub<2>(a.y * ppp);                         // < 3.2 p
-    a.x = x3; a.y = y3;
-    a.zz = a.zz * pp;
-    a.zzz = a.zzz * ppp;
-    return true;
-}
-
-// ---- complete group law on reduced-radix XYZZ points (bucket reduction kernels).  Infinity <=> zz limbs all zero.
-// Coordinate bounds maintained by every routine: x < 6.2 p, y < 4 p, zz, zzz < 1.2 p.
-template <class P>
-__device__ __forceinline__ bool is_zero_product(const Fp28<P> &v) {     // v is a product (< 1.2 p): v == 0 (mod p)  <=>  v in {0, p}
-    uint32_t z0 = 0, zp = 0;
-#pragma unroll
-    for (int i = 0; i < Fp28<P>::N; i++) { z0 |= v.l[i]; zp |= v.l[i] ^ Fp28<P>::mod28(i); }
-    return z0 == 0 || zp == 0;
-}
-template <class P>
-__device__ __noinline__ void dbl28(Acc28<P> &a) {                        // dbl-2008-s-1
-    using G = Fp28<P>;
-    if (a.zz.limbs_zero()) return;
-    G u = a.y.dbl(), v = u.sqr(), w = u * v, s = a.x * v;                // u < 8 p
-    G xx = a.x.sqr(), m = xx.dbl() + xx;                                 // m < 3.6 p
-    G x3 = m.sqr().template sub<3>(s.dbl());                             // < 4.2 p
-    G y3 = (m * s.template sub<5>(x3)).template sub<2>(w * a.y);         // < 3.2 p
-    a.x = x3; a.y = y3; a.zz = v * a.zz; a.zzz = w * a.zzz;
-}
-template <class P>
-__device__ __noinline__ void add28(Acc28<P> &a, const Acc28<P> &b) {     // add-2008-s, complete
-    using G = Fp28<P>;
-    if (b.zz.limbs_zero()) return;
-    if (a.zz.limbs_zero()) { a = b; return; }
-    G u1 = a.x * b.zz, u2 = b.x * a.zz, s1 = a.y * b.zzz, s2 = b.y * a.zzz;
-    G pd = u2.template sub<2>(u1), r = s2.template sub<2>(s1);           // < 3.2 p
-    G pp = pd.sqr();
-    if (is_zero_product<P>(pp)) {
-        if (is_zero_product<P>(r.sqr())) dbl28<P>(a);
-        else { a.x = G::zero(); a.y = G::zero(); a.zz = G::zero(); a.zzz = G::zero(); }
-        return;
-    }
-    G ppp = pd * pp, qq = u1 * pp;
-    G x3 = (r.sqr().template sub<2>(ppp)).template sub<3>(qq.dbl());     // < 6.2 p
-    G y3 = (r * qq.template sub<7>(x3)).template sub<2>(s1 * ppp);       // < 3.2 p
-    a.x = x3; a.y = y3;
-    a.zz = a.zz * b.zz * pp;
-    a.zzz = a.zzz * b.zzz * ppp;
-}
-template <class P>
-__device__ __forceinline__ Acc28<P> neg28(const Acc28<P> &a) { Acc28<P> r = a; r.y = Fp28<P>::zero().template sub<4>(a.y); return r; }
-template <class P>
-__device__ __forceinline__ Acc28<P> inf28() { Acc28<P> r; r.x = Fp28<P>::zero(); r.y = r.x; r.zz = r.x; r.zzz = r.x; return r; }
-template <class P>
-__device__ __forceinline__ XYZZ<Fp<P>> to_std_point(const Acc28<P> &a) {
-    XYZZ<Fp<P>> o;
-    if (a.zz.limbs_zero()) return XYZZ<Fp<P>>::inf();
-    o.x = a.x.to_std(); o.y = a.y.to_std(); o.zz = a.zz.to_std(); o.zzz = a.zzz.to_std();
-    return o;
-}
-template <class P>
-__device__ __forceinline__ Acc28<P> from_std_point(const XYZZ<Fp<P>> &a) {
-    if (a.is_inf()) return inf28<P>();
-    Acc28<P> o; o.x = Fp28<P>::from_std(a.x); o.y = Fp28<P>::from_std(a.y); o.zz = Fp28<P>::from_std(a.zz); o.zzz = Fp28<P>::from_std(a.zzz);
-    return o;
 }
 
 // standard (12 x 32, R = 2^384) bases -> reduced-radix copies; done once per SRS at key synthesis, or per call for ad-hoc bases
@@ -194,12 +120,12 @@ __global__ void k_convert_bases(const Affine<Fp<P>> *__restrict__ src, Affine28<
 // BUCKET_CAP-point overflow segments that k_accumulate_overflow sums in parallel and k_combine_overflow folds back -- so no input can
 // serialise the whole MSM on one lane.
 constexpr uint32_t BUCKET_CAP = 2048;
-__global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, uint32_t nb, uint32_t digit_mask, uint32_t *__restrict__ size_key,
+__global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, uint32_t nb, uint32_t *__restrict__ size_key,
                                uint32_t *__restrict__ ids, uint32_t *__restrict__ extra) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nb) return;
     uint32_t sz = end[k] - start[k];
-    extra[k] = ((k & digit_mask) != 0 && sz > BUCKET_CAP) ? (sz - 1) / BUCKET_CAP : 0;
+    extra[k] = sz > BUCKET_CAP ? (sz - 1) / BUCKET_CAP : 0;
     if (sz > 8191u) sz = 8191u;
     size_key[k] = 8191u - sz;             // ascending sort on this 13-bit key = descending bucket size (sizes above 8191 tie)
     ids[k] = k;
@@ -212,7 +138,7 @@ __global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_
 template <class P>
 __global__ void __launch_bounds__(64, 2) k_accumulate(const Affine28<P> *__restrict__ bases, const uint32_t *__restrict__ vals,
                                                        const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, const uint32_t *__restrict__ order,
-                                                       uint32_t nbuckets_total, uint32_t digit_mask, Acc28<P> *__restrict__ buckets,
+                                                       uint32_t nbuckets_total, Acc28<P> *__restrict__ buckets,
                                                        uint32_t *__restrict__ deferred, uint32_t deferred_cap, uint32_t *__restrict__ deferred_count) {
     using G = Fp28<P>;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -220,17 +146,18 @@ __global__ void __launch_bounds__(64, 2) k_accumulate(const Affine28<P> *__restr
     uint32_t k = order[t];
     Acc28<P> acc;
     bool acc_inf = true;
-    if ((k & digit_mask) != 0) {
+    {
         uint32_t s = start[k], e = end[k];
         if (e - s > BUCKET_CAP) e = s + BUCKET_CAP;                        // the remainder goes through the overflow kernels
         if (s < e) {
             uint32_t idx = vals[s];
-            Affine28<P> nxt = bases[idx];
+            Affine28<P> nxt = bases[idx & 0x7fffffffu];
             for (uint32_t i = s; i < e; i++) {
                 Affine28<P> p = nxt;
                 uint32_t cur = idx;
-                if (i + 1 < e) { idx = vals[i + 1]; nxt = bases[idx]; }   // prefetch the next gather under this add's ALU work
+                if (i + 1 < e) { idx = vals[i + 1]; nxt = bases[idx & 0x7fffffffu]; }   // prefetch the next gather under this add's ALU work
                 if (p.is_inf()) continue;
+                if (cur >> 31) p.y = G::zero().template sub<2>(p.y);                 // negative digit: add -P  (y < 1.2 p as a product, so 2p - y > 0)
                 if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_2_392(); acc.zzz = acc.zz; acc_inf = false; continue; }
                 if (!madd28(acc, p)) {
                     uint32_t slot = atomicAdd(deferred_count, 1u);
@@ -251,7 +178,9 @@ __global__ void k_accumulate_fixup(const Affine28<P> *__restrict__ bases, Acc28<
     if (n > deferred_cap) n = deferred_cap;
     for (uint32_t i = 0; i < n; i++) {
         XYZZ<Fp<P>> b = to_std_point<P>(buckets[deferred[2 * i]]);
-        b.madd(bases[deferred[2 * i + 1]].to_std());
+        uint32_t v = deferred[2 * i + 1];
+        Affine<Fp<P>> q = bases[v & 0x7fffffffu].to_std();
+        b.madd((v >> 31) ? q.neg() : q);
         buckets[deferred[2 * i]] = from_std_point<P>(b);
     }
 }
@@ -275,8 +204,9 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_overflow(const Affine28<P>
     bool acc_inf = true;
     for (uint32_t i = s; i < e; i++) {
         uint32_t cur = vals[i];
-        Affine28<P> p = bases[cur];
+        Affine28<P> p = bases[cur & 0x7fffffffu];
         if (p.is_inf()) continue;
+        if (cur >> 31) p.y = G::zero().template sub<2>(p.y);
         if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_2_392(); acc.zzz = acc.zz; acc_inf = false; continue; }
         if (!madd28(acc, p)) {
             uint32_t slot = atomicAdd(deferred_count, 1u);
@@ -299,10 +229,10 @@ __global__ void __launch_bounds__(64) k_combine_overflow(Acc28<P> *__restrict__ 
     buckets[k] = acc;
 }
 
-// Bucket reduction  sum_d d * B_d  per window, in three fully parallel levels:
-//   k_reduce_l1: lane (w, g) over the 16 buckets d0 = 16 g ..: S_g = sum B_d, W_g = sum (d - d0 + 1) B_d          (running sums only)
-//   k_reduce_l2: lane (w, h) over 32 segments: sum_g [W_g + (d0_g - 1) S_g] via a second running sum + ONE small scalar product
-//   k_reduce_window: LDS tree over the (2^c / 512) group partials of a window
+// Bucket reduction  sum_j (j + 1) * B_j  per window (bucket j holds digit magnitude j + 1), in three fully parallel levels:
+//   k_reduce_l1: lane (w, g) over the 8 buckets j0 = 8 g ..: S_g = sum B_j, W_g = sum (j - j0 + 1) B_j             (running sums only)
+//   k_reduce_l2: lane (w, h) over 8 segments: sum_g [W_g + 8 g S_g] via a second running sum + ONE small scalar product
+//   k_reduce_window: LDS tree over the group partials of a window
 constexpr int RED_L1 = 8, RED_L2 = 8;
 template <class P>
 __global__ void __launch_bounds__(64) k_reduce_l1(const Acc28<P> *__restrict__ buckets, int c, int nwin, Acc28<P> *__restrict__ seg_s, Acc28<P> *__restrict__ seg_w) {
@@ -334,14 +264,13 @@ __global__ void __launch_bounds__(64) k_reduce_l2(const Acc28<P> *__restrict__ s
         add28<P>(tot2, run);           // tot2 = sum (g - g0 + 1) S_g
         add28<P>(sw, W[g]);
     }
-    // sum_g [W_g + (L1 g - 1) S_g] = sw + L1 (tot2 - run) + (L1 g0 - 1) run     (run = sum S_g, L1 = 8)
+    // bucket j carries weight j + 1:  sum_g [W_g + L1 g S_g] = sw + L1 (tot2 - run) + (L1 g0) run     (run = sum S_g, L1 = 8)
     Acc28<P> a = tot2;
     add28<P>(a, neg28<P>(run));
     for (int i = 0; i < 3; i++) dbl28<P>(a);      // * RED_L1
     add28<P>(sw, a);
-    if (g0 == 0) add28<P>(sw, neg28<P>(run));
-    else {
-        uint32_t m = RED_L1 * g0 - 1;
+    if (g0 != 0) {
+        uint32_t m = RED_L1 * g0;
         Acc28<P> acc = inf28<P>();
         int top = 31 - __clz(m);
         for (int bit = top; bit >= 0; bit--) {
@@ -418,20 +347,21 @@ void msm_workspace_destroy(MsmWorkspace *w) {
 template <class P>
 static std::vector<XYZZ<Fp<P>>> run_buckets(MsmWorkspace &S, const Affine28<P> *bases, size_t pairs, int c, int nsets, size_t n_points, hipStream_t s, float *acc_ms) {
     using Fq = Fp<P>;
+    // c here = log2(buckets per set); keys run over [0, nb) plus the out-of-range key nb for zero digits
     size_t nb = (size_t)nsets << c;
-    int key_bits = c;
-    while ((1 << (key_bits - c)) < nsets) key_bits++;
+    int key_bits = 1;
+    while (((size_t)1 << key_bits) <= nb) key_bits++;
     size_t tmp_bytes = 0;
     HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys_a, S.keys_b, S.vals_a, S.vals_b, (int)pairs, 0, key_bits, s));
     if (tmp_bytes > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tmp_bytes); S.cap_tmp = tmp_bytes; }
     HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp, tmp_bytes, S.keys_a, S.keys_b, S.vals_a, S.vals_b, (int)pairs, 0, key_bits, s));
     HIP_CHECK(hipMemsetAsync(S.start, 0, nb * 4, s));
     HIP_CHECK(hipMemsetAsync(S.end, 0, nb * 4, s));
-    hipLaunchKernelGGL(k_bounds, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, S.keys_b, pairs, S.start, S.end);
+    hipLaunchKernelGGL(k_bounds, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, S.keys_b, pairs, (uint32_t)nb, S.start, S.end);
     HIP_LAUNCH_CHECK();
     // size-balanced visiting order of the buckets
     HIP_CHECK(hipMemsetAsync(S.extra + nb, 0, 4, s));
-    hipLaunchKernelGGL(k_bucket_sizes, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, S.start, S.end, (uint32_t)nb, (1u << c) - 1, S.size_key, S.ids, S.extra);
+    hipLaunchKernelGGL(k_bucket_sizes, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, S.start, S.end, (uint32_t)nb, S.size_key, S.ids, S.extra);
     HIP_LAUNCH_CHECK();
     {
         size_t tb = 0;
@@ -447,7 +377,7 @@ static std::vector<XYZZ<Fp<P>>> run_buckets(MsmWorkspace &S, const Affine28<P> *
     }
     HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 4, s));
     HIP_CHECK(hipEventRecord(S.ev0, s));
-    hipLaunchKernelGGL((k_accumulate<P>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, bases, S.vals_b, S.start, S.end, S.order, (uint32_t)nb, (1u << c) - 1,
+    hipLaunchKernelGGL((k_accumulate<P>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, bases, S.vals_b, S.start, S.end, S.order, (uint32_t)nb,
                        (Acc28<P> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
     HIP_CHECK(hipEventRecord(S.ev1, s));
@@ -506,17 +436,24 @@ XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws_, const Affine28<typename Curve::F
     auto t_begin = std::chrono::steady_clock::now();
     int lg = 0;
     while (((size_t)1 << lg) < n) lg++;
-    int c = lg - 3;
-    if (c < 6) c = 6;
-    if (c > 16) c = 16;
-    const int nwin = (Fr::BITS + c - 1) / c;
+    int c = lg - 2;                               // signed digits: 2^(c-1) buckets per window
+    if (c < 7) c = 7;
+    if (c > 17) c = 17;
+    const int nwin = (Fr::BITS + 1 + c - 1) / c;  // one extra bit for the recoding carry
     size_t pairs = n * (size_t)nwin;
+    const size_t nb = (size_t)nwin << (c - 1);
     MsmWorkspace &S = *ws_;
-    ensure_scratch(S, pairs, (size_t)nwin << c, sizeof(XYZZ<Fq>));
-    hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scalars, (uint32_t)n, c, nwin, S.keys_a, S.vals_a);
+    ensure_scratch(S, pairs, nb, sizeof(XYZZ<Fq>));
+    hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scalars, (uint32_t)n, c, nwin, (uint32_t)nb, S.keys_a, S.vals_a);
     HIP_LAUNCH_CHECK();
     float ms = 0;
-    std::vector<XYZZ<Fq>> ws = run_buckets<typename Curve::FqP>(S, bases, pairs, c, nwin, n, s, &ms);
+    std::vector<XYZZ<Fq>> ws = run_buckets<typename Curve::FqP>(S, bases, pairs, c - 1, nwin, n, s, &ms);
+    if (getenv("ZKAES_MSM_DEBUG")) {
+        for (int w = 0; w < nwin; w++) {
+            Affine<Fq> a = ws[w].to_affine();
+            fprintf(stderr, "window %d inf=%d x0=%08x y0=%08x\n", w, (int)a.is_inf(), a.x.l[0], a.y.l[0]);
+        }
+    }
     XYZZ<Fq> total = XYZZ<Fq>::inf();
     for (int w = nwin - 1; w >= 1; w--) {
         total.add(ws[w]);

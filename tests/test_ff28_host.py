@@ -51,3 +51,16 @@ def test_reduced_radix_field_matches_montgomery_reference():
         out = subprocess.run([exe], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout + out.stderr
         assert out.stdout.split() == ["fq377", "0", "fq381", "0"]
+
+
+
+def test_reduced_radix_group_law_matches_xyzz_reference():
+    """madd28 / add28 / dbl28 / neg28 (csrc/ec28.cuh) against XYZZ<Fq> on random points of both curves: accumulation chains with negated and
+    non-canonical (value >= p) coordinates, the running-sum pattern of the bucket reduction (P + P through the complete law), P - P = infinity."""
+    src_path = os.path.join(ROOT, "tests", "ec28_host_check.cpp")
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", CSRC, src_path, "-o", exe])
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert out.stdout.split() == ["bls377", "0", "bls381", "0"]
