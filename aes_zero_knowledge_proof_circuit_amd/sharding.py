@@ -34,7 +34,7 @@ def reduce_report(elapsed, accepted, total, negatives_ok, device=None):
     """max-over-ranks time and summed acceptance counters (no-op without an initialized process group)"""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return elapsed, accepted, total, negatives_ok
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

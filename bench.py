@@ -61,7 +61,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ            # under torchrun the RCCL group is created (and exercised) even for one rank
+    if use_dist:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from aes_zero_knowledge_proof_circuit_amd import api
@@ -87,7 +88,7 @@ def main():
     n_chunks = n_full + (1 if rem else 0)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -134,7 +135,7 @@ def main():
     first_cb = keys[0][3]
     bad = bytearray(ct[:first_cb]); bad[1] ^= 1; bad[-1] ^= 1
     rejected_wrong = not api.verify_encryption(vk, all_proofs[0][0][0], bytes(bad))
-    elapsed, acc_sum, tot_sum, neg_sum = sharding.reduce_report(elapsed, accepted, total, int(rejected_wrong), device="cuda" if world > 1 else None)
+    elapsed, acc_sum, tot_sum, neg_sum = sharding.reduce_report(elapsed, accepted, total, int(rejected_wrong), device="cuda" if use_dist else None)
     ok = [acc_sum, tot_sum, neg_sum]
 
     if rank == 0:
@@ -178,7 +179,7 @@ def main():
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = round(value / cb["value"], 2)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -123,3 +123,16 @@ def test_chunked_message_equals_individual_proofs(api, aes16):
     key, msg = mt_bytes(16, 500), mt_bytes(16 * 5, 501)
     proofs = pk.encrypt_chunked(msg, key)
     assert proofs == [api.encrypt(msg[16 * i:16 * i + 16], key, pk) for i in range(5)]
+
+
+def test_empty_message_and_size_limits(api):
+    """edge cases: a 0-byte message proves only the key schedule (no public inputs); 96 bytes is the largest plaintext that fits the
+    reference's universal-SRS literal (src/lib.rs:141), 112 bytes must be refused like arkworks' IndexTooLarge."""
+    pk, vk = api.synthesize_keys(0)
+    info = pk.info()
+    assert (info["raw_constraints"], info["raw_instance"]) == (36_768, 1)
+    proof = api.encrypt(b"", bytes(range(16)), pk)
+    assert api.verify_encryption(vk, proof, b"") is True
+    assert api.verify_encryption(vk, proof, bytes(16)) is False        # instance length does not match the index
+    with pytest.raises(api.ZkAesError, match="IndexTooLarge"):
+        api.synthesize_keys(112)
