@@ -241,10 +241,11 @@ def msm_bench(curve_id, bases_bytes, scalars_bytes, reps=3):
     return t.value, a.value
 
 
-def msm_bench_synth(n, window_bits=0, reps=3):
+def msm_bench_synth(n, window_bits=0, reps=3, want_point=False):
     t, a = C.c_double(), C.c_double()
-    _check(lib().zkaes_msm_bench_synth(C.c_size_t(n), int(window_bits), int(reps), C.byref(t), C.byref(a)))
-    return t.value, a.value
+    out = C.create_string_buffer(96)
+    _check(lib().zkaes_msm_bench_synth(C.c_size_t(n), int(window_bits), int(reps), C.byref(t), C.byref(a), out))
+    return (t.value, a.value, out.raw) if want_point else (t.value, a.value)
 
 
 def msm_stats(reset=False):

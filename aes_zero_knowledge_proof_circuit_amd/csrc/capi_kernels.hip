@@ -97,7 +97,7 @@ int zkaes_msm_bench(int curve_id, const uint8_t *bases, const uint8_t *scalars, 
 }
 // BLS12-377 only: n_points synthetic bases (powers of a fixed scalar times the generator, made on the device) and pseudo-random scalars;
 // window_bits = 0 -> classic per-window buckets, else the precomputed-table path.  Returns ms per MSM (whole pipeline / accumulate kernel).
-int zkaes_msm_bench_synth(size_t n, int window_bits, int reps, double *ms_total, double *ms_accumulate) {
+int zkaes_msm_bench_synth(size_t n, int window_bits, int reps, double *ms_total, double *ms_accumulate, uint8_t *out_xy) {
     return guardk([&] {
         using Fq = zk::Fq377; using Fr = zk::Fr377;
         zk::gpu::require_device();
@@ -118,7 +118,10 @@ int zkaes_msm_bench_synth(size_t n, int window_bits, int reps, double *ms_total,
         zk::gpu::sync(s);
         zk::gpu::MsmWorkspace *ws = zk::gpu::msm_workspace_create();
         auto run = [&] { return window_bits ? zk::gpu::msm_table<zk::Bls377>(ws, tab28, n, 0, window_bits, ds, n, s) : zk::gpu::msm<zk::Bls377>(ws, tab28, ds, n, s); };
-        run();
+        {
+            zk::Affine<Fq> a = run().to_affine();
+            if (out_xy) { memcpy(out_xy, a.x.l, 48); memcpy(out_xy + 48, a.y.l, 48); }
+        }
         zk::gpu::MsmStats before = zk::gpu::msm_stats(false);
         void *e0 = zk::gpu::event_create(), *e1 = zk::gpu::event_create();
         zk::gpu::event_record(e0, s);

@@ -112,8 +112,9 @@ int zkaes_msm_table(int curve_id, const uint8_t *bases, const uint8_t *scalars, 
 /* device-resident variant for benchmarking: repeats the MSM `reps` times over device copies, returns ms per MSM of the whole pipeline and of
  * the bucket-accumulation kernel alone */
 int zkaes_msm_bench(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, int reps, double *ms_total, double *ms_accumulate);
-/* BLS12-377, synthetic device-made bases and scalars: window_bits = 0 classic per-window buckets, else the precomputed-table path */
-int zkaes_msm_bench_synth(size_t n, int window_bits, int reps, double *ms_total, double *ms_accumulate);
+/* BLS12-377, synthetic device-made bases (powers of a fixed scalar times the generator) and xorshift scalars: window_bits = 0 per-window
+ * signed-digit buckets, else the precomputed-table path.  out_xy (96 B, may be NULL) receives the sum: the two paths must agree. */
+int zkaes_msm_bench_synth(size_t n, int window_bits, int reps, double *ms_total, double *ms_accumulate, uint8_t *out_xy);
 /* AES witness only: fills z (padded instance + witness, one byte per variable) for a message under the key's circuit */
 int zkaes_aes_witness(const zkaes_pk *pk, const uint8_t *message, size_t message_len, const uint8_t secret_key[16], uint8_t *z, size_t z_cap, size_t *z_len);
 

@@ -133,3 +133,12 @@ def test_msm_skewed_scalars_use_the_overflow_path(zko, api, distinct):
     ref_inf = zko.lib().zko_api_msm(377, bases, scalars, C.c_size_t(n), ref)
     got, inf = api.msm(377, bases, scalars)
     assert not inf and not ref_inf and got == ref.raw
+
+
+def test_msm_full_size_two_independent_paths_agree(api):
+    """BASELINE-size MSM (2^20 points = |H| of a 6-block proof; the oracle would need minutes): the signed-digit per-window path and the
+    precomputed-table single-bucket-set path are different algorithms over different table copies -- their sums must be identical."""
+    n = 1 << 20
+    _, _, p_classic = api.msm_bench_synth(n, 0, 1, want_point=True)
+    _, _, p_table = api.msm_bench_synth(n, 17, 1, want_point=True)
+    assert p_classic == p_table and p_classic != bytes(96)
