@@ -58,6 +58,14 @@ XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws, const Affine28<typename Cur
 // out[i] = (beta^(from+i)) * base for i < count   (KZG powers; fixed-base windows)   -- device output
 template <class Curve>
 void fixed_base_powers(Affine<typename Curve::Fq> *out, const Affine<typename Curve::Fq> &base, const typename Curve::Fr &beta, size_t from, size_t count, stream_t s);
+// out[i] = scalars[i] * base for device-resident scalars
+template <class Curve>
+void fixed_base_scalars(Affine<typename Curve::Fq> *out, const Affine<typename Curve::Fq> &base, const typename Curve::Fr *scalars, size_t count, stream_t s);
+// sum_i vals[i] * bases[i] for small integers |vals[i]| <= 2 (commitments of 0/1-valued evaluation vectors in a Lagrange-basis SRS): about one
+// mixed add per non-zero entry instead of one per window.  Returns false (result unusable) if a value is out of range or an addition
+// degenerates -- callers then use the generic MSM.  Synchronizes the stream.
+template <class Curve>
+bool class_sum(MsmWorkspace *ws, const Affine28<typename Curve::FqP> *bases, const int8_t *vals, size_t n, XYZZ<typename Curve::Fq> *out, stream_t s);
 // MSM-stage timing hooks for bench.py (accumulated kernel time of the bucket-accumulation kernel, measured with events)
 struct MsmStats { double accumulate_ms = 0; double total_ms = 0; uint64_t points = 0; uint64_t launches = 0; uint64_t pairs = 0; };   // pairs = sum of points x windows
 MsmStats msm_stats(bool reset);   // process-wide totals (thread-safe)
@@ -95,7 +103,12 @@ void aes_trace(uint8_t *trace, size_t trace_stride, const uint8_t *msgs, const u
 // z[col] (0/1 bytes) for every column, by descriptor
 void witness_expand(uint8_t *z, const uint32_t *desc, uint32_t ncols, const uint8_t *trace, const uint32_t *sbox_in_off, const uint32_t *sbox_tmpl, stream_t s);
 // out[r] = sum_i coeff[i] * z[col[i]] as a field element, rows with no entries give 0 (out has `rows_out` >= rows entries, tail zeroed)
-void spmv_bits(F *out, size_t rows_out, const uint32_t *rowptr, const uint32_t *col, const int64_t *coeff, size_t rows, const uint8_t *z, stream_t s);
+// small_out (may be null): the same values as int8 (saturated to +-127) for the Lagrange-basis commitment path
+void spmv_bits(F *out, int8_t *small_out, size_t rows_out, const uint32_t *rowptr, const uint32_t *col, const int64_t *coeff, size_t rows, const uint8_t *z, stream_t s);
+// w evaluation classes on H: 0 at the positions of X, else the witness bit (ark-marlin prover_first_round indexing)
+void w_classes(int8_t *out, const uint8_t *z, uint32_t n, uint32_t m, uint32_t num_witness, stream_t s);
+// Lagrange-basis scalars at the KZG trapdoor beta: lag[k] = L_k(beta) = (beta^n - 1) g^k / (n (beta - g^k));  lag_w[k] = 0 on X, else L_k(beta) / v_X(beta)
+void lagrange_scalars(F *lag, F *lag_w, const F *elems, const F &beta, uint32_t n, uint32_t m, stream_t s);
 // w evaluations on H (ark-marlin prover_first_round): out[k] = 0 if k % ratio == 0 else w_ext[k - k/ratio - 1] - x_evals[k]
 void w_evals(F *out, const uint8_t *z, const F *x_evals, uint32_t n, uint32_t m, uint32_t num_witness, stream_t s);
 void bits_to_field(F *out, const uint8_t *z, size_t n, stream_t s);

@@ -523,13 +523,11 @@ __global__ void __launch_bounds__(64) k_fixed_base(const Affine<Fq> *__restrict_
     out[i] = acc.to_affine();
 }
 
+namespace {
 template <class Curve>
-void fixed_base_powers(Affine<typename Curve::Fq> *out, const Affine<typename Curve::Fq> &base, const typename Curve::Fr &beta, size_t from, size_t count, stream_t s_) {
+Affine<typename Curve::Fq> *upload_fixed_base_table(const Affine<typename Curve::Fq> &base, hipStream_t s) {
     using Fq = typename Curve::Fq;
-    using Fr = typename Curve::Fr;
-    hipStream_t s = (hipStream_t)s_;
-    if (!count) return;
-    const int NW = Fr::N * 4;
+    const int NW = Curve::Fr::N * 4;
     std::vector<Affine<Fq>> table((size_t)NW * 255);
     XYZZ<Fq> wb = XYZZ<Fq>::from_affine(base);
     for (int w = 0; w < NW; w++) {
@@ -539,6 +537,18 @@ void fixed_base_powers(Affine<typename Curve::Fq> *out, const Affine<typename Cu
     }
     Affine<Fq> *d_table = (Affine<Fq> *)dmalloc(table.size() * sizeof(Affine<Fq>));
     HIP_CHECK(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(Affine<Fq>), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    return d_table;
+}
+}  // namespace
+
+template <class Curve>
+void fixed_base_powers(Affine<typename Curve::Fq> *out, const Affine<typename Curve::Fq> &base, const typename Curve::Fr &beta, size_t from, size_t count, stream_t s_) {
+    using Fq = typename Curve::Fq;
+    using Fr = typename Curve::Fr;
+    hipStream_t s = (hipStream_t)s_;
+    if (!count) return;
+    Affine<Fq> *d_table = upload_fixed_base_table<Curve>(base, s);
     const size_t CH = 1 << 20;
     Fr *d_sc = (Fr *)dmalloc(CH * sizeof(Fr));
     for (size_t off = 0; off < count; off += CH) {
@@ -551,6 +561,109 @@ void fixed_base_powers(Affine<typename Curve::Fq> *out, const Affine<typename Cu
     HIP_CHECK(hipStreamSynchronize(s));
     dfree(d_table); dfree(d_sc);
 }
+// out[i] = scalars[i] * base for device-resident scalars (Lagrange-basis SRS points)
+template <class Curve>
+void fixed_base_scalars(Affine<typename Curve::Fq> *out, const Affine<typename Curve::Fq> &base, const typename Curve::Fr *scalars, size_t count, stream_t s_) {
+    using Fq = typename Curve::Fq;
+    using Fr = typename Curve::Fr;
+    hipStream_t s = (hipStream_t)s_;
+    if (!count) return;
+    Affine<Fq> *d_table = upload_fixed_base_table<Curve>(base, s);
+    const size_t CH = 1 << 20;
+    for (size_t off = 0; off < count; off += CH) {
+        uint32_t m = (uint32_t)((count - off) < CH ? (count - off) : CH);
+        hipLaunchKernelGGL((k_fixed_base<Fq, Fr>), dim3((m + 63) / 64), dim3(64), 0, s, d_table, scalars + off, m, out + off);
+        HIP_LAUNCH_CHECK();
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+    dfree(d_table);
+}
+
+// ---- sum of bases weighted by SMALL integers (|v| <= 2): the Lagrange-basis commitments of 0/1-valued evaluation vectors.
+// One lane per 64 consecutive bases keeps two accumulators (|v| = 1, |v| = 2; the sign negates y); a two-level tree sums the partials.
+constexpr int CLS_CHUNK = 64;
+template <class P>
+__global__ void __launch_bounds__(64, 2) k_class_partials(const Affine28<P> *__restrict__ bases, const int8_t *__restrict__ vals, uint32_t n, Acc28<P> *__restrict__ part1,
+                                                           Acc28<P> *__restrict__ part2, uint32_t *__restrict__ flags) {
+    using G = Fp28<P>;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s0 = t * CLS_CHUNK;
+    if (s0 >= n) return;
+    uint32_t e = s0 + CLS_CHUNK < n ? s0 + CLS_CHUNK : n;
+    Acc28<P> a1, a2;
+    bool inf1 = true, inf2 = true;
+    for (uint32_t i = s0; i < e; i++) {
+        int v = vals[i];
+        if (v == 0) continue;
+        Affine28<P> p = bases[i];
+        if (p.is_inf()) continue;
+        if (v < 0) { p.y = G::zero().template sub<2>(p.y); v = -v; }
+        if (v == 1) {
+            if (inf1) { a1.x = p.x; a1.y = p.y; a1.zz = G::k_2_392(); a1.zzz = a1.zz; inf1 = false; }
+            else if (!madd28(a1, p)) atomicOr(flags, 1u);
+        } else if (v == 2) {
+            if (inf2) { a2.x = p.x; a2.y = p.y; a2.zz = G::k_2_392(); a2.zzz = a2.zz; inf2 = false; }
+            else if (!madd28(a2, p)) atomicOr(flags, 1u);
+        } else atomicOr(flags, 2u);
+    }
+    part1[t] = inf1 ? inf28<P>() : a1;
+    part2[t] = inf2 ? inf28<P>() : a2;
+}
+// out[b] = sum of in[b * per .. (b+1) * per)   (one block of 256 lanes per output)
+template <class P>
+__global__ void __launch_bounds__(256) k_sum_tree(const Acc28<P> *__restrict__ in, uint32_t total, uint32_t per, Acc28<P> *__restrict__ out) {
+    __shared__ Acc28<P> sh[256];
+    uint32_t b = blockIdx.x, t = threadIdx.x;
+    uint32_t lo = b * per, hi = lo + per < total ? lo + per : total;
+    Acc28<P> acc = inf28<P>();
+    for (uint32_t i = lo + t; i < hi; i += 256) add28<P>(acc, in[i]);
+    sh[t] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)t < s) { Acc28<P> a = sh[t]; add28<P>(a, sh[t + s]); sh[t] = a; }
+        __syncthreads();
+    }
+    if (t == 0) out[b] = sh[0];
+}
+template <class P>
+__global__ void k_points_to_std(const Acc28<P> *__restrict__ in, uint32_t n, XYZZ<Fp<P>> *__restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = to_std_point<P>(in[i]);
+}
+
+template <class Curve>
+bool class_sum(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *bases, const int8_t *vals, size_t n, XYZZ<typename Curve::Fq> *out, stream_t s_) {
+    using P = typename Curve::FqP;
+    using Fq = typename Curve::Fq;
+    hipStream_t s = (hipStream_t)s_;
+    *out = XYZZ<Fq>::inf();
+    if (n == 0) return true;
+    if (!ws_) throw GpuError("class_sum: null workspace");
+    MsmWorkspace &S = *ws_;
+    uint32_t chunks = (uint32_t)((n + CLS_CHUNK - 1) / CLS_CHUNK), mid = (chunks + 255) / 256;
+    // scratch carved from the bucket array (sized for >= 2 * chunks + 2 * mid + 2 points by any prior msm of this context, else grown here)
+    size_t need_buckets = 2 * (size_t)chunks + 2 * mid + 8;
+    ensure_scratch(S, 1, need_buckets, 0);
+    Acc28<P> *p1 = (Acc28<P> *)S.buckets, *p2 = p1 + chunks, *m1 = p2 + chunks, *m2 = m1 + mid, *fin = m2 + mid;
+    HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 4, s));
+    hipLaunchKernelGGL((k_class_partials<P>), dim3((chunks + 63) / 64), dim3(64), 0, s, bases, vals, (uint32_t)n, p1, p2, S.deferred_count);
+    HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_sum_tree<P>), dim3(mid), dim3(256), 0, s, (const Acc28<P> *)p1, chunks, 256u, m1); HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_sum_tree<P>), dim3(mid), dim3(256), 0, s, (const Acc28<P> *)p2, chunks, 256u, m2); HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_sum_tree<P>), dim3(1), dim3(256), 0, s, (const Acc28<P> *)m1, mid, mid, fin); HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_sum_tree<P>), dim3(1), dim3(256), 0, s, (const Acc28<P> *)m2, mid, mid, fin + 1); HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_points_to_std<P>), dim3(1), dim3(64), 0, s, (const Acc28<P> *)fin, 2u, (XYZZ<Fq> *)S.wsum); HIP_LAUNCH_CHECK();
+    XYZZ<Fq> r[2];
+    uint32_t flags = 0;
+    HIP_CHECK(hipMemcpyAsync(r, S.wsum, sizeof r, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(&flags, S.deferred_count, 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (flags) return false;          // a value outside [-2, 2] or a degenerate addition: the caller falls back to the generic MSM
+    XYZZ<Fq> t = r[1].dbl();
+    t.add(r[0]);
+    *out = t;
+    return true;
+}
 
 template XYZZ<Fq377> msm_table<Bls377>(MsmWorkspace *, const Affine28<Fq377P> *, size_t, size_t, int, const Fr377 *, size_t, stream_t);
 template XYZZ<Fq381> msm_table<Bls381>(MsmWorkspace *, const Affine28<Fq381P> *, size_t, size_t, int, const Fr381 *, size_t, stream_t);
@@ -562,6 +675,8 @@ template int table_windows<Bls377>(int);
 template int table_windows<Bls381>(int);
 template XYZZ<Fq377> msm<Bls377>(MsmWorkspace *, const Affine28<Fq377P> *, const Fr377 *, size_t, stream_t);
 template XYZZ<Fq381> msm<Bls381>(MsmWorkspace *, const Affine28<Fq381P> *, const Fr381 *, size_t, stream_t);
+template void fixed_base_scalars<Bls377>(Affine<Fq377> *, const Affine<Fq377> &, const Fr377 *, size_t, stream_t);
+template bool class_sum<Bls377>(MsmWorkspace *, const Affine28<Fq377P> *, const int8_t *, size_t, XYZZ<Fq377> *, stream_t);
 template void fixed_base_powers<Bls377>(Affine<Fq377> *, const Affine<Fq377> &, const Fr377 &, size_t, size_t, stream_t);
 template void fixed_base_powers<Bls381>(Affine<Fq381> *, const Affine<Fq381> &, const Fr381 &, size_t, size_t, stream_t);
 

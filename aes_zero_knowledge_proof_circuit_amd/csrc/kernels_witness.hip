@@ -113,16 +113,42 @@ void witness_expand(uint8_t *z, const uint32_t *desc, uint32_t ncols, const uint
 
 __device__ __forceinline__ F small_to_field(long long v) { return F::from_i64(v); }
 
-__global__ void k_spmv_bits(F *__restrict__ out, size_t rows_out, const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col, const int64_t *__restrict__ coeff,
+__global__ void k_spmv_bits(F *__restrict__ out, int8_t *__restrict__ small_out, size_t rows_out, const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col, const int64_t *__restrict__ coeff,
                             size_t rows, const uint8_t *__restrict__ z) {
     size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows_out) return;
     long long acc = 0;
     if (r < rows) for (uint32_t i = rowptr[r]; i < rowptr[r + 1]; i++) acc += z[col[i]] ? coeff[i] : 0;
     out[r] = acc == 0 ? F::zero() : small_to_field(acc);
+    if (small_out) small_out[r] = (int8_t)(acc > 127 ? 127 : (acc < -127 ? -127 : acc));
 }
-void spmv_bits(F *out, size_t rows_out, const uint32_t *rowptr, const uint32_t *col, const int64_t *coeff, size_t rows, const uint8_t *z, stream_t s) {
-    hipLaunchKernelGGL(k_spmv_bits, GRID(rows_out), 0, (hipStream_t)s, out, rows_out, rowptr, col, coeff, rows, z); HIP_LAUNCH_CHECK();
+void spmv_bits(F *out, int8_t *small_out, size_t rows_out, const uint32_t *rowptr, const uint32_t *col, const int64_t *coeff, size_t rows, const uint8_t *z, stream_t s) {
+    hipLaunchKernelGGL(k_spmv_bits, GRID(rows_out), 0, (hipStream_t)s, out, small_out, rows_out, rowptr, col, coeff, rows, z); HIP_LAUNCH_CHECK();
+}
+__global__ void k_w_classes(int8_t *__restrict__ out, const uint8_t *__restrict__ z, uint32_t n, uint32_t m, uint32_t num_witness) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t ratio = n / m;
+    if (k % ratio == 0) { out[k] = 0; return; }
+    uint32_t wi = k - k / ratio - 1;
+    out[k] = (wi < num_witness && z[m + wi]) ? 1 : 0;
+}
+void w_classes(int8_t *out, const uint8_t *z, uint32_t n, uint32_t m, uint32_t num_witness, stream_t s) {
+    hipLaunchKernelGGL(k_w_classes, GRID(n), 0, (hipStream_t)s, out, z, n, m, num_witness); HIP_LAUNCH_CHECK();
+}
+__global__ void k_lagrange_finish(F *__restrict__ lag, F *__restrict__ lag_w, const F *__restrict__ elems, uint32_t n, uint32_t m, F vx_inv) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    F v = lag[k] * elems[k];            // lag[k] arrives as (beta^n - 1) / (n (beta - g^k))
+    lag[k] = v;
+    lag_w[k] = (k % (n / m) == 0) ? F::zero() : v * vx_inv;
+}
+void lagrange_scalars(F *lag, F *lag_w, const F *elems, const F &beta, uint32_t n, uint32_t m, stream_t s) {
+    F c = (beta.pow_u64(n) - F::one()) * F::from_u64(n).inverse();
+    F vx_inv = (beta.pow_u64(m) - F::one()).inverse();
+    sub_from_scalar(lag, elems, beta, n, s);
+    batch_inverse(lag, n, &c, s);
+    hipLaunchKernelGGL(k_lagrange_finish, GRID(n), 0, (hipStream_t)s, lag, lag_w, elems, n, m, vx_inv); HIP_LAUNCH_CHECK();
 }
 
 __global__ void k_w_evals(F *__restrict__ out, const uint8_t *__restrict__ z, const F *__restrict__ x_evals, uint32_t n, uint32_t m, uint32_t num_witness) {

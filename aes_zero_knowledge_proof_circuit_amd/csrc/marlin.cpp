@@ -218,6 +218,7 @@ struct ProverContext {
     gpu::stream_t stream = nullptr;
     gpu::MsmWorkspace *msm_ws = nullptr;
     uint8_t *d_trace = nullptr, *d_z = nullptr, *d_msg = nullptr, *d_key = nullptr;
+    int8_t *d_cls[3] = {nullptr, nullptr, nullptr};   // small-integer evaluation classes of w, z_A, z_B on H (Lagrange-basis commitments)
     DevBuf za_ev, zb_ev, x_poly, x_tmp, x_evals, tmp_n, ra_ev, ra_poly, zpoly, t_partial;
     DevBuf poly[9];                    // w z_a z_b mask t g_1 h_1 g_2 h_2
     size_t poly_len[9] = {0};
@@ -226,6 +227,7 @@ struct ProverContext {
     ProverContext() { stream = gpu::stream_create(); msm_ws = gpu::msm_workspace_create(); }
     ~ProverContext() {
         gpu::dfree(d_trace); gpu::dfree(d_z); gpu::dfree(d_msg); gpu::dfree(d_key);
+        for (auto p : d_cls) gpu::dfree(p);
         for (DevBuf *b : {&za_ev, &zb_ev, &x_poly, &x_tmp, &x_evals, &tmp_n, &ra_ev, &ra_poly, &zpoly, &t_partial, &big_tmp, &f_poly, &acc, &wit, &scratch}) b->release();
         for (auto &b : poly) b.release();
         for (auto &b : e) b.release();
@@ -249,6 +251,12 @@ class ProvingKeyImpl {
     G1A gamma_powers[3];
     // device: SRS as precomputed window tables: copy j holds 2^(table_c * j) * powers_of_g[i] (gpu.hpp msm_table)
     Affine28<Fq377P> *d_powers = nullptr, *d_shifted = nullptr;   // reduced-radix copies (ff28.cuh) -- what k_accumulate gathers
+    // Lagrange-basis SRS over H (ZKAES_LAGRANGE=0 disables): L_k(beta) G for z_A, z_B; L_k(beta)/v_X(beta) G (zero on X) for w;
+    // P_j for the public-input part of w; v_H(beta) G and (v_H/v_X)(beta) G for the blinding terms
+    bool use_lagrange = true;
+    Affine28<Fq377P> *d_lag_h = nullptr, *d_lag_w = nullptr;
+    std::vector<G1A> lag_pj;
+    G1A lag_vh, lag_vw;
     int table_c = 16;
     bool use_tables = false;   // ZKAES_MSM_TABLES=1: precomputed-window path (measured slower than per-window buckets on MI355X today: DESIGN.md §3)
     // device: circuit
@@ -262,7 +270,7 @@ class ProvingKeyImpl {
     ProverTimings last_timings;
 
     ~ProvingKeyImpl() {
-        gpu::dfree(d_powers); gpu::dfree(d_shifted); gpu::dfree(d_desc); gpu::dfree(d_sbox_in); gpu::dfree(d_sbox_tmpl);
+        gpu::dfree(d_powers); gpu::dfree(d_shifted); gpu::dfree(d_lag_h); gpu::dfree(d_lag_w); gpu::dfree(d_desc); gpu::dfree(d_sbox_in); gpu::dfree(d_sbox_tmpl);
         gpu::dfree(d_a_rowptr); gpu::dfree(d_a_col); gpu::dfree(d_b_rowptr); gpu::dfree(d_b_col); gpu::dfree(d_a_coeff); gpu::dfree(d_b_coeff);
         gpu::dfree(d_t_colptr); gpu::dfree(d_t_seg_start); gpu::dfree(d_t_seg_end); gpu::dfree(d_t_row); gpu::dfree(d_t_mat); gpu::dfree(d_t_coeff);
         for (auto &b : ix_ev) b.release();
@@ -284,6 +292,7 @@ class ProvingKeyImpl {
         size_t n4 = next_pow2(3 * n + 1), k2 = 2 * k;
         cx.d_trace = (uint8_t *)gpu::dmalloc(c.trace_bytes + 64); cx.d_z = (uint8_t *)gpu::dmalloc(c.num_variables() + 64);
         cx.d_msg = (uint8_t *)gpu::dmalloc(std::max<size_t>(message_len, 16)); cx.d_key = (uint8_t *)gpu::dmalloc(16);
+        for (auto &p : cx.d_cls) p = (int8_t *)gpu::dmalloc(n + 64);
         cx.za_ev.alloc(n); cx.zb_ev.alloc(n); cx.x_poly.alloc(m); cx.x_tmp.alloc(m); cx.x_evals.alloc(n); cx.tmp_n.alloc(n + 1); cx.ra_ev.alloc(n); cx.ra_poly.alloc(n);
         cx.zpoly.alloc(n + 1); cx.t_partial.alloc(t_nseg + 1);
         size_t caps[9] = {n + 1, n + 1, n + 1, 3 * n, n, n, 3 * n, k, k + 1};
@@ -318,6 +327,19 @@ class ProvingKeyImpl {
             for (int i = 0; i < 3; i++) c.add(mul_fr(XYZZ<Fq377>::from_affine(gamma_powers[i]), rnd.b[i]));
         }
         return c.to_affine();
+    }
+    // commitment of w / z_A / z_B through the Lagrange-basis SRS: sum of the bases whose evaluation is non-zero (+-1, 2) + the blinding term
+    // rho * V + the hiding part.  Same group element as MSM(powers, coefficients); falls back to the MSM if the class sum declines.
+    bool lagrange_commit(ProverContext &cx, int which, const std::vector<uint8_t> &inst, const Fr &rho, KzgRand &rnd, ChaChaRng &zk, G1A &out) {
+        XYZZ<Fq377> c;
+        if (!gpu::class_sum<Bls377>(cx.msm_ws, which == 0 ? d_lag_w : d_lag_h, cx.d_cls[which], n, &c, cx.stream)) return false;
+        if (which == 0) for (size_t j = 0; j < m; j++) if (inst[j]) c.madd(lag_pj[j].neg());
+        c.add(mul_fr(XYZZ<Fq377>::from_affine(which == 0 ? lag_vw : lag_vh), rho));
+        rnd.hiding = true;
+        for (int i = 0; i < 3; i++) rnd.b[i] = zk.rand_field<Fr>();
+        for (int i = 0; i < 3; i++) c.add(mul_fr(XYZZ<Fq377>::from_affine(gamma_powers[i]), rnd.b[i]));
+        out = c.to_affine();
+        return true;
     }
     struct Labeled { int idx; long bound; bool hiding; KzgRand rand, shifted_rand; Commitment comm; };
     void mpc_commit(ProverContext &cx, Labeled &lp, ChaChaRng &zk) {
@@ -396,6 +418,39 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
     };
     d_powers = make_srs(0, supported_degree + 1);
     d_shifted = make_srs(lowest_shift, bounds[1] + 1);
+    if (const char *e = getenv("ZKAES_LAGRANGE")) use_lagrange = atoi(e) != 0;
+    if (use_lagrange) {
+        // With the (public, test_rng-derived) trapdoor the Lagrange-basis points are direct fixed-base products; a trapdoor-free universal SRS
+        // yields the same points through an inverse FFT over the group elements powers_of_g[0..|H|) (one time per key).
+        F *d_lag = (F *)gpu::dmalloc(n * sizeof(F)), *d_lagw = (F *)gpu::dmalloc(n * sizeof(F));
+        gpu::lagrange_scalars(d_lag, d_lagw, gpu::domain_elements<F>(lg_n), srs_beta, (uint32_t)n, (uint32_t)m, stream);
+        G1A *tmp = (G1A *)gpu::dmalloc(n * sizeof(G1A));
+        auto to28 = [&](const F *sc) {
+            gpu::fixed_base_scalars<Bls377>(tmp, g, sc, n, stream);
+            Affine28<Fq377P> *dst = (Affine28<Fq377P> *)gpu::dmalloc(n * sizeof(Affine28<Fq377P>));
+            gpu::convert_bases<Bls377>(dst, tmp, n, stream);
+            gpu::sync(stream);
+            return dst;
+        };
+        d_lag_h = to28(d_lag);
+        d_lag_w = to28(d_lagw);
+        // P_j = sum_{k not in X} l_j(h_k) L_k(beta)/v_X(beta) G = (l_j(beta) - L_{j n/m}(beta)) / v_X(beta) G, j < |X|
+        Fr vh = eval_vanishing(n, srs_beta), vx = eval_vanishing(m, srs_beta), vx_inv = vx.inverse();
+        Fr cm = vx * Fr::from_u64(m).inverse(), cn = vh * Fr::from_u64(n).inverse();
+        std::vector<Fr> pj(m), den(m);
+        Fr gx = domain_gen(lg_m), e = Fr::one();
+        for (size_t j = 0; j < m; j++) { den[j] = srs_beta - e; pj[j] = e; e = e * gx; }
+        { std::vector<Fr> pre(m); Fr acc = Fr::one(); for (size_t j = 0; j < m; j++) { pre[j] = acc; acc = acc * den[j]; } Fr inv = acc.inverse(); for (size_t j = m; j-- > 0;) { Fr d = den[j]; den[j] = inv * pre[j]; inv = inv * d; } }
+        for (size_t j = 0; j < m; j++) pj[j] = pj[j] * den[j] * (cm - cn) * vx_inv;
+        F *d_pj = (F *)gpu::dmalloc(m * sizeof(F));
+        gpu::h2d(d_pj, pj.data(), m * sizeof(F), stream);
+        gpu::fixed_base_scalars<Bls377>(tmp, g, d_pj, m, stream);
+        lag_pj.resize(m);
+        gpu::d2h(lag_pj.data(), tmp, m * sizeof(G1A), stream);
+        lag_vh = mul_affine(g, vh);
+        lag_vw = mul_affine(g, vh * vx_inv);
+        gpu::dfree(d_lag); gpu::dfree(d_lagw); gpu::dfree(tmp); gpu::dfree(d_pj);
+    }
     { Fr bp = Fr::one(); for (int i = 0; i < 3; i++) { gamma_powers[i] = mul_affine(gamma_g, bp); bp = bp * srs_beta; } }
     vk.g = g; vk.gamma_g = gamma_g;
     vk.h = pairing::g2_generator();
@@ -482,8 +537,9 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
         gpu::aes_trace(d_trace, c.trace_bytes, d_msg, d_key, 1, (uint32_t)c.n_blocks, s);
     }
     gpu::witness_expand(d_z, d_desc, (uint32_t)c.num_variables(), d_trace, d_sbox_in, d_sbox_tmpl, s);
-    gpu::spmv_bits(za_ev.p, n, d_a_rowptr, d_a_col, d_a_coeff, c.num_constraints, d_z, s);
-    gpu::spmv_bits(zb_ev.p, n, d_b_rowptr, d_b_col, d_b_coeff, c.num_constraints, d_z, s);
+    gpu::spmv_bits(za_ev.p, cx.d_cls[1], n, d_a_rowptr, d_a_col, d_a_coeff, c.num_constraints, d_z, s);
+    gpu::spmv_bits(zb_ev.p, cx.d_cls[2], n, d_b_rowptr, d_b_col, d_b_coeff, c.num_constraints, d_z, s);
+    if (use_lagrange) gpu::w_classes(cx.d_cls[0], d_z, (uint32_t)n, (uint32_t)m, (uint32_t)c.num_witness, s);
     std::vector<uint8_t> inst(m);
     gpu::d2h(inst.data(), d_z, m, s);
     timings.witness_ms = ms_since(t0); t0 = Clock::now();
@@ -504,15 +560,16 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     gpu::ntt<F>(x_evals.p, x_poly.p, m, lg_n, false, s);
     gpu::w_evals(tmp_n.p, d_z, x_evals.p, (uint32_t)n, (uint32_t)m, (uint32_t)c.num_witness, s);
     gpu::ntt<F>(e[0].p, tmp_n.p, n, lg_n, true, s);                         // interpolate
-    Fr rho = zk.rand_field<Fr>();
+    Fr rhos[3];
+    Fr rho = zk.rand_field<Fr>(); rhos[0] = rho;
     gpu::poly_add_at(e[0].p, 0, rho.neg(), s); gpu::poly_set_at(e[0].p, n, rho, s);   // + rho * v_H
     gpu::divide_by_vanishing(poly[0].p, e[1].p, e[0].p, n + 1, m, s);       // / v_X ; remainder must vanish
     poly_len[0] = n + 1 - m;
     gpu::ntt<F>(poly[1].p, za_ev.p, n, lg_n, true, s);
-    rho = zk.rand_field<Fr>();
+    rho = zk.rand_field<Fr>(); rhos[1] = rho;
     gpu::poly_add_at(poly[1].p, 0, rho.neg(), s); gpu::poly_set_at(poly[1].p, n, rho, s); poly_len[1] = n + 1;
     gpu::ntt<F>(poly[2].p, zb_ev.p, n, lg_n, true, s);
-    rho = zk.rand_field<Fr>();
+    rho = zk.rand_field<Fr>(); rhos[2] = rho;
     gpu::poly_add_at(poly[2].p, 0, rho.neg(), s); gpu::poly_set_at(poly[2].p, n, rho, s); poly_len[2] = n + 1;
     {   // mask polynomial: degree 3|H| + 2 zk_bound - 3, sum over H forced to zero
         std::vector<Fr> mask(3 * n);
@@ -523,7 +580,10 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
         gpu::sync(s);
         poly_len[3] = 3 * n;
     }
-    for (auto &lp : r1) mpc_commit(cx, lp, zk);
+    for (auto &lp : r1) {
+        if (use_lagrange && lp.idx < 3 && lagrange_commit(cx, lp.idx, inst, rhos[lp.idx], lp.rand, zk, lp.comm.comm)) { lp.comm.has_shifted = false; continue; }
+        mpc_commit(cx, lp, zk);
+    }
     { Bytes o; for (auto &lp : r1) o.commitment_tobytes(lp.comm); fs.absorb(o.b); }
     auto sample_outside_h = [&]() { Fr t; do { t = fs.rng().rand_field<Fr>(); } while (eval_vanishing(n, t).is_zero()); return t; };
     Fr alpha = sample_outside_h();
