@@ -118,6 +118,13 @@ void bits_to_field(F *out, const uint8_t *z, size_t n, stream_t s);
 constexpr uint32_t T_SEG = 32;
 void t_evals(F *out, uint32_t n, F *partial, uint32_t nseg, const uint32_t *col_seg_ptr, const uint32_t *seg_start, const uint32_t *seg_end, const uint32_t *row, const uint8_t *mat,
              const int64_t *coeff, const F *r_alpha, const F &eta_a, const F &eta_b, const F &eta_c, stream_t s);
+// `count` field elements drawn exactly as ark-ff's Fp::rand would draw them from a ChaCha block RNG (rand_chacha layout: 64-bit block
+// counter, word stream) positioned at word `word_pos`: 8 words per candidate, top bits shaved, candidates >= p rejected, limbs used AS the
+// Montgomery form.  Candidates are generated and filtered in parallel (flag + exclusive scan + compaction).  Returns the stream position
+// (in words) after the last accepted candidate so the host RNG can continue from there.  scratch: >= 2.2 * count * 9 words.
+uint64_t chacha_field_stream(F *out, size_t count, const uint32_t key[8], int rounds, uint64_t word_pos, void *scratch, size_t scratch_bytes, stream_t s);
+// mask-polynomial fix-up of ark-marlin: p[0] -= p[0] + p[n] + p[2n]
+void mask_fixup(F *p, size_t n, stream_t s);
 // e_ra[i] = e_ra[i] * (eta_a za + eta_b zb + eta_c za zb)[i] - t[i] * z[i]
 void q1_pointwise(F *e_ra, const F *e_za, const F *e_zb, const F *e_t, const F *e_z, const F &eta_a, const F &eta_b, const F &eta_c, size_t n, stream_t s);
 void round3_den(F *den, const F *row, const F *col, const F &alpha, const F &beta, size_t k, stream_t s);     // (beta - row)(alpha - col)

@@ -3,6 +3,7 @@
 // They replace the dense-polynomial plumbing of ark-poly 0.3.0 (DensePolynomial add/mul_by_vanishing/divide_by_vanishing_poly,
 // `p / (X - z)`, evaluate, batch_inversion of ark-ff) that ark-marlin's prover_{first,second,third}_round and
 // KZG10::open call.  All are HBM-streaming: one 32-byte element per lane per access.
+#include <hipcub/hipcub.hpp>
 #include "hip_util.hpp"
 
 namespace zk {
@@ -210,6 +211,89 @@ __global__ void k_z_poly(F *__restrict__ zp, const F *__restrict__ w, size_t wle
     zp[i] = v;
 }
 void z_poly_from_w(F *zp, const F *w, size_t wlen, const F *x_poly, uint32_t m, size_t n, stream_t s) { hipLaunchKernelGGL(k_z_poly, GRID(n + 1), 0, (hipStream_t)s, zp, w, wlen, x_poly, m, n + 1); HIP_LAUNCH_CHECK(); }
+
+// ---- prover randomness on the device: the ChaCha key stream -> rejection-sampled field elements (ark-ff UniformRand), in parallel
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+__global__ void k_chacha_blocks(uint32_t *__restrict__ words, uint64_t first_block, uint32_t nblocks, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t k4, uint32_t k5,
+                                uint32_t k6, uint32_t k7, int rounds) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    uint64_t ctr = first_block + b;
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, k0, k1, k2, k3, k4, k5, k6, k7, (uint32_t)ctr, (uint32_t)(ctr >> 32), 0, 0};
+    uint32_t x[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = s[i];
+#define ZK_QR(a, b, c, d) \
+    x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 16); x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 12); \
+    x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 8); x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 7);
+    for (int r = 0; r < rounds; r += 2) {
+        ZK_QR(0, 4, 8, 12) ZK_QR(1, 5, 9, 13) ZK_QR(2, 6, 10, 14) ZK_QR(3, 7, 11, 15)
+        ZK_QR(0, 5, 10, 15) ZK_QR(1, 6, 11, 12) ZK_QR(2, 7, 8, 13) ZK_QR(3, 4, 9, 14)
+    }
+#undef ZK_QR
+#pragma unroll
+    for (int i = 0; i < 16; i++) words[(size_t)b * 16 + i] = x[i] + s[i];
+}
+__global__ void k_rand_flags(const uint32_t *__restrict__ words, uint32_t word_off, uint32_t ncand, uint32_t *__restrict__ flags) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ncand) return;
+    uint32_t l[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) l[i] = words[(size_t)word_off + 8 * (size_t)j + i];
+    l[7] &= 0xffffffffu >> (256 - F::BITS);
+    flags[j] = F::geq_mod(l) ? 0u : 1u;
+}
+__global__ void k_rand_compact(const uint32_t *__restrict__ words, uint32_t word_off, uint32_t ncand, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos,
+                               F *__restrict__ out, uint32_t count, uint32_t *__restrict__ last_cand) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ncand || !flags[j]) return;
+    uint32_t q = pos[j];
+    if (q >= count) return;
+    F v;
+#pragma unroll
+    for (int i = 0; i < 8; i++) v.l[i] = words[(size_t)word_off + 8 * (size_t)j + i];
+    v.l[7] &= 0xffffffffu >> (256 - F::BITS);
+    out[q] = v;
+    if (q + 1 == count) *last_cand = j;
+}
+uint64_t chacha_field_stream(F *out, size_t count, const uint32_t key[8], int rounds, uint64_t word_pos, void *scratch, size_t scratch_bytes, stream_t s_) {
+    hipStream_t s = (hipStream_t)s_;
+    if (count == 0) return word_pos;
+    // acceptance probability p / 2^BITS; oversample, and loop in the (practically impossible) case the batch falls short
+    const double accept = 0.58;   // BLS12-377 Fr: 0x12ab.. / 0x2000..
+    uint64_t pos_words = word_pos;
+    size_t done = 0;
+    while (done < count) {
+        size_t want = count - done;
+        uint32_t ncand = (uint32_t)((double)want / accept * 1.02) + 4096;
+        uint64_t first_block = pos_words / 16;
+        uint32_t word_off = (uint32_t)(pos_words % 16);
+        uint32_t nblocks = (uint32_t)(((uint64_t)word_off + 8ull * ncand + 15) / 16);
+        size_t need = (size_t)nblocks * 64 + (size_t)ncand * 8 + 64 + (1 << 20);
+        if (need > scratch_bytes) throw GpuError("chacha_field_stream: scratch too small");
+        uint32_t *words = (uint32_t *)scratch, *flags = words + (size_t)nblocks * 16, *pos = flags + ncand, *last = pos + ncand;
+        void *tmp = (void *)(last + 16);
+        size_t tmp_bytes = scratch_bytes - ((char *)tmp - (char *)scratch);
+        hipLaunchKernelGGL(k_chacha_blocks, GRID(nblocks), 0, s, words, first_block, nblocks, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7], rounds); HIP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_rand_flags, GRID(ncand), 0, s, (const uint32_t *)words, word_off, ncand, flags); HIP_LAUNCH_CHECK();
+        size_t tb = 0;
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flags, pos, (int)ncand, s));
+        if (tb > tmp_bytes) throw GpuError("chacha_field_stream: scan scratch too small");
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, flags, pos, (int)ncand, s));
+        HIP_CHECK(hipMemsetAsync(last, 0xff, 4, s));
+        hipLaunchKernelGGL(k_rand_compact, GRID(ncand), 0, s, (const uint32_t *)words, word_off, ncand, (const uint32_t *)flags, (const uint32_t *)pos, out + done, (uint32_t)want, last); HIP_LAUNCH_CHECK();
+        uint32_t h_last = 0, h_tail[2] = {0, 0};
+        HIP_CHECK(hipMemcpyAsync(&h_last, last, 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(&h_tail[0], pos + ncand - 1, 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(&h_tail[1], flags + ncand - 1, 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (h_last != 0xffffffffu) { pos_words += 8ull * ((uint64_t)h_last + 1); done = count; }
+        else { done += (size_t)h_tail[0] + h_tail[1]; pos_words += 8ull * ncand; }   // every accepted candidate of the batch was used
+    }
+    return pos_words;
+}
+__global__ void k_mask_fixup(F *p, size_t n) { if (blockIdx.x == 0 && threadIdx.x == 0) p[0] = p[0] - (p[0] + p[n] + p[2 * n]); }
+void mask_fixup(F *p, size_t n, stream_t s) { hipLaunchKernelGGL(k_mask_fixup, dim3(1), dim3(64), 0, (hipStream_t)s, p, n); HIP_LAUNCH_CHECK(); }
 
 // ---- indexer: evaluations of the joint-matrix arithmetization on K (ark-marlin arithmetize_matrix)
 __global__ void k_index_rowcol(F *__restrict__ row, F *__restrict__ col, F *__restrict__ rowcol, F *__restrict__ u, const uint32_t *__restrict__ ci, const uint32_t *__restrict__ ri,

@@ -218,6 +218,7 @@ struct ProverContext {
     gpu::stream_t stream = nullptr;
     gpu::MsmWorkspace *msm_ws = nullptr;
     uint8_t *d_trace = nullptr, *d_z = nullptr, *d_msg = nullptr, *d_key = nullptr;
+    void *d_rng = nullptr; size_t rng_bytes = 0;      // scratch of the device-side ChaCha12 / Fr::rand stream
     int8_t *d_cls[3] = {nullptr, nullptr, nullptr};   // small-integer evaluation classes of w, z_A, z_B on H (Lagrange-basis commitments)
     DevBuf za_ev, zb_ev, x_poly, x_tmp, x_evals, tmp_n, ra_ev, ra_poly, zpoly, t_partial;
     DevBuf poly[9];                    // w z_a z_b mask t g_1 h_1 g_2 h_2
@@ -228,6 +229,7 @@ struct ProverContext {
     ~ProverContext() {
         gpu::dfree(d_trace); gpu::dfree(d_z); gpu::dfree(d_msg); gpu::dfree(d_key);
         for (auto p : d_cls) gpu::dfree(p);
+        gpu::dfree(d_rng);
         for (DevBuf *b : {&za_ev, &zb_ev, &x_poly, &x_tmp, &x_evals, &tmp_n, &ra_ev, &ra_poly, &zpoly, &t_partial, &big_tmp, &f_poly, &acc, &wit, &scratch}) b->release();
         for (auto &b : poly) b.release();
         for (auto &b : e) b.release();
@@ -293,6 +295,7 @@ class ProvingKeyImpl {
         cx.d_trace = (uint8_t *)gpu::dmalloc(c.trace_bytes + 64); cx.d_z = (uint8_t *)gpu::dmalloc(c.num_variables() + 64);
         cx.d_msg = (uint8_t *)gpu::dmalloc(std::max<size_t>(message_len, 16)); cx.d_key = (uint8_t *)gpu::dmalloc(16);
         for (auto &p : cx.d_cls) p = (int8_t *)gpu::dmalloc(n + 64);
+        { size_t ncand = (size_t)(3.0 * n / 0.58 * 1.02) + 8192; cx.rng_bytes = (ncand * 8 / 16 + 2) * 64 + ncand * 8 + (4u << 20); cx.d_rng = gpu::dmalloc(cx.rng_bytes); }
         cx.za_ev.alloc(n); cx.zb_ev.alloc(n); cx.x_poly.alloc(m); cx.x_tmp.alloc(m); cx.x_evals.alloc(n); cx.tmp_n.alloc(n + 1); cx.ra_ev.alloc(n); cx.ra_poly.alloc(n);
         cx.zpoly.alloc(n + 1); cx.t_partial.alloc(t_nseg + 1);
         size_t caps[9] = {n + 1, n + 1, n + 1, 3 * n, n, n, 3 * n, k, k + 1};
@@ -571,13 +574,11 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     gpu::ntt<F>(poly[2].p, zb_ev.p, n, lg_n, true, s);
     rho = zk.rand_field<Fr>(); rhos[2] = rho;
     gpu::poly_add_at(poly[2].p, 0, rho.neg(), s); gpu::poly_set_at(poly[2].p, n, rho, s); poly_len[2] = n + 1;
-    {   // mask polynomial: degree 3|H| + 2 zk_bound - 3, sum over H forced to zero
-        std::vector<Fr> mask(3 * n);
-        for (auto &x : mask) x = zk.rand_field<Fr>();
-        Fr sigma = mask[0] + mask[n] + mask[2 * n];
-        mask[0] = mask[0] - sigma;
-        gpu::h2d(poly[3].p, mask.data(), mask.size() * sizeof(Fr), s);
-        gpu::sync(s);
+    {   // mask polynomial: degree 3|H| + 2 zk_bound - 3, sum over H forced to zero.  The 3|H| coefficients are the next 3|H| Fr::rand draws
+        // of the prover RNG: generated on the device from the same ChaCha12 key stream, then the host RNG skips past them.
+        uint64_t next = gpu::chacha_field_stream(poly[3].p, 3 * n, zk.key_words(), zk.rounds(), zk.word_pos(), cx.d_rng, cx.rng_bytes, s);
+        zk.set_word_pos(next);
+        gpu::mask_fixup(poly[3].p, n, s);
         poly_len[3] = 3 * n;
     }
     for (auto &lp : r1) {

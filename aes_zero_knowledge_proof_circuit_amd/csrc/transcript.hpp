@@ -67,6 +67,11 @@ class ChaChaRng {
         rounds_ = rounds; counter_ = 0; idx_ = 64;
     }
     uint32_t next_u32() { if (idx_ >= 64) refill(); return buf_[idx_++]; }
+    // position in the key stream, in 32-bit words (the next word next_u32 would return)
+    uint64_t word_pos() const { return idx_ >= 64 ? counter_ * 16 : (counter_ - 4) * 16 + (uint64_t)idx_; }
+    void set_word_pos(uint64_t pos) { counter_ = (pos / 64) * 4; refill(); idx_ = (int)(pos % 64); }
+    const uint32_t *key_words() const { return key_; }
+    int rounds() const { return rounds_; }
     uint64_t next_u64() {
         if (idx_ < 63) { uint64_t lo = buf_[idx_], hi = buf_[idx_ + 1]; idx_ += 2; return hi << 32 | lo; }
         if (idx_ >= 64) { refill(); idx_ = 2; return (uint64_t)buf_[1] << 32 | buf_[0]; }
