@@ -48,6 +48,13 @@ void msm_workspace_destroy(MsmWorkspace *ws);
 template <class Curve> void convert_bases(Affine28<typename Curve::FqP> *dst, const Affine<typename Curve::Fq> *src, size_t n, stream_t s);
 template <class Curve>
 XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws, const Affine28<typename Curve::FqP> *bases, const typename Curve::Fr *scalars, size_t n, stream_t s);
+// The same MSM in two steps.  msm_prepare: digits + sort + bucket ranges of scal1 (bases 0..n1) and optionally scal2 (bases val_off2..val_off2+n2
+// of the same array) as ONE Pippenger instance; msm_finish: accumulate from `bases` + reduce.  msm_finish may be called several times on one
+// prepared state with different base arrays (the plain and the shifted commitment of a degree-bounded polynomial share their scalars).
+template <class Curve>
+void msm_prepare(MsmWorkspace *ws, const typename Curve::Fr *scal1, size_t n1, const typename Curve::Fr *scal2, size_t n2, size_t val_off2, stream_t s);
+template <class Curve>
+XYZZ<typename Curve::Fq> msm_finish(MsmWorkspace *ws, const Affine28<typename Curve::FqP> *bases, stream_t s);
 // Precomputed-window variant for FIXED bases (the SRS): tables[j * stride + i] = 2^(c j) * P_i for j < table_windows(c); with one
 // table copy per window all windows share ONE bucket set, so bucket reduction is paid once and c can grow (fewer windows = fewer adds).
 // build_window_tables fills copies 1.. from copy 0 (already in tables[0..stride)); msm_table sums scalars[i] * P_{off+i}, i < n.

@@ -32,8 +32,11 @@ MsmStats msm_stats(bool reset) {
 
 // Signed window digits d in [-2^(c-1), 2^(c-1)] (carry recoding): bucket index = |d| - 1 in a window of 2^(c-1) buckets, the sign rides
 // in bit 31 of the value (the accumulate kernel negates y).  Zero digits get the out-of-range key `nb` and sort past every bucket.
+// A launch covers one PART of the scalar list: part element i sits at position i_off + i of every window segment (segment length ntot) and
+// names base index val_off + i, so that two scalar vectors over two base ranges can share one Pippenger instance.
 template <class Fr>
-__global__ void k_digits(const Fr *__restrict__ scalars, uint32_t n, int c, int nwin, uint32_t nb, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+__global__ void k_digits(const Fr *__restrict__ scalars, uint32_t n, uint32_t i_off, uint32_t ntot, uint32_t val_off, int c, int nwin, uint32_t nb,
+                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t raw[Fr::N + 1];
@@ -48,8 +51,8 @@ __global__ void k_digits(const Fr *__restrict__ scalars, uint32_t n, int c, int 
         uint32_t neg = 0;
         carry = 0;
         if (v > half) { v = (1u << c) - v; neg = 1u << 31; carry = 1; }
-        keys[(size_t)w * n + i] = v ? (((uint32_t)w << (c - 1)) | (v - 1)) : nb;
-        vals[(size_t)w * n + i] = i | neg;
+        keys[(size_t)w * ntot + i_off + i] = v ? (((uint32_t)w << (c - 1)) | (v - 1)) : nb;
+        vals[(size_t)w * ntot + i_off + i] = (val_off + i) | neg;
     }
 }
 
@@ -303,6 +306,7 @@ struct MsmWorkspace {
     uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr, *start = nullptr, *end = nullptr;
     uint32_t *size_key = nullptr, *size_key2 = nullptr, *ids = nullptr, *order = nullptr, *extra = nullptr, *extra_off = nullptr;
     void *ovf_partial = nullptr; size_t cap_ovf = 0;
+    size_t plan_n = 0, plan_pairs = 0; int plan_c = 0, plan_nwin = 0;     // state between msm_prepare and msm_finish
     uint32_t *deferred = nullptr, *deferred_count = nullptr;
     void *buckets = nullptr, *seg_s = nullptr, *seg_w = nullptr, *partial = nullptr, *wsum = nullptr, *tmp = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -342,11 +346,9 @@ void msm_workspace_destroy(MsmWorkspace *w) {
     delete w;
 }
 
-// shared tail: sort the (key, value) pairs, find bucket ranges, visit buckets by descending size, accumulate, reduce.
-// nsets bucket sets of 2^c buckets each (keys < nsets << c); returns the nsets window sums.
+// shared middle: sort the (key, value) pairs, find bucket ranges, order buckets by descending size, cut oversized buckets
 template <class P>
-static std::vector<XYZZ<Fp<P>>> run_buckets(MsmWorkspace &S, const Affine28<P> *bases, size_t pairs, int c, int nsets, size_t n_points, hipStream_t s, float *acc_ms) {
-    using Fq = Fp<P>;
+static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, hipStream_t s) {
     // c here = log2(buckets per set); keys run over [0, nb) plus the out-of-range key nb for zero digits
     size_t nb = (size_t)nsets << c;
     int key_bits = 1;
@@ -375,6 +377,13 @@ static std::vector<XYZZ<Fp<P>>> run_buckets(MsmWorkspace &S, const Affine28<P> *
         if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
         HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp, tb, S.size_key, S.size_key2, S.ids, S.order, (int)nb, 0, 13, s));
     }
+}
+// shared tail over prepared buckets: accumulate from `bases`, fold overflow segments and deferred degenerate additions, reduce; returns the
+// nsets window sums.  May be called several times on one prepared state with different base arrays (same scalars, e.g. plain + shifted powers).
+template <class P>
+static std::vector<XYZZ<Fp<P>>> run_buckets(MsmWorkspace &S, const Affine28<P> *bases, size_t pairs, int c, int nsets, size_t n_points, hipStream_t s, float *acc_ms) {
+    using Fq = Fp<P>;
+    size_t nb = (size_t)nsets << c;
     HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 4, s));
     HIP_CHECK(hipEventRecord(S.ev0, s));
     hipLaunchKernelGGL((k_accumulate<P>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, bases, S.vals_b, S.start, S.end, S.order, (uint32_t)nb,
@@ -424,16 +433,19 @@ void convert_bases(Affine28<typename Curve::FqP> *dst, const Affine<typename Cur
     HIP_LAUNCH_CHECK();
 }
 
+// ---- signed-digit Pippenger as two steps, so that one digit/sort pass can serve several base arrays:
+//   msm_prepare : window digits of up to two scalar vectors (the second one naming bases `val_off2` further on), sort, bucket ranges
+//   msm_finish  : accumulate from `bases` + reduce + Horner on the host
 template <class Curve>
-XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *bases, const typename Curve::Fr *scalars, size_t n, stream_t s_) {
-    using Fq = typename Curve::Fq;
+void msm_prepare(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_t n1, const typename Curve::Fr *scal2, size_t n2, size_t val_off2, stream_t s_) {
     using Fr = typename Curve::Fr;
-    static_assert(sizeof(XYZZ<Fq>) == 192, "XYZZ layout");
     hipStream_t s = (hipStream_t)s_;
-    if (n == 0) return XYZZ<Fq>::inf();
-    if (n >= (1u << 31)) throw GpuError("msm: too many points");
     if (!ws_) throw GpuError("msm: null workspace");
-    auto t_begin = std::chrono::steady_clock::now();
+    MsmWorkspace &S = *ws_;
+    size_t n = n1 + n2;
+    S.plan_n = n;
+    if (n == 0) return;
+    if (n >= (1u << 30) || val_off2 + n2 >= (1u << 31)) throw GpuError("msm: too many points");
     int lg = 0;
     while (((size_t)1 << lg) < n) lg++;
     int c = lg - 2;                               // signed digits: 2^(c-1) buckets per window
@@ -442,12 +454,24 @@ XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws_, const Affine28<typename Curve::F
     const int nwin = (Fr::BITS + 1 + c - 1) / c;  // one extra bit for the recoding carry
     size_t pairs = n * (size_t)nwin;
     const size_t nb = (size_t)nwin << (c - 1);
+    S.plan_c = c; S.plan_nwin = nwin; S.plan_pairs = pairs;
+    ensure_scratch(S, pairs, nb, 0);
+    if (n1) { hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, scal1, (uint32_t)n1, 0u, (uint32_t)n, 0u, c, nwin, (uint32_t)nb, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
+    if (n2) { hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, scal2, (uint32_t)n2, (uint32_t)n1, (uint32_t)n, (uint32_t)val_off2, c, nwin, (uint32_t)nb, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
+    prepare_buckets<typename Curve::FqP>(S, pairs, c - 1, nwin, s);
+}
+template <class Curve>
+XYZZ<typename Curve::Fq> msm_finish(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *bases, stream_t s_) {
+    using Fq = typename Curve::Fq;
+    static_assert(sizeof(XYZZ<Fq>) == 192, "XYZZ layout");
+    hipStream_t s = (hipStream_t)s_;
+    if (!ws_) throw GpuError("msm: null workspace");
     MsmWorkspace &S = *ws_;
-    ensure_scratch(S, pairs, nb, sizeof(XYZZ<Fq>));
-    hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scalars, (uint32_t)n, c, nwin, (uint32_t)nb, S.keys_a, S.vals_a);
-    HIP_LAUNCH_CHECK();
+    if (S.plan_n == 0) return XYZZ<Fq>::inf();
+    auto t_begin = std::chrono::steady_clock::now();
+    const int c = S.plan_c, nwin = S.plan_nwin;
     float ms = 0;
-    std::vector<XYZZ<Fq>> ws = run_buckets<typename Curve::FqP>(S, bases, pairs, c - 1, nwin, n, s, &ms);
+    std::vector<XYZZ<Fq>> ws = run_buckets<typename Curve::FqP>(S, bases, S.plan_pairs, c - 1, nwin, S.plan_n, s, &ms);
     if (getenv("ZKAES_MSM_DEBUG")) {
         for (int w = 0; w < nwin; w++) {
             Affine<Fq> a = ws[w].to_affine();
@@ -460,8 +484,14 @@ XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws_, const Affine28<typename Curve::F
         for (int k = 0; k < c; k++) total = total.dbl();
     }
     total.add(ws[0]);
-    add_stats(ms, n, pairs, t_begin);
+    add_stats(ms, S.plan_n, S.plan_pairs, t_begin);
     return total;
+}
+template <class Curve>
+XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *bases, const typename Curve::Fr *scalars, size_t n, stream_t s_) {
+    if (n == 0) return XYZZ<typename Curve::Fq>::inf();
+    msm_prepare<Curve>(ws_, scalars, n, nullptr, 0, 0, s_);
+    return msm_finish<Curve>(ws_, bases, s_);
 }
 
 template <class Curve>
@@ -497,6 +527,7 @@ XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws_, const Affine28<typename Cu
     hipLaunchKernelGGL((k_digits_table<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scalars, (uint32_t)n, c, nwin, (uint32_t)stride, (uint32_t)off, S.keys_a, S.vals_a);
     HIP_LAUNCH_CHECK();
     float ms = 0;
+    prepare_buckets<typename Curve::FqP>(S, pairs, c, 1, s);
     std::vector<XYZZ<Fq>> ws = run_buckets<typename Curve::FqP>(S, tables, pairs, c, 1, n, s, &ms);
     add_stats(ms, n, pairs, t_begin);
     return ws[0];
@@ -673,6 +704,10 @@ template void build_window_tables<Bls377>(Affine<Fq377> *, size_t, int, stream_t
 template void build_window_tables<Bls381>(Affine<Fq381> *, size_t, int, stream_t);
 template int table_windows<Bls377>(int);
 template int table_windows<Bls381>(int);
+template void msm_prepare<Bls377>(MsmWorkspace *, const Fr377 *, size_t, const Fr377 *, size_t, size_t, stream_t);
+template void msm_prepare<Bls381>(MsmWorkspace *, const Fr381 *, size_t, const Fr381 *, size_t, size_t, stream_t);
+template XYZZ<Fq377> msm_finish<Bls377>(MsmWorkspace *, const Affine28<Fq377P> *, stream_t);
+template XYZZ<Fq381> msm_finish<Bls381>(MsmWorkspace *, const Affine28<Fq381P> *, stream_t);
 template XYZZ<Fq377> msm<Bls377>(MsmWorkspace *, const Affine28<Fq377P> *, const Fr377 *, size_t, stream_t);
 template XYZZ<Fq381> msm<Bls381>(MsmWorkspace *, const Affine28<Fq381P> *, const Fr381 *, size_t, stream_t);
 template void fixed_base_scalars<Bls377>(Affine<Fq377> *, const Affine<Fq377> &, const Fr377 *, size_t, stream_t);

@@ -223,14 +223,14 @@ struct ProverContext {
     DevBuf za_ev, zb_ev, x_poly, x_tmp, x_evals, tmp_n, ra_ev, ra_poly, zpoly, t_partial;
     DevBuf poly[9];                    // w z_a z_b mask t g_1 h_1 g_2 h_2
     size_t poly_len[9] = {0};
-    DevBuf e[5], big_tmp, f_poly, ab[2], acc, wit, scratch;
+    DevBuf e[5], big_tmp, f_poly, ab[2], acc, wit, wit2, scratch;
     ProverTimings timings;
     ProverContext() { stream = gpu::stream_create(); msm_ws = gpu::msm_workspace_create(); }
     ~ProverContext() {
         gpu::dfree(d_trace); gpu::dfree(d_z); gpu::dfree(d_msg); gpu::dfree(d_key);
         for (auto p : d_cls) gpu::dfree(p);
         gpu::dfree(d_rng);
-        for (DevBuf *b : {&za_ev, &zb_ev, &x_poly, &x_tmp, &x_evals, &tmp_n, &ra_ev, &ra_poly, &zpoly, &t_partial, &big_tmp, &f_poly, &acc, &wit, &scratch}) b->release();
+        for (DevBuf *b : {&za_ev, &zb_ev, &x_poly, &x_tmp, &x_evals, &tmp_n, &ra_ev, &ra_poly, &zpoly, &t_partial, &big_tmp, &f_poly, &acc, &wit, &wit2, &scratch}) b->release();
         for (auto &b : poly) b.release();
         for (auto &b : e) b.release();
         for (auto &b : ab) b.release();
@@ -272,7 +272,7 @@ class ProvingKeyImpl {
     ProverTimings last_timings;
 
     ~ProvingKeyImpl() {
-        gpu::dfree(d_powers); gpu::dfree(d_shifted); gpu::dfree(d_lag_h); gpu::dfree(d_lag_w); gpu::dfree(d_desc); gpu::dfree(d_sbox_in); gpu::dfree(d_sbox_tmpl);
+        gpu::dfree(d_powers); if (use_tables) gpu::dfree(d_shifted); gpu::dfree(d_lag_h); gpu::dfree(d_lag_w); gpu::dfree(d_desc); gpu::dfree(d_sbox_in); gpu::dfree(d_sbox_tmpl);
         gpu::dfree(d_a_rowptr); gpu::dfree(d_a_col); gpu::dfree(d_b_rowptr); gpu::dfree(d_b_col); gpu::dfree(d_a_coeff); gpu::dfree(d_b_coeff);
         gpu::dfree(d_t_colptr); gpu::dfree(d_t_seg_start); gpu::dfree(d_t_seg_end); gpu::dfree(d_t_row); gpu::dfree(d_t_mat); gpu::dfree(d_t_coeff);
         for (auto &b : ix_ev) b.release();
@@ -303,7 +303,7 @@ class ProvingKeyImpl {
         size_t big = std::max(n4, k2);
         for (auto &b : cx.e) b.alloc(big);
         cx.big_tmp.alloc(big); cx.f_poly.alloc(k); cx.ab[0].alloc(k); cx.ab[1].alloc(k);
-        cx.acc.alloc(std::max(3 * n, k) + 1); cx.wit.alloc(std::max(3 * n, k) + 1); cx.scratch.alloc(std::max(3 * n, k) / 32 + 1024);
+        cx.acc.alloc(std::max(3 * n, k) + 1); cx.wit.alloc(std::max(3 * n, k) + 1); cx.wit2.alloc(std::max(n, k) + 1); cx.scratch.alloc(std::max(3 * n, k) / 32 + 1024);
     }
 
     template <class T> static T *upload(const std::vector<T> &v, gpu::stream_t s) {
@@ -345,14 +345,43 @@ class ProvingKeyImpl {
         return true;
     }
     struct Labeled { int idx; long bound; bool hiding; KzgRand rand, shifted_rand; Commitment comm; };
-    void mpc_commit(ProverContext &cx, Labeled &lp, ChaChaRng &zk) {
-        lp.comm.comm = kzg_commit(cx, false, 0, cx.poly[lp.idx].p, cx.poly_len[lp.idx], lp.hiding, lp.rand, zk);
-        lp.comm.has_shifted = false;
-        if (lp.bound >= 0) {
-            size_t off = (max_degree - (size_t)lp.bound) - lowest_shift;
-            lp.comm.shifted = kzg_commit(cx, true, off, cx.poly[lp.idx].p, cx.poly_len[lp.idx], lp.hiding, lp.shifted_rand, zk);
-            lp.comm.has_shifted = true;
+    void add_hiding(XYZZ<Fq377> &c, bool hiding, KzgRand &rnd, ChaChaRng &zk) {
+        rnd.hiding = hiding;
+        for (auto &x : rnd.b) x = Fr::zero();
+        if (hiding) {
+            for (int i = 0; i < 3; i++) rnd.b[i] = zk.rand_field<Fr>();
+            for (int i = 0; i < 3; i++) c.add(mul_fr(XYZZ<Fq377>::from_affine(gamma_powers[i]), rnd.b[i]));
         }
+    }
+    void mpc_commit(ProverContext &cx, Labeled &lp, ChaChaRng &zk) {
+        const F *coeffs = cx.poly[lp.idx].p;
+        size_t len = cx.poly_len[lp.idx];
+        lp.comm.has_shifted = false;
+        if (lp.bound < 0 || use_tables) {
+            lp.comm.comm = kzg_commit(cx, false, 0, coeffs, len, lp.hiding, lp.rand, zk);
+            if (lp.bound >= 0) {
+                size_t off = (max_degree - (size_t)lp.bound) - lowest_shift;
+                lp.comm.shifted = kzg_commit(cx, true, off, coeffs, len, lp.hiding, lp.shifted_rand, zk);
+                lp.comm.has_shifted = true;
+            }
+            return;
+        }
+        // degree-bounded polynomial: the plain and the shifted commitment have the same scalars -> one digit / sort pass, two accumulations
+        size_t off = (max_degree - (size_t)lp.bound) - lowest_shift;
+        if (len > supported_degree + 1 || off + len > bounds[1] + 1) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
+        gpu::msm_prepare<Bls377>(cx.msm_ws, coeffs, len, nullptr, 0, 0, cx.stream);
+        XYZZ<Fq377> c1 = gpu::msm_finish<Bls377>(cx.msm_ws, d_powers, cx.stream);
+        add_hiding(c1, lp.hiding, lp.rand, zk);
+        XYZZ<Fq377> c2 = gpu::msm_finish<Bls377>(cx.msm_ws, d_shifted + off, cx.stream);
+        add_hiding(c2, lp.hiding, lp.shifted_rand, zk);
+        lp.comm.comm = c1.to_affine(); lp.comm.shifted = c2.to_affine(); lp.comm.has_shifted = true;
+    }
+    // opening witness = MSM(powers, wit) + MSM(shifted powers from shift_off, swit) as ONE Pippenger instance over the contiguous SRS array
+    XYZZ<Fq377> msm_opening(ProverContext &cx, const F *wit, size_t wlen, const F *swit, size_t slen, size_t shift_off) {
+        if (wlen > supported_degree + 1 || shift_off + slen > bounds[1] + 1) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
+        if (use_tables) { XYZZ<Fq377> w = msm_powers(cx, false, 0, wit, wlen); w.add(msm_powers(cx, true, shift_off, swit, slen)); return w; }
+        gpu::msm_prepare<Bls377>(cx.msm_ws, wit, wlen, swit, slen, (supported_degree + 1) + shift_off, cx.stream);
+        return gpu::msm_finish<Bls377>(cx.msm_ws, d_powers, cx.stream);
     }
 
     void setup(int kind, size_t message_len, const SrsLiterals &srs);
@@ -409,18 +438,26 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
     // window bits of the table path: the top window must keep enough significant bits or a handful of buckets receive most points
     table_c = lg_k >= 22 ? 20 : (lg_k >= 19 ? 17 : 8);
     const size_t n_tab = use_tables ? (size_t)gpu::table_windows<Bls377>(table_c) : 1;
-    auto make_srs = [&](size_t from, size_t count) {
+    // powers_of_g[0..=supported_degree] and the shifted range live in ONE reduced-radix array (shifted part right after the plain part), so
+    // an MSM may name bases of both through one index space (merged openings).  Table mode keeps two separate multi-copy arrays.
+    const size_t n_plain = supported_degree + 1, n_shift = bounds[1] + 1;
+    auto make_srs = [&](Affine28<Fq377P> *dst, size_t from, size_t count) {
         G1A *tmp = (G1A *)gpu::dmalloc(n_tab * count * sizeof(G1A));
         gpu::fixed_base_powers<Bls377>(tmp, g, srs_beta, from, count, stream);
         if (use_tables) gpu::build_window_tables<Bls377>(tmp, count, table_c, stream);
-        Affine28<Fq377P> *dst = (Affine28<Fq377P> *)gpu::dmalloc(n_tab * count * sizeof(Affine28<Fq377P>));
         gpu::convert_bases<Bls377>(dst, tmp, n_tab * count, stream);
         gpu::sync(stream);
         gpu::dfree(tmp);
-        return dst;
     };
-    d_powers = make_srs(0, supported_degree + 1);
-    d_shifted = make_srs(lowest_shift, bounds[1] + 1);
+    if (use_tables) {
+        d_powers = (Affine28<Fq377P> *)gpu::dmalloc(n_tab * n_plain * sizeof(Affine28<Fq377P>));
+        d_shifted = (Affine28<Fq377P> *)gpu::dmalloc(n_tab * n_shift * sizeof(Affine28<Fq377P>));
+    } else {
+        d_powers = (Affine28<Fq377P> *)gpu::dmalloc((n_plain + n_shift) * sizeof(Affine28<Fq377P>));
+        d_shifted = d_powers + n_plain;
+    }
+    make_srs(d_powers, 0, n_plain);
+    make_srs(d_shifted, lowest_shift, n_shift);
     if (const char *e = getenv("ZKAES_LAGRANGE")) use_lagrange = atoi(e) != 0;
     if (use_lagrange) {
         // With the (public, test_rng-derived) trapdoor the Lagrange-basis points are direct fixed-base products; a trapdoor-free universal SRS
@@ -528,7 +565,7 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     auto &za_ev = cx.za_ev; auto &zb_ev = cx.zb_ev; auto &x_poly = cx.x_poly; auto &x_tmp = cx.x_tmp; auto &x_evals = cx.x_evals; auto &tmp_n = cx.tmp_n;
     auto &ra_ev = cx.ra_ev; auto &ra_poly = cx.ra_poly; auto &zpoly = cx.zpoly; auto &t_partial = cx.t_partial;
     auto &poly = cx.poly; auto &poly_len = cx.poly_len; auto &e = cx.e; auto &big_tmp = cx.big_tmp; auto &f_poly = cx.f_poly; auto &ab = cx.ab;
-    auto &acc = cx.acc; auto &wit = cx.wit; auto &scratch = cx.scratch; auto &timings = cx.timings;
+    auto &acc = cx.acc; auto &wit = cx.wit; auto &wit2 = cx.wit2; auto &scratch = cx.scratch; auto &timings = cx.timings;
     auto t_all = Clock::now(), t0 = t_all;
     ChaChaRng zk(zk_seed ? zk_seed : ark_test_rng_seed(), 12);
     const size_t n4 = next_pow2(3 * n + 1), k2 = 2 * k;
@@ -672,14 +709,13 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
         gpu::poly_axpy(acc.p, poly[4].p, chp[3], poly_len[4], s);
         gpu::poly_axpy(acc.p, poly[2].p, chp[4], poly_len[2], s); rand_axpy(rb, chp[4], r1[2].rand);
         gpu::divide_by_linear(wit.p, acc.p, plen, beta, scratch.p, s);
-        XYZZ<Fq377> w = msm_powers(cx, false, 0, wit.p, plen - 1);
+        // shifted part (g_1, degree bound |H| - 2) rides in the same Pippenger instance
+        gpu::divide_by_linear(wit2.p, poly[5].p, poly_len[5], beta, scratch.p, s);
+        gpu::poly_scale(wit2.p, chp[1], poly_len[5] - 1, s);
+        XYZZ<Fq377> w = msm_opening(cx, wit.p, plen - 1, wit2.p, poly_len[5] - 1, bounds[1] - (n - 2));
         Fr rq[2]; host_divide_by_linear(rq, rb, beta);
         for (int i = 0; i < 2; i++) w.add(mul_fr(XYZZ<Fq377>::from_affine(gamma_powers[i]), rq[i]));
         Fr rv = host_eval3(rb, beta);
-        // shifted part (g_1, degree bound |H| - 2)
-        gpu::divide_by_linear(wit.p, poly[5].p, poly_len[5], beta, scratch.p, s);
-        gpu::poly_scale(wit.p, chp[1], poly_len[5] - 1, s);
-        w.add(msm_powers(cx, true, bounds[1] - (n - 2), wit.p, poly_len[5] - 1));
         Fr srb[3]; for (int i = 0; i < 3; i++) srb[i] = chp[1] * r2[1].shifted_rand.b[i];
         host_divide_by_linear(rq, srb, beta);
         for (int i = 0; i < 2; i++) w.add(mul_fr(XYZZ<Fq377>::from_affine(gamma_powers[i]), rq[i]));
@@ -698,10 +734,9 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
         gpu::poly_axpy(acc.p, ix_co[5].p, chp[2] * c_rc, k, s);
         gpu::poly_axpy(acc.p, poly[8].p, chp[2] * c_h2, poly_len[8], s);
         gpu::divide_by_linear(wit.p, acc.p, plen, gamma, scratch.p, s);
-        XYZZ<Fq377> w = msm_powers(cx, false, 0, wit.p, plen - 1);
-        gpu::divide_by_linear(wit.p, poly[7].p, poly_len[7], gamma, scratch.p, s);
-        gpu::poly_scale(wit.p, chp[1], poly_len[7] - 1, s);
-        w.add(msm_powers(cx, true, bounds[1] - (k - 2), wit.p, poly_len[7] - 1));
+        gpu::divide_by_linear(wit2.p, poly[7].p, poly_len[7], gamma, scratch.p, s);
+        gpu::poly_scale(wit2.p, chp[1], poly_len[7] - 1, s);
+        XYZZ<Fq377> w = msm_opening(cx, wit.p, plen - 1, wit2.p, poly_len[7] - 1, bounds[1] - (k - 2));
         pf.w_gamma = w.to_affine();
     }
     for (int i = 0; i < 4; i++) pf.comms[i] = r1[i].comm;
