@@ -126,7 +126,9 @@ void ntt(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, stream_t s
     Fr w = Tables<Fr>::gen(lg);
     const Fr *tw = inverse ? tables<Fr>().powers(tables<Fr>().inv, lg, w.inverse(), n / 2) : tables<Fr>().powers(tables<Fr>().fwd, lg, w, n / 2);
     Fr n_inv = Fr::from_u64(n).inverse();
-    // pass plan
+    // pass plan: pass 1 covers min(lg, 10) stages on contiguous 1024-element tiles; the remaining R stages are split EVENLY over
+    // ceil(R / 8) passes, each on full 1024-element tiles made of 2^S strided runs of 2^L = 2^(10 - S) contiguous elements (>= 128 B runs),
+    // so that every pass keeps all 256 lanes busy (a lopsided 10 + 8 + 4 plan left the last pass with 64-element tiles and made it the slowest).
     int s0 = 0;
     int S1 = lg < 10 ? lg : 10;
     int remaining = lg - S1;
@@ -136,14 +138,18 @@ void ntt(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, stream_t s
         HIP_LAUNCH_CHECK();
         s0 = S1;
     }
+    int passes = (remaining + 7) / 8;
     while (remaining > 0) {
-        const int L = 2;
-        int S = remaining < 8 ? remaining : 8;
+        int S = (remaining + passes - 1) / passes;        // even split
+        int L = 10 - S;
+        if (L > s0) L = s0;
+        if (L < 2) L = 2;
         bool last = remaining == S;
         hipLaunchKernelGGL((k_ntt_pass<Fr, 10>), dim3(n >> (S + L)), dim3(256), 0, s, dst, (const Fr *)dst, n, lg, s0, S, L, tw, false, inverse && last, n_inv);
         HIP_LAUNCH_CHECK();
         s0 += S;
         remaining -= S;
+        passes--;
     }
 }
 

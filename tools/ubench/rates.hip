@@ -64,6 +64,13 @@ __global__ void k_fmul28(G *out, G a, int iters) {
     for (int i = 0; i < iters; i++) { x = x * y; y = y * x; }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x + y;
 }
+template <class G>
+__global__ void k_fsqr28(G *out, G a, int iters) {
+    G x = a, y = a;
+    x.l[0] += threadIdx.x & 0xff;
+    for (int i = 0; i < iters; i++) { x = x.sqr() + y; y = y.sqr() + x; }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x + y;
+}
 template <class Fn> float timeit(Fn fn) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     fn(); hipDeviceSynchronize();
@@ -91,5 +98,7 @@ int main() {
     Fq377x28 g = Fq377x28::from_std(one);
     ms = timeit([&] { hipLaunchKernelGGL((k_fmul28<Fq377x28>), dim3(blocks), dim3(threads), 0, 0, (Fq377x28 *)buf, g, 200); });
     printf("Fq377x28 mul  : %.2f Gmul/s (%.3f ms)\n", lanes * 400 / ms / 1e6, ms);
+    ms = timeit([&] { hipLaunchKernelGGL((k_fsqr28<Fq377x28>), dim3(blocks), dim3(threads), 0, 0, (Fq377x28 *)buf, g, 200); });
+    printf("Fq377x28 sqr  : %.2f Gsqr/s (%.3f ms)\n", lanes * 400 / ms / 1e6, ms);
     return 0;
 }
