@@ -122,9 +122,10 @@ void bits_to_field(F *out, const uint8_t *z, size_t n, stream_t s);
 // t evaluations on H: out[h] = sum over entries (row r, weight w = eta_M * coeff) in column bucket h of  w * r_alpha[r].
 // The indexer buckets A, B, C by (re-indexed) column and cuts every bucket into segments of <= T_SEG entries:
 // seg_start/seg_end[nseg] (entry ranges), col_seg_ptr[n+1] (segments of column h), row[], mat[] (0/1/2), coeff[]; partial = nseg scratch elements
-constexpr uint32_t T_SEG = 32;
-void t_evals(F *out, uint32_t n, F *partial, uint32_t nseg, const uint32_t *col_seg_ptr, const uint32_t *seg_start, const uint32_t *seg_end, const uint32_t *row, const uint8_t *mat,
-             const int64_t *coeff, const F *r_alpha, const F &eta_a, const F &eta_b, const F &eta_c, stream_t s);
+// heavy[n_heavy] = columns with more than T_HEAVY_SEGMENTS segments (summed by a whole workgroup each)
+constexpr uint32_t T_SEG = 32, T_HEAVY_SEGMENTS = 256;
+void t_evals(F *out, uint32_t n, F *partial, uint32_t nseg, const uint32_t *col_seg_ptr, const uint32_t *seg_start, const uint32_t *seg_end, const uint32_t *heavy, uint32_t n_heavy,
+             const uint32_t *row, const uint8_t *mat, const int64_t *coeff, const F *r_alpha, const F &eta_a, const F &eta_b, const F &eta_c, stream_t s);
 // `count` field elements drawn exactly as ark-ff's Fp::rand would draw them from a ChaCha block RNG (rand_chacha layout: 64-bit block
 // counter, word stream) positioned at word `word_pos`: 8 words per candidate, top bits shaved, candidates >= p rejected, limbs used AS the
 // Montgomery form.  Candidates are generated and filtered in parallel (flag + exclusive scan + compaction).  Returns the stream position

@@ -183,17 +183,31 @@ __global__ void k_t_partials(F *__restrict__ partial, uint32_t nseg, const uint3
     }
     partial[sgi] = acc;
 }
+// columns with more than T_HEAVY_SEGMENTS segments (the constant One, key bits) get a whole workgroup: k_t_heavy
 __global__ void k_t_columns(F *__restrict__ out, uint32_t n, const uint32_t *__restrict__ col_seg_ptr, const F *__restrict__ partial) {
     uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= n) return;
+    uint32_t a = col_seg_ptr[h], b = col_seg_ptr[h + 1];
+    if (b - a > T_HEAVY_SEGMENTS) return;        // summed by k_t_heavy
     F acc = F::zero();
-    for (uint32_t i = col_seg_ptr[h]; i < col_seg_ptr[h + 1]; i++) acc = acc + partial[i];
+    for (uint32_t i = a; i < b; i++) acc = acc + partial[i];
     out[h] = acc;
 }
-void t_evals(F *out, uint32_t n, F *partial, uint32_t nseg, const uint32_t *col_seg_ptr, const uint32_t *seg_start, const uint32_t *seg_end, const uint32_t *row, const uint8_t *mat,
-             const int64_t *coeff, const F *r_alpha, const F &eta_a, const F &eta_b, const F &eta_c, stream_t s) {
+__global__ void __launch_bounds__(256) k_t_heavy(F *__restrict__ out, const uint32_t *__restrict__ heavy, const uint32_t *__restrict__ col_seg_ptr, const F *__restrict__ partial) {
+    __shared__ F sh[256];
+    uint32_t h = heavy[blockIdx.x], t = threadIdx.x;
+    F acc = F::zero();
+    for (uint32_t i = col_seg_ptr[h] + t; i < col_seg_ptr[h + 1]; i += 256) acc = acc + partial[i];
+    sh[t] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)t < s) sh[t] = sh[t] + sh[t + s]; __syncthreads(); }
+    if (t == 0) out[h] = sh[0];
+}
+void t_evals(F *out, uint32_t n, F *partial, uint32_t nseg, const uint32_t *col_seg_ptr, const uint32_t *seg_start, const uint32_t *seg_end, const uint32_t *heavy, uint32_t n_heavy,
+             const uint32_t *row, const uint8_t *mat, const int64_t *coeff, const F *r_alpha, const F &eta_a, const F &eta_b, const F &eta_c, stream_t s) {
     if (nseg) { hipLaunchKernelGGL(k_t_partials, GRID(nseg), 0, (hipStream_t)s, partial, nseg, seg_start, seg_end, row, mat, coeff, r_alpha, eta_a, eta_b, eta_c); HIP_LAUNCH_CHECK(); }
     hipLaunchKernelGGL(k_t_columns, GRID(n), 0, (hipStream_t)s, out, n, col_seg_ptr, partial); HIP_LAUNCH_CHECK();
+    if (n_heavy) { hipLaunchKernelGGL(k_t_heavy, dim3(n_heavy), dim3(256), 0, (hipStream_t)s, out, heavy, col_seg_ptr, partial); HIP_LAUNCH_CHECK(); }
 }
 
 }  // namespace gpu

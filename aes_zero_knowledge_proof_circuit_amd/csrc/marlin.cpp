@@ -266,7 +266,8 @@ class ProvingKeyImpl {
     uint32_t *d_a_rowptr = nullptr, *d_a_col = nullptr, *d_b_rowptr = nullptr, *d_b_col = nullptr;
     int64_t *d_a_coeff = nullptr, *d_b_coeff = nullptr;
     uint32_t *d_t_colptr = nullptr, *d_t_seg_start = nullptr, *d_t_seg_end = nullptr, *d_t_row = nullptr; uint8_t *d_t_mat = nullptr; int64_t *d_t_coeff = nullptr;
-    uint32_t t_nseg = 0;
+    uint32_t t_nseg = 0, t_nheavy = 0;
+    uint32_t *d_t_heavy = nullptr;
     // device: index polynomials (evaluations on K and coefficients); order row col a_val b_val c_val row_col
     DevBuf ix_ev[6], ix_co[6];
     ProverTimings last_timings;
@@ -274,7 +275,7 @@ class ProvingKeyImpl {
     ~ProvingKeyImpl() {
         gpu::dfree(d_powers); if (use_tables) gpu::dfree(d_shifted); gpu::dfree(d_lag_h); gpu::dfree(d_lag_w); gpu::dfree(d_desc); gpu::dfree(d_sbox_in); gpu::dfree(d_sbox_tmpl);
         gpu::dfree(d_a_rowptr); gpu::dfree(d_a_col); gpu::dfree(d_b_rowptr); gpu::dfree(d_b_col); gpu::dfree(d_a_coeff); gpu::dfree(d_b_coeff);
-        gpu::dfree(d_t_colptr); gpu::dfree(d_t_seg_start); gpu::dfree(d_t_seg_end); gpu::dfree(d_t_row); gpu::dfree(d_t_mat); gpu::dfree(d_t_coeff);
+        gpu::dfree(d_t_heavy); gpu::dfree(d_t_colptr); gpu::dfree(d_t_seg_start); gpu::dfree(d_t_seg_end); gpu::dfree(d_t_row); gpu::dfree(d_t_mat); gpu::dfree(d_t_coeff);
         for (auto &b : ix_ev) b.release();
         for (auto &b : ix_co) b.release();
         ctxs.clear();
@@ -534,6 +535,11 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
             col_seg_ptr[h + 1] = (uint32_t)seg_start.size();
         }
         t_nseg = (uint32_t)seg_start.size();
+        std::vector<uint32_t> heavy;
+        for (size_t h = 0; h < n; h++) if (col_seg_ptr[h + 1] - col_seg_ptr[h] > gpu::T_HEAVY_SEGMENTS) heavy.push_back((uint32_t)h);
+        t_nheavy = (uint32_t)heavy.size();
+        if (heavy.empty()) heavy.push_back(0);
+        d_t_heavy = upload(heavy, stream);
         if (seg_start.empty()) { seg_start.push_back(0); seg_end.push_back(0); }
         d_t_colptr = upload(col_seg_ptr, stream); d_t_seg_start = upload(seg_start, stream); d_t_seg_end = upload(seg_end, stream);
         d_t_row = upload(trow, stream); d_t_mat = upload(tmat, stream); d_t_coeff = upload(tcoef, stream);
@@ -633,7 +639,7 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     const F *elems = gpu::domain_elements<F>(lg_n);
     gpu::sub_from_scalar(ra_ev.p, elems, alpha, n, s);
     gpu::batch_inverse(ra_ev.p, n, &vh_alpha, s);                            // r(alpha, h) = v_H(alpha) / (alpha - h)
-    gpu::t_evals(tmp_n.p, (uint32_t)n, t_partial.p, t_nseg, d_t_colptr, d_t_seg_start, d_t_seg_end, d_t_row, d_t_mat, d_t_coeff, ra_ev.p, eta_a, eta_b, eta_c, s);
+    gpu::t_evals(tmp_n.p, (uint32_t)n, t_partial.p, t_nseg, d_t_colptr, d_t_seg_start, d_t_seg_end, d_t_heavy, t_nheavy, d_t_row, d_t_mat, d_t_coeff, ra_ev.p, eta_a, eta_b, eta_c, s);
     gpu::ntt<F>(poly[4].p, tmp_n.p, n, lg_n, true, s); poly_len[4] = n;
     gpu::ntt<F>(ra_poly.p, ra_ev.p, n, lg_n, true, s);
     gpu::z_poly_from_w(zpoly.p, poly[0].p, poly_len[0], x_poly.p, (uint32_t)m, n, s);
