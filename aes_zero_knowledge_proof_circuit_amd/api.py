@@ -226,6 +226,17 @@ def msm(curve_id, bases_bytes, scalars_bytes):
     return out.raw, bool(inf.value)
 
 
+def g1_sum(curve_id, points):
+    """Host-side sum of [(xy_bytes96, is_inf), ...] -> (xy_bytes96, is_inf)."""
+    n = len(points)
+    buf = b"".join(bytes(p[0]) for p in points)
+    inf = (C.c_int * max(n, 1))(*[1 if p[1] else 0 for p in points])
+    out = C.create_string_buffer(96)
+    oinf = C.c_int()
+    _check(lib().zkaes_g1_sum(int(curve_id), buf, inf, C.c_size_t(n), out, C.byref(oinf)))
+    return out.raw, bool(oinf.value)
+
+
 def msm_table(curve_id, bases_bytes, scalars_bytes, window_bits):
     n = len(scalars_bytes) // 32
     out = C.create_string_buffer(96)
@@ -246,6 +257,13 @@ def msm_bench_synth(n, window_bits=0, reps=3, want_point=False):
     out = C.create_string_buffer(96)
     _check(lib().zkaes_msm_bench_synth(C.c_size_t(n), int(window_bits), int(reps), C.byref(t), C.byref(a), out))
     return (t.value, a.value, out.raw) if want_point else (t.value, a.value)
+
+
+def stream_copy_bench(nbytes=1 << 30, reps=20):
+    """Measured HBM stream-copy rate (read + write GB/s) of a plain 16 B/lane copy kernel -- printed beside the nominal peak."""
+    g = C.c_double()
+    _check(lib().zkaes_stream_copy_bench(C.c_size_t(nbytes), int(reps), C.byref(g)))
+    return g.value
 
 
 def msm_stats(reset=False):

@@ -6,6 +6,11 @@
 #include "hip_util.hpp"
 #include "marlin.hpp"
 
+// stream-copy probe for the measured HBM peak bench.py prints next to the nominal 8 TB/s: 16 B per lane, grid-stride
+__global__ void __launch_bounds__(256) k_stream_copy(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 struct zkaes_pk { std::unique_ptr<zk::ProvingKey> pk; };
 extern "C" const char *zkaes_last_error(void);
 namespace zk { void capi_set_error(const std::string &); }
@@ -79,9 +84,26 @@ template <class Curve> void run_msm_table(const uint8_t *bases, const uint8_t *s
     zk::gpu::msm_workspace_destroy(ws);
     zk::gpu::dfree(tab); zk::gpu::dfree(ds); zk::gpu::stream_destroy(s);
 }
+// host-side sum of a handful of affine partial results: the "local EC add" after the all-gather of a point-range-sharded MSM
+template <class Curve> void run_g1_sum(const uint8_t *points_xy, const int *inf, size_t n, uint8_t *out_xy, int *out_inf) {
+    using Fq = typename Curve::Fq;
+    zk::XYZZ<Fq> acc = zk::XYZZ<Fq>::inf();
+    for (size_t i = 0; i < n; i++) {
+        if (inf && inf[i]) continue;
+        zk::Affine<Fq> a;
+        memcpy(a.x.l, points_xy + 96 * i, 48); memcpy(a.y.l, points_xy + 96 * i + 48, 48);
+        acc.add(zk::XYZZ<Fq>::from_affine(a));
+    }
+    zk::Affine<Fq> r = acc.to_affine();
+    *out_inf = r.is_inf() ? 1 : 0;
+    memcpy(out_xy, r.x.l, 48); memcpy(out_xy + 48, r.y.l, 48);
+}
 }  // namespace
 
 extern "C" {
+int zkaes_g1_sum(int curve_id, const uint8_t *points_xy, const int *inf, size_t n, uint8_t *out_xy, int *out_inf) {
+    return guardk([&] { if (curve_id == 381) run_g1_sum<zk::Bls381>(points_xy, inf, n, out_xy, out_inf); else if (curve_id == 377) run_g1_sum<zk::Bls377>(points_xy, inf, n, out_xy, out_inf); else throw std::invalid_argument("curve_id must be 377 or 381"); });
+}
 int zkaes_msm_table(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, int window_bits, uint8_t *out_xy, int *out_inf) {
     return guardk([&] { if (curve_id == 381) run_msm_table<zk::Bls381>(bases, scalars, n, window_bits, out_xy, out_inf); else if (curve_id == 377) run_msm_table<zk::Bls377>(bases, scalars, n, window_bits, out_xy, out_inf); else throw std::invalid_argument("curve_id must be 377 or 381"); });
 }
@@ -134,6 +156,27 @@ int zkaes_msm_bench_synth(size_t n, int window_bits, int reps, double *ms_total,
         zk::gpu::msm_workspace_destroy(ws);
         zk::gpu::dfree(tab28);
         zk::gpu::dfree(tab); zk::gpu::dfree(ds); zk::gpu::stream_destroy(s);
+    });
+}
+
+int zkaes_stream_copy_bench(size_t bytes, int reps, double *gb_per_s) {
+    return guardk([&] {
+        zk::gpu::require_device();
+        if (bytes < 4096 || reps < 1) throw std::invalid_argument("zkaes_stream_copy_bench: bytes >= 4096, reps >= 1");
+        zk::gpu::stream_t s = zk::gpu::stream_create();
+        const size_t n16 = bytes / 16;
+        uint4 *a = (uint4 *)zk::gpu::dmalloc(n16 * 16), *b = (uint4 *)zk::gpu::dmalloc(n16 * 16);
+        zk::gpu::dzero(a, n16 * 16, s);
+        hipStream_t hs = (hipStream_t)s;
+        k_stream_copy<<<256 * 32, 256, 0, hs>>>(b, a, n16);
+        void *e0 = zk::gpu::event_create(), *e1 = zk::gpu::event_create();
+        zk::gpu::event_record(e0, s);
+        for (int i = 0; i < reps; i++) k_stream_copy<<<256 * 32, 256, 0, hs>>>(i & 1 ? a : b, i & 1 ? b : a, n16);
+        zk::gpu::event_record(e1, s);
+        float ms = zk::gpu::event_elapsed_ms(e0, e1);
+        *gb_per_s = 2.0 * (double)(n16 * 16) * reps / 1e9 / (ms / 1e3);   // read + write
+        zk::gpu::event_destroy(e0); zk::gpu::event_destroy(e1);
+        zk::gpu::dfree(a); zk::gpu::dfree(b); zk::gpu::stream_destroy(s);
     });
 }
 }

@@ -45,3 +45,44 @@ def reduce_report(elapsed, accepted, total, negatives_ok, device=None):
 
 def aggregate_value(world, blocks_per_rank, steps, elapsed_max):
     return world * blocks_per_rank * steps / elapsed_max
+
+
+def point_range(n, rank, world):
+    """contiguous share [lo, hi) of an n-point MSM for this rank"""
+    return split_chunks(n, rank, world)
+
+
+def msm_sharded(curve_id, bases_bytes, scalars_bytes, local_msm=None, device=None):
+    """ONE multi-scalar multiplication sharded by point range over the ranks of the default process group (second row).
+
+    Every rank runs the Pippenger MSM over its own slice of (base, scalar) pairs -- on its GPU through the C ABI -- and the per-rank partial
+    sums (96 B affine + an infinity flag) are exchanged with ONE all-gather; each rank then folds the `world` partials with the host-side EC add
+    (`zkaes_g1_sum`).  EC addition is not an RCCL reduction operator, hence all-gather + local add instead of an all-reduce; the payload is
+    100 B per rank, so the exchange is latency- not bandwidth-bound on xGMI.  `local_msm` is a test seam (CPU tests supply the oracle's MSM
+    because there is no GPU there); the product path leaves it None and fails loudly without a GPU.
+    """
+    import torch
+    import torch.distributed as dist
+    from . import api
+    n = len(scalars_bytes) // 32
+    if len(bases_bytes) != 96 * n:
+        raise ValueError("bases must be n x 96 bytes and scalars n x 32 bytes")
+    rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+    lo, hi = point_range(n, rank, world)
+    run = local_msm if local_msm is not None else (lambda b, s: api.msm(curve_id, b, s))
+    if hi > lo:
+        xy, inf = run(bases_bytes[96 * lo:96 * hi], scalars_bytes[32 * lo:32 * hi])
+    else:
+        xy, inf = bytes(96), True
+    if world == 1:
+        return bytes(xy), bool(inf)
+    mine = torch.frombuffer(bytearray(bytes(xy) + bytes([1 if inf else 0, 0, 0, 0])), dtype=torch.uint8)
+    if device is not None:
+        mine = mine.to(device)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    pts = []
+    for p in parts:
+        raw = bytes(p.cpu().numpy().tobytes())
+        pts.append((raw[:96], raw[96] != 0))
+    return api.g1_sum(curve_id, pts)

@@ -154,6 +154,10 @@ def main():
             traffic = round(pmc["hbm_bytes_per_point_window"] * stats["pairs"] / max(launches, 1))
         except Exception:
             pass
+        try:
+            copy_gbs = round(api.stream_copy_bench(1 << 30, 20), 1)
+        except Exception:
+            copy_gbs = None
         out = {
             "metric": "AES-ECB blocks proven/sec (Marlin), proof verifies", "value": round(value, 4), "unit": "blocks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
@@ -168,6 +172,7 @@ def main():
             "phase_ms_last_proof_avg": {k: round(v / args.steps, 2) for k, v in phase.items()},
             "roofline": {"bound": "hbm", "kernel": "k_accumulate (Pippenger bucket accumulation)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "peak_measured_stream_copy": copy_gbs,
                          "traffic_source": "profiles/r01_pmc_k_accumulate_v4.json (PMC bytes per point-window x pairs of this run)",
                          "int_multiplier": {"unit": "T v_mad_u64_u32/s", "achieved": round(3598.0 * stats["pairs"] / 1e12 / (acc_ms / 1e3), 2) if acc_ms > 0 else 0.0,
                                             "peak": 28.1, "frac": round(3598.0 * stats["pairs"] / 1e12 / (acc_ms / 1e3) / 28.1, 4) if acc_ms > 0 else 0.0,

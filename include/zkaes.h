@@ -107,6 +107,10 @@ int zkaes_msm_stats(double out[5], int reset);
 int zkaes_ntt(int field_id, uint8_t *data, size_t n, int inverse);
 /* curve_id 377 / 381.  bases: n x 96 B affine (x||y Montgomery), scalars: n x 32 B Montgomery Fr; out_xy 96 B, *out_inf = 1 if infinity */
 int zkaes_msm(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, uint8_t *out_xy, int *out_inf);
+/* host-side sum of n affine points (n x 96 B, inf[i] != 0 marks the point at infinity; inf may be NULL): the local EC add that follows the
+ * all-gather when ONE MSM is sharded by point range over ranks (SURVEY.md 8e "inside one proof"; the upstream analogue is the final fold of the
+ * per-window sums in ark-ec's VariableBaseMSM::multi_scalar_mul).  Runs on the host: a few hundred field products. */
+int zkaes_g1_sum(int curve_id, const uint8_t *points_xy, const int *inf, size_t n, uint8_t *out_xy, int *out_inf);
 /* same sum through the precomputed-window path the prover uses for the SRS (tables 2^(c j) P_i built on the fly here; one bucket set) */
 int zkaes_msm_table(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, int window_bits, uint8_t *out_xy, int *out_inf);
 /* device-resident variant for benchmarking: repeats the MSM `reps` times over device copies, returns ms per MSM of the whole pipeline and of
@@ -115,6 +119,9 @@ int zkaes_msm_bench(int curve_id, const uint8_t *bases, const uint8_t *scalars, 
 /* BLS12-377, synthetic device-made bases (powers of a fixed scalar times the generator) and xorshift scalars: window_bits = 0 per-window
  * signed-digit buckets, else the precomputed-table path.  out_xy (96 B, may be NULL) receives the sum: the two paths must agree. */
 int zkaes_msm_bench_synth(size_t n, int window_bits, int reps, double *ms_total, double *ms_accumulate, uint8_t *out_xy);
+/* stream-copy probe: copies `bytes` device-to-device `reps` times with a plain 16 B/lane kernel and returns read+write GB/s -- the measured
+ * HBM peak bench.py prints beside the nominal 8 TB/s (SURVEY.md 8d "measure achievable with a stream-copy kernel and report both") */
+int zkaes_stream_copy_bench(size_t bytes, int reps, double *gb_per_s);
 /* AES witness only: fills z (padded instance + witness, one byte per variable) for a message under the key's circuit */
 int zkaes_aes_witness(const zkaes_pk *pk, const uint8_t *message, size_t message_len, const uint8_t secret_key[16], uint8_t *z, size_t z_cap, size_t *z_len);
 

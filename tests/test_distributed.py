@@ -58,3 +58,73 @@ def test_plan_edges():
     with pytest.raises(ValueError):
         sharding.plan(0, 4)
     assert [sharding.split_chunks(5, r, 8) for r in range(8)] == [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 5), (5, 5), (5, 5)]
+
+
+# ---- ONE MSM sharded by point range: all-gather of per-rank partial sums + host-side EC add (second row) ----------------
+def _msm_inputs(cid, n, seed):
+    import ctypes as C
+    import numpy as np
+    from oracle import zko
+    rs = np.random.RandomState(seed)
+    gen = b"".join((int.from_bytes(rs.bytes(32), "little") % zko.FR[cid]).to_bytes(32, "little") for _ in range(n))
+    bases = C.create_string_buffer(96 * n)
+    zko.lib().zko_api_fixed_base(cid, gen, C.c_size_t(n), bases)
+    scalars = b"".join((int.from_bytes(rs.bytes(32), "little") % zko.FR[cid]).to_bytes(32, "little") for _ in range(n))
+    return bases.raw, scalars
+
+
+def _oracle_msm(cid):
+    import ctypes as C
+    from oracle import zko
+
+    def run(bases, scalars):
+        out = C.create_string_buffer(96)
+        inf = zko.lib().zko_api_msm(cid, bytes(bases), bytes(scalars), C.c_size_t(len(scalars) // 32), out)
+        return out.raw, bool(inf)
+    return run
+
+
+def _msm_worker(rank, world, port, cid, n, use_gpu, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bases, scalars = _msm_inputs(cid, n, 4000 + n)
+    out[rank] = sharding.msm_sharded(cid, bases, scalars, local_msm=None if use_gpu else _oracle_msm(cid))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cid,n", [(377, 301), (381, 64), (377, 1)])
+def test_point_range_sharded_msm_two_ranks(cid, n):
+    """per-rank partials come from the oracle here (no GPU); the exchange + zkaes_g1_sum fold is the product code under test"""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_msm_worker, args=(world, port, cid, n, False, out), nprocs=world, join=True)
+    bases, scalars = _msm_inputs(cid, n, 4000 + n)
+    ref = _oracle_msm(cid)(bases, scalars)
+    assert out[0] == out[1] == ref
+
+
+def test_g1_sum_edges():
+    from aes_zero_knowledge_proof_circuit_amd import api
+    from oracle import zko
+    bases, _ = _msm_inputs(377, 2, 9)
+    p, q = bases[:96], bases[96:]
+    (px, py), = zko.pt_unpack(p)
+    neg_p = zko.pt_pack([(px, (-py) % zko.Q377)])
+    assert api.g1_sum(377, [])[1] is True
+    assert api.g1_sum(377, [(p, False)]) == (p, False)
+    assert api.g1_sum(377, [(p, False), (neg_p, False)])[1] is True                     # P + (-P)
+    assert api.g1_sum(377, [(p, True), (q, False)]) == (q, False)                      # flagged infinity is skipped
+    two_p = _oracle_msm(377)(p, zko.fr_pack([2]))
+    assert api.g1_sum(377, [(p, False), (p, False)]) == two_p                          # P + P takes the doubling branch
+    assert api.g1_sum(377, [(p, False), (q, False)]) == _oracle_msm(377)(p + q, zko.fr_pack([1, 1]))
+
+
+@pytest.mark.gpu
+def test_point_range_sharded_msm_two_gpu_processes():
+    """both ranks run the HIP Pippenger on their slice through the C ABI (sharing GPU 0 on a one-GPU box), then all-gather + fold"""
+    world, port, cid, n = 2, _free_port(), 377, 5000
+    out = mp.Manager().dict()
+    mp.spawn(_msm_worker, args=(world, port, cid, n, True, out), nprocs=world, join=True)
+    bases, scalars = _msm_inputs(cid, n, 4000 + n)
+    assert out[0] == out[1] == _oracle_msm(cid)(bases, scalars)
