@@ -72,6 +72,18 @@ class VerifyingKey:
         _check(lib().zkaes_vk_deserialize(bytes(b), C.c_size_t(len(b)), C.byref(p)))
         return VerifyingKey(p.value)
 
+    def to_ark_bytes(self):
+        """ark-serialize 0.3 compressed IndexVerifierKey bytes (what the Rust side's CanonicalSerialize writes)"""
+        out, n = C.c_void_p(), C.c_size_t()
+        _check(lib().zkaes_vk_serialize_ark(self._p, C.byref(out), C.byref(n)))
+        return _take(out, n)
+
+    @staticmethod
+    def from_ark_bytes(b):
+        p = C.c_void_p()
+        _check(lib().zkaes_vk_deserialize_ark(bytes(b), C.c_size_t(len(b)), C.byref(p)))
+        return VerifyingKey(p.value)
+
     @staticmethod
     def from_trapdoor(info, index_comms, beta_mont, gamma_mont):
         arr = (C.c_uint64 * 7)(*info)

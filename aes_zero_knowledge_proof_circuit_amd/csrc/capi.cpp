@@ -136,6 +136,19 @@ int zkaes_vk_serialize(const zkaes_vk *vk, uint8_t **out, size_t *out_len) {
         *out = give(w.b); *out_len = w.b.size();
     });
 }
+int zkaes_vk_serialize_ark(const zkaes_vk *vk, uint8_t **out, size_t *out_len) {
+    return guard([&] {
+        if (!vk || !out || !out_len) throw std::invalid_argument("null argument");
+        auto b = zk::serialize_vk_ark(vk->vk);
+        *out = give(b); *out_len = b.size();
+    });
+}
+int zkaes_vk_deserialize_ark(const uint8_t *bytes, size_t len, zkaes_vk **vk) {
+    return guard([&] {
+        if (!bytes || !vk) throw std::invalid_argument("null argument");
+        *vk = new zkaes_vk{zk::deserialize_vk_ark(bytes, len)};
+    });
+}
 int zkaes_vk_deserialize(const uint8_t *bytes, size_t len, zkaes_vk **vk) {
     return guard([&] {
         R r{bytes, len};

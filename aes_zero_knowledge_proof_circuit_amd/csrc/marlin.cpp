@@ -139,7 +139,101 @@ struct Reader {
     }
 };
 
+
+// Fq2 = Fq[u]/(u^2 + 5): lexicographic order of ark-ff's QuadExtField (c1 first, then c0) for the compressed-point sign flag
+bool fq2_gt(const pairing::Fq2 &a, const pairing::Fq2 &b) {
+    uint32_t x[12], y[12];
+    a.c1.to_raw(x); b.c1.to_raw(y);
+    for (int i = 11; i >= 0; i--) if (x[i] != y[i]) return x[i] > y[i];
+    a.c0.to_raw(x); b.c0.to_raw(y);
+    for (int i = 11; i >= 0; i--) if (x[i] != y[i]) return x[i] > y[i];
+    return false;
+}
+// square root in Fq2 through the norm: a = a0 + a1 u, alpha = sqrt(a0^2 + 5 a1^2), delta = (a0 +- alpha)/2, c0 = sqrt(delta), c1 = a1/(2 c0)
+bool fq2_sqrt(const pairing::Fq2 &a, pairing::Fq2 &out) {
+    using pairing::Fq2;
+    if (a.is_zero()) { out = a; return true; }
+    Fq377 inv2 = Fq377::from_u64(2).inverse();
+    if (a.c1.is_zero()) {
+        Fq377 r;
+        if (fq_sqrt(a.c0, r)) { out = Fq2{r, Fq377::zero()}; return true; }
+        if (!fq_sqrt((a.c0 * Fq377::from_u64(5).inverse()).neg(), r)) return false;
+        out = Fq2{Fq377::zero(), r};
+        return true;
+    }
+    Fq377 alpha;
+    if (!fq_sqrt(a.c0.sqr() + pairing::times5(a.c1.sqr()), alpha)) return false;
+    Fq377 delta = (a.c0 + alpha) * inv2, c0;
+    if (!fq_sqrt(delta, c0)) { delta = (a.c0 - alpha) * inv2; if (!fq_sqrt(delta, c0)) return false; }
+    out = Fq2{c0, a.c1 * (c0.dbl()).inverse()};
+    return out.sqr() == a;
+}
+void put_g2_compressed(Bytes &o, const pairing::G2Affine &p) {
+    uint8_t buf[96] = {0};
+    if (p.inf) { buf[95] |= 1 << 6; o.put(buf, 96); return; }
+    uint32_t x0[12], x1[12];
+    p.x.c0.to_raw(x0); p.x.c1.to_raw(x1);
+    for (int i = 0; i < 48; i++) { buf[i] = (uint8_t)(x0[i / 4] >> (8 * (i % 4))); buf[48 + i] = (uint8_t)(x1[i / 4] >> (8 * (i % 4))); }
+    if (fq2_gt(p.y, p.y.neg())) buf[95] |= 1 << 7;
+    o.put(buf, 96);
+}
+pairing::G2Affine get_g2_compressed(Reader &r) {
+    r.need(96);
+    uint8_t buf[96];
+    memcpy(buf, r.p + r.off, 96); r.off += 96;
+    bool inf = buf[95] & (1 << 6), y_gt = buf[95] & (1 << 7);
+    buf[95] &= 0x3f;
+    if (inf) return pairing::G2Affine::infinity();
+    uint32_t raw[2][12];
+    for (int h = 0; h < 2; h++) {
+        for (int i = 0; i < 12; i++) { const uint8_t *q = buf + 48 * h + 4 * i; raw[h][i] = (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24; }
+        if (Fq377::geq_mod(raw[h])) throw std::runtime_error("deserialize: non-canonical G2 x coordinate");
+    }
+    pairing::G2Affine a;
+    a.inf = false;
+    a.x = pairing::Fq2{Fq377::from_raw(raw[0]), Fq377::from_raw(raw[1])};
+    pairing::Fq2 y;
+    if (!fq2_sqrt(a.x.sqr() * a.x + pairing::g2_b(), y)) throw std::runtime_error("deserialize: G2 x is not on the twist");
+    a.y = (fq2_gt(y, y.neg()) == y_gt) ? y : y.neg();
+    return a;
+}
+
 }  // namespace
+
+// ark-serialize 0.3 compressed layout of ark_marlin::IndexVerifierKey<Fr, MarlinKZG10<Bls12_377, _>> [RECALL, SURVEY.md A.5]:
+//   index_info   : num_variables, num_constraints, num_non_zero, num_instance_variables            (4 x u64 LE; PhantomData = 0 bytes)
+//   index_comms  : u64 len, then per marlin_pc::Commitment: comm (G1 compressed 48 B), shifted_comm Option tag (0 = None)
+//   verifier_key : marlin_pc::VerifierKey = kzg10::VerifierKey { g, gamma_g (G1 48 B each), h, beta_h (G2 compressed 96 B each); the
+//                  prepared G2 elements are not serialized }, degree_bounds_and_shift_powers Option<Vec<(usize, G1)>> (tag, u64 len,
+//                  (u64, 48 B) each), max_degree u64, supported_degree u64
+std::vector<uint8_t> serialize_vk_ark(const VerifyingKey &vk) {
+    Bytes o;
+    o.u64(vk.num_variables); o.u64(vk.num_constraints); o.u64(vk.num_non_zero); o.u64(vk.num_instance);
+    o.u64(6);
+    for (int i = 0; i < 6; i++) { o.g1_compressed(vk.index_comms[i]); o.u8(0); }
+    o.g1_compressed(vk.g); o.g1_compressed(vk.gamma_g);
+    put_g2_compressed(o, vk.h); put_g2_compressed(o, vk.beta_h);
+    o.u8(1); o.u64(2);
+    for (int i = 0; i < 2; i++) { o.u64(vk.degree_bounds[i]); o.g1_compressed(vk.shift_powers[i]); }
+    o.u64(vk.max_degree); o.u64(vk.supported_degree);
+    return o.b;
+}
+VerifyingKey deserialize_vk_ark(const uint8_t *bytes, size_t len) {
+    Reader r{bytes, len};
+    VerifyingKey vk;
+    vk.num_variables = r.u64(); vk.num_constraints = r.u64(); vk.num_non_zero = r.u64(); vk.num_instance = r.u64();
+    if (r.u64() != 6) throw std::runtime_error("deserialize_vk: expected 6 index commitments");
+    for (int i = 0; i < 6; i++) { vk.index_comms[i] = r.g1(); if (r.u8() != 0) throw std::runtime_error("deserialize_vk: index commitments carry no degree bound"); }
+    vk.g = r.g1(); vk.gamma_g = r.g1();
+    vk.h = get_g2_compressed(r); vk.beta_h = get_g2_compressed(r);
+    if (r.u8() != 1 || r.u64() != 2) throw std::runtime_error("deserialize_vk: expected two enforced degree bounds");
+    for (int i = 0; i < 2; i++) { vk.degree_bounds[i] = (size_t)r.u64(); vk.shift_powers[i] = r.g1(); }
+    vk.max_degree = (size_t)r.u64(); vk.supported_degree = (size_t)r.u64();
+    if (r.off != len) throw std::runtime_error("deserialize_vk: trailing bytes");
+    if (vk.num_instance == 0 || vk.num_variables < vk.num_instance) throw std::runtime_error("deserialize_vk: inconsistent index info");
+    vk.num_public_inputs = (size_t)vk.num_instance - 1;   // the padded count; the verifier zero-pads shorter inputs the same way
+    return vk;
+}
 
 std::vector<uint8_t> serialize_proof(const Proof &p) {
     Bytes o;

@@ -47,6 +47,10 @@ struct VerifyingKey {
     size_t supported_degree = 0, max_degree = 0;
 };
 
+// ark-serialize 0.3 compressed layout of ark_marlin::IndexVerifierKey (what a Rust caller gets from CanonicalSerialize::serialize)
+std::vector<uint8_t> serialize_vk_ark(const VerifyingKey &vk);
+VerifyingKey deserialize_vk_ark(const uint8_t *bytes, size_t len);
+
 struct ProverTimings { double witness_ms = 0, round1_ms = 0, round2_ms = 0, round3_ms = 0, open_ms = 0, total_ms = 0; };
 
 class ProvingKeyImpl;

@@ -72,9 +72,14 @@ int zkaes_encrypt_batch(size_t n, const uint8_t *messages, const uint8_t *secret
 int zkaes_prove_ops(const zkaes_pk *pk, uint32_t x, uint32_t y, const uint8_t *zk_seed32, uint8_t **proof, size_t *proof_len);
 /* generic verify: public_input_bits = instance assignment without the leading One, one byte (0/1) per variable */
 int zkaes_verify(const zkaes_vk *vk, const uint8_t *proof, size_t proof_len, const uint8_t *public_input_bits, size_t n_bits, int *accepted);
-/* verifying-key transport (library-private layout, versioned; NOT the ark-serialize layout yet -- SURVEY.md §8f item 1) */
+/* verifying-key transport, library-private layout (versioned POD image; fastest, same-build only) */
 int zkaes_vk_serialize(const zkaes_vk *vk, uint8_t **out, size_t *out_len);
 int zkaes_vk_deserialize(const uint8_t *bytes, size_t len, zkaes_vk **vk);
+/* verifying-key transport in the ark-serialize 0.3 compressed layout of ark_marlin::IndexVerifierKey<Fr, MarlinKZG10<Bls12_377, _>>
+ * (759 bytes for the AES keys): what `VerifyingKey::serialize` writes / `VerifyingKey::deserialize` reads on the Rust side of
+ * src/lib.rs:116 -- SURVEY.md 8f item 1.  Layout restated from the published crates (the reference holds no VK bytes to pin it). */
+int zkaes_vk_serialize_ark(const zkaes_vk *vk, uint8_t **out, size_t *out_len);
+int zkaes_vk_deserialize_ark(const uint8_t *bytes, size_t len, zkaes_vk **vk);
 
 /* host-only: assemble a verifying key from an index made elsewhere with the SAME (public, test_rng-derived) KZG trapdoor:
  * info = {num_variables, num_constraints, num_non_zero, num_instance (padded), num_public_inputs, max_degree, supported_degree};

@@ -21,4 +21,5 @@ out = os.path.join(ROOT, "gpurun_out")
 os.makedirs(out, exist_ok=True)
 open(os.path.join(out, "gpu_aes16_proof.bin"), "wb").write(proof)
 open(os.path.join(out, "gpu_aes16_vk.bin"), "wb").write(vk.to_bytes())
+open(os.path.join(out, "gpu_aes16_vk_ark.bin"), "wb").write(vk.to_ark_bytes())      # ark-serialize IndexVerifierKey layout (for a Rust verifier)
 print("wrote", len(proof), "proof bytes and", len(vk.to_bytes()), "vk bytes")

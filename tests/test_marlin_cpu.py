@@ -91,3 +91,94 @@ def test_gpu_made_fixture_verifies_on_the_host(api, vectors):
     proof = open(os.path.join(GOLD, "gpu_aes16_proof.bin"), "rb").read()
     assert api.verify_encryption(vk, proof, bytes(vectors["ciphertext"])) is True
     assert api.verify_encryption(vk, proof, bytes(vectors["wrong_ciphertext_16"])) is False      # tests/integration_tests.rs:332-336
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "gpu_aes16_vk_ark.bin")), reason="GPU-made fixture not generated yet")
+def test_gpu_made_ark_layout_key_verifies_on_the_host(api, vectors):
+    """the same key in the ark-serialize IndexVerifierKey layout (what integration/rust_verify_harness feeds to the reference verifier)"""
+    raw = open(os.path.join(GOLD, "gpu_aes16_vk_ark.bin"), "rb").read()
+    vk = api.VerifyingKey.from_ark_bytes(raw)
+    assert vk.to_ark_bytes() == raw and len(raw) == 759
+    proof = open(os.path.join(GOLD, "gpu_aes16_proof.bin"), "rb").read()
+    assert api.verify_encryption(vk, proof, bytes(vectors["ciphertext"])) is True
+    assert api.verify_encryption(vk, proof, bytes(vectors["wrong_ciphertext_16"])) is False
+
+
+# ---------------- ark-serialize layout of the verifying key (SURVEY.md 8f item 1) ----------------
+def _g1_compressed(x, y, q):
+    b = bytearray(x.to_bytes(48, "little"))
+    if y > (q - y) % q:
+        b[47] |= 0x80
+    return bytes(b)
+
+
+def _g2_compressed(P, q):
+    (x0, x1), (y0, y1) = P
+    ny = ((q - y0) % q, (q - y1) % q)
+    b = bytearray(x0.to_bytes(48, "little") + x1.to_bytes(48, "little"))
+    if (y1, y0) > (ny[1], ny[0]):                 # ark-ff QuadExtField order: c1 first, then c0
+        b[95] |= 0x80
+    return bytes(b)
+
+
+def test_vk_ark_layout_against_the_python_curve_model(zko, api, xor_setup):
+    """field by field: the C++ encoder against tools/curve_math.py (independent big-int model) for every group element of the key"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import curve_math as cm
+    ix, vk = xor_setup
+    info = ix.info()
+    beta, gamma = ix.srs_scalars()
+    raw = vk.to_ark_bytes()
+    q, F = cm.Q377, cm.Fq2(cm.Q377, -5)
+    off = 0
+    for name in ("num_variables", "num_constraints", "num_non_zero", "num_instance"):
+        assert int.from_bytes(raw[off:off + 8], "little") == info[name]
+        off += 8
+    assert int.from_bytes(raw[off:off + 8], "little") == 6
+    off += 8
+    comms = zko.pt_unpack(ix.comms())
+    for (x, y) in comms:
+        assert raw[off:off + 48] == _g1_compressed(x, y, q) and raw[off + 48] == 0
+        off += 49
+    g = cm.G1_377
+    assert raw[off:off + 48] == _g1_compressed(g[0], g[1], q)
+    gg = cm.ec_mul(gamma, g, q)
+    assert raw[off + 48:off + 96] == _g1_compressed(gg[0], gg[1], q)
+    off += 96
+    _, h, _ = cm.derive_g2_377()
+    assert raw[off:off + 96] == _g2_compressed(h, q)
+    assert raw[off + 96:off + 192] == _g2_compressed(cm.ec2_mul(F, beta, h), q)
+    off += 192
+    assert raw[off] == 1 and int.from_bytes(raw[off + 1:off + 9], "little") == 2
+    off += 9
+    bounds = sorted((info["h"] - 2, info["k"] - 2))
+    for b in bounds:
+        assert int.from_bytes(raw[off:off + 8], "little") == b
+        sp = cm.ec_mul(pow(beta, info["max_degree"] - b, cm.R377), g, q)
+        assert raw[off + 8:off + 56] == _g1_compressed(sp[0], sp[1], q)
+        off += 56
+    assert int.from_bytes(raw[off:off + 8], "little") == info["max_degree"]
+    assert int.from_bytes(raw[off + 8:off + 16], "little") == info["supported_degree"]
+    assert off + 16 == len(raw) == 759
+
+
+def test_vk_ark_roundtrip_verifies_and_rejects_garbage(zko, api, xor_setup):
+    ix, vk = xor_setup
+    raw = vk.to_ark_bytes()
+    vk2 = api.VerifyingKey.from_ark_bytes(raw)           # G1 and G2 points are decompressed (Fq and Fq2 square roots)
+    assert vk2.to_ark_bytes() == raw
+    cs, _ = zko.synth_ops("xor", 0xCAFE, 0xF00D, field=377)
+    proof = ix.prove(cs).to_bytes()
+    assert vk2.verify(proof, b"") is True
+    with pytest.raises(api.ZkAesError):
+        api.VerifyingKey.from_ark_bytes(raw[:-1])
+    with pytest.raises(api.ZkAesError):
+        api.VerifyingKey.from_ark_bytes(raw + b"\0")
+    bad = bytearray(raw)
+    bad[32] = 7                                          # index_comms length
+    with pytest.raises(api.ZkAesError):
+        api.VerifyingKey.from_ark_bytes(bytes(bad))
+    flipped = bytearray(raw)
+    flipped[40 + 6 * 49 + 96 + 95] ^= 0x80               # sign flag of h: -h is a valid point, the pairing check must now fail
+    assert api.VerifyingKey.from_ark_bytes(bytes(flipped)).verify(proof, b"") is False
