@@ -55,57 +55,67 @@ void divide_by_vanishing(F *q, F *rem, const F *p, size_t len, size_t m, stream_
     hipLaunchKernelGGL(k_div_vanishing, GRID(m), 0, (hipStream_t)s, q, rem, p, len, m); HIP_LAUNCH_CHECK();
 }
 
-// ---- p / (X - z):  q_i = p_{i+1} + z q_{i+1}, computed as a chunked linear-recurrence scan (chunk = 256 coefficients)
-constexpr int DL_CHUNK = 256;
-__global__ void k_divlin_local(F *__restrict__ q, const F *__restrict__ p, size_t qlen, F z, F *__restrict__ chunk_a, F *__restrict__ chunk_m) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t nch = (qlen + DL_CHUNK - 1) / DL_CHUNK;
-    if (t >= nch) return;
-    size_t s0 = t * DL_CHUNK, e = s0 + DL_CHUNK < qlen ? s0 + DL_CHUNK : qlen;
-    F acc = F::zero(), zp = F::one();
-    for (size_t i = e; i-- > s0;) { acc = p[i + 1] + z * acc; q[i] = acc; zp = zp * z; }
-    chunk_a[t] = acc;      // q at chunk start assuming zero carry-in
-    chunk_m[t] = zp;       // z^(chunk length)
+// ---- p / (X - z):  q_i = p_{i+1} + z q_{i+1}  =  z^-(i+1) * sum_{j > i} p_j z^j.
+// One single-pass device scan (rocPRIM look-back, through hipcub) over the REVERSED sequence t_j = p_j z^j, with the two scalings folded into
+// the scan's input and output iterators: reads p once, writes q once, everything coalesced.  z^j = ZL[j mod 1024] * ZH[j div 1024] from two
+// small tables built per opening point (and the same for 1/z).  Field arithmetic is exact, so the result is bit-identical to the recurrence.
+constexpr int DL_LO_BITS = 10;
+__global__ void k_divlin_tables(F z, F zinv, uint32_t hi_count, F *__restrict__ zl, F *__restrict__ zh, F *__restrict__ il, F *__restrict__ ih) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (1u << DL_LO_BITS)) { zl[i] = z.pow_u64(i); il[i] = zinv.pow_u64(i); }
+    if (i < hi_count) { zh[i] = z.pow_u64((uint64_t)i << DL_LO_BITS); ih[i] = zinv.pow_u64((uint64_t)i << DL_LO_BITS); }
 }
-// one wave: carry C_t = true q at the start of chunk t+1 (C_{last} = 0); C_t = A_{t+1} + M_{t+1} C_{t+1}
-__global__ void __launch_bounds__(64) k_divlin_carries(const F *__restrict__ chunk_a, const F *__restrict__ chunk_m, size_t nch, F *__restrict__ carry) {
-    __shared__ F seg_a[64], seg_m[64], seg_c[64];
-    int lane = threadIdx.x;
-    size_t per = (nch + 63) / 64;
-    // lane handles chunks [lo, hi) ; lanes ordered from the TOP of the polynomial: lane 0 = highest chunks
-    size_t hi = nch > (size_t)lane * per ? nch - (size_t)lane * per : 0;
-    size_t lo = hi > per ? hi - per : 0;
-    // compose the affine maps of the segment: carry below the segment = a + m * (carry above the segment)
-    F a = F::zero(), m = F::one();
-    for (size_t t = hi; t-- > lo;) { a = chunk_a[t] + chunk_m[t] * a; m = chunk_m[t] * m; }
-    seg_a[lane] = a; seg_m[lane] = m;
-    __syncthreads();
-    if (lane == 0) {
-        F c = F::zero();
-        for (int l = 0; l < 64; l++) { seg_c[l] = c; c = seg_a[l] + seg_m[l] * c; }
-    }
-    __syncthreads();
-    F c = seg_c[lane];     // true q just above this lane's segment
-    for (size_t t = hi; t-- > lo;) { carry[t] = c; c = chunk_a[t] + chunk_m[t] * c; }
+struct DivlinIn {           // k-th input = t_j with j = top - k
+    using iterator_category = std::random_access_iterator_tag; using value_type = F; using difference_type = ptrdiff_t; using pointer = const F *; using reference = F;
+    const F *p, *zl, *zh; ptrdiff_t top, k;
+    __host__ __device__ F operator[](ptrdiff_t d) const { size_t j = (size_t)(top - (k + d)); return p[j] * (zl[j & ((1u << DL_LO_BITS) - 1)] * zh[j >> DL_LO_BITS]); }
+    __host__ __device__ F operator*() const { return (*this)[0]; }
+    __host__ __device__ DivlinIn operator+(ptrdiff_t d) const { DivlinIn r = *this; r.k += d; return r; }
+    __host__ __device__ DivlinIn operator-(ptrdiff_t d) const { DivlinIn r = *this; r.k -= d; return r; }
+    __host__ __device__ ptrdiff_t operator-(const DivlinIn &o) const { return k - o.k; }
+    __host__ __device__ DivlinIn &operator+=(ptrdiff_t d) { k += d; return *this; }
+    __host__ __device__ DivlinIn &operator++() { ++k; return *this; }
+};
+struct DivlinOut {          // k-th output = S_j (suffix sum from j = top - k) -> q[j - 1] = S_j z^-j
+    struct Ref {
+        F *q; const F *il, *ih; size_t j;
+        __host__ __device__ const Ref &operator=(const F &v) const { q[j - 1] = v * (il[j & ((1u << DL_LO_BITS) - 1)] * ih[j >> DL_LO_BITS]); return *this; }
+    };
+    using iterator_category = std::random_access_iterator_tag; using value_type = F; using difference_type = ptrdiff_t; using pointer = F *; using reference = Ref;
+    F *q; const F *il, *ih; ptrdiff_t top, k;
+    __host__ __device__ Ref operator[](ptrdiff_t d) const { return Ref{q, il, ih, (size_t)(top - (k + d))}; }
+    __host__ __device__ Ref operator*() const { return (*this)[0]; }
+    __host__ __device__ DivlinOut operator+(ptrdiff_t d) const { DivlinOut r = *this; r.k += d; return r; }
+    __host__ __device__ DivlinOut operator-(ptrdiff_t d) const { DivlinOut r = *this; r.k -= d; return r; }
+    __host__ __device__ ptrdiff_t operator-(const DivlinOut &o) const { return k - o.k; }
+    __host__ __device__ DivlinOut &operator+=(ptrdiff_t d) { k += d; return *this; }
+    __host__ __device__ DivlinOut &operator++() { ++k; return *this; }
+};
+struct FieldAdd { __host__ __device__ F operator()(const F &a, const F &b) const { return a + b; } };
+size_t divide_by_linear_scratch(size_t len) {       // in field elements
+    size_t tables = 2 * ((1u << DL_LO_BITS) + (len >> DL_LO_BITS) + 1);
+    size_t temp = 0;
+    DivlinIn in{nullptr, nullptr, nullptr, 0, 0}; DivlinOut out{nullptr, nullptr, nullptr, 0, 0};
+    HIP_CHECK(hipcub::DeviceScan::InclusiveScan(nullptr, temp, in, out, FieldAdd(), (int)len, (hipStream_t)0));
+    return tables + (temp + sizeof(F) - 1) / sizeof(F) + 8;
 }
-__global__ void k_divlin_fix(F *__restrict__ q, size_t qlen, F z, const F *__restrict__ carry) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t nch = (qlen + DL_CHUNK - 1) / DL_CHUNK;
-    if (t >= nch) return;
-    F c = carry[t];
-    if (c.is_zero()) return;
-    size_t s0 = t * DL_CHUNK, e = s0 + DL_CHUNK < qlen ? s0 + DL_CHUNK : qlen;
-    F pw = z;
-    for (size_t i = e; i-- > s0;) { q[i] = q[i] + pw * c; pw = pw * z; }
-}
-void divide_by_linear(F *q, const F *p, size_t len, const F &z, F *scratch, stream_t s_) {
+void divide_by_linear(F *q, const F *p, size_t len, const F &z, F *scratch, size_t scratch_elems, stream_t s_) {
     hipStream_t s = (hipStream_t)s_;
     if (len < 2) return;
-    size_t qlen = len - 1, nch = (qlen + DL_CHUNK - 1) / DL_CHUNK;
-    F *ca = scratch, *cm = scratch + nch, *cc = scratch + 2 * nch;
-    hipLaunchKernelGGL(k_divlin_local, GRID(nch), 0, s, q, p, qlen, z, ca, cm); HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_divlin_carries, dim3(1), dim3(64), 0, s, ca, cm, nch, cc); HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_divlin_fix, GRID(nch), 0, s, q, qlen, z, cc); HIP_LAUNCH_CHECK();
+    if (len >= ((size_t)1 << 31)) throw GpuError("divide_by_linear: polynomial too long");
+    const size_t qlen = len - 1;
+    if (z.is_zero()) { HIP_CHECK(hipMemcpyAsync(q, p + 1, qlen * sizeof(F), hipMemcpyDeviceToDevice, s)); return; }
+    const uint32_t hi_count = (uint32_t)(len >> DL_LO_BITS) + 1, lo_count = 1u << DL_LO_BITS;
+    F *zl = scratch, *zh = zl + lo_count, *il = zh + hi_count, *ih = il + lo_count;
+    void *temp = (void *)(ih + hi_count);
+    size_t used = 2 * ((size_t)lo_count + hi_count), temp_bytes = 0;
+    DivlinIn in{p, zl, zh, (ptrdiff_t)(len - 1), 0};
+    DivlinOut out{q, il, ih, (ptrdiff_t)(len - 1), 0};
+    HIP_CHECK(hipcub::DeviceScan::InclusiveScan(nullptr, temp_bytes, in, out, FieldAdd(), (int)qlen, s));
+    if (used * sizeof(F) + temp_bytes > scratch_elems * sizeof(F)) throw GpuError("divide_by_linear: scratch too small");
+    uint32_t tn = hi_count > lo_count ? hi_count : lo_count;
+    hipLaunchKernelGGL(k_divlin_tables, GRID(tn), 0, s, z, z.inverse(), hi_count, zl, zh, il, ih); HIP_LAUNCH_CHECK();
+    HIP_CHECK(hipcub::DeviceScan::InclusiveScan(temp, temp_bytes, in, out, FieldAdd(), (int)qlen, s));
 }
 
 // ---- evaluation: chunks of 64 coefficients by Horner, then sum_t partial_t * (x^64)^t

@@ -398,7 +398,7 @@ class ProvingKeyImpl {
         size_t big = std::max(n4, k2);
         for (auto &b : cx.e) b.alloc(big);
         cx.big_tmp.alloc(big); cx.f_poly.alloc(k); cx.ab[0].alloc(k); cx.ab[1].alloc(k);
-        cx.acc.alloc(std::max(3 * n, k) + 1); cx.wit.alloc(std::max(3 * n, k) + 1); cx.wit2.alloc(std::max(n, k) + 1); cx.scratch.alloc(std::max(3 * n, k) / 32 + 1024);
+        cx.acc.alloc(std::max(3 * n, k) + 1); cx.wit.alloc(std::max(3 * n, k) + 1); cx.wit2.alloc(std::max(n, k) + 1); cx.scratch.alloc(std::max(std::max(3 * n, k) / 32 + 1024, gpu::divide_by_linear_scratch(std::max(3 * n, k) + 1)));
     }
 
     template <class T> static T *upload(const std::vector<T> &v, gpu::stream_t s) {
@@ -808,9 +808,9 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
         gpu::poly_axpy(acc.p, poly[6].p, chp[2] * c_h1, poly_len[6], s);
         gpu::poly_axpy(acc.p, poly[4].p, chp[3], poly_len[4], s);
         gpu::poly_axpy(acc.p, poly[2].p, chp[4], poly_len[2], s); rand_axpy(rb, chp[4], r1[2].rand);
-        gpu::divide_by_linear(wit.p, acc.p, plen, beta, scratch.p, s);
+        gpu::divide_by_linear(wit.p, acc.p, plen, beta, scratch.p, scratch.n, s);
         // shifted part (g_1, degree bound |H| - 2) rides in the same Pippenger instance
-        gpu::divide_by_linear(wit2.p, poly[5].p, poly_len[5], beta, scratch.p, s);
+        gpu::divide_by_linear(wit2.p, poly[5].p, poly_len[5], beta, scratch.p, scratch.n, s);
         gpu::poly_scale(wit2.p, chp[1], poly_len[5] - 1, s);
         XYZZ<Fq377> w = msm_opening(cx, wit.p, plen - 1, wit2.p, poly_len[5] - 1, bounds[1] - (n - 2));
         Fr rq[2]; host_divide_by_linear(rq, rb, beta);
@@ -833,8 +833,8 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
         gpu::poly_axpy(acc.p, ix_co[1].p, chp[2] * c_col, k, s);
         gpu::poly_axpy(acc.p, ix_co[5].p, chp[2] * c_rc, k, s);
         gpu::poly_axpy(acc.p, poly[8].p, chp[2] * c_h2, poly_len[8], s);
-        gpu::divide_by_linear(wit.p, acc.p, plen, gamma, scratch.p, s);
-        gpu::divide_by_linear(wit2.p, poly[7].p, poly_len[7], gamma, scratch.p, s);
+        gpu::divide_by_linear(wit.p, acc.p, plen, gamma, scratch.p, scratch.n, s);
+        gpu::divide_by_linear(wit2.p, poly[7].p, poly_len[7], gamma, scratch.p, scratch.n, s);
         gpu::poly_scale(wit2.p, chp[1], poly_len[7] - 1, s);
         XYZZ<Fq377> w = msm_opening(cx, wit.p, plen - 1, wit2.p, poly_len[7] - 1, bounds[1] - (k - 2));
         pf.w_gamma = w.to_affine();
