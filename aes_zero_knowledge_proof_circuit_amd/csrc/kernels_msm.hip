@@ -612,8 +612,8 @@ void fixed_base_scalars(Affine<typename Curve::Fq> *out, const Affine<typename C
 }
 
 // ---- sum of bases weighted by SMALL integers (|v| <= 2): the Lagrange-basis commitments of 0/1-valued evaluation vectors.
-// One lane per 64 consecutive bases keeps two accumulators (|v| = 1, |v| = 2; the sign negates y); a two-level tree sums the partials.
-constexpr int CLS_CHUNK = 64;
+// One lane per 16 consecutive bases (short chains: the lanes of a wave diverge between the two classes) keeps two accumulators (|v| = 1, |v| = 2; the sign negates y); a two-level tree sums the partials.
+constexpr int CLS_CHUNK = 16;
 template <class P>
 __global__ void __launch_bounds__(64, 2) k_class_partials(const Affine28<P> *__restrict__ bases, const int8_t *__restrict__ vals, uint32_t n, Acc28<P> *__restrict__ part1,
                                                            Acc28<P> *__restrict__ part2, uint32_t *__restrict__ flags) {
