@@ -39,6 +39,7 @@ ZK_FIELD_PARAMS(Fq381P, FQ381, 12, 381)
 
 template <class P>
 struct Fp {
+    using Params = P;
     static constexpr int N = P::N;
     static constexpr int BITS = P::BITS;
     uint32_t l[N];

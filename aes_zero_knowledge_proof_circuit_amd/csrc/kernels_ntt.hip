@@ -12,6 +12,7 @@
 #include <mutex>
 #include <vector>
 #include "hip_util.hpp"
+#include "ff29.cuh"
 
 namespace zk {
 namespace gpu {
@@ -22,11 +23,25 @@ __global__ void k_fill_powers(Fr w, uint32_t n, Fr *__restrict__ out) {
     if (i < n) out[i] = w.pow_u64(i);
 }
 
+// standard twiddle table (w^i R) -> reduced-radix table (w^i R' as 9 x 29-bit limbs, ff29.cuh)
+template <class Fr>
+__global__ void k_twiddles29(const Fr *__restrict__ tw, uint32_t n, Fp29<typename Fr::Params> *__restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = Fp29<typename Fr::Params>::twiddle_from_std(tw[i]);
+}
+
 // tile element e = (a << L) | lo ; global index = (hi << (s0+S)) | (a << s0) | (mid << L) | lo
+//
+// Butterflies run on the reduced-radix form (ff29.cuh): data is only re-limbed (8 x 32 -> 9 x 29 bits, still x R), the twiddles come from a
+// table of w R' so one 162-multiply product gives t = y w (< 1.5 p); x + t and x - t + 2 p are carry-light limb additions that let the values
+// grow -- bounded statically: every pass starts from canonical inputs (< p); in its first three stages the butterflies with twiddle 1 skip the
+// product (y is still small: bounds 1, 3, 7 p -> K = 1, 4, 8 in x - y + K p), from then on every y is multiplied, so the bound grows by 2 p per
+// stage: < 29 p after ten stages, far below R' = 2^261 >= 64 p.  The store peels 16 p, 8 p, ..., p and re-packs canonical 8 x 32-bit words.
 template <class Fr, int TILE_LG>
 __global__ void __launch_bounds__(256) k_ntt_pass(Fr *dst, const Fr *src, uint32_t in_len, int lg, int s0, int S, int L,
-                                                   const Fr *__restrict__ tw, bool bitrev_load, bool scale, Fr scale_by) {
-    constexpr int N = Fr::N;
+                                                   const Fp29<typename Fr::Params> *__restrict__ tw, bool bitrev_load, bool scale, Fp29<typename Fr::Params> scale_by) {
+    using G = Fp29<typename Fr::Params>;
+    constexpr int N = G::N;
     constexpr uint32_t TILE = 1u << TILE_LG;
     __shared__ uint32_t lds[N][TILE];
     const uint32_t tile_elems = 1u << (S + L);
@@ -44,8 +59,9 @@ __global__ void __launch_bounds__(256) k_ntt_pass(Fr *dst, const Fr *src, uint32
         } else {
             v = src[gi];
         }
+        G g = G::split(v.l);
 #pragma unroll
-        for (int k = 0; k < N; k++) lds[k][e] = v.l[k];
+        for (int k = 0; k < N; k++) lds[k][e] = g.l[k];
     }
     __syncthreads();
     const uint32_t half_tile = tile_elems >> 1;
@@ -57,11 +73,17 @@ __global__ void __launch_bounds__(256) k_ntt_pass(Fr *dst, const Fr *src, uint32
             uint32_t a0 = (a_high << (st + 1)) | a_low, a1 = a0 | (1u << st);
             uint32_t e0 = (a0 << L) | lo, e1 = (a1 << L) | lo;
             uint32_t j = (a_low << s0) | (mid << L) | lo;               // position inside the half-span
-            Fr x, y;
+            G x, y;
 #pragma unroll
             for (int k = 0; k < N; k++) { x.l[k] = lds[k][e0]; y.l[k] = lds[k][e1]; }
-            if (j != 0) y = y * tw[(size_t)j << (lg - s - 1)];
-            Fr p = x + y, q = x - y;
+            G p, q;
+            if (j == 0 && st < 3) {                  // twiddle 1 while the values are still small: no product
+                p = x + y;
+                q = st == 0 ? x.template sub<1>(y) : (st == 1 ? x.template sub<4>(y) : x.template sub<8>(y));
+            } else {
+                G t = y * tw[(size_t)j << (lg - s - 1)];
+                p = x + t; q = x.template sub<2>(t);
+            }
 #pragma unroll
             for (int k = 0; k < N; k++) { lds[k][e0] = p.l[k]; lds[k][e1] = q.l[k]; }
         }
@@ -70,10 +92,12 @@ __global__ void __launch_bounds__(256) k_ntt_pass(Fr *dst, const Fr *src, uint32
     for (uint32_t e = threadIdx.x; e < tile_elems; e += 256) {
         uint32_t a = e >> L, lo = e & ((1u << L) - 1);
         uint32_t gi = base | (a << s0) | lo;
-        Fr v;
+        G g;
 #pragma unroll
-        for (int k = 0; k < N; k++) v.l[k] = lds[k][e];
-        if (scale) v = v * scale_by;
+        for (int k = 0; k < N; k++) g.l[k] = lds[k][e];
+        Fr v;
+        if (scale) (g * scale_by).template canonical<1>().pack(v.l);
+        else g.template canonical<4>().pack(v.l);
         dst[gi] = v;
     }
 }
@@ -87,6 +111,7 @@ template <class Fr>
 struct Tables {
     std::mutex mu;
     std::map<int, Fr *> fwd, inv, elems;
+    std::map<int, Fp29<typename Fr::Params> *> fwd29, inv29;
     static Fr gen(int lg) {
         Fr r = RootOf<Fr>::root();
         for (int i = lg; i < RootOf<Fr>::TWO_ADICITY; i++) r = r.sqr();
@@ -107,6 +132,23 @@ struct Tables {
     }
 };
 template <class Fr> Tables<Fr> &tables() { static Tables<Fr> t; return t; }
+// reduced-radix copy of a twiddle table (built once per domain size and direction)
+template <class Fr>
+const Fp29<typename Fr::Params> *twiddles29(std::map<int, Fp29<typename Fr::Params> *> &m, int lg, const Fr *std_table, uint32_t count) {
+    using G = Fp29<typename Fr::Params>;
+    Tables<Fr> &T = tables<Fr>();
+    std::lock_guard<std::mutex> g(T.mu);
+    auto it = m.find(lg);
+    if (it != m.end()) return it->second;
+    G *d = (G *)dmalloc((size_t)(count ? count : 1) * sizeof(G));
+    if (count) {
+        hipLaunchKernelGGL((k_twiddles29<Fr>), dim3((count + 255) / 256), dim3(256), 0, 0, std_table, count, d);
+        HIP_LAUNCH_CHECK();
+        HIP_CHECK(hipDeviceSynchronize());
+    }
+    m[lg] = d;
+    return d;
+}
 }  // namespace
 
 template <class Fr>
@@ -124,8 +166,9 @@ void ntt(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, stream_t s
     if (dst == src) throw GpuError("ntt: dst must differ from src (first pass gathers bit-reversed)");
     if (lg == 0) { HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(Fr) * (in_len ? 1 : 0), hipMemcpyDeviceToDevice, s)); if (!in_len) HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(Fr), s)); return; }
     Fr w = Tables<Fr>::gen(lg);
-    const Fr *tw = inverse ? tables<Fr>().powers(tables<Fr>().inv, lg, w.inverse(), n / 2) : tables<Fr>().powers(tables<Fr>().fwd, lg, w, n / 2);
-    Fr n_inv = Fr::from_u64(n).inverse();
+    const Fr *tw_std = inverse ? tables<Fr>().powers(tables<Fr>().inv, lg, w.inverse(), n / 2) : tables<Fr>().powers(tables<Fr>().fwd, lg, w, n / 2);
+    const Fp29<typename Fr::Params> *tw = twiddles29<Fr>(inverse ? tables<Fr>().inv29 : tables<Fr>().fwd29, lg, tw_std, n / 2);
+    Fp29<typename Fr::Params> n_inv = Fp29<typename Fr::Params>::twiddle_from_std(Fr::from_u64(n).inverse());
     // pass plan: pass 1 covers min(lg, 10) stages on contiguous 1024-element tiles; the remaining R stages are split EVENLY over
     // ceil(R / 8) passes, each on full 1024-element tiles made of 2^S strided runs of 2^L = 2^(10 - S) contiguous elements (>= 128 B runs),
     // so that every pass keeps all 256 lanes busy (a lopsided 10 + 8 + 4 plan left the last pass with 64-element tiles and made it the slowest).

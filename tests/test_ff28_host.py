@@ -64,3 +64,59 @@ def test_reduced_radix_group_law_matches_xyzz_reference():
         out = subprocess.run([exe], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout + out.stderr
         assert out.stdout.split() == ["bls377", "0", "bls381", "0"]
+
+
+SRC29 = r'''
+#include "ff29.cuh"
+#include <cstdio>
+#include <cstdlib>
+using namespace zk;
+template <class P> int run(const char *name) {
+    using F = Fp<P>; using G = Fp29<P>;
+    srand(11);
+    int bad = 0;
+    for (int it = 0; it < 4000; it++) {
+        uint32_t ra[8], rb[8];
+        for (int i = 0; i < 8; i++) { ra[i] = (uint32_t)rand() * 2654435761u ^ (uint32_t)rand(); rb[i] = (uint32_t)rand() * 40503u ^ ((uint32_t)rand() << 3); }
+        ra[7] &= 0x0fffffff; rb[7] &= 0x0fffffff;            // < 2^252 < p for both fields
+        F a = F::from_raw(ra), b = F::from_raw(rb);
+        if (it == 0) a = F::zero();
+        if (it == 1) { a = F::one(); b = F::one().neg(); }
+        if (it == 2) { a = F::one().neg(); b = F::one().neg(); }
+        G A = G::from_std_relimb(a), B = G::from_std_relimb(b), W = G::twiddle_from_std(b);
+        bad += !(A.template to_std_relimb<0>() == a);
+        bad += !((A * W).template to_std_relimb<1>() == a * b);
+        bad += !((A + B).template to_std_relimb<1>() == a + b);
+        bad += !((A.template sub<1>(B)).template to_std_relimb<1>() == a - b);
+        // the NTT's growth pattern: three product-free stages (K = 1, 4, 8), then seven multiplied stages, values up to ~29 p
+        G x = A, y = B; F xs = a, ys = b;
+        { G p = x + y, q = x.template sub<1>(y); x = p; y = q; F ps = xs + ys, qs = xs - ys; xs = ps; ys = qs; }
+        { G p = x + y, q = x.template sub<4>(y); x = p + p; y = q; F ps = xs + ys, qs = xs - ys; xs = ps + ps; ys = qs; }     // x < 8 p
+        { G p = x + y, q = x.template sub<8>(y); x = p; y = q; F ps = xs + ys, qs = xs - ys; xs = ps; ys = qs; }             // x < 14 p, y < 16 p
+        for (int st = 0; st < 7; st++) {
+            G t = y * W; F ts = ys * b;
+            G p = x + t, q = x.template sub<2>(t); F ps = xs + ts, qs = xs - ts;
+            x = p; y = q; xs = ps; ys = qs;
+            if (st & 1) { G tmp = x; x = y; y = tmp; F tt = xs; xs = ys; ys = tt; }
+        }
+        bad += !(x.template to_std_relimb<4>() == xs);
+        bad += !(y.template to_std_relimb<4>() == ys);
+        bad += !((x * W).template to_std_relimb<1>() == xs * b);
+    }
+    printf("%s %d\n", name, bad);
+    return bad;
+}
+int main() { return run<Fr377P>("fr377") + run<Fr381P>("fr381"); }
+'''
+
+
+def test_reduced_radix_scalar_field_matches_montgomery_reference():
+    """csrc/ff29.cuh (9 x 29-bit limbs, the NTT butterflies' arithmetic) against the 8 x 32-bit Montgomery field, including the lazy value growth
+    of a ten-stage pass (K = 1, 4, 8 product-free stages, then multiplied stages) and the final canonicalisation."""
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "t.cpp"), os.path.join(d, "t")
+        open(src, "w").write(SRC29)
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", CSRC, src, "-o", exe])
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert out.stdout.split() == ["fr377", "0", "fr381", "0"]
