@@ -26,7 +26,7 @@ ZK_HD bool madd28(Acc28<P> &a, const Affine28<P> &q) {
     G ppp = pd * pp, qq = a.x * pp;
     G x3 = (r.sqr().template sub<2>(ppp)).template sub<3>(qq.dbl());   // r^2 - ppp - 2 qq + 5p  < 6.2 p
     G t = qq.template sub<7>(x3);                                      // < 8.2 p
-    G y3 = (r * t).template sub<2>(a.y * ppp);                         // < 3.2 p
+    G y3 = G::fma2(r, t, G::zero().template sub<4>(a.y), ppp);         // r t + (4p - y1) ppp, one reduction: < 1.01 p
     a.x = x3; a.y = y3;
     a.zz = a.zz * pp;
     a.zzz = a.zzz * ppp;
@@ -67,7 +67,7 @@ ZK_EC_FN void add28(Acc28<P> &a, const Acc28<P> &b) {     // add-2008-s, complet
     }
     G ppp = pd * pp, qq = u1 * pp;
     G x3 = (r.sqr().template sub<2>(ppp)).template sub<3>(qq.dbl());     // < 6.2 p
-    G y3 = (r * qq.template sub<7>(x3)).template sub<2>(s1 * ppp);       // < 3.2 p
+    G y3 = G::fma2(r, qq.template sub<7>(x3), G::zero().template sub<2>(s1), ppp);   // r (qq - x3) + (2p - s1) ppp, one reduction: < 1.01 p
     a.x = x3; a.y = y3;
     a.zz = a.zz * b.zz * pp;
     a.zzz = a.zzz * b.zzz * ppp;

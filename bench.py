@@ -174,13 +174,13 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "peak_measured_stream_copy": copy_gbs,
                          "traffic_source": "profiles/r01_pmc_k_accumulate_v4.json (PMC bytes per point-window x pairs of this run)",
-                         "int_multiplier": {"unit": "T v_mad_u64_u32/s", "achieved": round(3598.0 * stats["pairs"] / 1e12 / (acc_ms / 1e3), 2) if acc_ms > 0 else 0.0,
-                                            "peak": 28.1, "frac": round(3598.0 * stats["pairs"] / 1e12 / (acc_ms / 1e3) / 28.1, 4) if acc_ms > 0 else 0.0,
-                                            "frac_of_wall": round(3598.0 * stats["pairs"] / 1e12 / elapsed / 28.1, 4),
-                                            "note": "frac divides by the SUM of launch durations (launches of concurrent prover contexts overlap, so it understates); frac_of_wall divides by the whole timed region. the kernel's real roof: 3598 v_mad_u64_u32 per mixed add (8 products x 378 + 2 squarings x 287), one mixed add per (point, window) pair; "
+                         "int_multiplier": {"unit": "T v_mad_u64_u32/s", "achieved": round(3416.0 * stats["pairs"] / 1e12 / (acc_ms / 1e3), 2) if acc_ms > 0 else 0.0,
+                                            "peak": 28.1, "frac": round(3416.0 * stats["pairs"] / 1e12 / (acc_ms / 1e3) / 28.1, 4) if acc_ms > 0 else 0.0,
+                                            "frac_of_wall": round(3416.0 * stats["pairs"] / 1e12 / elapsed / 28.1, 4),
+                                            "note": "frac divides by the SUM of launch durations (launches of concurrent prover contexts overlap, so it understates); frac_of_wall divides by the whole timed region. the kernel's real roof: 3416 v_mad_u64_u32 per mixed add (6 products x 378 + 2 squarings x 287 + one two-product sum with a shared reduction, 574), one mixed add per (point, window) pair; "
                                                     "peak = rate of the same Fq product stream in isolation (tools/ubench/rates.hip: 74.4 G products/s x 378)"},
                          "launches": launches, "avg_launch_ms": round(acc_ms / max(launches, 1), 4), "algorithmic_bytes_per_launch": round(128.0 * pts / max(launches, 1)),
-                         "note": "integer-ALU bound (10 Fq products of 392 v_mad_u64_u32 per mixed add); HBM fraction of O(1%) is the expected regime (BASELINE.md §3)"},
+                         "note": "integer-ALU bound (10 Fq limb products, 9 Montgomery reductions = 3416 v_mad_u64_u32 per mixed add); HBM fraction of O(1%) is the expected regime (BASELINE.md §3)"},
         }
         if int(ok[0]) != int(ok[1]) or int(ok[2]) != world:
             out["error"] = "verification failure"
