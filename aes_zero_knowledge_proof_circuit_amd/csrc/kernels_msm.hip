@@ -31,9 +31,13 @@ MsmStats msm_stats(bool reset) {
 }
 
 // Signed window digits d in [-2^(c-1), 2^(c-1)] (carry recoding): bucket index = |d| - 1 in a window of 2^(c-1) buckets, the sign rides
-// in bit 31 of the value (the accumulate kernel negates y).  Zero digits get the out-of-range key `nb` and sort past every bucket.
+// in bit 31 of the value (the accumulate kernel negates y).  Zero digits (probability 2^-c) stay in bucket 0 of their window with the SKIP bit
+// (bit 30) set in the value, so every key is a valid (window, bucket) pair: the pairs are written window-major and the radix sort is stable,
+// hence sorting on the c-1 BUCKET bits alone (two 8-bit passes instead of three) already leaves every (window, bucket) group contiguous --
+// ordered by (bucket, window), which k_bounds does not care about.
 // A launch covers one PART of the scalar list: part element i sits at position i_off + i of every window segment (segment length ntot) and
 // names base index val_off + i, so that two scalar vectors over two base ranges can share one Pippenger instance.
+constexpr uint32_t VAL_SKIP = 1u << 30, VAL_INDEX = VAL_SKIP - 1;     // value word: bit 31 = negate, bit 30 = skip (zero digit), low 30 bits = base index
 template <class Fr>
 __global__ void k_digits(const Fr *__restrict__ scalars, uint32_t n, uint32_t i_off, uint32_t ntot, uint32_t val_off, int c, int nwin, uint32_t nb,
                          uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
@@ -51,8 +55,8 @@ __global__ void k_digits(const Fr *__restrict__ scalars, uint32_t n, uint32_t i_
         uint32_t neg = 0;
         carry = 0;
         if (v > half) { v = (1u << c) - v; neg = 1u << 31; carry = 1; }
-        keys[(size_t)w * ntot + i_off + i] = v ? (((uint32_t)w << (c - 1)) | (v - 1)) : nb;
-        vals[(size_t)w * ntot + i_off + i] = (val_off + i) | neg;
+        keys[(size_t)w * ntot + i_off + i] = ((uint32_t)w << (c - 1)) | (v ? v - 1 : 0u);
+        vals[(size_t)w * ntot + i_off + i] = v ? ((val_off + i) | neg) : VAL_SKIP;
     }
 }
 
@@ -154,12 +158,12 @@ __global__ void __launch_bounds__(64, 2) k_accumulate(const Affine28<P> *__restr
         if (e - s > BUCKET_CAP) e = s + BUCKET_CAP;                        // the remainder goes through the overflow kernels
         if (s < e) {
             uint32_t idx = vals[s];
-            Affine28<P> nxt = bases[idx & 0x7fffffffu];
+            Affine28<P> nxt = bases[idx & VAL_INDEX];
             for (uint32_t i = s; i < e; i++) {
                 Affine28<P> p = nxt;
                 uint32_t cur = idx;
-                if (i + 1 < e) { idx = vals[i + 1]; nxt = bases[idx & 0x7fffffffu]; }   // prefetch the next gather under this add's ALU work
-                if (p.is_inf()) continue;
+                if (i + 1 < e) { idx = vals[i + 1]; nxt = bases[idx & VAL_INDEX]; }   // prefetch the next gather under this add's ALU work
+                if ((cur & VAL_SKIP) || p.is_inf()) continue;
                 if (cur >> 31) p.y = G::zero().template sub<2>(p.y);                 // negative digit: add -P  (y < 1.2 p as a product, so 2p - y > 0)
                 if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_2_392(); acc.zzz = acc.zz; acc_inf = false; continue; }
                 if (!madd28(acc, p)) {
@@ -182,7 +186,7 @@ __global__ void k_accumulate_fixup(const Affine28<P> *__restrict__ bases, Acc28<
     for (uint32_t i = 0; i < n; i++) {
         XYZZ<Fp<P>> b = to_std_point<P>(buckets[deferred[2 * i]]);
         uint32_t v = deferred[2 * i + 1];
-        Affine<Fp<P>> q = bases[v & 0x7fffffffu].to_std();
+        Affine<Fp<P>> q = bases[v & VAL_INDEX].to_std();
         b.madd((v >> 31) ? q.neg() : q);
         buckets[deferred[2 * i]] = from_std_point<P>(b);
     }
@@ -207,8 +211,8 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_overflow(const Affine28<P>
     bool acc_inf = true;
     for (uint32_t i = s; i < e; i++) {
         uint32_t cur = vals[i];
-        Affine28<P> p = bases[cur & 0x7fffffffu];
-        if (p.is_inf()) continue;
+        Affine28<P> p = bases[cur & VAL_INDEX];
+        if ((cur & VAL_SKIP) || p.is_inf()) continue;
         if (cur >> 31) p.y = G::zero().template sub<2>(p.y);
         if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_2_392(); acc.zzz = acc.zz; acc_inf = false; continue; }
         if (!madd28(acc, p)) {
@@ -348,11 +352,12 @@ void msm_workspace_destroy(MsmWorkspace *w) {
 
 // shared middle: sort the (key, value) pairs, find bucket ranges, order buckets by descending size, cut oversized buckets
 template <class P>
-static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, hipStream_t s) {
+static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int sort_bits, hipStream_t s) {
     // c here = log2(buckets per set); keys run over [0, nb) plus the out-of-range key nb for zero digits
     size_t nb = (size_t)nsets << c;
     int key_bits = 1;
     while (((size_t)1 << key_bits) <= nb) key_bits++;
+    if (sort_bits > 0 && sort_bits < key_bits) key_bits = sort_bits;       // stable sort on the bucket bits only (window-major input)
     size_t tmp_bytes = 0;
     HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys_a, S.keys_b, S.vals_a, S.vals_b, (int)pairs, 0, key_bits, s));
     if (tmp_bytes > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tmp_bytes); S.cap_tmp = tmp_bytes; }
@@ -445,7 +450,7 @@ void msm_prepare(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_t n1, 
     size_t n = n1 + n2;
     S.plan_n = n;
     if (n == 0) return;
-    if (n >= (1u << 30) || val_off2 + n2 >= (1u << 31)) throw GpuError("msm: too many points");
+    if (n >= (1u << 30) || val_off2 + n2 >= (1u << 30)) throw GpuError("msm: too many points");
     int lg = 0;
     while (((size_t)1 << lg) < n) lg++;
     int c = lg - 2;                               // signed digits: 2^(c-1) buckets per window
@@ -459,7 +464,7 @@ void msm_prepare(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_t n1, 
     ensure_scratch(S, pairs, nb, 0);
     if (n1) { hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, scal1, (uint32_t)n1, 0u, (uint32_t)n, 0u, c, nwin, (uint32_t)nb, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
     if (n2) { hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, scal2, (uint32_t)n2, (uint32_t)n1, (uint32_t)n, (uint32_t)val_off2, c, nwin, (uint32_t)nb, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
-    prepare_buckets<typename Curve::FqP>(S, pairs, c - 1, nwin, s);
+    prepare_buckets<typename Curve::FqP>(S, pairs, c - 1, nwin, c - 1, s);
 }
 template <class Curve>
 XYZZ<typename Curve::Fq> msm_finish(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *bases, stream_t s_) {
@@ -528,7 +533,7 @@ XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws_, const Affine28<typename Cu
     hipLaunchKernelGGL((k_digits_table<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scalars, (uint32_t)n, c, nwin, (uint32_t)stride, (uint32_t)off, S.keys_a, S.vals_a);
     HIP_LAUNCH_CHECK();
     float ms = 0;
-    prepare_buckets<typename Curve::FqP>(S, pairs, c, 1, s);
+    prepare_buckets<typename Curve::FqP>(S, pairs, c, 1, 0, s);
     std::vector<XYZZ<Fq>> ws = run_buckets<typename Curve::FqP>(S, tables, pairs, c, 1, n, s, &ms);
     add_stats(ms, n, pairs, t_begin);
     return ws[0];
