@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""PMC passes for the MSM bucket-accumulation kernel (run ON THE GPU BOX, from the repo root):
+
+    python tools/pmc_accumulate.py [lg_n=22] [tag=v11]   ->  gpurun_out/r01_pmc_k_accumulate_<tag>.json
+
+Three separate rocprofv3 runs of `tools/ubench/msm_one.py <lg_n>` (FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ counters in a third), each with
+`--pmc ... --kernel-trace --output-format csv` only (MI355X_MICROARCH.md, HBM / rocprofv3 sections).  The absolute FETCH_SIZE scale is calibrated on
+kernels of the same run whose byte counts are known exactly: k_convert_bases (reads 96 B, writes 112 B per point, 16 B-per-lane array-of-structures
+access -- the pattern of k_accumulate's gathers) and k_digits (reads 32 B per scalar, fully coalesced).
+"""
+import csv
+import json
+import os
+import subprocess
+import sys
+
+lg = int(sys.argv[1]) if len(sys.argv) > 1 else 22
+tag = sys.argv[2] if len(sys.argv) > 2 else "v11"
+n = 1 << lg
+out_dir = os.path.join("gpurun_out", "pmc_" + tag)
+os.makedirs(out_dir, exist_ok=True)
+env = dict(os.environ, TMPDIR="/tmp")
+PASSES = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"],
+          "sq": ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"]}
+
+
+def collect(name, counters):
+    cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", out_dir, "-o", "pmc_" + name, "--",
+           sys.executable, "tools/ubench/msm_one.py", str(lg), "0"]
+    subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    path = None
+    for root, _, files in os.walk(out_dir):
+        for f in files:
+            if f == "pmc_%s_counter_collection.csv" % name:
+                path = os.path.join(root, f)
+    rows = {}
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"]
+        short = "k_accumulate" if "k_accumulate<" in k else ("k_convert_bases" if "k_convert_bases" in k else ("k_digits" if "k_digits<" in k else None))
+        if short:
+            rows.setdefault((short, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in rows.items()}, {k: len(v) for k, v in rows.items()}
+
+
+vals, counts = {}, {}
+for name, ctrs in PASSES.items():
+    v, c = collect(name, ctrs)
+    vals.update(v); counts.update(c)
+
+KIB = 1024.0
+nwin = 15
+fetch = vals[("k_accumulate", "FETCH_SIZE")] * KIB
+write = vals[("k_accumulate", "WRITE_SIZE")] * KIB
+cal = {
+    "k_convert_bases_known_read_bytes": 96 * n, "k_convert_bases_FETCH_SIZE_bytes": vals[("k_convert_bases", "FETCH_SIZE")] * KIB,
+    "k_convert_bases_known_write_bytes": 112 * n, "k_convert_bases_WRITE_SIZE_bytes": vals[("k_convert_bases", "WRITE_SIZE")] * KIB,
+    "k_digits_known_read_bytes": 32 * n, "k_digits_FETCH_SIZE_bytes": vals[("k_digits", "FETCH_SIZE")] * KIB,
+}
+cal["fetch_scale_aos_16B_per_lane"] = cal["k_convert_bases_FETCH_SIZE_bytes"] / cal["k_convert_bases_known_read_bytes"]
+cal["fetch_scale_coalesced_stream"] = cal["k_digits_FETCH_SIZE_bytes"] / cal["k_digits_known_read_bytes"]
+cal["write_scale"] = cal["k_convert_bases_WRITE_SIZE_bytes"] / cal["k_convert_bases_known_write_bytes"]
+hbm = fetch / cal["fetch_scale_aos_16B_per_lane"] + write / cal["write_scale"]
+res = {
+    "kernel": "k_accumulate (%s), n = 2^%d points, %d signed-digit windows of 17 bits, averages over %d launches" % (tag, lg, nwin, counts[("k_accumulate", "FETCH_SIZE")]),
+    "command": "rocprofv3 --pmc <one counter group> --kernel-trace --output-format csv -- python tools/ubench/msm_one.py %d 0   (three separate passes: %s)" % (lg, PASSES),
+    "counters": {c: vals[("k_accumulate", c)] for grp in PASSES.values() for c in grp},
+    "units": "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them",
+    "calibration": cal,
+    "algorithmic_bytes_per_launch": 128 * n,
+    "hbm_bytes_per_launch": hbm,
+    "hbm_bytes_per_point_window": hbm / (n * nwin),
+}
+dst = os.path.join("gpurun_out", "r01_pmc_k_accumulate_%s.json" % tag)
+json.dump(res, open(dst, "w"), indent=1)
+print(json.dumps(res, indent=1))
