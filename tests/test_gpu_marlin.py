@@ -2,6 +2,8 @@
 oracle's; every proof must be accepted by the verifier and wrong ciphertexts rejected (tests/integration_tests.rs:313-372)."""
 import os
 
+import numpy as np
+
 import pytest
 
 from conftest import mt_bytes
@@ -88,6 +90,27 @@ def test_encrypt_64_bytes_and_verify(api, vectors):
     proof = api.encrypt(bytes(vectors["plaintext_64"]), bytes(vectors["key"]), pk)
     assert api.verify_encryption(vk, proof, bytes(vectors["ciphertext_64"])) is True
     assert api.verify_encryption(vk, proof, bytes(vectors["wrong_ciphertext_64"])) is False
+
+
+def test_monolithic_proof_beyond_the_reference_srs_literal(zko, api):
+    """A 16-block message as ONE proof (|H| = 2^22, |K| = 2^24): does not fit the reference's SRS literal (src/lib.rs:141), so the key is
+    synthesized for the circuit's own counts -- the same code path as tools/monolith.py's 64-block (BASELINE configs[1]) run."""
+    blocks = 16
+    ci = api.circuit_info(api.CIRCUIT_AES, 16 * blocks)
+    assert ci["raw_constraints"] == 148_272 * blocks + 36_768                  # SURVEY.md A.3 formula
+    with pytest.raises(api.ZkAesError):
+        api.synthesize_keys(16 * blocks)                                         # the default literal is too small for 16 blocks
+    pk, vk = api.synthesize_keys(16 * blocks, srs=(int(ci["constraints"]), int(ci["instance"]), int(ci["nnz_a"] + ci["nnz_b"] + ci["nnz_c"])))
+    info = pk.info()
+    assert (info["h"], info["k"]) == (1 << 22, 1 << 24)
+    rs = np.random.RandomState(16)
+    msg, key = rs.bytes(16 * blocks), rs.bytes(16)
+    proof = api.encrypt(msg, key, pk)
+    ct = zko.aes_encrypt(msg, key)
+    assert len(proof) == 855
+    assert api.verify_encryption(vk, proof, ct) is True
+    bad = bytearray(ct); bad[-1] ^= 1
+    assert api.verify_encryption(vk, proof, bytes(bad)) is False
 
 
 @pytest.mark.slow
