@@ -85,10 +85,10 @@ class VerifyingKey:
         return VerifyingKey(p.value)
 
     @staticmethod
-    def from_trapdoor(info, index_comms, beta_mont, gamma_mont):
+    def from_trapdoor(info, index_comms, beta_mont):
         arr = (C.c_uint64 * 7)(*info)
         p = C.c_void_p()
-        _check(lib().zkaes_vk_from_trapdoor(arr, bytes(index_comms), bytes(beta_mont), bytes(gamma_mont), C.byref(p)))
+        _check(lib().zkaes_vk_from_trapdoor(arr, bytes(index_comms), bytes(beta_mont), C.byref(p)))
         return VerifyingKey(p.value)
 
     def verify(self, proof, public_input_bits):

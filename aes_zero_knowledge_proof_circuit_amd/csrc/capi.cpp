@@ -160,20 +160,22 @@ int zkaes_vk_deserialize(const uint8_t *bytes, size_t len, zkaes_vk **vk) {
         *vk = v;
     });
 }
-int zkaes_vk_from_trapdoor(const uint64_t info[7], const uint8_t *index_comms, const uint8_t *beta_b, const uint8_t *gamma_b, zkaes_vk **vk) {
+int zkaes_vk_from_trapdoor(const uint64_t info[7], const uint8_t *index_comms, const uint8_t *beta_b, zkaes_vk **vk) {
     return guard([&] {
+        if (!info || !index_comms || !beta_b || !vk) throw std::invalid_argument("null argument");
+        zk::Fr beta_in, beta;
+        memcpy(beta_in.l, beta_b, 32);
+        zk::G1A g, gamma_g;
+        zk::pairing::G2Affine h;
+        zk::kzg_setup_points(beta, g, gamma_g, h);                   // this library's own replay of KZG10::setup's draws from test_rng
+        if (!(beta == beta_in)) throw std::invalid_argument("vk_from_trapdoor: beta is not the first Fr draw of ark_std::test_rng()");
         zkaes_vk *v = new zkaes_vk();
         zk::VerifyingKey &k = v->vk;
         k.num_variables = info[0]; k.num_constraints = info[1]; k.num_non_zero = info[2]; k.num_instance = info[3];
         k.num_public_inputs = info[4]; k.max_degree = info[5]; k.supported_degree = info[6];
         for (int i = 0; i < 6; i++) { memcpy(k.index_comms[i].x.l, index_comms + 96 * i, 48); memcpy(k.index_comms[i].y.l, index_comms + 96 * i + 48, 48); }
-        zk::Fr beta, gamma;
-        memcpy(beta.l, beta_b, 32); memcpy(gamma.l, gamma_b, 32);
-        zk::G1A g;
-        for (int i = 0; i < 12; i++) { g.x.l[i] = G1_377_X_MONT[i]; g.y.l[i] = G1_377_Y_MONT[i]; }
         auto mulg = [&](const zk::Fr &s) { return zk::mul_fr(zk::XYZZ<zk::Fq377>::from_affine(g), s).to_affine(); };
-        k.g = g; k.gamma_g = mulg(gamma);
-        k.h = zk::pairing::g2_generator();
+        k.g = g; k.gamma_g = gamma_g; k.h = h;
         uint32_t raw[8]; beta.to_raw(raw);
         k.beta_h = zk::pairing::g2_mul_raw(k.h, raw, 8);
         size_t n = next_pow2(k.num_constraints), kk = next_pow2(k.num_non_zero);

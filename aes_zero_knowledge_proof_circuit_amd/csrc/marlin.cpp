@@ -198,7 +198,51 @@ pairing::G2Affine get_g2_compressed(Reader &r) {
     return a;
 }
 
+
+// canonical-integer comparison a < b (ark-ff's Ord on Fp)
+bool fq_lt(const Fq377 &a, const Fq377 &b) {
+    uint32_t x[12], y[12];
+    a.to_raw(x); b.to_raw(y);
+    for (int i = 11; i >= 0; i--) if (x[i] != y[i]) return x[i] < y[i];
+    return false;
+}
+// ark-ec 0.3.0 `impl Distribution<GroupProjective<P>> for Standard` [RECALL]: loop { x = BaseField::rand; greatest = rng.gen::<bool>();
+// get_point_from_x(x, greatest) } then scale_by_cofactor.  gen::<bool>() = top bit of one next_u32; y = (y < -y) ^ greatest ? y : -y.
+G1A sample_g1(ChaChaRng &rng) {
+    for (;;) {
+        Fq377 x = rng.rand_field<Fq377>();
+        bool greatest = (rng.next_u32() >> 31) != 0;
+        Fq377 y;
+        if (!fq_sqrt(x.sqr() * x + Bls377::b(), y)) continue;
+        Fq377 ny = y.neg();
+        G1A p; p.x = x; p.y = (fq_lt(y, ny) != greatest) ? y : ny;
+        return XYZZ<Fq377>::from_affine(p).mul_raw(G1_377_COFACTOR, G1_377_COFACTOR_LIMBS).to_affine();
+    }
+}
+pairing::G2Affine sample_g2(ChaChaRng &rng) {
+    using pairing::Fq2;
+    for (;;) {
+        Fq2 x;
+        x.c0 = rng.rand_field<Fq377>(); x.c1 = rng.rand_field<Fq377>();          // QuadExtField::rand: c0 then c1
+        bool greatest = (rng.next_u32() >> 31) != 0;
+        Fq2 y;
+        if (!fq2_sqrt(x.sqr() * x + pairing::g2_b(), y)) continue;
+        Fq2 ny = y.neg();
+        pairing::G2Affine p; p.inf = false; p.x = x; p.y = (fq2_gt(ny, y) != greatest) ? y : ny;    // (y < -y) ^ greatest
+        return pairing::g2_mul_raw(p, G2_377_COFACTOR, G2_377_COFACTOR_LIMBS);
+    }
+}
+
 }  // namespace
+
+// KZG10::setup's draws from ark_std::test_rng(), in upstream's order [RECALL ark-poly-commit 0.3.0]: beta, g, gamma_g, h
+void kzg_setup_points(Fr &beta, G1A &g, G1A &gamma_g, pairing::G2Affine &h) {
+    ChaChaRng rng(ark_test_rng_seed(), 12);
+    beta = rng.rand_field<Fr>();
+    g = sample_g1(rng);
+    gamma_g = sample_g1(rng);
+    h = sample_g2(rng);
+}
 
 // ark-serialize 0.3 compressed layout of ark_marlin::IndexVerifierKey<Fr, MarlinKZG10<Bls12_377, _>> [RECALL, SURVEY.md A.5]:
 //   index_info   : num_variables, num_constraints, num_non_zero, num_instance_variables            (4 x u64 LE; PhantomData = 0 bytes)
@@ -523,12 +567,10 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
     if (supported_degree > max_degree) throw std::runtime_error("IndexTooLarge: the circuit needs degree " + std::to_string(supported_degree) + " but the universal SRS supports " + std::to_string(max_degree));
     bounds[0] = std::min(n - 2, k - 2); bounds[1] = std::max(n - 2, k - 2);
     lowest_shift = max_degree - bounds[1];
-    // KZG10::setup trapdoor from ark_std::test_rng(): beta first (as upstream); g = generator and gamma_g = gamma*g is this
-    // build's documented deviation (upstream samples g, gamma_g, h as random curve points)
-    ChaChaRng setup_rng(ark_test_rng_seed(), 12);
-    srs_beta = setup_rng.rand_field<Fr>();
-    Fr gamma = setup_rng.rand_field<Fr>();
-    G1A g = g1_generator(), gamma_g = mul_affine(g, gamma);
+    // KZG10::setup from ark_std::test_rng() in upstream's draw order: the trapdoor beta, then g, gamma_g (G1) and h (G2) as random curve points
+    G1A g, gamma_g;
+    pairing::G2Affine srs_h;
+    kzg_setup_points(srs_beta, g, gamma_g, srs_h);
     if (const char *e = getenv("ZKAES_MSM_TABLES")) use_tables = atoi(e) != 0;
     // window bits of the table path: the top window must keep enough significant bits or a handful of buckets receive most points
     table_c = lg_k >= 22 ? 20 : (lg_k >= 19 ? 17 : 8);
@@ -588,7 +630,7 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
     }
     { Fr bp = Fr::one(); for (int i = 0; i < 3; i++) { gamma_powers[i] = mul_affine(gamma_g, bp); bp = bp * srs_beta; } }
     vk.g = g; vk.gamma_g = gamma_g;
-    vk.h = pairing::g2_generator();
+    vk.h = srs_h;
     { uint32_t raw[8]; srs_beta.to_raw(raw); vk.beta_h = pairing::g2_mul_raw(vk.h, raw, 8); }
     vk.degree_bounds[0] = bounds[0]; vk.degree_bounds[1] = bounds[1];
     for (int i = 0; i < 2; i++) vk.shift_powers[i] = mul_affine(g, srs_beta.pow_u64(max_degree - bounds[i]));

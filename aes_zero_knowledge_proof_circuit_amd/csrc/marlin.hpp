@@ -47,6 +47,8 @@ struct VerifyingKey {
     size_t supported_degree = 0, max_degree = 0;
 };
 
+// the four draws of KZG10::setup from ark_std::test_rng(): trapdoor beta, base points g, gamma_g (G1) and h (G2)
+void kzg_setup_points(Fr &beta, G1A &g, G1A &gamma_g, pairing::G2Affine &h);
 // ark-serialize 0.3 compressed layout of ark_marlin::IndexVerifierKey (what a Rust caller gets from CanonicalSerialize::serialize)
 std::vector<uint8_t> serialize_vk_ark(const VerifyingKey &vk);
 VerifyingKey deserialize_vk_ark(const uint8_t *bytes, size_t len);

@@ -81,11 +81,12 @@ int zkaes_vk_deserialize(const uint8_t *bytes, size_t len, zkaes_vk **vk);
 int zkaes_vk_serialize_ark(const zkaes_vk *vk, uint8_t **out, size_t *out_len);
 int zkaes_vk_deserialize_ark(const uint8_t *bytes, size_t len, zkaes_vk **vk);
 
-/* host-only: assemble a verifying key from an index made elsewhere with the SAME (public, test_rng-derived) KZG trapdoor:
- * info = {num_variables, num_constraints, num_non_zero, num_instance (padded), num_public_inputs, max_degree, supported_degree};
- * index_comms = 6 x 96 B affine Montgomery (row col a_val b_val c_val row_col); beta, gamma = 32 B Montgomery Fr.
- * g = G1 generator, gamma_g = gamma*g, h = G2 generator, beta_h = beta*h, shift powers = beta^(max_degree - bound) * g. */
-int zkaes_vk_from_trapdoor(const uint64_t info[7], const uint8_t *index_comms, const uint8_t *beta, const uint8_t *gamma, zkaes_vk **vk);
+/* host-only: assemble a verifying key from an index made elsewhere over the SAME universal SRS, i.e. KZG10::setup replayed from
+ * ark_std::test_rng() (the reference's generate_rand(), src/lib.rs:139): info = {num_variables, num_constraints, num_non_zero,
+ * num_instance (padded), num_public_inputs, max_degree, supported_degree}; index_comms = 6 x 96 B affine Montgomery (row col a_val b_val
+ * c_val row_col); beta = 32 B Montgomery Fr, must equal the replayed trapdoor (else error).  g, gamma_g, h are the replay's random curve
+ * points, beta_h = beta*h, shift powers = beta^(max_degree - bound) * g. */
+int zkaes_vk_from_trapdoor(const uint64_t info[7], const uint8_t *index_comms, const uint8_t *beta, zkaes_vk **vk);
 
 /* ---- introspection used by tests / bench ----------------------------------------------------------------------- */
 /* counters the reference logs through debug_constraint_system_status (src/helpers/mod.rs:73-81) and the Marlin index sizes:

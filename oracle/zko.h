@@ -95,6 +95,9 @@ void zko_chacha_init(zko_chacha *r, const uint8_t seed[32], int rounds);
 uint32_t zko_chacha_u32(zko_chacha *r);
 uint64_t zko_chacha_u64(zko_chacha *r);
 void zko_fr_rand(fr_t *out, zko_chacha *rng, const fr_params *F);   /* ark-ff UniformRand */
+void zko_fq_rand(fq_t *out, zko_chacha *rng, const fq_params *Q);
+int zko_fq_sqrt(fq_t *out, const fq_t *a, const fq_params *Q);
+void zko_g1_rand(g1a_t *out, zko_chacha *rng, const zko_curve *C);   /* ark-ec GroupProjective::rand (BLS12-377 G1) */
 
 typedef struct { zko_chacha r; uint8_t seed[32]; } zko_fsrng;       /* SimpleHashFiatShamirRng<Blake2s,ChaChaRng> */
 void zko_fs_init(zko_fsrng *fs, const uint8_t *bytes, size_t len);

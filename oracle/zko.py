@@ -172,11 +172,13 @@ class Index:
         lib().zko_api_index_comms(self.ptr, buf)
         return buf.raw
 
-    def srs_scalars(self):
+    def srs_trapdoor(self):
+        """(beta, g, gamma_g): the KZG10::setup trapdoor scalar and its two random G1 base points (96-byte affine, Montgomery coordinates)"""
         b = C.create_string_buffer(32)
-        g = C.create_string_buffer(32)
-        lib().zko_api_srs_info(self.ptr, b, g)
-        return fr_unpack(b.raw)[0], fr_unpack(g.raw)[0]
+        g = C.create_string_buffer(96)
+        gg = C.create_string_buffer(96)
+        lib().zko_api_srs_info(self.ptr, b, g, gg)
+        return fr_unpack(b.raw)[0], g.raw, gg.raw
 
     def srs_powers(self, start, count):
         buf = C.create_string_buffer(96 * count)

@@ -101,7 +101,8 @@ void zko_api_index_poly(const zko_index *ix, int which, int form, fr_t *out) {
     memcpy(out, form ? p[which]->c : e[which], ix->K.size * sizeof(fr_t));
 }
 void zko_api_index_comms(const zko_index *ix, uint8_t *out /* 6 x 96 */) { for (int i = 0; i < 6; i++) store_pt(out + 96 * i, &ix->index_comms[i]); }
-void zko_api_srs_info(const zko_index *ix, fr_t *beta, fr_t *gamma) { *beta = ix->ck.beta; *gamma = ix->ck.gamma; }
+/* trapdoor beta and the two G1 base points of the SRS (96 B affine each) */
+void zko_api_srs_info(const zko_index *ix, fr_t *beta, uint8_t *g_xy, uint8_t *gamma_g_xy) { *beta = ix->ck.beta; store_pt(g_xy, &ix->ck.g); store_pt(gamma_g_xy, &ix->ck.gamma_g); }
 /* powers_of_g[from .. from+count) as affine; only ranges the committer key holds */
 int zko_api_srs_powers(const zko_index *ix, size_t from, size_t count, uint8_t *out) {
     const zko_ck *ck = &ix->ck;

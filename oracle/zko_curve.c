@@ -159,6 +159,70 @@ int g1a_eq(const g1a_t *a, const g1a_t *b) {
 
 /* ark-ec 0.3.0 VariableBaseMSM::multi_scalar_mul: c = 3 if n < 32 else ln(n)+2; one task per window;
  * scalar == 1 handled in window 0; zero scalars skipped; running-sum bucket reduction; Horner over windows. */
+/* ---- random group elements as ark-ec 0.3.0 draws them (short_weierstrass_jacobian.rs `impl Distribution<GroupProjective<P>> for Standard`,
+ * not under /root/reference) [RECALL]: loop { x = BaseField::rand(rng); greatest = rng.gen::<bool>(); get_point_from_x(x, greatest) } then
+ * scale_by_cofactor.  BaseField::rand = ark-ff UniformRand (limbs from next_u64, shave, reject, limbs ARE the Montgomery form);
+ * gen::<bool>() = top bit of one next_u32 (rand 0.8); get_point_from_x picks y by (y < -y) ^ greatest on the canonical integers. */
+void zko_fq_rand(fq_t *out, zko_chacha *rng, const fq_params *Q) {
+    int shave = 384 - Q->bits;
+    for (;;) {
+        for (int i = 0; i < 6; i++) out->l[i] = zko_chacha_u64(rng);
+        out->l[5] &= (~(uint64_t)0) >> shave;
+        if (!fq_geq_raw(out->l, Q->p)) return;
+    }
+}
+/* Tonelli-Shanks square root in Fq; returns 0 for a non-residue */
+int zko_fq_sqrt(fq_t *out, const fq_t *a, const fq_params *Q) {
+    if (fq_is_zero(a)) { *out = *a; return 1; }
+    uint64_t t[6], half[6], tp1h[6];
+    int S = 0;
+    memcpy(t, Q->p, 48); t[0] -= 1;                                   /* p - 1 (p odd: no borrow) */
+    for (int i = 0; i < 6; i++) half[i] = (t[i] >> 1) | (i < 5 ? t[i + 1] << 63 : 0);
+    while (!(t[0] & 1)) { for (int i = 0; i < 6; i++) t[i] = (t[i] >> 1) | (i < 5 ? t[i + 1] << 63 : 0); S++; }
+    memcpy(tp1h, t, 48); tp1h[0] += 1;                                /* t odd and != 2^64 - 1 in limb 0 for both curves */
+    for (int i = 0; i < 6; i++) tp1h[i] = (tp1h[i] >> 1) | (i < 5 ? tp1h[i + 1] << 63 : 0);
+    fq_t one, minus_one, chk;
+    fq_set_one(&one, Q); fq_neg(&minus_one, &one, Q);
+    fq_pow(&chk, a, half, 6, Q);
+    if (!fq_eq(&chk, &one)) return 0;
+    fq_t z, c, x, b;
+    for (uint64_t cand = 2;; cand++) { fq_from_u64(&z, cand, Q); fq_pow(&chk, &z, half, 6, Q); if (fq_eq(&chk, &minus_one)) break; }
+    fq_pow(&c, &z, t, 6, Q); fq_pow(&x, a, tp1h, 6, Q); fq_pow(&b, a, t, 6, Q);
+    int m = S;
+    while (!fq_eq(&b, &one)) {
+        int i = 0;
+        fq_t bb = b;
+        while (!fq_eq(&bb, &one)) { fq_sqr(&bb, &bb, Q); i++; }
+        fq_t g = c;
+        for (int k = 0; k < m - i - 1; k++) fq_sqr(&g, &g, Q);
+        fq_mul(&x, &x, &g, Q); fq_sqr(&c, &g, Q); fq_mul(&b, &b, &c, Q); m = i;
+    }
+    *out = x;
+    return 1;
+}
+void zko_g1_rand(g1a_t *out, zko_chacha *rng, const zko_curve *C) {
+    const fq_params *Q = C->fq;
+    for (;;) {
+        fq_t x, y, ny, rhs;
+        zko_fq_rand(&x, rng, Q);
+        int greatest = (int)(zko_chacha_u32(rng) >> 31);
+        fq_sqr(&rhs, &x, Q); fq_mul(&rhs, &rhs, &x, Q); fq_add(&rhs, &rhs, &C->b, Q);
+        if (!zko_fq_sqrt(&y, &rhs, Q)) continue;
+        fq_neg(&ny, &y, Q);
+        uint64_t ry[6], rny[6];
+        fq_to_raw(ry, &y, Q); fq_to_raw(rny, &ny, Q);
+        int y_lt = 0;
+        for (int i = 5; i >= 0; i--) if (ry[i] != rny[i]) { y_lt = ry[i] < rny[i]; break; }
+        g1a_t p; p.x = x; p.y = (y_lt ^ greatest) ? y : ny; p.inf = 0;
+        g1j_t pj, r;
+        g1j_from_affine(&pj, &p, C);
+        if (C->id != 377) abort();                                    /* cofactor constant generated for BLS12-377 only */
+        g1j_mul_raw(&r, &pj, G1_377_COFACTOR, G1_377_COFACTOR_LIMBS, C);
+        g1j_to_affine(out, &r, C);
+        return;
+    }
+}
+
 void zko_msm(g1j_t *out, const g1a_t *bases, const fr_t *scalars, size_t n, const zko_curve *C) {
     const fr_params *F = C->fr;
     if (n == 0) { g1j_set_inf(out); return; }

@@ -6,8 +6,8 @@
  *     Fiat-Shamir transcript (SimpleHashFiatShamirRng<Blake2s, ChaChaRng>),
  *   ark-poly-commit 0.3.0 (Cargo.lock:248): MarlinKZG10 setup / trim / commit / open_combinations,
  * none of which is under /root/reference -> restated from the published algorithms;
- * "parity unpinned" at this boundary.  Documented deviation: the SRS uses g = the G1 generator and
- * gamma_g = gamma*g (arkworks samples both as random curve points from the same test_rng) -- SURVEY §8f item 4.
+ * "parity unpinned" at this boundary.  The SRS follows KZG10::setup's draw order from ark_std::test_rng(): beta, then g and gamma_g as
+ * random curve points (ark-ec GroupProjective::rand: x, sign bit, cofactor clearing) -- restated from memory like the rest, SURVEY §8f item 4.
  */
 #include "zko_marlin.h"
 #include <stdio.h>
@@ -228,20 +228,19 @@ zko_index *zko_marlin_index(zko_cs *cs, size_t srs_nc, size_t srs_nv, size_t srs
     size_t index_max = zko_ahp_max_degree(ix->num_constraints, ix->num_variables, ix->num_non_zero, F);
     if (index_max > ck->max_degree) { fprintf(stderr, "zko: IndexTooLarge %zu > %zu\n", index_max, ck->max_degree); abort(); }
     zko_chacha rng; zko_chacha_init(&rng, ARK_TEST_RNG_SEED, 12);
-    zko_fr_rand(&ck->beta, &rng, F);
-    zko_fr_rand(&ck->gamma, &rng, F);
+    zko_fr_rand(&ck->beta, &rng, F);                     /* KZG10::setup draw order [RECALL ark-poly-commit 0.3.0]: beta, g, gamma_g, h */
+    zko_g1_rand(&ck->g, &rng, C);
+    zko_g1_rand(&ck->gamma_g, &rng, C);                  /* (h is a G2 point: only the verifying key needs it) */
     ck->supported_degree = index_max;
     ck->powers = malloc((index_max + 1) * sizeof(g1a_t));
-    srs_powers(ck->powers, C, &C->gen, &ck->beta, 0, index_max + 1);
-    g1j_t gj, ggj; g1j_from_affine(&gj, &C->gen, C); g1j_mul_fr(&ggj, &gj, &ck->gamma, C);
-    g1a_t gamma_g; g1j_to_affine(&gamma_g, &ggj, C);
-    srs_powers(ck->gamma_powers, C, &gamma_g, &ck->beta, 0, 3);
+    srs_powers(ck->powers, C, &ck->g, &ck->beta, 0, index_max + 1);
+    srs_powers(ck->gamma_powers, C, &ck->gamma_g, &ck->beta, 0, 3);
     ck->bounds[0] = n - 2; ck->bounds[1] = k - 2;
     if (ck->bounds[0] > ck->bounds[1]) { size_t t = ck->bounds[0]; ck->bounds[0] = ck->bounds[1]; ck->bounds[1] = t; }
     ck->lowest_shift = ck->max_degree - ck->bounds[1];
     size_t ns = ck->bounds[1] + 1;
     ck->shifted_powers = malloc(ns * sizeof(g1a_t));
-    srs_powers(ck->shifted_powers, C, &C->gen, &ck->beta, ck->lowest_shift, ns);
+    srs_powers(ck->shifted_powers, C, &ck->g, &ck->beta, ck->lowest_shift, ns);
     /* index commitments (no hiding, no bounds) */
     const zko_poly *ip[6] = {&ix->row, &ix->col, &ix->val_a, &ix->val_b, &ix->val_c, &ix->row_col};
     for (int i = 0; i < 6; i++) zko_commit_plain(&ix->index_comms[i], ck, ip[i]->c, ip[i]->len, 0, 0);

@@ -8,7 +8,8 @@ typedef struct { fr_t *c; size_t len; } zko_poly;   /* dense coefficients, low d
 typedef struct {
     const zko_curve *C;
     size_t max_degree;                 /* universal SRS degree (AHPForR1CS::max_degree of the setup literals) */
-    fr_t beta, gamma;                  /* trapdoor; public because the reference seeds it with test_rng (F7) */
+    fr_t beta;                         /* trapdoor; public because the reference seeds it with test_rng (F7) */
+    g1a_t g, gamma_g;                  /* KZG10::setup's random base points (drawn after beta from the same rng) */
     size_t supported_degree;           /* committer key: powers_of_g[0..=supported_degree] */
     g1a_t *powers;
     g1a_t gamma_powers[3];             /* powers_of_gamma_g[0..=hiding_bound+1] */

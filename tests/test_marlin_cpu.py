@@ -9,10 +9,10 @@ SMALL_SRS = (200, 200, 600)
 
 def vk_for(api, zko, ix, n_public):
     info = ix.info()
-    beta, gamma = ix.srs_scalars()
+    beta, _, _ = ix.srs_trapdoor()
     return api.VerifyingKey.from_trapdoor(
         [info["num_variables"], info["num_constraints"], info["num_non_zero"], info["num_instance"], n_public, info["max_degree"], info["supported_degree"]],
-        ix.comms(), zko.fr_pack([beta]), zko.fr_pack([gamma]))
+        ix.comms(), zko.fr_pack([beta]))
 
 
 @pytest.fixture(scope="module")
@@ -128,7 +128,9 @@ def test_vk_ark_layout_against_the_python_curve_model(zko, api, xor_setup):
     import curve_math as cm
     ix, vk = xor_setup
     info = ix.info()
-    beta, gamma = ix.srs_scalars()
+    beta, g_or, gg_or = ix.srs_trapdoor()
+    mb, g, gg, h = cm.ark_kzg10_setup_points()          # third, independent model of KZG10::setup's draws (tools/curve_math.py)
+    assert mb == beta and zko.pt_unpack(g_or)[0] == g and zko.pt_unpack(gg_or)[0] == gg
     raw = vk.to_ark_bytes()
     q, F = cm.Q377, cm.Fq2(cm.Q377, -5)
     off = 0
@@ -141,12 +143,9 @@ def test_vk_ark_layout_against_the_python_curve_model(zko, api, xor_setup):
     for (x, y) in comms:
         assert raw[off:off + 48] == _g1_compressed(x, y, q) and raw[off + 48] == 0
         off += 49
-    g = cm.G1_377
     assert raw[off:off + 48] == _g1_compressed(g[0], g[1], q)
-    gg = cm.ec_mul(gamma, g, q)
     assert raw[off + 48:off + 96] == _g1_compressed(gg[0], gg[1], q)
     off += 96
-    _, h, _ = cm.derive_g2_377()
     assert raw[off:off + 96] == _g2_compressed(h, q)
     assert raw[off + 96:off + 192] == _g2_compressed(cm.ec2_mul(F, beta, h), q)
     off += 192

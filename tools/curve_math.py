@@ -215,3 +215,137 @@ if __name__ == "__main__":
     bt, G, cof = derive_g2_377()
     print("twist b =", bt)
     print("G2 gen =", G)
+
+
+# ---------------- ark_std::test_rng() + arkworks 0.3 sampling order of KZG10::setup [RECALL] -------------
+# rand 0.8 StdRng = ChaCha12 through rand_core's BlockRng with a 64-word buffer; ark-ff UniformRand for Fp: limbs from next_u64, shave the
+# unused top bits, reject >= p, the limbs ARE the Montgomery representation; ark-ec GroupProjective::rand: x = BaseField::rand,
+# greatest = rng.gen::<bool>() (top bit of one next_u32), get_point_from_x (pick y by (y < -y) ^ greatest), scale_by_cofactor.
+ARK_TEST_RNG_SEED = bytes([1, 0, 0, 0, 23, 0, 0, 0, 200, 1, 0, 0, 210, 30, 0, 0] + [0] * 16)
+
+
+class StdRngModel:
+    def __init__(self, seed=ARK_TEST_RNG_SEED, rounds=12):
+        self.key = [int.from_bytes(seed[4 * i:4 * i + 4], "little") for i in range(8)]
+        self.rounds, self.counter, self.buf, self.idx = rounds, 0, [], 64
+
+    def _block(self, ctr):
+        M = 0xFFFFFFFF
+        s = [0x61707865, 0x3320646e, 0x79622d32, 0x6b206574] + self.key + [ctr & M, ctr >> 32, 0, 0]
+        x = list(s)
+
+        def rol(v, n):
+            return ((v << n) | (v >> (32 - n))) & M
+
+        def Q(a, b, c, d):
+            x[a] = (x[a] + x[b]) & M; x[d] = rol(x[d] ^ x[a], 16); x[c] = (x[c] + x[d]) & M; x[b] = rol(x[b] ^ x[c], 12)
+            x[a] = (x[a] + x[b]) & M; x[d] = rol(x[d] ^ x[a], 8); x[c] = (x[c] + x[d]) & M; x[b] = rol(x[b] ^ x[c], 7)
+        for _ in range(self.rounds // 2):
+            Q(0, 4, 8, 12); Q(1, 5, 9, 13); Q(2, 6, 10, 14); Q(3, 7, 11, 15)
+            Q(0, 5, 10, 15); Q(1, 6, 11, 12); Q(2, 7, 8, 13); Q(3, 4, 9, 14)
+        return [(x[i] + s[i]) & M for i in range(16)]
+
+    def _refill(self):
+        self.buf = sum((self._block(self.counter + b) for b in range(4)), [])
+        self.counter += 4
+        self.idx = 0
+
+    def next_u32(self):
+        if self.idx >= 64:
+            self._refill()
+        v = self.buf[self.idx]
+        self.idx += 1
+        return v
+
+    def next_u64(self):
+        if self.idx < 63:
+            lo, hi = self.buf[self.idx], self.buf[self.idx + 1]
+            self.idx += 2
+        elif self.idx >= 64:
+            self._refill()
+            lo, hi = self.buf[0], self.buf[1]
+            self.idx = 2
+        else:
+            lo = self.buf[63]
+            self._refill()
+            hi = self.buf[0]
+            self.idx = 1
+        return (hi << 32) | lo
+
+    def rand_fp(self, p, limbs64):
+        """returns the VALUE of the sampled element (the sampled limbs are its Montgomery representation)"""
+        bits = p.bit_length()
+        R = 1 << (64 * limbs64)
+        while True:
+            v = 0
+            for i in range(limbs64):
+                v |= self.next_u64() << (64 * i)
+            v &= (1 << bits) - 1                     # shave the top limb down to the modulus bit length
+            if v < p:
+                return v * pow(R, -1, p) % p
+
+    def rand_bool(self):
+        return (self.next_u32() >> 31) == 1
+
+
+def fp_sqrt(a, p):
+    """Tonelli-Shanks in Fp (any root, or None)"""
+    a %= p
+    if a == 0:
+        return 0
+    if pow(a, (p - 1) // 2, p) != 1:
+        return None
+    s, t = 0, p - 1
+    while t % 2 == 0:
+        s += 1
+        t //= 2
+    z = 2
+    while pow(z, (p - 1) // 2, p) != p - 1:
+        z += 1
+    c, x, b, m = pow(z, t, p), pow(a, (t + 1) // 2, p), pow(a, t, p), s
+    while b != 1:
+        i, bb = 0, b
+        while bb != 1:
+            bb = bb * bb % p
+            i += 1
+        g = pow(c, 1 << (m - i - 1), p)
+        x, c, m = x * g % p, g * g % p, i
+        b = b * c % p
+    return x
+
+
+G1_377_COFACTOR = (X377 - 1) ** 2 // 3
+
+
+def ark_kzg10_setup_points():
+    """(beta, g, gamma_g, h) exactly in the order ark-poly-commit 0.3.0 KZG10::setup draws them from ark_std::test_rng() [RECALL]"""
+    rng = StdRngModel()
+    q = Q377
+    beta = rng.rand_fp(R377, 4)
+
+    def g1():
+        while True:
+            x = rng.rand_fp(q, 6)
+            greatest = rng.rand_bool()
+            y = fp_sqrt((x * x * x + 1) % q, q)
+            if y is None:
+                continue
+            ny = (q - y) % q
+            y = y if (y < ny) != greatest else ny
+            return ec_mul(G1_377_COFACTOR, (x, y), q)
+    g = g1()
+    gamma_g = g1()
+    bt, _, cof = derive_g2_377()
+    F = Fq2(q, -5)
+    while True:
+        x = (rng.rand_fp(q, 6), rng.rand_fp(q, 6))
+        greatest = rng.rand_bool()
+        y = F.sqrt(F.add(F.mul(F.mul(x, x), x), bt))
+        if y is None:
+            continue
+        ny = ((q - y[0]) % q, (q - y[1]) % q)
+        lt = (y[1], y[0]) < (ny[1], ny[0])              # QuadExtField order: c1 first, then c0
+        y = y if lt != greatest else ny
+        h = ec2_mul(F, cof, (x, y))
+        break
+    return beta, g, gamma_g, h
