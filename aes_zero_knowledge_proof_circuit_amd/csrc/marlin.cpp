@@ -36,7 +36,6 @@ size_t ahp_max_degree(size_t nc, size_t nv, size_t nnz) {                       
     size_t h = next_pow2(std::max(nc, nv)), k = next_pow2(nnz);
     return std::max({2 * h - 1, 3 * h - 1, h, 3 * k - 3});
 }
-G1A g1_generator() { G1A g; for (int i = 0; i < 12; i++) { g.x.l[i] = G1_377_X_MONT[i]; g.y.l[i] = G1_377_Y_MONT[i]; } return g; }
 G1A mul_affine(const G1A &p, const Fr &k) { return mul_fr(XYZZ<Fq377>::from_affine(p), k).to_affine(); }
 
 // ------------------------------------------------------------------ byte encodings (ark-ff ToBytes / ark-serialize)
