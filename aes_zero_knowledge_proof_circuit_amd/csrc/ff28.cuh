@@ -95,6 +95,23 @@ struct Fp28 {
         return r;
     }
 
+    // one row of the Montgomery reduction: make limb i of t a multiple of 2^28 by adding m p, then carry it into limb i + 1.
+    // For p = 1 (mod 2^28) (BLS12-377's q: -p^-1 = -1, limb 0 of p = 1) m = -t_i mod 2^28 and the low limb needs no multiply and no
+    // 64-bit add of m: t_i + m clears the low 28 bits and carries exactly one unit when they were non-zero, i.e. (t_i + 2^28 - 1) >> 28.
+    ZK_HD static void reduce_row(uint64_t *t, int i) {
+        if constexpr (mod28(0) == 1u && PINV == MASK) {
+            uint32_t m = (0u - (uint32_t)t[i]) & MASK;
+#pragma unroll
+            for (int j = 1; j < N; j++) t[i + j] += (uint64_t)m * mod28(j);
+            t[i + 1] += (t[i] + MASK) >> 28;           // = (t_i + m) >> 28: the low 28 bits carry one unit exactly when they are non-zero
+        } else {
+            uint32_t m = (((uint32_t)t[i] & MASK) * PINV) & MASK;
+#pragma unroll
+            for (int j = 0; j < N; j++) t[i + j] += (uint64_t)m * mod28(j);
+            t[i + 1] += t[i] >> 28;
+        }
+    }
+
     // almost-Montgomery product: row-wise operand scanning, 64-bit column accumulators, no carry chain
     ZK_HD Fp28 operator*(const Fp28 &b) const {
         uint64_t t[2 * N];
@@ -104,10 +121,7 @@ struct Fp28 {
         for (int i = 0; i < N; i++) {
 #pragma unroll
             for (int j = 0; j < N; j++) t[i + j] += (uint64_t)l[j] * b.l[i];
-            uint32_t m = (((uint32_t)t[i] & MASK) * PINV) & MASK;
-#pragma unroll
-            for (int j = 0; j < N; j++) t[i + j] += (uint64_t)m * mod28(j);
-            t[i + 1] += t[i] >> 28;
+            reduce_row(t, i);
         }
         Fp28 r;
         uint64_t c = 0;
@@ -129,10 +143,7 @@ struct Fp28 {
             for (int j = 0; j < N; j++) t[i + j] += (uint64_t)a.l[j] * b.l[i];
 #pragma unroll
             for (int j = 0; j < N; j++) t[i + j] += (uint64_t)c.l[j] * d.l[i];
-            uint32_t m = (((uint32_t)t[i] & MASK) * PINV) & MASK;
-#pragma unroll
-            for (int j = 0; j < N; j++) t[i + j] += (uint64_t)m * mod28(j);
-            t[i + 1] += t[i] >> 28;
+            reduce_row(t, i);
         }
         Fp28 r;
         uint64_t cy = 0;
@@ -157,10 +168,7 @@ struct Fp28 {
         }
 #pragma unroll
         for (int i = 0; i < N; i++) {
-            uint32_t m = (((uint32_t)t[i] & MASK) * PINV) & MASK;
-#pragma unroll
-            for (int j = 0; j < N; j++) t[i + j] += (uint64_t)m * mod28(j);
-            t[i + 1] += t[i] >> 28;
+            reduce_row(t, i);
         }
         Fp28 r;
         uint64_t c = 0;

@@ -89,10 +89,17 @@ struct Fp29 {
         for (int i = 0; i < N; i++) {
 #pragma unroll
             for (int j = 0; j < N; j++) t[i + j] += (uint64_t)l[j] * b.l[i];
-            uint32_t m = (((uint32_t)t[i] & MASK) * PINV) & MASK;
+            if constexpr (mod29(0) == 1u && PINV == MASK) {       // p = 1 (mod 2^29) (both BLS scalar fields): m = -t_i, no multiply for limb 0
+                uint32_t m = (0u - (uint32_t)t[i]) & MASK;
 #pragma unroll
-            for (int j = 0; j < N; j++) t[i + j] += (uint64_t)m * mod29(j);
-            t[i + 1] += t[i] >> B;
+                for (int j = 1; j < N; j++) t[i + j] += (uint64_t)m * mod29(j);
+                t[i + 1] += (t[i] + MASK) >> B;                   // = (t_i + m) >> 29
+            } else {
+                uint32_t m = (((uint32_t)t[i] & MASK) * PINV) & MASK;
+#pragma unroll
+                for (int j = 0; j < N; j++) t[i + j] += (uint64_t)m * mod29(j);
+                t[i + 1] += t[i] >> B;
+            }
         }
         Fp29 r;
         uint64_t c = 0;
