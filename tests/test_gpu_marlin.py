@@ -127,6 +127,25 @@ def test_aes16_proof_bytes_identical_to_oracle(zko, api, aes16, vectors):
     assert proof == ref.to_bytes()
 
 
+@pytest.mark.slow
+def test_aes32_proof_bytes_identical_to_oracle(zko, api):
+    """The same byte-for-byte parity on a 2-block message (|H| = 2^19, |K| = 2^21: other NTT pass plans and MSM sizes than the 16-byte case),
+    with a non-default prover seed so the mask polynomial and the hiding blinders differ as well (about two minutes of CPU)."""
+    msg, key, seed = mt_bytes(32, 77), mt_bytes(16, 78), bytes(range(100, 132))
+    pk, vk = api.synthesize_keys(32)
+    info = pk.info()
+    assert (info["h"], info["k"]) == (1 << 19, 1 << 21)
+    proof = api.encrypt(msg, key, pk, zk_seed=seed)
+    cs, _ = zko.synth_aes(bytes(32), bytes(16))
+    ix = zko.Index(cs)
+    cs, _ = zko.synth_aes(msg, key)
+    ref = ix.prove(cs, seed)
+    for poly in zko.POLY_NAMES:
+        assert pk.debug_fetch(poly) == ref.poly(poly), poly
+    assert proof == ref.to_bytes()
+    assert api.verify_encryption(vk, proof, zko.aes_encrypt(msg, key))
+
+
 def test_batch_of_independent_single_block_proofs(zko, api, aes16):
     """BASELINE config 5 shape (many small proofs on one SRS), reduced to 12 proofs: each (message, key) pair gets its own proof."""
     pk, vk = aes16
