@@ -138,7 +138,12 @@ void mask_fixup(F *p, size_t n, stream_t s);
 void q1_pointwise(F *e_ra, const F *e_za, const F *e_zb, const F *e_t, const F *e_z, const F &eta_a, const F &eta_b, const F &eta_c, size_t n, stream_t s);
 void round3_den(F *den, const F *row, const F *col, const F &alpha, const F &beta, size_t k, stream_t s);     // (beta - row)(alpha - col)
 void mul_pointwise(F *out, const F *a, const F *b, size_t n, stream_t s);                                       // out = a * b
-void mul_sub(F *acc, const F *b, const F *f, size_t n, stream_t s);                                             // acc -= b * f
+void mul_sub(F *acc, const F *b, const F *f, size_t n, stream_t s);
+// out[j] = in[j] * g^j for j < n (in zero-padded beyond in_len): coefficients of p(g X)
+void coset_scale(F *out, const F *in, const F &g, size_t in_len, size_t n, stream_t s);
+// round 3 on one coset of K: out = ((ea va + eb vb + ec vc) - (alpha beta - alpha row - beta col + row_col) f) * vinv, all arrays = values on the coset
+void h2_coset(F *out, const F *row, const F *col, const F *va, const F *vb, const F *vc, const F *rc, const F *f, const F &alpha, const F &beta, const F &alpha_beta,
+              const F &ea, const F &eb, const F &ec, const F &vinv, size_t k, stream_t s);                                             // acc -= b * f
 // indexer (one-time): row/col/row_col/val_* evaluations on K from the joint matrix entries; tmp = k scratch elements
 void index_evals(F *row, F *col, F *rowcol, F *va, F *vb, F *vc, F *tmp, const uint32_t *ci, const uint32_t *ri, const int64_t *ca, const int64_t *cb, const int64_t *cc, size_t cnt,
                  size_t k, const F *elems, uint32_t n, stream_t s);

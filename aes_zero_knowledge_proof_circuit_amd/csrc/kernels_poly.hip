@@ -231,6 +231,35 @@ __global__ void k_mul(F *__restrict__ out, const F *__restrict__ a, const F *__r
 void mul_pointwise(F *out, const F *a, const F *b, size_t n, stream_t s) { if (!n) return; hipLaunchKernelGGL(k_mul, GRID(n), 0, (hipStream_t)s, out, a, b, n); HIP_LAUNCH_CHECK(); }
 __global__ void k_mul_sub(F *__restrict__ acc, const F *__restrict__ b, const F *__restrict__ f, size_t n) { size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) acc[i] = acc[i] - b[i] * f[i]; }
 void mul_sub(F *acc, const F *b, const F *f, size_t n, stream_t s) { if (!n) return; hipLaunchKernelGGL(k_mul_sub, GRID(n), 0, (hipStream_t)s, acc, b, f, n); HIP_LAUNCH_CHECK(); }
+// ---- coset tools for round 3: h_2 = (a - b f) / v_K has degree <= |K| - 2, so its |K| values on ONE coset g K determine it and there
+// v_K(g w^i) = g^|K| - 1 is a non-zero constant: no 2|K|-point transforms, no division by the vanishing polynomial.
+// out[j] = in[j] * g^j  (coefficients of p(g X)); 16 consecutive coefficients per lane, one pow per lane
+__global__ void k_coset_scale(F *__restrict__ out, const F *__restrict__ in, F g, size_t in_len, size_t n) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t j0 = t * 16;
+    if (j0 >= n) return;
+    size_t e = j0 + 16 < n ? j0 + 16 : n;
+    F pw = g.pow_u64(j0);
+    for (size_t j = j0; j < e; j++) { out[j] = j < in_len ? in[j] * pw : F::zero(); pw = pw * g; }
+}
+void coset_scale(F *out, const F *in, const F &g, size_t in_len, size_t n, stream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_coset_scale, GRID((n + 15) / 16), 0, (hipStream_t)s, out, in, g, in_len, n); HIP_LAUNCH_CHECK();
+}
+// values of h_2 on the coset from the coset values of the six index polynomials and of f:
+//   a = ea va + eb vb + ec vc,  b = alpha beta - alpha row - beta col + row_col,  out = (a - b f) * vinv
+__global__ void k_h2_coset(F *__restrict__ out, const F *__restrict__ row, const F *__restrict__ col, const F *__restrict__ va, const F *__restrict__ vb,
+                           const F *__restrict__ vc, const F *__restrict__ rc, const F *__restrict__ f, F alpha, F beta, F alpha_beta, F ea, F eb, F ec, F vinv, size_t k) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    F a = ea * va[i] + eb * vb[i] + ec * vc[i];
+    F b = alpha_beta - alpha * row[i] - beta * col[i] + rc[i];
+    out[i] = (a - b * f[i]) * vinv;
+}
+void h2_coset(F *out, const F *row, const F *col, const F *va, const F *vb, const F *vc, const F *rc, const F *f, const F &alpha, const F &beta, const F &alpha_beta,
+              const F &ea, const F &eb, const F &ec, const F &vinv, size_t k, stream_t s) {
+    hipLaunchKernelGGL(k_h2_coset, GRID(k), 0, (hipStream_t)s, out, row, col, va, vb, vc, rc, f, alpha, beta, alpha_beta, ea, eb, ec, vinv, k); HIP_LAUNCH_CHECK();
+}
 // z_poly = w * (X^m - 1) + x_poly : zp[i] = (i >= m ? w[i-m] : 0) - (i < wlen ? w[i] : 0) + (i < m ? x[i] : 0), i <= n
 __global__ void k_z_poly(F *__restrict__ zp, const F *__restrict__ w, size_t wlen, const F *__restrict__ x, uint32_t m, size_t n1) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -360,7 +360,7 @@ struct ProverContext {
     DevBuf za_ev, zb_ev, x_poly, x_tmp, x_evals, tmp_n, ra_ev, ra_poly, zpoly, t_partial;
     DevBuf poly[9];                    // w z_a z_b mask t g_1 h_1 g_2 h_2
     size_t poly_len[9] = {0};
-    DevBuf e[5], big_tmp, f_poly, ab[2], acc, wit, wit2, scratch;
+    DevBuf e[5], big_tmp, f_poly, acc, wit, wit2, scratch;
     ProverTimings timings;
     ProverContext() { stream = gpu::stream_create(); msm_ws = gpu::msm_workspace_create(); }
     ~ProverContext() {
@@ -370,7 +370,6 @@ struct ProverContext {
         for (DevBuf *b : {&za_ev, &zb_ev, &x_poly, &x_tmp, &x_evals, &tmp_n, &ra_ev, &ra_poly, &zpoly, &t_partial, &big_tmp, &f_poly, &acc, &wit, &wit2, &scratch}) b->release();
         for (auto &b : poly) b.release();
         for (auto &b : e) b.release();
-        for (auto &b : ab) b.release();
         gpu::msm_workspace_destroy(msm_ws);
         gpu::stream_destroy(stream);
     }
@@ -406,7 +405,8 @@ class ProvingKeyImpl {
     uint32_t t_nseg = 0, t_nheavy = 0;
     uint32_t *d_t_heavy = nullptr;
     // device: index polynomials (evaluations on K and coefficients); order row col a_val b_val c_val row_col
-    DevBuf ix_ev[6], ix_co[6];
+    DevBuf ix_ev[6], ix_co[6], ix_cs[6];       // index polynomials: values on K, coefficients, values on the coset g K (round 3)
+    Fr coset_g, coset_g_inv, coset_vk_inv;     // g = the field's multiplicative generator, 1 / (g^|K| - 1)
     ProverTimings last_timings;
 
     ~ProvingKeyImpl() {
@@ -415,6 +415,7 @@ class ProvingKeyImpl {
         gpu::dfree(d_t_heavy); gpu::dfree(d_t_colptr); gpu::dfree(d_t_seg_start); gpu::dfree(d_t_seg_end); gpu::dfree(d_t_row); gpu::dfree(d_t_mat); gpu::dfree(d_t_coeff);
         for (auto &b : ix_ev) b.release();
         for (auto &b : ix_co) b.release();
+        for (auto &b : ix_cs) b.release();
         ctxs.clear();
     }
     // context i, created on first use (workspace allocation happens outside any timed region when callers warm up)
@@ -440,7 +441,7 @@ class ProvingKeyImpl {
         for (int i = 0; i < 9; i++) cx.poly[i].alloc(caps[i]);
         size_t big = std::max(n4, k2);
         for (auto &b : cx.e) b.alloc(big);
-        cx.big_tmp.alloc(big); cx.f_poly.alloc(k); cx.ab[0].alloc(k); cx.ab[1].alloc(k);
+        cx.big_tmp.alloc(big); cx.f_poly.alloc(k);
         cx.acc.alloc(std::max(3 * n, k) + 1); cx.wit.alloc(std::max(3 * n, k) + 1); cx.wit2.alloc(std::max(n, k) + 1); cx.scratch.alloc(std::max(std::max(3 * n, k) / 32 + 1024, gpu::divide_by_linear_scratch(std::max(3 * n, k) + 1)));
     }
 
@@ -693,6 +694,19 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
         gpu::dfree(d_ci); gpu::dfree(d_ri); gpu::dfree(d_ja); gpu::dfree(d_jb); gpu::dfree(d_jc);
     }
     for (int i = 0; i < 6; i++) vk.index_comms[i] = msm_powers(*cx0, false, 0, ix_co[i].p, k).to_affine();
+    {   // values of the index polynomials on the coset g K, once per key: round 3 then needs no transform for a(X) and b(X)
+        for (int i = 0; i < 8; i++) coset_g.l[i] = FR377_GEN_MONT[i];
+        coset_g_inv = coset_g.inverse();
+        coset_vk_inv = (coset_g.pow_u64(k) - Fr::one()).inverse();
+        F *tmp = (F *)gpu::dmalloc(k * sizeof(F));
+        for (int i = 0; i < 6; i++) {
+            ix_cs[i].alloc(k);
+            gpu::coset_scale(tmp, ix_co[i].p, coset_g, k, k, stream);
+            gpu::ntt<F>(ix_cs[i].p, tmp, k, lg_k, false, stream);
+        }
+        gpu::sync(stream);
+        gpu::dfree(tmp);
+    }
     // ---- workspace of context 0 (further contexts are created on demand)
     alloc_workspace(*cx0);
     ctxs.push_back(std::move(cx0));
@@ -705,7 +719,7 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     auto &d_trace = cx.d_trace; auto &d_z = cx.d_z; auto &d_msg = cx.d_msg; auto &d_key = cx.d_key;
     auto &za_ev = cx.za_ev; auto &zb_ev = cx.zb_ev; auto &x_poly = cx.x_poly; auto &x_tmp = cx.x_tmp; auto &x_evals = cx.x_evals; auto &tmp_n = cx.tmp_n;
     auto &ra_ev = cx.ra_ev; auto &ra_poly = cx.ra_poly; auto &zpoly = cx.zpoly; auto &t_partial = cx.t_partial;
-    auto &poly = cx.poly; auto &poly_len = cx.poly_len; auto &e = cx.e; auto &big_tmp = cx.big_tmp; auto &f_poly = cx.f_poly; auto &ab = cx.ab;
+    auto &poly = cx.poly; auto &poly_len = cx.poly_len; auto &e = cx.e; auto &big_tmp = cx.big_tmp; auto &f_poly = cx.f_poly;
     auto &acc = cx.acc; auto &wit = cx.wit; auto &wit2 = cx.wit2; auto &scratch = cx.scratch; auto &timings = cx.timings;
     auto t_all = Clock::now(), t0 = t_all;
     ChaChaRng zk(zk_seed ? zk_seed : ark_test_rng_seed(), 12);
@@ -803,15 +817,13 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     gpu::mul_pointwise(e[1].p, e[1].p, e[0].p, k, s);                         // f on K
     gpu::ntt<F>(f_poly.p, e[1].p, k, lg_k, true, s);
     gpu::d2d(poly[7].p, f_poly.p + 1, (k - 1) * sizeof(F), s); poly_len[7] = k - 1;   // g_2 = (f - f(0)) / X
-    gpu::poly_lincomb3(ab[0].p, ix_co[2].p, ix_co[3].p, ix_co[4].p, ea_vv, eb_vv, ec_vv, k, s);                 // a(X)
-    gpu::poly_lincomb3(ab[1].p, ix_co[5].p, ix_co[0].p, ix_co[1].p, Fr::one(), alpha.neg(), beta.neg(), k, s);   // b(X) - alpha*beta
-    gpu::poly_add_at(ab[1].p, 0, alpha_beta, s);
-    gpu::ntt<F>(e[0].p, ab[0].p, k, lg_k2, false, s);
-    gpu::ntt<F>(e[1].p, ab[1].p, k, lg_k2, false, s);
-    gpu::ntt<F>(e[2].p, f_poly.p, k, lg_k2, false, s);
-    gpu::mul_sub(e[0].p, e[1].p, e[2].p, k2, s);
-    gpu::ntt<F>(big_tmp.p, e[0].p, k2, lg_k2, true, s);
-    gpu::divide_by_vanishing(poly[8].p, e[3].p, big_tmp.p, k2, k, s);          // h_2 ; remainder must vanish
+    // h_2 = (a - b f) / v_K with a = sum eta_M v_H(alpha) v_H(beta) val_M, b = (beta - row)(alpha - col) expanded with row_col: degree <= |K| - 2,
+    // so it is interpolated from ONE coset of K, where v_K is the constant g^|K| - 1 and a, b come from the key's precomputed coset values
+    gpu::coset_scale(e[1].p, f_poly.p, coset_g, k, k, s);
+    gpu::ntt<F>(e[2].p, e[1].p, k, lg_k, false, s);                           // f on g K
+    gpu::h2_coset(e[0].p, ix_cs[0].p, ix_cs[1].p, ix_cs[2].p, ix_cs[3].p, ix_cs[4].p, ix_cs[5].p, e[2].p, alpha, beta, alpha_beta, ea_vv, eb_vv, ec_vv, coset_vk_inv, k, s);
+    gpu::ntt<F>(big_tmp.p, e[0].p, k, lg_k, true, s);                         // coefficients of h_2(g X)
+    gpu::coset_scale(poly[8].p, big_tmp.p, coset_g_inv, k - 1, k - 1, s);     // h_2 (the coefficient of X^(|K|-1) is zero for a satisfied instance)
     poly_len[8] = k - 1;
     for (auto &lp : r3) mpc_commit(cx, lp, zk);
     { Bytes o; for (auto &lp : r3) o.commitment_tobytes(lp.comm); fs.absorb(o.b); }
