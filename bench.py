@@ -62,9 +62,16 @@ def main():
     import torch
     import torch.distributed as dist
     use_dist = world > 1 or "RANK" in os.environ            # under torchrun the RCCL group is created (and exercised) even for one rank
+    # rehearsal hooks for a one-GPU box (not used by the driver): ZKAES_BENCH_BACKEND=gloo + ZKAES_BENCH_ONE_GPU=1 run N ranks on device 0
+    backend = os.environ.get("ZKAES_BENCH_BACKEND", "nccl")
+    if os.environ.get("ZKAES_BENCH_ONE_GPU"):
+        local_rank = 0
     if use_dist:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     from aes_zero_knowledge_proof_circuit_amd import api
     if api.device_count() <= 0:
         raise SystemExit("bench.py needs a HIP device: libzkaes has no CPU fallback")
@@ -135,7 +142,7 @@ def main():
     first_cb = keys[0][3]
     bad = bytearray(ct[:first_cb]); bad[1] ^= 1; bad[-1] ^= 1
     rejected_wrong = not api.verify_encryption(vk, all_proofs[0][0][0], bytes(bad))
-    elapsed, acc_sum, tot_sum, neg_sum = sharding.reduce_report(elapsed, accepted, total, int(rejected_wrong), device="cuda" if use_dist else None)
+    elapsed, acc_sum, tot_sum, neg_sum = sharding.reduce_report(elapsed, accepted, total, int(rejected_wrong), device="cuda" if (use_dist and backend == "nccl") else None)
     ok = [acc_sum, tot_sum, neg_sum]
 
     if rank == 0:
