@@ -1,0 +1,88 @@
+//! Bindings + safe wrappers for libzkaes (include/zkaes.h): the MI355X implementation of zk_aes::{synthesize_keys, encrypt, verify_encryption}.
+//!
+//! In `zk-aes` the three functions of src/lib.rs (:60, :116, :138) become one-liners over `zkaes_sys::{synthesize_keys, encrypt,
+//! verify_encryption}`; proofs cross the boundary as the ark-serialize bytes of `ark_marlin::Proof`, verifying keys (optionally) as the
+//! ark-serialize bytes of `IndexVerifierKey` (`VerifyingKey::to_ark_bytes`), the proving key stays a device-resident handle.
+use anyhow::{anyhow, Result};
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_int};
+use std::sync::Arc;
+
+#[repr(C)]
+pub struct zkaes_pk { _private: [u8; 0] }
+#[repr(C)]
+pub struct zkaes_vk { _private: [u8; 0] }
+
+extern "C" {
+    fn zkaes_last_error() -> *const c_char;
+    fn zkaes_bytes_free(p: *mut u8);
+    fn zkaes_pk_free(pk: *mut zkaes_pk);
+    fn zkaes_vk_free(vk: *mut zkaes_vk);
+    fn zkaes_synthesize_keys(plaintext_length: usize, pk: *mut *mut zkaes_pk, vk: *mut *mut zkaes_vk) -> c_int;
+    fn zkaes_encrypt(message: *const u8, message_len: usize, secret_key: *const u8, pk: *const zkaes_pk, proof: *mut *mut u8, proof_len: *mut usize) -> c_int;
+    fn zkaes_verify_encryption(vk: *const zkaes_vk, proof: *const u8, proof_len: usize, ciphertext: *const u8, ciphertext_len: usize, accepted: *mut c_int) -> c_int;
+    fn zkaes_vk_serialize_ark(vk: *const zkaes_vk, out: *mut *mut u8, out_len: *mut usize) -> c_int;
+    fn zkaes_vk_deserialize_ark(bytes: *const u8, len: usize, vk: *mut *mut zkaes_vk) -> c_int;
+}
+
+fn last_error() -> anyhow::Error {
+    // thread-local message of the failing call (mirrors the anyhow::Error the reference returns)
+    let msg = unsafe { CStr::from_ptr(zkaes_last_error()) }.to_string_lossy().into_owned();
+    anyhow!(msg)
+}
+fn take_bytes(p: *mut u8, n: usize) -> Vec<u8> {
+    let v = unsafe { std::slice::from_raw_parts(p, n) }.to_vec();
+    unsafe { zkaes_bytes_free(p) };
+    v
+}
+
+struct PkHandle(*mut zkaes_pk);
+struct VkHandle(*mut zkaes_vk);
+// the handles are immutable after synthesis and libzkaes serialises access to its prover contexts internally
+unsafe impl Send for PkHandle {}
+unsafe impl Sync for PkHandle {}
+unsafe impl Send for VkHandle {}
+unsafe impl Sync for VkHandle {}
+impl Drop for PkHandle { fn drop(&mut self) { unsafe { zkaes_pk_free(self.0) } } }
+impl Drop for VkHandle { fn drop(&mut self) { unsafe { zkaes_vk_free(self.0) } } }
+
+/// Keys are passed by value in the reference API and callers `.clone()` them per call (tests/integration_tests.rs:330): Clone = Arc clone.
+#[derive(Clone)]
+pub struct ProvingKey(Arc<PkHandle>);
+#[derive(Clone)]
+pub struct VerifyingKey(Arc<VkHandle>);
+
+impl VerifyingKey {
+    /// ark-serialize bytes of `ark_marlin::IndexVerifierKey` -- feed to `simpleworks::marlin::VerifyingKey::deserialize`
+    pub fn to_ark_bytes(&self) -> Result<Vec<u8>> {
+        let (mut p, mut n) = (std::ptr::null_mut(), 0usize);
+        if unsafe { zkaes_vk_serialize_ark((self.0).0, &mut p, &mut n) } != 0 { return Err(last_error()); }
+        Ok(take_bytes(p, n))
+    }
+    pub fn from_ark_bytes(bytes: &[u8]) -> Result<Self> {
+        let mut vk = std::ptr::null_mut();
+        if unsafe { zkaes_vk_deserialize_ark(bytes.as_ptr(), bytes.len(), &mut vk) } != 0 { return Err(last_error()); }
+        Ok(VerifyingKey(Arc::new(VkHandle(vk))))
+    }
+}
+
+/// zk_aes::synthesize_keys (src/lib.rs:138)
+pub fn synthesize_keys(plaintext_length: usize) -> Result<(ProvingKey, VerifyingKey)> {
+    let (mut pk, mut vk) = (std::ptr::null_mut(), std::ptr::null_mut());
+    if unsafe { zkaes_synthesize_keys(plaintext_length, &mut pk, &mut vk) } != 0 { return Err(last_error()); }
+    Ok((ProvingKey(Arc::new(PkHandle(pk))), VerifyingKey(Arc::new(VkHandle(vk)))))
+}
+
+/// zk_aes::encrypt (src/lib.rs:60): returns the ark-serialize bytes of the MarlinProof (`deserialize_proof(bytes)` gives the arkworks type)
+pub fn encrypt(message: &[u8], secret_key: &[u8; 16], proving_key: &ProvingKey) -> Result<Vec<u8>> {
+    let (mut p, mut n) = (std::ptr::null_mut(), 0usize);
+    if unsafe { zkaes_encrypt(message.as_ptr(), message.len(), secret_key.as_ptr(), (proving_key.0).0, &mut p, &mut n) } != 0 { return Err(last_error()); }
+    Ok(take_bytes(p, n))
+}
+
+/// zk_aes::verify_encryption (src/lib.rs:116): Ok(false) for a wrong ciphertext, Err only for malformed input
+pub fn verify_encryption(verifying_key: &VerifyingKey, proof: &[u8], ciphertext: &[u8]) -> Result<bool> {
+    let mut accepted: c_int = 0;
+    if unsafe { zkaes_verify_encryption((verifying_key.0).0, proof.as_ptr(), proof.len(), ciphertext.as_ptr(), ciphertext.len(), &mut accepted) } != 0 { return Err(last_error()); }
+    Ok(accepted != 0)
+}
