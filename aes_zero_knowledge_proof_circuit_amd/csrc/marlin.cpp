@@ -352,6 +352,7 @@ struct KzgRand { bool hiding = false; Fr b[3]; };
 // chunk-proofs concurrently (zkaes_encrypt_chunked): the latency-bound phases of one proof (bucket reductions, scans, host
 // transcript work) overlap with the throughput-bound kernels of the others.
 struct ProverContext {
+    std::mutex in_use;                                // one proof at a time per context: concurrent callers of one key queue up here
     gpu::stream_t stream = nullptr;
     gpu::MsmWorkspace *msm_ws = nullptr;
     uint8_t *d_trace = nullptr, *d_z = nullptr, *d_msg = nullptr, *d_key = nullptr;
@@ -714,6 +715,7 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
 }
 
 Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const uint8_t *msg, size_t len, const uint8_t *key, const uint8_t *zk_seed) {
+    std::lock_guard<std::mutex> busy(cx.in_use);
     const Circuit &c = circuit;
     gpu::stream_t s = cx.stream;
     auto &d_trace = cx.d_trace; auto &d_z = cx.d_z; auto &d_msg = cx.d_msg; auto &d_key = cx.d_key;
@@ -917,6 +919,7 @@ std::vector<uint8_t> ProvingKey::aes_witness(const uint8_t *message, size_t len,
     if (len != impl->circuit.n_blocks * 16) throw std::invalid_argument("InstanceDoesNotMatchIndex: proving key was synthesized for " + std::to_string(impl->circuit.n_blocks * 16) + " bytes");
     const Circuit &c = impl->circuit;
     ProverContext &cx = impl->context(0);
+    std::lock_guard<std::mutex> busy(cx.in_use);
     gpu::stream_t s = cx.stream;
     gpu::h2d(cx.d_msg, message, len, s); gpu::h2d(cx.d_key, key, 16, s);
     gpu::aes_trace(cx.d_trace, c.trace_bytes, cx.d_msg, cx.d_key, 1, (uint32_t)c.n_blocks, s);

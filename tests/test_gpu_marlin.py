@@ -178,3 +178,24 @@ def test_empty_message_and_size_limits(api):
     assert api.verify_encryption(vk, proof, bytes(16)) is False        # instance length does not match the index
     with pytest.raises(api.ZkAesError, match="IndexTooLarge"):
         api.synthesize_keys(112)
+
+
+def test_concurrent_encrypt_calls_on_one_key(zko, api, aes16):
+    """callers may share a proving key across threads (the Rust wrapper is Send + Sync): concurrent zkaes_encrypt calls on one handle queue on the
+    prover context instead of racing; every proof equals the one a lone call produces (proofs are deterministic)"""
+    import threading
+    pk, vk = aes16
+    msgs = [mt_bytes(16, 900 + i) for i in range(6)]
+    key = mt_bytes(16, 899)
+    expected = [api.encrypt(m, key, pk) for m in msgs]
+    got = [None] * len(msgs)
+
+    def run(i):
+        got[i] = api.encrypt(msgs[i], key, pk)
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(len(msgs))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert got == expected
+    assert all(api.verify_encryption(vk, p, zko.aes_encrypt(m, key)) for m, p in zip(msgs, got))
