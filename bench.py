@@ -153,12 +153,13 @@ def main():
         acc_ms, pts, launches = stats["accumulate_ms"], stats["points"], stats["launches"]
         achieved = (128.0 * pts / 1e9) / (acc_ms / 1e3) if acc_ms > 0 else 0.0
         # HBM traffic per launch: the PMC pass of the same kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, calibrated on a
-        # known byte count of the same access pattern -- profiles/r01_pmc_k_accumulate_v11.json) gives bytes per (point, window) gather;
+        # known byte count of the same access pattern -- profiles/r01_pmc_k_accumulate_v12.json) gives bytes per (point, window) gather;
         # scaled by the (point, window) pairs this run's launches actually processed.
-        traffic = None
+        traffic = valu_busy = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_k_accumulate_v11.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_k_accumulate_v12.json")))
             traffic = round(pmc["hbm_bytes_per_point_window"] * stats["pairs"] / max(launches, 1))
+            valu_busy = round(pmc.get("valu_busy_percent", 0.0), 1) or None
         except Exception:
             pass
         try:
@@ -180,7 +181,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_accumulate (Pippenger bucket accumulation)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "peak_measured_stream_copy": copy_gbs,
-                         "traffic_source": "profiles/r01_pmc_k_accumulate_v11.json (PMC bytes per point-window x pairs of this run)",
+                         "valu_busy_percent": valu_busy,       # rocprofv3 PMC pass on the isolated kernel (same file as `traffic`): VALUBusy
+                         "traffic_source": "profiles/r01_pmc_k_accumulate_v12.json (PMC bytes per point-window x pairs of this run)",
                          "int_multiplier": {"unit": "T v_mad_u64_u32/s", "achieved": round(3416.0 * stats["pairs"] / 1e12 / (acc_ms / 1e3), 2) if acc_ms > 0 else 0.0,
                                             "peak": 28.1, "frac": round(3416.0 * stats["pairs"] / 1e12 / (acc_ms / 1e3) / 28.1, 4) if acc_ms > 0 else 0.0,
                                             "frac_of_wall": round(3416.0 * stats["pairs"] / 1e12 / elapsed / 28.1, 4),

@@ -21,7 +21,8 @@ out_dir = os.path.join("gpurun_out", "pmc_" + tag)
 os.makedirs(out_dir, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
 PASSES = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"],
-          "sq": ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"]}
+          "sq": ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"],
+          "valu": ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"]}
 
 
 def collect(name, counters):
@@ -64,6 +65,9 @@ res = {
     "kernel": "k_accumulate (%s), n = 2^%d points, %d signed-digit windows of 17 bits, averages over %d launches" % (tag, lg, nwin, counts[("k_accumulate", "FETCH_SIZE")]),
     "command": "rocprofv3 --pmc <one counter group> --kernel-trace --output-format csv -- python tools/ubench/msm_one.py %d 0   (three separate passes: %s)" % (lg, PASSES),
     "counters": {c: vals[("k_accumulate", c)] for grp in PASSES.values() for c in grp},
+    # rocprofv3's derived VALUBusy = 100 * SQ_ACTIVE_INST_VALU * 4 / SIMD_NUM / GRBM_GUI_ACTIVE with GRBM_GUI_ACTIVE per XCD (the raw counter is the
+    # sum over the 8 XCDs) and 1024 SIMDs: share of cycles in which a SIMD is executing a VALU instruction
+    "valu_busy_percent": 100.0 * vals[("k_accumulate", "SQ_ACTIVE_INST_VALU")] * 4 / 1024 / (vals[("k_accumulate", "GRBM_GUI_ACTIVE")] / 8),
     "units": "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them",
     "calibration": cal,
     "algorithmic_bytes_per_launch": 128 * n,
