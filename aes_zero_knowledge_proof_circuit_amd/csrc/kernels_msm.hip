@@ -107,13 +107,24 @@ __global__ void __launch_bounds__(64) k_table_next(const Affine<Fq> *__restrict_
     }
 }
 
+// four consecutive sorted keys per lane (one 16-byte load + the two neighbours): a group starts where the key changes
 __global__ void k_bounds(const uint32_t *__restrict__ keys, size_t total, uint32_t nb, uint32_t *__restrict__ start, uint32_t *__restrict__ end) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    uint32_t k = keys[i];
-    if (k >= nb) return;                       // zero digits
-    if (i == 0 || keys[i - 1] != k) start[k] = (uint32_t)i;
-    if (i + 1 == total || keys[i + 1] != k) end[k] = (uint32_t)(i + 1);
+    size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= total) return;
+    uint32_t k[6];                                        // k[0] = key before the quad, k[5] = key after it
+    if (i0 + 4 <= total) { uint4 v = *reinterpret_cast<const uint4 *>(keys + i0); k[1] = v.x; k[2] = v.y; k[3] = v.z; k[4] = v.w; }
+    else { for (int j = 0; j < 4; j++) k[1 + j] = i0 + j < total ? keys[i0 + j] : 0xffffffffu; }
+    k[0] = i0 ? keys[i0 - 1] : 0xffffffffu;
+    k[5] = i0 + 4 < total ? keys[i0 + 4] : 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        size_t i = i0 + j;
+        if (i >= total) break;
+        uint32_t key = k[1 + j];
+        if (key >= nb) continue;                          // table-mode marker for zero digits
+        if (i == 0 || k[j] != key) start[key] = (uint32_t)i;
+        if (i + 1 == total || k[2 + j] != key) end[key] = (uint32_t)(i + 1);
+    }
 }
 
 // standard (12 x 32, R = 2^384) bases -> reduced-radix copies; done once per SRS at key synthesis, or per call for ad-hoc bases
@@ -364,7 +375,7 @@ static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int
     HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp, tmp_bytes, S.keys_a, S.keys_b, S.vals_a, S.vals_b, (int)pairs, 0, key_bits, s));
     HIP_CHECK(hipMemsetAsync(S.start, 0, nb * 4, s));
     HIP_CHECK(hipMemsetAsync(S.end, 0, nb * 4, s));
-    hipLaunchKernelGGL(k_bounds, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, S.keys_b, pairs, (uint32_t)nb, S.start, S.end);
+    hipLaunchKernelGGL(k_bounds, dim3((unsigned)(((pairs + 3) / 4 + 255) / 256)), dim3(256), 0, s, S.keys_b, pairs, (uint32_t)nb, S.start, S.end);
     HIP_LAUNCH_CHECK();
     // size-balanced visiting order of the buckets
     HIP_CHECK(hipMemsetAsync(S.extra + nb, 0, 4, s));
