@@ -90,6 +90,8 @@ void poly_set_at(F *p, size_t idx, const F &val, stream_t s);                 //
 void poly_add_at(F *p, size_t idx, const F &val, stream_t s);                 // p[idx] += val
 void poly_axpy(F *acc, const F *p, const F &sc, size_t n, stream_t s);        // acc[i] += sc * p[i]
 void poly_scale(F *p, const F &sc, size_t n, stream_t s);                     // p[i] *= sc
+// out[i] = sum_j scalars[j] * polys[j][i] for i < n, each polynomial contributing only below its own length (1..8 terms)
+void poly_lincomb_n(F *out, size_t n, const F *const *polys, const size_t *lens, const F *scalars, int count, stream_t s);
 void poly_lincomb3(F *out, const F *a, const F *b, const F *c, const F &sa, const F &sb, const F &sc, size_t n, stream_t s);
 // q = p / (X^m - 1) (len - m coefficients), rem = remainder (m coefficients); requires len > m
 void divide_by_vanishing(F *q, F *rem, const F *p, size_t len, size_t m, stream_t s);

@@ -30,6 +30,23 @@ void poly_lincomb3(F *out, const F *a, const F *b, const F *c, const F &sa, cons
     if (!n) return;
     hipLaunchKernelGGL(k_lincomb3, GRID(n), 0, (hipStream_t)s, out, a, b, c, sa, sb, sc, n); HIP_LAUNCH_CHECK();
 }
+// out[i] = sum_j sc[j] * p[j][i] over the (up to 8) polynomials long enough to have a coefficient i: the opening combinations in ONE pass
+struct LincombArgs { const F *p[8]; size_t len[8]; F sc[8]; int count; };
+__global__ void k_lincomb_n(F *__restrict__ out, LincombArgs a, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F acc = F::zero();
+    for (int j = 0; j < a.count; j++) if (i < a.len[j]) acc = acc + a.sc[j] * a.p[j][i];
+    out[i] = acc;
+}
+void poly_lincomb_n(F *out, size_t n, const F *const *polys, const size_t *lens, const F *scalars, int count, stream_t s) {
+    if (!n) return;
+    if (count < 1 || count > 8) throw GpuError("poly_lincomb_n: 1..8 terms");
+    LincombArgs a;
+    a.count = count;
+    for (int j = 0; j < 8; j++) { a.p[j] = j < count ? polys[j] : nullptr; a.len[j] = j < count ? lens[j] : 0; a.sc[j] = j < count ? scalars[j] : F::zero(); }
+    hipLaunchKernelGGL(k_lincomb_n, GRID(n), 0, (hipStream_t)s, out, a, n); HIP_LAUNCH_CHECK();
+}
 __global__ void k_sub_from_scalar(F *__restrict__ out, const F *__restrict__ v, F sc, size_t n) { size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = sc - v[i]; }
 void sub_from_scalar(F *out, const F *v, const F &sc, size_t n, stream_t s) { if (!n) return; hipLaunchKernelGGL(k_sub_from_scalar, GRID(n), 0, (hipStream_t)s, out, v, sc, n); HIP_LAUNCH_CHECK(); }
 

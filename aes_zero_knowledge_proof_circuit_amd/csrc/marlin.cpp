@@ -854,15 +854,14 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     auto host_eval3 = [](const Fr p[3], const Fr &z) { return p[0] + z * (p[1] + z * p[2]); };
     {   // open at beta: g_1 (ch^0; shifted ch^1), outer_sumcheck (ch^2), t (ch^3), z_b (ch^4)
         size_t plen = 3 * n;
-        gpu::dzero(acc.p, plen * sizeof(F), s);
         Fr rb[3] = {Fr::zero(), Fr::zero(), Fr::zero()};
-        gpu::poly_axpy(acc.p, poly[5].p, chp[0], poly_len[5], s); rand_axpy(rb, chp[0], r2[1].rand);
-        gpu::poly_axpy(acc.p, poly[3].p, chp[2], poly_len[3], s);
-        gpu::poly_axpy(acc.p, poly[1].p, chp[2] * c_za, poly_len[1], s); rand_axpy(rb, chp[2] * c_za, r1[1].rand);
-        gpu::poly_axpy(acc.p, poly[0].p, chp[2] * c_w, poly_len[0], s); rand_axpy(rb, chp[2] * c_w, r1[0].rand);
-        gpu::poly_axpy(acc.p, poly[6].p, chp[2] * c_h1, poly_len[6], s);
-        gpu::poly_axpy(acc.p, poly[4].p, chp[3], poly_len[4], s);
-        gpu::poly_axpy(acc.p, poly[2].p, chp[4], poly_len[2], s); rand_axpy(rb, chp[4], r1[2].rand);
+        {
+            const F *ps[7] = {poly[5].p, poly[3].p, poly[1].p, poly[0].p, poly[6].p, poly[4].p, poly[2].p};
+            size_t ls[7] = {poly_len[5], poly_len[3], poly_len[1], poly_len[0], poly_len[6], poly_len[4], poly_len[2]};
+            Fr sc[7] = {chp[0], chp[2], chp[2] * c_za, chp[2] * c_w, chp[2] * c_h1, chp[3], chp[4]};
+            gpu::poly_lincomb_n(acc.p, plen, ps, ls, sc, 7, s);
+        }
+        rand_axpy(rb, chp[0], r2[1].rand); rand_axpy(rb, chp[2] * c_za, r1[1].rand); rand_axpy(rb, chp[2] * c_w, r1[0].rand); rand_axpy(rb, chp[4], r1[2].rand);
         gpu::divide_by_linear(wit.p, acc.p, plen, beta, scratch.p, scratch.n, s);
         // shifted part (g_1, degree bound |H| - 2) rides in the same Pippenger instance
         gpu::divide_by_linear(wit2.p, poly[5].p, poly_len[5], beta, scratch.p, scratch.n, s);
@@ -879,15 +878,12 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     }
     {   // open at gamma: g_2 (ch^0; shifted ch^1), inner_sumcheck (ch^2)
         size_t plen = k;
-        gpu::dzero(acc.p, plen * sizeof(F), s);
-        gpu::poly_axpy(acc.p, poly[7].p, chp[0], poly_len[7], s);
-        gpu::poly_axpy(acc.p, ix_co[2].p, chp[2] * ea_vv, k, s);
-        gpu::poly_axpy(acc.p, ix_co[3].p, chp[2] * eb_vv, k, s);
-        gpu::poly_axpy(acc.p, ix_co[4].p, chp[2] * ec_vv, k, s);
-        gpu::poly_axpy(acc.p, ix_co[0].p, chp[2] * c_row, k, s);
-        gpu::poly_axpy(acc.p, ix_co[1].p, chp[2] * c_col, k, s);
-        gpu::poly_axpy(acc.p, ix_co[5].p, chp[2] * c_rc, k, s);
-        gpu::poly_axpy(acc.p, poly[8].p, chp[2] * c_h2, poly_len[8], s);
+        {
+            const F *ps[8] = {poly[7].p, ix_co[2].p, ix_co[3].p, ix_co[4].p, ix_co[0].p, ix_co[1].p, ix_co[5].p, poly[8].p};
+            size_t ls[8] = {poly_len[7], k, k, k, k, k, k, poly_len[8]};
+            Fr sc[8] = {chp[0], chp[2] * ea_vv, chp[2] * eb_vv, chp[2] * ec_vv, chp[2] * c_row, chp[2] * c_col, chp[2] * c_rc, chp[2] * c_h2};
+            gpu::poly_lincomb_n(acc.p, plen, ps, ls, sc, 8, s);
+        }
         gpu::divide_by_linear(wit.p, acc.p, plen, gamma, scratch.p, scratch.n, s);
         gpu::divide_by_linear(wit2.p, poly[7].p, poly_len[7], gamma, scratch.p, scratch.n, s);
         gpu::poly_scale(wit2.p, chp[1], poly_len[7] - 1, s);

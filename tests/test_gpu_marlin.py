@@ -199,3 +199,19 @@ def test_concurrent_encrypt_calls_on_one_key(zko, api, aes16):
         t.join()
     assert got == expected
     assert all(api.verify_encryption(vk, p, zko.aes_encrypt(m, key)) for m, p in zip(msgs, got))
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(not os.environ.get("ZKAES_LONG_TESTS"), reason="about ten minutes of CPU for the oracle: set ZKAES_LONG_TESTS=1 (tools/parity_full.py is the same check as a script)")
+def test_aes96_proof_bytes_identical_to_oracle_at_the_bench_size(zko, api):
+    """the bench configuration itself: 6-block chunk-proof, |H| = 2^20, |K| = 2^22, the reference's SRS literal"""
+    msg, key = mt_bytes(96, 5), mt_bytes(16, 6)
+    pk, vk = api.synthesize_keys(96)
+    proof = api.encrypt(msg, key, pk)
+    cs, _ = zko.synth_aes(bytes(96), bytes(16))
+    ix = zko.Index(cs)
+    cs, _ = zko.synth_aes(msg, key)
+    ref = ix.prove(cs)
+    for poly in zko.POLY_NAMES:
+        assert pk.debug_fetch(poly) == ref.poly(poly), poly
+    assert proof == ref.to_bytes()
