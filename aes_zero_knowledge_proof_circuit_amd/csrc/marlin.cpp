@@ -387,6 +387,8 @@ class ProvingKeyImpl {
     int lg_n = 0, lg_k = 0, lg_m = 0;
     size_t max_degree = 0, supported_degree = 0, lowest_shift = 0, bounds[2] = {0, 0};
     Fr srs_beta;
+    int device = 0;                            // the HIP device this key (SRS, index, contexts) lives on; every entry point re-selects it,
+                                               // because HIP's current device is per thread and callers may arrive on fresh threads
     G1A gamma_powers[3];
     // device: SRS as precomputed window tables: copy j holds 2^(table_c * j) * powers_of_g[i] (gpu.hpp msm_table)
     Affine28<Fq377P> *d_powers = nullptr, *d_shifted = nullptr;   // reduced-radix copies (ff28.cuh) -- what k_accumulate gathers
@@ -421,6 +423,7 @@ class ProvingKeyImpl {
     }
     // context i, created on first use (workspace allocation happens outside any timed region when callers warm up)
     ProverContext &context(size_t i) {
+        gpu::set_device(device);
         std::lock_guard<std::mutex> g(ctx_mu);
         while (ctxs.size() <= i) {
             std::unique_ptr<ProverContext> c(new ProverContext());
@@ -530,6 +533,7 @@ class ProvingKeyImpl {
 
 void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs) {
     gpu::require_device();
+    device = gpu::current_device();
     message_len = message_len_;
     std::unique_ptr<ProverContext> cx0(new ProverContext());
     gpu::stream_t stream = cx0->stream;
@@ -715,6 +719,7 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
 }
 
 Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const uint8_t *msg, size_t len, const uint8_t *key, const uint8_t *zk_seed) {
+    gpu::set_device(device);
     std::lock_guard<std::mutex> busy(cx.in_use);
     const Circuit &c = circuit;
     gpu::stream_t s = cx.stream;
@@ -899,7 +904,7 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     return pf;
 }
 
-ProvingKey::~ProvingKey() { delete impl; }
+ProvingKey::~ProvingKey() { if (impl) { try { gpu::set_device(impl->device); } catch (...) {} } delete impl; }
 const VerifyingKey &ProvingKey::vk() const { return impl->vk; }
 const Circuit &ProvingKey::circuit() const { return impl->circuit; }
 const ProverTimings &ProvingKey::last_timings() const { return impl->last_timings; }
@@ -932,7 +937,7 @@ static std::vector<Proof> prove_many(ProvingKeyImpl *impl, const uint8_t *messag
     for (size_t i = 0; i < n_contexts; i++) impl->context(i);           // allocate outside the worker threads
     std::atomic<size_t> next{0};
     std::vector<std::string> errors(n_contexts);
-    int device = gpu::current_device();
+    const int device = impl->device;
     auto worker = [&](size_t ci) {
         try {
             gpu::set_device(device);

@@ -105,6 +105,7 @@ def main():
         out = [None] * len(keys)
 
         def run(i):
+            api.set_device(local_rank)                        # HIP's current device is per thread (libzkaes re-selects the key's device itself, too)
             (kpk, _), lo, hi, cb = keys[i]
             out[i] = kpk.encrypt_chunked(msg[lo:hi], key)     # ctypes releases the GIL: the remainder key proves alongside the main one
         threads = [threading.Thread(target=run, args=(i,)) for i in range(1, len(keys))]
