@@ -32,7 +32,9 @@ void zkaes_pk_free(zkaes_pk *pk);
 void zkaes_vk_free(zkaes_vk *vk);
 /* number of visible HIP devices (0 on a host without a GPU) */
 int zkaes_device_count(void);
-/* select the HIP device subsequent key handles are created on (one process per GPU) */
+/* select the HIP device for the CALLING THREAD (hipSetDevice semantics): key handles synthesized afterwards live on it, and the kernel-level
+ * entry points below run on it.  A proving key remembers its device: zkaes_encrypt* / zkaes_prove_ops re-select it on whatever thread calls them.
+ * Intended deployment: one process per GPU (the NTT twiddle cache is per process). */
 int zkaes_set_device(int ordinal);
 
 /* ---- the reference's public API ------------------------------------------------------------------------------- */
