@@ -319,6 +319,7 @@ constexpr uint32_t DEFERRED_CAP = 1u << 20;
 struct MsmWorkspace {
     size_t cap_pairs = 0, cap_buckets = 0, cap_tmp = 0;
     uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr, *start = nullptr, *end = nullptr;
+    uint32_t *sorted_keys = nullptr, *sorted_vals = nullptr;      // whichever half of the double buffers the radix sort finished in
     uint32_t *size_key = nullptr, *size_key2 = nullptr, *ids = nullptr, *order = nullptr, *extra = nullptr, *extra_off = nullptr;
     void *ovf_partial = nullptr; size_t cap_ovf = 0;
     size_t plan_n = 0, plan_pairs = 0; int plan_c = 0, plan_nwin = 0;     // state between msm_prepare and msm_finish
@@ -370,12 +371,15 @@ static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int
     while (((size_t)1 << key_bits) <= nb) key_bits++;
     if (sort_bits > 0 && sort_bits < key_bits) key_bits = sort_bits;       // stable sort on the bucket bits only (window-major input)
     size_t tmp_bytes = 0;
-    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys_a, S.keys_b, S.vals_a, S.vals_b, (int)pairs, 0, key_bits, s));
+    // ping-pong sort: the result stays in whichever buffer the last radix pass wrote (no copy back)
+    hipcub::DoubleBuffer<uint32_t> dk(S.keys_a, S.keys_b), dv(S.vals_a, S.vals_b);
+    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, dk, dv, (int)pairs, 0, key_bits, s));
     if (tmp_bytes > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tmp_bytes); S.cap_tmp = tmp_bytes; }
-    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp, tmp_bytes, S.keys_a, S.keys_b, S.vals_a, S.vals_b, (int)pairs, 0, key_bits, s));
+    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp, tmp_bytes, dk, dv, (int)pairs, 0, key_bits, s));
+    S.sorted_keys = dk.Current(); S.sorted_vals = dv.Current();
     HIP_CHECK(hipMemsetAsync(S.start, 0, nb * 4, s));
     HIP_CHECK(hipMemsetAsync(S.end, 0, nb * 4, s));
-    hipLaunchKernelGGL(k_bounds, dim3((unsigned)(((pairs + 3) / 4 + 255) / 256)), dim3(256), 0, s, S.keys_b, pairs, (uint32_t)nb, S.start, S.end);
+    hipLaunchKernelGGL(k_bounds, dim3((unsigned)(((pairs + 3) / 4 + 255) / 256)), dim3(256), 0, s, S.sorted_keys, pairs, (uint32_t)nb, S.start, S.end);
     HIP_LAUNCH_CHECK();
     // size-balanced visiting order of the buckets
     HIP_CHECK(hipMemsetAsync(S.extra + nb, 0, 4, s));
@@ -402,13 +406,13 @@ static std::vector<XYZZ<Fp<P>>> run_buckets(MsmWorkspace &S, const Affine28<P> *
     size_t nb = (size_t)nsets << c;
     HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 4, s));
     HIP_CHECK(hipEventRecord(S.ev0, s));
-    hipLaunchKernelGGL((k_accumulate<P>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, bases, S.vals_b, S.start, S.end, S.order, (uint32_t)nb,
+    hipLaunchKernelGGL((k_accumulate<P>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, bases, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb,
                        (Acc28<P> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
     HIP_CHECK(hipEventRecord(S.ev1, s));
     {   // oversized buckets (none for uniformly distributed digits: both kernels exit at once)
         uint32_t max_seg = (uint32_t)(pairs / BUCKET_CAP + 1);
-        hipLaunchKernelGGL((k_accumulate_overflow<P>), dim3((max_seg + 63) / 64), dim3(64), 0, s, bases, S.vals_b, S.start, S.end, S.extra_off, (uint32_t)nb, max_seg,
+        hipLaunchKernelGGL((k_accumulate_overflow<P>), dim3((max_seg + 63) / 64), dim3(64), 0, s, bases, S.sorted_vals, S.start, S.end, S.extra_off, (uint32_t)nb, max_seg,
                            (Acc28<P> *)S.ovf_partial, S.deferred, DEFERRED_CAP, S.deferred_count);
         HIP_LAUNCH_CHECK();
         hipLaunchKernelGGL((k_combine_overflow<P>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, (Acc28<P> *)S.buckets, S.extra_off, (uint32_t)nb, max_seg, (const Acc28<P> *)S.ovf_partial);
