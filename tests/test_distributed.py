@@ -1,4 +1,5 @@
 """CPU test of the N > 1 path: two gloo ranks shard chunk-proofs, reduce the report the way bench.py does."""
+import json
 import os
 import socket
 import sys
@@ -49,6 +50,127 @@ def test_two_rank_report_reduction():
     assert r0[5] == r1[5] and r0[6] != r1[6]           # shared key, per-rank message
     assert r0[7] == (0, 4) and r1[7] == (4, 7)         # contiguous split of 7 chunks
     assert sharding.aggregate_value(2, 12, 3, 2.0) == 36.0
+
+
+# ---- bench.py's own rank path (bench.run) on two gloo ranks with a stub prover: strong scaling = ONE job sharded by chunk range, proofs
+# all-gathered, rank 0 verifies every one (BASELINE configs[3] / [4]); weak scaling = every rank its own message (configs[2])
+class _StubKey:
+    def __init__(self, nbytes, log):
+        self.nbytes, self.log = nbytes, log
+
+    def info(self):
+        return {"raw_instance": 8 * self.nbytes + 1, "h": 1 << 20, "k": 1 << 22}
+
+    def timings(self):
+        return dict(witness_ms=0.0, round1_ms=0.0, round2_ms=0.0, round3_ms=0.0, open_ms=0.0, total_ms=0.0)
+
+    @staticmethod
+    def make(ct):
+        import hashlib
+        return (hashlib.sha256(bytes(ct)).digest() * 27)[:855]          # a "proof" is a digest of the ciphertext it attests
+
+    def encrypt_chunked(self, message, key):
+        from oracle import zko
+        n = self.nbytes
+        assert len(message) % n == 0
+        self.log.append(("chunked", n, len(message) // n))
+        return [self.make(zko.aes_encrypt(message[i:i + n], key)) for i in range(0, len(message), n)]
+
+    def encrypt_batch(self, messages, keys):
+        from oracle import zko
+        self.log.append(("batch", self.nbytes, len(messages)))
+        return [self.make(zko.aes_encrypt(m, k)) for m, k in zip(messages, keys)]
+
+
+class _StubApi:
+    """stands in for aes_zero_knowledge_proof_circuit_amd.api (no GPU here): same calls bench.run makes, proofs are ciphertext digests"""
+
+    def __init__(self):
+        self.log = []
+
+    def device_count(self):
+        return 1
+
+    def set_device(self, _):
+        pass
+
+    def synthesize_keys(self, nbytes):
+        k = _StubKey(nbytes, self.log)
+        return k, k
+
+    def msm_stats(self, reset=False):
+        return dict(accumulate_ms=0.0, total_ms=0.0, points=0, launches=0, pairs=0)
+
+    def verify_encryption(self, vk, proof, ct):
+        return len(ct) == vk.nbytes and proof == _StubKey.make(ct)
+
+    def stream_copy_bench(self, *a):
+        raise RuntimeError("no device")
+
+
+def _bench_worker(rank, world, port, argv, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), ZKAES_BENCH_BACKEND="gloo")
+    import contextlib
+    import io
+    import bench
+    api = _StubApi()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        res = bench.run(bench.build_parser().parse_args(argv), api)
+    timed = [e for e in api.log]
+    out[rank] = (res, timed, buf.getvalue())
+
+
+def _run_bench(argv, world=2):
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_bench_worker, args=(world, port, argv, out), nprocs=world, join=True)
+    return out
+
+
+def test_bench_strong_mode_two_ranks_gathers_and_verifies_every_proof():
+    out = _run_bench(["--gpus", "2", "--mode", "strong", "--blocks", "64", "--chunk", "6", "--steps", "2", "--warmup", "1", "--contexts", "3", "--no-cpu-baseline"])
+    res, log0, printed = out[0]
+    assert out[1][0] is None and out[1][2] == ""               # only rank 0 reports
+    assert json.loads(printed)["value"] == res["value"]         # ONE JSON line
+    assert res["scaling"] == "strong" and res["n_gpus"] == 2 and "error" not in res
+    assert res["proofs_verified"] == "11/11" and res["wrong_ciphertext_rejected"] is True     # 10 chunks of 6 blocks + 1 of 4, all on rank 0 after the gather
+    assert res["config"]["blocks_total"] == 64 and res["config"]["proofs_total"] == 11
+    # rank 0 proved chunks [0, 6) in two timed steps, rank 1 chunks [6, 11) = four 96-byte chunks + the 64-byte remainder (own key)
+    timed0 = [e for e in log0 if e[0] == "chunked"][1:]          # drop the warm-up call
+    assert [e for e in timed0 if e[1] == 96][:2] == [("chunked", 96, 3), ("chunked", 96, 3)]
+    log1 = out[1][1]
+    assert sum(e[2] for e in log1 if e[1] == 96) - 3 == 4 and ("chunked", 64, 1) in log1      # 3 = warm-up (contexts) chunk-proofs
+
+
+def test_bench_batch_mode_two_ranks():
+    out = _run_bench(["--gpus", "2", "--mode", "batch", "--proofs", "9", "--steps", "2", "--warmup", "0", "--no-cpu-baseline"])
+    res = out[0][0]
+    assert res["scaling"] == "strong" and res["proofs_verified"] == "9/9" and "error" not in res
+    assert sum(e[2] for e in out[0][1] if e[0] == "batch") == 5 and sum(e[2] for e in out[1][1] if e[0] == "batch") == 4
+
+
+def test_bench_headline_mode_two_ranks_is_weak_scaling():
+    out = _run_bench(["--gpus", "2", "--blocks", "10", "--chunk", "4", "--steps", "3", "--warmup", "1", "--contexts", "2", "--no-cpu-baseline"])
+    res = out[0][0]
+    assert res["scaling"] == "weak" and res["proofs_verified"] == "6/6" and "error" not in res       # 2 ranks x (2 chunks of 4 + 1 of 2)
+    assert res["config"]["blocks_total"] == 20
+    assert abs(res["value"] * res["ms_per_step"] * 3 / 1e3 - 20) < 0.5                               # value = all ranks' blocks / timed region (ms_per_step is rounded)
+
+
+def _gather_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = [bytes([7]) * (855 - i) for i in range(3 if rank == 0 else 0)]                          # rank 1 contributes nothing
+    out[rank] = sharding.gather_proofs(mine)
+    dist.destroy_process_group()
+
+
+def test_gather_proofs_uneven_shares():
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_gather_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out[0] == out[1] == [b"\x07" * 855, b"\x07" * 854, b"\x07" * 853]
 
 
 def test_plan_edges():
