@@ -141,12 +141,16 @@ class ProvingKey:
         _check(lib().zkaes_prove_ops(self._p, C.c_uint32(x), C.c_uint32(y), zk_seed, C.byref(out), C.byref(n)))
         return _take(out, n)
 
-    def encrypt_chunked(self, message, secret_key):
+    def encrypt_chunked(self, message, secret_key, zk_seed=None):
+        if len(secret_key) != 16:
+            raise ZkAesError("secret_key must be 16 bytes")
+        if zk_seed is not None and len(zk_seed) != 32:
+            raise ZkAesError("zk_seed must be 32 bytes")
         chunk = (self.info()["raw_instance"] - 1) // 8          # 8 public-input bits per ciphertext byte
         n_chunks = len(message) // chunk
         lens = (C.c_size_t * max(n_chunks, 1))()
         out, n = C.c_void_p(), C.c_size_t()
-        _check(lib().zkaes_encrypt_chunked(bytes(message), C.c_size_t(len(message)), bytes(secret_key), self._p, C.byref(out), C.byref(n), lens, C.c_size_t(n_chunks)))
+        _check(lib().zkaes_encrypt_chunked_seeded(bytes(message), C.c_size_t(len(message)), bytes(secret_key), self._p, zk_seed, C.byref(out), C.byref(n), lens, C.c_size_t(n_chunks)))
         blob = _take(out, n)
         proofs, off = [], 0
         for i in range(n_chunks):
@@ -154,12 +158,22 @@ class ProvingKey:
             off += lens[i]
         return proofs
 
-    def encrypt_batch(self, messages, secret_keys):
-        """n independent proofs: messages = list of equal-length byte strings, secret_keys = list of 16-byte keys"""
+    def encrypt_batch(self, messages, secret_keys, zk_seed=None):
+        """n independent proofs: messages = list of equal-length byte strings (the key's plaintext length), secret_keys = list of 16-byte keys"""
         n = len(messages)
+        chunk = (self.info()["raw_instance"] - 1) // 8
+        if len(secret_keys) != n:
+            raise ZkAesError("one secret key per message")
+        if any(len(m) != chunk for m in messages):
+            raise ZkAesError("every message must be %d bytes (the key's plaintext length)" % chunk)
+        if any(len(k) != 16 for k in secret_keys):
+            raise ZkAesError("secret_key must be 16 bytes")
+        if zk_seed is not None and len(zk_seed) != 32:
+            raise ZkAesError("zk_seed must be 32 bytes")
         lens = (C.c_size_t * max(n, 1))()
         out, total = C.c_void_p(), C.c_size_t()
-        _check(lib().zkaes_encrypt_batch(C.c_size_t(n), b"".join(bytes(m) for m in messages), b"".join(bytes(k) for k in secret_keys), self._p, C.byref(out), C.byref(total), lens))
+        mb, kb = b"".join(bytes(m) for m in messages), b"".join(bytes(k) for k in secret_keys)
+        _check(lib().zkaes_encrypt_batch_seeded(C.c_size_t(n), mb, C.c_size_t(len(mb)), kb, C.c_size_t(len(kb)), self._p, zk_seed, C.byref(out), C.byref(total), lens))
         blob = _take(out, total)
         proofs, off = [], 0
         for i in range(n):

@@ -68,37 +68,45 @@ int zkaes_encrypt_seeded(const uint8_t *msg, size_t len, const uint8_t key[16], 
 int zkaes_encrypt(const uint8_t *msg, size_t len, const uint8_t key[16], const zkaes_pk *pk, uint8_t **proof, size_t *proof_len) {
     return zkaes_encrypt_seeded(msg, len, key, pk, nullptr, proof, proof_len);
 }
-int zkaes_encrypt_chunked(const uint8_t *msg, size_t len, const uint8_t key[16], const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens, size_t n_chunks) {
+static size_t default_contexts() {
+    size_t n_ctx = ZKAES_DEFAULT_CONTEXTS;
+    if (const char *e = getenv("ZKAES_CONTEXTS")) n_ctx = (size_t)std::max(1, atoi(e));
+    return n_ctx;
+}
+static void pack_proofs(const std::vector<zk::Proof> &ps, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens) {
+    std::vector<uint8_t> all;
+    for (size_t i = 0; i < ps.size(); i++) {
+        auto b = zk::serialize_proof(ps[i]);
+        if (proof_lens) proof_lens[i] = b.size();
+        all.insert(all.end(), b.begin(), b.end());
+    }
+    *proofs = give(all); *proofs_len = all.size();
+}
+int zkaes_encrypt_chunked_seeded(const uint8_t *msg, size_t len, const uint8_t key[16], const zkaes_pk *pk, const uint8_t *zk_seed32, uint8_t **proofs, size_t *proofs_len,
+                                 size_t *proof_lens, size_t n_chunks) {
     return guard([&] {
-        if (!pk || !proofs || !proofs_len) throw std::invalid_argument("null argument");
+        if (!pk || !proofs || !proofs_len || !key || (!msg && len)) throw std::invalid_argument("null argument");
         size_t chunk = pk->pk->circuit().n_blocks * 16;
         if (chunk == 0 || len % chunk || len / chunk != n_chunks) throw std::invalid_argument("message length must be n_chunks * the key's plaintext length");
-        std::vector<uint8_t> all;
-        size_t n_ctx = 4;
-        if (const char *e = getenv("ZKAES_CONTEXTS")) n_ctx = (size_t)std::max(1, atoi(e));
-        auto ps = pk->pk->prove_aes_chunked(msg, len, key, n_ctx);
-        for (size_t i = 0; i < n_chunks; i++) {
-            auto b = zk::serialize_proof(ps[i]);
-            if (proof_lens) proof_lens[i] = b.size();
-            all.insert(all.end(), b.begin(), b.end());
-        }
-        *proofs = give(all); *proofs_len = all.size();
+        pack_proofs(pk->pk->prove_aes_chunked(msg, len, key, default_contexts(), zk_seed32), proofs, proofs_len, proof_lens);
+    });
+}
+int zkaes_encrypt_chunked(const uint8_t *msg, size_t len, const uint8_t key[16], const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens, size_t n_chunks) {
+    return zkaes_encrypt_chunked_seeded(msg, len, key, pk, nullptr, proofs, proofs_len, proof_lens, n_chunks);
+}
+int zkaes_encrypt_batch_seeded(size_t n, const uint8_t *messages, size_t messages_len, const uint8_t *secret_keys, size_t secret_keys_len, const zkaes_pk *pk,
+                               const uint8_t *zk_seed32, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens) {
+    return guard([&] {
+        if (!pk || !proofs || !proofs_len || (n && (!messages || !secret_keys))) throw std::invalid_argument("null argument");
+        size_t chunk = pk->pk->circuit().n_blocks * 16;
+        if (messages_len != n * chunk) throw std::invalid_argument("messages must hold n x " + std::to_string(chunk) + " bytes (the key's plaintext length)");
+        if (secret_keys_len != n * 16) throw std::invalid_argument("secret_keys must hold n x 16 bytes");
+        pack_proofs(pk->pk->prove_aes_batch(messages, secret_keys, n, default_contexts(), zk_seed32), proofs, proofs_len, proof_lens);
     });
 }
 int zkaes_encrypt_batch(size_t n, const uint8_t *messages, const uint8_t *secret_keys, const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens) {
-    return guard([&] {
-        if (!pk || !proofs || !proofs_len) throw std::invalid_argument("null argument");
-        size_t n_ctx = 4;
-        if (const char *e = getenv("ZKAES_CONTEXTS")) n_ctx = (size_t)std::max(1, atoi(e));
-        auto ps = pk->pk->prove_aes_batch(messages, secret_keys, n, n_ctx);
-        std::vector<uint8_t> all;
-        for (size_t i = 0; i < n; i++) {
-            auto b = zk::serialize_proof(ps[i]);
-            if (proof_lens) proof_lens[i] = b.size();
-            all.insert(all.end(), b.begin(), b.end());
-        }
-        *proofs = give(all); *proofs_len = all.size();
-    });
+    size_t chunk = pk ? pk->pk->circuit().n_blocks * 16 : 0;
+    return zkaes_encrypt_batch_seeded(n, messages, n * chunk, secret_keys, n * 16, pk, nullptr, proofs, proofs_len, proof_lens);
 }
 int zkaes_prove_ops(const zkaes_pk *pk, uint32_t x, uint32_t y, const uint8_t *seed, uint8_t **proof, size_t *proof_len) {
     return guard([&] {

@@ -25,7 +25,8 @@ void d2h(void *dst, const void *src, size_t bytes, stream_t s);
 void d2d(void *dst, const void *src, size_t bytes, stream_t s);
 void dzero(void *dst, size_t bytes, stream_t s);
 void sync(stream_t s);
-stream_t stream_create();
+stream_t stream_create();                 // high priority unless ZKAES_STREAM_PRIORITY=0
+bool stream_priorities_enabled();
 void stream_destroy(stream_t s);
 // event timing on a stream (ms)
 void *event_create();

@@ -135,7 +135,7 @@ __global__ void k_convert_bases(const Affine<Fp<P>> *__restrict__ src, Affine28<
 }
 
 // A bucket lane adds at most BUCKET_CAP points; the rest of an oversized bucket (skewed scalars: many equal digits) is cut into
-// BUCKET_CAP-point overflow segments that k_accumulate_overflow sums in parallel and k_combine_overflow folds back -- so no input can
+// BUCKET_CAP-point overflow segments that k_accumulate_tail sums in parallel and k_reduce_l1 folds back -- so no input can
 // serialise the whole MSM on one lane.
 constexpr uint32_t BUCKET_CAP = 2048;
 __global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, uint32_t nb, uint32_t *__restrict__ size_key,
@@ -151,7 +151,7 @@ __global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_
 
 // ONE LANE PER BUCKET, buckets visited in descending-size order so the 64 lanes of a wave run the same trip count.
 // The loop body has no function call: the (cryptographically negligible, but reachable with repeated bases) P == +-Q case is
-// appended to a deferred list and replayed by k_accumulate_fixup with the complete addition law.  Buckets stay in the
+// appended to a deferred list and replayed by the last workgroup of k_accumulate_tail with the complete addition law.  Buckets stay in the
 // reduced-radix form through the reduction kernels; only the per-window sums are converted back for the host.
 template <class P>
 __global__ void __launch_bounds__(64, 2) k_accumulate(const Affine28<P> *__restrict__ bases, const uint32_t *__restrict__ vals,
@@ -189,9 +189,8 @@ __global__ void __launch_bounds__(64, 2) k_accumulate(const Affine28<P> *__restr
 }
 // replay of the deferred (bucket, point) pairs with the complete formulas; one lane, sequential (the list is empty in practice)
 template <class P>
-__global__ void k_accumulate_fixup(const Affine28<P> *__restrict__ bases, Acc28<P> *__restrict__ buckets, const uint32_t *__restrict__ deferred, uint32_t deferred_cap,
-                                   const uint32_t *__restrict__ deferred_count) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+__device__ void accumulate_fixup(const Affine28<P> *__restrict__ bases, Acc28<P> *__restrict__ buckets, const uint32_t *__restrict__ deferred, uint32_t deferred_cap,
+                                 const volatile uint32_t *deferred_count) {
     uint32_t n = *deferred_count;
     if (n > deferred_cap) n = deferred_cap;
     for (uint32_t i = 0; i < n; i++) {
@@ -204,47 +203,60 @@ __global__ void k_accumulate_fixup(const Affine28<P> *__restrict__ bases, Acc28<
 }
 
 // overflow segment t of bucket k covers sorted positions [start[k] + (j+1) CAP, min(start[k] + (j+2) CAP, end[k])), j = t - extra_off[k]
+// ONE tail launch per MSM (it used to be three): the overflow segments, then -- in whichever workgroup finishes last (ticket counter
+// deferred_count[1]) -- the replay of the deferred degenerate additions of this kernel and of k_accumulate.  The overflow partials are folded
+// into their buckets by k_reduce_l1 when it loads them.  For uniformly distributed digits there are no segments and no deferred pairs: every
+// lane exits after two loads.
 template <class P>
-__global__ void __launch_bounds__(64, 2) k_accumulate_overflow(const Affine28<P> *__restrict__ bases, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ start,
-                                                                const uint32_t *__restrict__ end, const uint32_t *__restrict__ extra_off, uint32_t nb, uint32_t max_segments,
-                                                                Acc28<P> *__restrict__ partial, uint32_t *__restrict__ deferred, uint32_t deferred_cap,
-                                                                uint32_t *__restrict__ deferred_count) {
+__global__ void __launch_bounds__(64, 2) k_accumulate_tail(const Affine28<P> *__restrict__ bases, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ start,
+                                                            const uint32_t *__restrict__ end, const uint32_t *__restrict__ extra_off, uint32_t nb, uint32_t max_segments,
+                                                            Acc28<P> *__restrict__ partial, Acc28<P> *__restrict__ buckets, uint32_t *__restrict__ deferred, uint32_t deferred_cap,
+                                                            uint32_t *__restrict__ deferred_count) {
     using G = Fp28<P>;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t total = extra_off[nb];                   // exclusive scan has nb + 1 entries
     if (total > max_segments) total = max_segments;
-    if (t >= total) return;
-    uint32_t lo = 0, hi = nb;                         // largest k with extra_off[k] <= t
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (extra_off[mid] <= t) lo = mid; else hi = mid; }
-    uint32_t k = lo, j = t - extra_off[k];
-    uint32_t s = start[k] + (j + 1) * BUCKET_CAP, e = s + BUCKET_CAP < end[k] ? s + BUCKET_CAP : end[k];
-    Acc28<P> acc;
-    bool acc_inf = true;
-    for (uint32_t i = s; i < e; i++) {
-        uint32_t cur = vals[i];
-        Affine28<P> p = bases[cur & VAL_INDEX];
-        if ((cur & VAL_SKIP) || p.is_inf()) continue;
-        if (cur >> 31) p.y = G::zero().template sub<2>(p.y);
-        if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_2_392(); acc.zzz = acc.zz; acc_inf = false; continue; }
-        if (!madd28(acc, p)) {
-            uint32_t slot = atomicAdd(deferred_count, 1u);
-            if (slot < deferred_cap) { deferred[2 * slot] = k; deferred[2 * slot + 1] = cur; }
+    if (t < total) {
+        uint32_t lo = 0, hi = nb;                         // largest k with extra_off[k] <= t
+        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (extra_off[mid] <= t) lo = mid; else hi = mid; }
+        uint32_t k = lo, j = t - extra_off[k];
+        uint32_t s = start[k] + (j + 1) * BUCKET_CAP, e = s + BUCKET_CAP < end[k] ? s + BUCKET_CAP : end[k];
+        Acc28<P> acc;
+        bool acc_inf = true;
+        for (uint32_t i = s; i < e; i++) {
+            uint32_t cur = vals[i];
+            Affine28<P> p = bases[cur & VAL_INDEX];
+            if ((cur & VAL_SKIP) || p.is_inf()) continue;
+            if (cur >> 31) p.y = G::zero().template sub<2>(p.y);
+            if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_2_392(); acc.zzz = acc.zz; acc_inf = false; continue; }
+            if (!madd28(acc, p)) {
+                uint32_t slot = atomicAdd(deferred_count, 1u);
+                if (slot < deferred_cap) { deferred[2 * slot] = k; deferred[2 * slot + 1] = cur; }
+            }
         }
+        if (acc_inf) acc = inf28<P>();
+        partial[t] = acc;
     }
-    if (acc_inf) acc = inf28<P>();
-    partial[t] = acc;
+    __shared__ uint32_t ticket;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = atomicAdd(deferred_count + 1, 1u);
+    __syncthreads();
+    if (ticket != gridDim.x - 1 || threadIdx.x != 0) return;
+    __threadfence();
+    accumulate_fixup<P>(bases, buckets, deferred, deferred_cap, deferred_count);
 }
+// bucket k with its overflow partials folded in (k_reduce_l1's load)
 template <class P>
-__global__ void __launch_bounds__(64) k_combine_overflow(Acc28<P> *__restrict__ buckets, const uint32_t *__restrict__ extra_off, uint32_t nb, uint32_t max_segments,
-                                                          const Acc28<P> *__restrict__ partial) {
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nb) return;
-    uint32_t a = extra_off[k], b = extra_off[k + 1];
-    if (a == b) return;
-    if (b > max_segments) b = max_segments;
+__device__ __forceinline__ Acc28<P> load_bucket(const Acc28<P> *__restrict__ buckets, size_t k, const uint32_t *__restrict__ extra_off, uint32_t max_segments,
+                                                const Acc28<P> *__restrict__ partial) {
     Acc28<P> acc = buckets[k];
-    for (uint32_t i = a; i < b; i++) add28<P>(acc, partial[i]);
-    buckets[k] = acc;
+    uint32_t a = extra_off[k], b = extra_off[k + 1];
+    if (a != b) {
+        if (b > max_segments) b = max_segments;
+        for (uint32_t i = a; i < b; i++) add28<P>(acc, partial[i]);
+    }
+    return acc;
 }
 
 // Bucket reduction  sum_j (j + 1) * B_j  per window (bucket j holds digit magnitude j + 1), in three fully parallel levels:
@@ -253,15 +265,16 @@ __global__ void __launch_bounds__(64) k_combine_overflow(Acc28<P> *__restrict__ 
 //   k_reduce_window: LDS tree over the group partials of a window
 constexpr int RED_L1 = 8, RED_L2 = 8;
 template <class P>
-__global__ void __launch_bounds__(64) k_reduce_l1(const Acc28<P> *__restrict__ buckets, int c, int nwin, Acc28<P> *__restrict__ seg_s, Acc28<P> *__restrict__ seg_w) {
+__global__ void __launch_bounds__(64) k_reduce_l1(const Acc28<P> *__restrict__ buckets, int c, int nwin, Acc28<P> *__restrict__ seg_s, Acc28<P> *__restrict__ seg_w,
+                                                   const uint32_t *__restrict__ extra_off, uint32_t max_segments, const Acc28<P> *__restrict__ ovf_partial) {
     uint32_t segs = (1u << c) / RED_L1;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= segs * (uint32_t)nwin) return;
     uint32_t w = t / segs, g = t % segs;
-    const Acc28<P> *B = buckets + ((size_t)w << c) + (size_t)g * RED_L1;
+    const size_t k0 = ((size_t)w << c) + (size_t)g * RED_L1;
     Acc28<P> run = inf28<P>(), tot = inf28<P>();
     for (int d = RED_L1 - 1; d >= 0; d--) {
-        Acc28<P> b = B[d];
+        Acc28<P> b = load_bucket<P>(buckets, k0 + d, extra_off, max_segments, ovf_partial);
         add28<P>(run, b);
         add28<P>(tot, run);
     }
@@ -325,12 +338,13 @@ struct MsmWorkspace {
     size_t plan_n = 0, plan_pairs = 0; int plan_c = 0, plan_nwin = 0;     // state between msm_prepare and msm_finish
     uint32_t *deferred = nullptr, *deferred_count = nullptr;
     void *buckets = nullptr, *seg_s = nullptr, *seg_w = nullptr, *partial = nullptr, *wsum = nullptr, *tmp = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, fence_a = nullptr, fence_b = nullptr;
+    hipStream_t low = nullptr;                                     // low-priority side stream for k_accumulate (ZKAES_STREAM_PRIORITY, default on)
 };
 static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t xyzz_bytes) {
     if (!S.ev0) {
         HIP_CHECK(hipEventCreate(&S.ev0)); HIP_CHECK(hipEventCreate(&S.ev1));
-        S.deferred = (uint32_t *)dmalloc(2 * DEFERRED_CAP * 4); S.deferred_count = (uint32_t *)dmalloc(4);
+        S.deferred = (uint32_t *)dmalloc(2 * DEFERRED_CAP * 4); S.deferred_count = (uint32_t *)dmalloc(8);
     }
     if (pairs / BUCKET_CAP + 64 > S.cap_ovf) { dfree(S.ovf_partial); S.cap_ovf = pairs / BUCKET_CAP + 64; S.ovf_partial = dmalloc(S.cap_ovf * 224); }
     if (pairs > S.cap_pairs) {
@@ -353,12 +367,29 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
     }
     (void)xyzz_bytes;
 }
-MsmWorkspace *msm_workspace_create() { return new MsmWorkspace(); }
+bool stream_priorities_enabled() {
+    static const bool on = [] { const char *e = getenv("ZKAES_STREAM_PRIORITY"); return !e || atoi(e) != 0; }();
+    return on;
+}
+MsmWorkspace *msm_workspace_create() {
+    MsmWorkspace *w = new MsmWorkspace();
+    if (stream_priorities_enabled()) {
+        int lo = 0, hi = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));          // numerically: lo = least urgent, hi = most urgent
+        if (lo != hi) {
+            HIP_CHECK(hipStreamCreateWithPriority(&w->low, hipStreamNonBlocking, lo));
+            HIP_CHECK(hipEventCreateWithFlags(&w->fence_a, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&w->fence_b, hipEventDisableTiming));
+        }
+    }
+    return w;
+}
 void msm_workspace_destroy(MsmWorkspace *w) {
     if (!w) return;
     for (void *p : {(void *)w->keys_a, (void *)w->keys_b, (void *)w->vals_a, (void *)w->vals_b, (void *)w->start, (void *)w->end, (void *)w->size_key, (void *)w->size_key2, (void *)w->ids,
                     (void *)w->order, (void *)w->extra, (void *)w->extra_off, w->ovf_partial, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->wsum, w->tmp}) dfree(p);
     if (w->ev0) { (void)hipEventDestroy(w->ev0); (void)hipEventDestroy(w->ev1); }
+    if (w->low) { (void)hipStreamDestroy(w->low); (void)hipEventDestroy(w->fence_a); (void)hipEventDestroy(w->fence_b); }
     delete w;
 }
 
@@ -404,24 +435,26 @@ template <class P>
 static std::vector<XYZZ<Fp<P>>> run_buckets(MsmWorkspace &S, const Affine28<P> *bases, size_t pairs, int c, int nsets, size_t n_points, hipStream_t s, float *acc_ms) {
     using Fq = Fp<P>;
     size_t nb = (size_t)nsets << c;
-    HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 4, s));
-    HIP_CHECK(hipEventRecord(S.ev0, s));
-    hipLaunchKernelGGL((k_accumulate<P>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, bases, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb,
+    HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 8, s));        // [0] deferred pairs, [1] the tail kernel's workgroup ticket
+    // k_accumulate goes to the context's LOW-priority side stream (when there is one): its grid fills the chip for milliseconds, and the short
+    // latency-bound kernels of the other prover contexts (sort passes, reductions, NTT passes, scans -- on their HIGH-priority main streams) must not
+    // queue behind its waves
+    hipStream_t sa = S.low ? S.low : s;
+    if (S.low) { HIP_CHECK(hipEventRecord(S.fence_a, s)); HIP_CHECK(hipStreamWaitEvent(S.low, S.fence_a, 0)); }
+    HIP_CHECK(hipEventRecord(S.ev0, sa));
+    hipLaunchKernelGGL((k_accumulate<P>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, sa, bases, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb,
                        (Acc28<P> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
-    HIP_CHECK(hipEventRecord(S.ev1, s));
-    {   // oversized buckets (none for uniformly distributed digits: both kernels exit at once)
-        uint32_t max_seg = (uint32_t)(pairs / BUCKET_CAP + 1);
-        hipLaunchKernelGGL((k_accumulate_overflow<P>), dim3((max_seg + 63) / 64), dim3(64), 0, s, bases, S.sorted_vals, S.start, S.end, S.extra_off, (uint32_t)nb, max_seg,
-                           (Acc28<P> *)S.ovf_partial, S.deferred, DEFERRED_CAP, S.deferred_count);
-        HIP_LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_combine_overflow<P>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, (Acc28<P> *)S.buckets, S.extra_off, (uint32_t)nb, max_seg, (const Acc28<P> *)S.ovf_partial);
-        HIP_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL((k_accumulate_fixup<P>), dim3(1), dim3(64), 0, s, bases, (Acc28<P> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
+    HIP_CHECK(hipEventRecord(S.ev1, sa));
+    if (S.low) { HIP_CHECK(hipEventRecord(S.fence_b, S.low)); HIP_CHECK(hipStreamWaitEvent(s, S.fence_b, 0)); }
+    uint32_t max_seg = (uint32_t)(pairs / BUCKET_CAP + 1);
+    // oversized buckets + deferred degenerate additions (none for uniformly distributed digits: every lane exits at once)
+    hipLaunchKernelGGL((k_accumulate_tail<P>), dim3((max_seg + 63) / 64), dim3(64), 0, s, bases, S.sorted_vals, S.start, S.end, S.extra_off, (uint32_t)nb, max_seg,
+                       (Acc28<P> *)S.ovf_partial, (Acc28<P> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
     uint32_t segs = (1u << c) / RED_L1, groups = (segs + RED_L2 - 1) / RED_L2;
-    hipLaunchKernelGGL((k_reduce_l1<P>), dim3((unsigned)((segs * nsets + 63) / 64)), dim3(64), 0, s, (const Acc28<P> *)S.buckets, c, nsets, (Acc28<P> *)S.seg_s, (Acc28<P> *)S.seg_w);
+    hipLaunchKernelGGL((k_reduce_l1<P>), dim3((unsigned)((segs * nsets + 63) / 64)), dim3(64), 0, s, (const Acc28<P> *)S.buckets, c, nsets, (Acc28<P> *)S.seg_s, (Acc28<P> *)S.seg_w,
+                       S.extra_off, max_seg, (const Acc28<P> *)S.ovf_partial);
     HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_reduce_l2<P>), dim3((unsigned)((groups * nsets + 63) / 64)), dim3(64), 0, s, (const Acc28<P> *)S.seg_s, (const Acc28<P> *)S.seg_w, c, nsets, (Acc28<P> *)S.partial);
     HIP_LAUNCH_CHECK();
@@ -474,6 +507,7 @@ void msm_prepare(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_t n1, 
     if (const char *e = getenv("ZKAES_MSM_C")) { int v = atoi(e); if (v >= 4 && v <= 22) c = v; }   // tuning knob (tools/ubench/msm_sweep.py)
     const int nwin = (Fr::BITS + 1 + c - 1) / c;  // one extra bit for the recoding carry
     size_t pairs = n * (size_t)nwin;
+    if (pairs >= ((size_t)1 << 31)) throw GpuError("msm: n x windows exceeds the 2^31 pairs the sort indexes with int");
     const size_t nb = (size_t)nwin << (c - 1);
     S.plan_c = c; S.plan_nwin = nwin; S.plan_pairs = pairs;
     ensure_scratch(S, pairs, nb, 0);

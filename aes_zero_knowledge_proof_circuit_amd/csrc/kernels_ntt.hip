@@ -117,8 +117,11 @@ struct Tables {
         for (int i = lg; i < RootOf<Fr>::TWO_ADICITY; i++) r = r.sqr();
         return r;
     }
-    Fr *powers(std::map<int, Fr *> &m, int lg, const Fr &w, uint32_t count) {
+    // the caches are keyed by (HIP device, log n): keys synthesized on different GPUs of one process get their own tables
+    static int cache_key(int lg) { int d = 0; HIP_CHECK(hipGetDevice(&d)); return d * 64 + lg; }
+    Fr *powers(std::map<int, Fr *> &m, int lg_, const Fr &w, uint32_t count) {
         std::lock_guard<std::mutex> g(mu);
+        const int lg = cache_key(lg_);
         auto it = m.find(lg);
         if (it != m.end()) return it->second;
         Fr *d = (Fr *)dmalloc((size_t)(count ? count : 1) * sizeof(Fr));
@@ -134,10 +137,11 @@ struct Tables {
 template <class Fr> Tables<Fr> &tables() { static Tables<Fr> t; return t; }
 // reduced-radix copy of a twiddle table (built once per domain size and direction)
 template <class Fr>
-const Fp29<typename Fr::Params> *twiddles29(std::map<int, Fp29<typename Fr::Params> *> &m, int lg, const Fr *std_table, uint32_t count) {
+const Fp29<typename Fr::Params> *twiddles29(std::map<int, Fp29<typename Fr::Params> *> &m, int lg_, const Fr *std_table, uint32_t count) {
     using G = Fp29<typename Fr::Params>;
     Tables<Fr> &T = tables<Fr>();
     std::lock_guard<std::mutex> g(T.mu);
+    const int lg = Tables<Fr>::cache_key(lg_);
     auto it = m.find(lg);
     if (it != m.end()) return it->second;
     G *d = (G *)dmalloc((size_t)(count ? count : 1) * sizeof(G));

@@ -8,6 +8,7 @@
 //                     its bit -- S-box mux-tree variables are a table lookup S[(node << (level+1)) | (x & mask)],
 //   k_spmv_bits       z_A = A z, z_B = B z over 0/1 assignments with small integer coefficients (ark-marlin prover_init),
 //   k_t_evals         the round-2 "t" accumulation through a column-bucketed copy of A, B, C.
+#include <mutex>
 #include "hip_util.hpp"
 #include "trace_layout.h"
 
@@ -16,10 +17,23 @@ namespace gpu {
 
 #define GRID(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
 
-static uint8_t *g_sbox = nullptr;   // device copy of the S-box table
+// device copies of the S-box table, one per HIP device (keys on several GPUs of one process each use their own)
+static uint8_t *g_sbox_dev[64] = {nullptr};
+static std::mutex g_sbox_mu;
+static uint8_t *sbox_here() {
+    int d = 0;
+    HIP_CHECK(hipGetDevice(&d));
+    if (d < 0 || d >= 64) throw GpuError("device ordinal out of range");
+    std::lock_guard<std::mutex> g(g_sbox_mu);
+    return g_sbox_dev[d];
+}
 void upload_sbox(const uint8_t table[256]) {
-    if (!g_sbox) g_sbox = (uint8_t *)dmalloc(256);
-    HIP_CHECK(hipMemcpy(g_sbox, table, 256, hipMemcpyHostToDevice));
+    int d = 0;
+    HIP_CHECK(hipGetDevice(&d));
+    if (d < 0 || d >= 64) throw GpuError("device ordinal out of range");
+    std::lock_guard<std::mutex> g(g_sbox_mu);
+    if (!g_sbox_dev[d]) g_sbox_dev[d] = (uint8_t *)dmalloc(256);
+    HIP_CHECK(hipMemcpy(g_sbox_dev[d], table, 256, hipMemcpyHostToDevice));
 }
 
 __device__ __forceinline__ uint8_t xtime(uint8_t c) { return (uint8_t)((c << 1) ^ (((c >> 7) & 1) * 0x1B)); }
@@ -80,7 +94,8 @@ __global__ void k_aes_trace(uint8_t *__restrict__ trace, size_t stride, const ui
     }
 }
 void aes_trace(uint8_t *trace, size_t stride, const uint8_t *msgs, const uint8_t *keys, uint32_t nproofs, uint32_t nblocks, stream_t s) {
-    if (!g_sbox) throw GpuError("aes_trace: S-box table not uploaded");
+    uint8_t *g_sbox = sbox_here();
+    if (!g_sbox) throw GpuError("aes_trace: S-box table not uploaded on this device");
     uint32_t lanes = nproofs * (nblocks + 1);
     hipLaunchKernelGGL(k_aes_trace, dim3((lanes + 63) / 64), dim3(64), 0, (hipStream_t)s, trace, stride, msgs, keys, nproofs, nblocks, g_sbox);
     HIP_LAUNCH_CHECK();
@@ -106,7 +121,8 @@ __global__ void k_witness_expand(uint8_t *__restrict__ z, const uint32_t *__rest
     z[i] = (uint8_t)bit;
 }
 void witness_expand(uint8_t *z, const uint32_t *desc, uint32_t ncols, const uint8_t *trace, const uint32_t *sbox_in_off, const uint32_t *sbox_tmpl, stream_t s) {
-    if (!g_sbox) throw GpuError("witness_expand: S-box table not uploaded");
+    uint8_t *g_sbox = sbox_here();
+    if (!g_sbox) throw GpuError("witness_expand: S-box table not uploaded on this device");
     hipLaunchKernelGGL(k_witness_expand, GRID(ncols), 0, (hipStream_t)s, z, desc, ncols, trace, sbox_in_off, sbox_tmpl, g_sbox);
     HIP_LAUNCH_CHECK();
 }

@@ -67,13 +67,11 @@ struct Bytes {
 };
 
 // Fq square root (Tonelli-Shanks; q - 1 = 2^46 * t) for point decompression
-bool fq_sqrt(const Fq377 &a, Fq377 &out) {
-    if (a.is_zero()) { out = a; return true; }
-    static bool init = false;
-    static uint32_t t_limbs[12], tp1h_limbs[12], half_limbs[12];
-    static Fq377 z_t;   // nonresidue^t
-    static int S = 0;
-    if (!init) {
+struct SqrtConsts {
+    uint32_t t_limbs[12], tp1h_limbs[12], half_limbs[12];
+    Fq377 z_t;   // nonresidue^t
+    int S = 0;
+    SqrtConsts() {
         uint32_t qm1[12];
         for (int i = 0; i < 12; i++) qm1[i] = FQ377_P[i];
         qm1[0] -= 1;
@@ -86,11 +84,14 @@ bool fq_sqrt(const Fq377 &a, Fq377 &out) {
         shr1(tp1h_limbs);
         Fq377 minus_one = Fq377::one().neg();
         for (uint64_t c = 2;; c++) { Fq377 cand = Fq377::from_u64(c); if (cand.pow(half_limbs, 12) == minus_one) { z_t = cand.pow(t_limbs, 12); break; } }
-        init = true;
     }
-    if (!(a.pow(half_limbs, 12) == Fq377::one())) return false;
-    Fq377 c = z_t, x = a.pow(tp1h_limbs, 12), b = a.pow(t_limbs, 12);
-    int m = S;
+};
+bool fq_sqrt(const Fq377 &a, Fq377 &out) {
+    if (a.is_zero()) { out = a; return true; }
+    static const SqrtConsts K;          // C++11 magic static: initialised exactly once, also when the first callers race (verifier-only processes, several threads)
+    if (!(a.pow(K.half_limbs, 12) == Fq377::one())) return false;
+    Fq377 c = K.z_t, x = a.pow(K.tp1h_limbs, 12), b = a.pow(K.t_limbs, 12);
+    int m = K.S;
     while (!(b == Fq377::one())) {
         int i = 0;
         Fq377 bb = b;
@@ -121,11 +122,15 @@ struct Reader {
         uint8_t buf[48];
         memcpy(buf, p + off, 48); off += 48;
         bool inf = buf[47] & (1 << 6), y_gt = buf[47] & (1 << 7);
+        if (inf && y_gt) throw std::runtime_error("deserialize_proof: invalid point flags (infinity and sign both set)");   // ark-serialize SWFlags::from_u8 -> None
         buf[47] &= 0x3f;
-        if (inf) return G1A::inf();
         uint32_t raw[12];
         for (int i = 0; i < 12; i++) raw[i] = (uint32_t)buf[4 * i] | (uint32_t)buf[4 * i + 1] << 8 | (uint32_t)buf[4 * i + 2] << 16 | (uint32_t)buf[4 * i + 3] << 24;
         if (Fq377::geq_mod(raw)) throw std::runtime_error("deserialize_proof: non-canonical x coordinate");
+        if (inf) {
+            for (int i = 0; i < 12; i++) if (raw[i]) throw std::runtime_error("deserialize_proof: point at infinity with a non-zero x coordinate");   // one encoding per point
+            return G1A::inf();
+        }
         G1A a; a.x = Fq377::from_raw(raw);
         Fq377 y;
         if (!fq_sqrt(a.x.sqr() * a.x + Bls377::b(), y)) throw std::runtime_error("deserialize_proof: x is not on the curve");
@@ -134,6 +139,9 @@ struct Reader {
         bool gt = false;
         for (int i = 11; i >= 0; i--) if (yr[i] != nyr[i]) { gt = yr[i] > nyr[i]; break; }
         a.y = (gt == y_gt) ? y : y.neg();
+        // ark-ec 0.3 GroupAffine::deserialize: is_in_correct_subgroup_assuming_on_curve, i.e. [r]P == O (the curve has cofactor (x-1)^2/3: a
+        // small-order component would survive the pairing check and make proofs malleable)
+        if (!XYZZ<Fq377>::from_affine(a).mul_raw(FR377_P, 8).is_inf()) throw std::runtime_error("deserialize_proof: point is not in the prime-order subgroup");
         return a;
     }
 };
@@ -181,12 +189,16 @@ pairing::G2Affine get_g2_compressed(Reader &r) {
     uint8_t buf[96];
     memcpy(buf, r.p + r.off, 96); r.off += 96;
     bool inf = buf[95] & (1 << 6), y_gt = buf[95] & (1 << 7);
+    if (inf && y_gt) throw std::runtime_error("deserialize: invalid G2 point flags (infinity and sign both set)");
     buf[95] &= 0x3f;
-    if (inf) return pairing::G2Affine::infinity();
     uint32_t raw[2][12];
     for (int h = 0; h < 2; h++) {
         for (int i = 0; i < 12; i++) { const uint8_t *q = buf + 48 * h + 4 * i; raw[h][i] = (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24; }
         if (Fq377::geq_mod(raw[h])) throw std::runtime_error("deserialize: non-canonical G2 x coordinate");
+    }
+    if (inf) {
+        for (int h = 0; h < 2; h++) for (int i = 0; i < 12; i++) if (raw[h][i]) throw std::runtime_error("deserialize: G2 point at infinity with a non-zero x coordinate");
+        return pairing::G2Affine::infinity();
     }
     pairing::G2Affine a;
     a.inf = false;
@@ -194,6 +206,7 @@ pairing::G2Affine get_g2_compressed(Reader &r) {
     pairing::Fq2 y;
     if (!fq2_sqrt(a.x.sqr() * a.x + pairing::g2_b(), y)) throw std::runtime_error("deserialize: G2 x is not on the twist");
     a.y = (fq2_gt(y, y.neg()) == y_gt) ? y : y.neg();
+    if (!pairing::g2_mul_raw(a, FR377_P, 8).inf) throw std::runtime_error("deserialize: G2 point is not in the prime-order subgroup");
     return a;
 }
 
@@ -929,7 +942,16 @@ std::vector<uint8_t> ProvingKey::aes_witness(const uint8_t *message, size_t len,
     gpu::d2h(z.data(), cx.d_z, z.size(), s);
     return z;
 }
-static std::vector<Proof> prove_many(ProvingKeyImpl *impl, const uint8_t *messages, const uint8_t *keys, size_t key_stride, size_t n_chunks, size_t n_contexts) {
+// zero-knowledge randomness of proof i of a chunked / batch call: the caller's seed is domain-separated per proof, Blake2s(seed || i as u64 LE), so no two
+// proofs share rho, the KZG hiding coefficients or the mask polynomial.  seed == nullptr keeps the reference's behaviour (every encrypt() call
+// draws from ark_std::test_rng(), src/lib.rs:65): bit-parity mode for tests, NOT zero-knowledge across proofs.
+static void derive_zk_seed(uint8_t out[32], const uint8_t *seed32, uint64_t index) {
+    uint8_t buf[40];
+    memcpy(buf, seed32, 32);
+    for (int i = 0; i < 8; i++) buf[32 + i] = (uint8_t)(index >> (8 * i));
+    Blake2s::digest(out, buf, sizeof buf);
+}
+static std::vector<Proof> prove_many(ProvingKeyImpl *impl, const uint8_t *messages, const uint8_t *keys, size_t key_stride, size_t n_chunks, size_t n_contexts, const uint8_t *zk_seed) {
     size_t chunk = impl->circuit.n_blocks * 16;
     if (n_contexts == 0) n_contexts = 1;
     n_contexts = std::min(n_contexts, std::max<size_t>(n_chunks, 1));
@@ -945,7 +967,9 @@ static std::vector<Proof> prove_many(ProvingKeyImpl *impl, const uint8_t *messag
             for (;;) {
                 size_t i = next.fetch_add(1);
                 if (i >= n_chunks) break;
-                proofs[i] = impl->prove(cx, nullptr, messages + i * chunk, chunk, keys + i * key_stride, nullptr);
+                uint8_t seed_i[32];
+                if (zk_seed) derive_zk_seed(seed_i, zk_seed, (uint64_t)i);
+                proofs[i] = impl->prove(cx, nullptr, messages + i * chunk, chunk, keys + i * key_stride, zk_seed ? seed_i : nullptr);
             }
         } catch (const std::exception &e) { errors[ci] = e.what(); }
     };
@@ -956,16 +980,16 @@ static std::vector<Proof> prove_many(ProvingKeyImpl *impl, const uint8_t *messag
     for (auto &e : errors) if (!e.empty()) throw std::runtime_error(e);
     return proofs;
 }
-std::vector<Proof> ProvingKey::prove_aes_chunked(const uint8_t *message, size_t len, const uint8_t key[16], size_t n_contexts) {
+std::vector<Proof> ProvingKey::prove_aes_chunked(const uint8_t *message, size_t len, const uint8_t key[16], size_t n_contexts, const uint8_t *zk_seed) {
     if (impl->circuit.kind != CIRCUIT_AES) throw std::invalid_argument("proving key was not synthesized for the AES circuit");
     size_t chunk = impl->circuit.n_blocks * 16;
     if (chunk == 0 || len % chunk) throw std::invalid_argument("message length must be a multiple of the key's plaintext length (" + std::to_string(chunk) + " bytes)");
-    return prove_many(impl, message, key, 0, len / chunk, n_contexts);
+    return prove_many(impl, message, key, 0, len / chunk, n_contexts, zk_seed);
 }
-std::vector<Proof> ProvingKey::prove_aes_batch(const uint8_t *messages, const uint8_t *keys, size_t n, size_t n_contexts) {
+std::vector<Proof> ProvingKey::prove_aes_batch(const uint8_t *messages, const uint8_t *keys, size_t n, size_t n_contexts, const uint8_t *zk_seed) {
     if (impl->circuit.kind != CIRCUIT_AES) throw std::invalid_argument("proving key was not synthesized for the AES circuit");
     if (impl->circuit.n_blocks == 0) throw std::invalid_argument("proving key has an empty plaintext");
-    return prove_many(impl, messages, keys, 16, n, n_contexts);
+    return prove_many(impl, messages, keys, 16, n, n_contexts, zk_seed);
 }
 Proof ProvingKey::prove_ops(uint32_t x, uint32_t y, const uint8_t *zk_seed) {
     if (impl->circuit.kind == CIRCUIT_AES) throw std::invalid_argument("proving key was synthesized for the AES circuit");

@@ -65,9 +65,10 @@ class ProvingKey {
     // ark_std::test_rng()'s (what simpleworks::marlin::generate_rand() returns)
     Proof prove_aes(const uint8_t *message, size_t len, const uint8_t key[16], const uint8_t *zk_seed);
     // ceil(len / chunk) independent chunk-proofs of a long ECB message, `n_contexts` proofs in flight on separate HIP streams
-    std::vector<Proof> prove_aes_chunked(const uint8_t *message, size_t len, const uint8_t key[16], size_t n_contexts);
+    // zk_seed: 32-byte seed, domain-separated per proof (Blake2s(seed || index)); nullptr = the reference's fixed test_rng seed for every proof (parity mode)
+    std::vector<Proof> prove_aes_chunked(const uint8_t *message, size_t len, const uint8_t key[16], size_t n_contexts, const uint8_t *zk_seed = nullptr);
     // n independent (message_i, key_i) pairs, each message of the key's plaintext length; keys = n x 16 bytes
-    std::vector<Proof> prove_aes_batch(const uint8_t *messages, const uint8_t *keys, size_t n, size_t n_contexts);
+    std::vector<Proof> prove_aes_batch(const uint8_t *messages, const uint8_t *keys, size_t n, size_t n_contexts, const uint8_t *zk_seed = nullptr);
     Proof prove_ops(uint32_t x, uint32_t y, const uint8_t *zk_seed);
     // witness generation only (kernels aes_trace + witness_expand): z = padded instance || witness, one byte per variable
     std::vector<uint8_t> aes_witness(const uint8_t *message, size_t len, const uint8_t key[16]);

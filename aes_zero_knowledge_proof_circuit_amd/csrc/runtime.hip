@@ -21,7 +21,15 @@ void d2h(void *dst, const void *src, size_t bytes, stream_t s) { if (bytes) { HI
 void d2d(void *dst, const void *src, size_t bytes, stream_t s) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s)); }
 void dzero(void *dst, size_t bytes, stream_t s) { if (bytes) HIP_CHECK(hipMemsetAsync(dst, 0, bytes, (hipStream_t)s)); }
 void sync(stream_t s) { HIP_CHECK(hipStreamSynchronize((hipStream_t)s)); }
-stream_t stream_create() { hipStream_t s; HIP_CHECK(hipStreamCreate(&s)); return (stream_t)s; }
+// Prover streams are HIGH priority; the MSM workspace of the same context owns a LOW-priority side stream that carries only k_accumulate
+// (kernels_msm.hip run_buckets).  ZKAES_STREAM_PRIORITY=0 puts everything back on plain default-priority streams.
+stream_t stream_create() {
+    hipStream_t s;
+    int lo = 0, hi = 0;
+    if (stream_priorities_enabled() && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamDefault, hi));
+    else HIP_CHECK(hipStreamCreate(&s));
+    return (stream_t)s;
+}
 void stream_destroy(stream_t s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
 void *event_create() { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return (void *)e; }
 void event_record(void *ev, stream_t s) { HIP_CHECK(hipEventRecord((hipEvent_t)ev, (hipStream_t)s)); }

@@ -68,8 +68,20 @@ int zkaes_encrypt_seeded(const uint8_t *message, size_t message_len, const uint8
 int zkaes_encrypt_chunked(const uint8_t *message, size_t message_len, const uint8_t secret_key[16], const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len,
                           size_t *proof_lens, size_t n_chunks);
 /* n independent (message_i, secret_key_i) pairs on one key / one SRS (BASELINE config 5: many small proofs): messages = n x plaintext
- * length bytes, secret_keys = n x 16 bytes.  Up to ZKAES_CONTEXTS (default 4) proofs are in flight on separate HIP streams. */
+ * length bytes, secret_keys = n x 16 bytes.  Up to ZKAES_CONTEXTS (environment; default ZKAES_DEFAULT_CONTEXTS, the configuration bench.py
+ * measures) proofs are in flight per call, each on its own pair of HIP streams.  This entry point cannot check its buffer lengths: prefer
+ * zkaes_encrypt_batch_seeded. */
+#define ZKAES_DEFAULT_CONTEXTS 10
 int zkaes_encrypt_batch(size_t n, const uint8_t *messages, const uint8_t *secret_keys, const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens);
+/* the chunked / batch calls with explicit buffer lengths (checked: messages_len == n x plaintext length, secret_keys_len == n x 16) and a
+ * 32-byte seed for the provers' zero-knowledge randomness.  Proof i draws from StdRng(Blake2s(zk_seed32 || i as u64 LE)), so no two proofs of a
+ * call share blinding factors or the mask polynomial.  zk_seed32 == NULL (and the unseeded entry points above) reproduce the reference, where EVERY
+ * encrypt() call draws from the fixed ark_std::test_rng() seed (src/lib.rs:65): byte-parity with the reference, but differences of hiding
+ * commitments across proofs are then unblinded -- not zero-knowledge; use a fresh random seed per call in production. */
+int zkaes_encrypt_chunked_seeded(const uint8_t *message, size_t message_len, const uint8_t secret_key[16], const zkaes_pk *pk, const uint8_t *zk_seed32, uint8_t **proofs,
+                                 size_t *proofs_len, size_t *proof_lens, size_t n_chunks);
+int zkaes_encrypt_batch_seeded(size_t n, const uint8_t *messages, size_t messages_len, const uint8_t *secret_keys, size_t secret_keys_len, const zkaes_pk *pk,
+                               const uint8_t *zk_seed32, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens);
 /* src/ops.rs toy gates proven with Marlin (public input: none) */
 int zkaes_prove_ops(const zkaes_pk *pk, uint32_t x, uint32_t y, const uint8_t *zk_seed32, uint8_t **proof, size_t *proof_len);
 /* generic verify: public_input_bits = instance assignment without the leading One, one byte (0/1) per variable */

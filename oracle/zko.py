@@ -109,6 +109,11 @@ class CS:
         lib().zko_api_cs_matrix(self.ptr, which, rowptr.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p), coeff.ctypes.data_as(C.c_void_p))
         return rowptr, col[:nnz], coeff[:nnz]
 
+    def set_witness(self, idx, val):
+        """fault injection: overwrite witness variable idx (tests flip a bit and expect is_satisfied() to fail)"""
+        if lib().zko_api_cs_set_witness(self.ptr, C.c_size_t(idx), int(val)) != 0:
+            raise IndexError(idx)
+
     def is_satisfied(self):
         return lib().zko_cs_is_satisfied(self.ptr)
 

@@ -82,6 +82,8 @@ void zko_api_cs_assignment(const zko_cs *cs, uint8_t *instance, uint8_t *witness
     if (witness) memcpy(witness, cs->witness_val, cs->num_witness);
 }
 /* CSR of matrix `which` (0 A, 1 B, 2 C): rowptr[n+1] (u64), col[nnz] (final column index), coeff[nnz] (i64) */
+/* fault injection for tests: overwrite witness variable `idx` (corrupted-witness test) */
+int zko_api_cs_set_witness(zko_cs *cs, size_t idx, int val) { if (idx >= cs->num_witness) return -1; cs->witness_val[idx] = (uint8_t)(val != 0); return 0; }
 void zko_api_cs_matrix(const zko_cs *cs, int which, uint64_t *rowptr, uint32_t *col, int64_t *coeff) {
     const zko_mat *M = which == 0 ? &cs->A : which == 1 ? &cs->B : &cs->C;
     for (size_t i = 0; i <= M->n; i++) rowptr[i] = M->rowptr[i];

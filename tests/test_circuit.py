@@ -36,12 +36,21 @@ def test_64_byte_circuit_matches_the_srs_literal_pins(zko, vectors):
 
 
 def test_corrupted_witness_is_rejected(zko, vectors):
-    cs, _ = zko.synth_aes(bytes(vectors["plaintext"]), bytes(vectors["key"]))
-    # flip one witness bit deep inside the circuit through the raw struct: use a second system with a different message instead
-    cs2, _ = zko.synth_aes(bytes(16), bytes(vectors["key"]))
-    _, w1 = cs.assignment()
-    _, w2 = cs2.assignment()
-    assert w1 != w2 and cs2.is_satisfied() == 1
+    """SURVEY.md section 5 fault injection: flip ONE witness bit of a satisfied system -> is_satisfied() names a violated constraint.
+    Bits from every region of the variable order: a message bit, a key bit, key-schedule / round internals, the last witness."""
+    key, pt = bytes(vectors["key"]), bytes(vectors["plaintext"])
+    cs, _ = zko.synth_aes(pt, key)
+    assert cs.is_satisfied() == 1
+    _, wit = cs.assignment()
+    n = len(wit)
+    for idx in (0, 5, 128 + 77, 256 + 3, 5_000, 36_768 + 99, n // 2, n - 129, n - 1):
+        cs.set_witness(idx, 1 - wit[idx])
+        r = cs.is_satisfied()
+        assert r < 0, "flipping witness %d went unnoticed" % idx          # -(row + 1) of the first violated constraint
+        cs.set_witness(idx, wit[idx])
+    assert cs.is_satisfied() == 1                                         # restored
+    with pytest.raises(IndexError):
+        cs.set_witness(n, 0)
 
 
 def test_empty_and_ragged_messages(zko, api):

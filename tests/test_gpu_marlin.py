@@ -201,17 +201,119 @@ def test_concurrent_encrypt_calls_on_one_key(zko, api, aes16):
     assert all(api.verify_encryption(vk, p, zko.aes_encrypt(m, key)) for m, p in zip(msgs, got))
 
 
-@pytest.mark.slow
-@pytest.mark.skipif(not os.environ.get("ZKAES_LONG_TESTS"), reason="about ten minutes of CPU for the oracle: set ZKAES_LONG_TESTS=1 (tools/parity_full.py is the same check as a script)")
-def test_aes96_proof_bytes_identical_to_oracle_at_the_bench_size(zko, api):
-    """the bench configuration itself: 6-block chunk-proof, |H| = 2^20, |K| = 2^22, the reference's SRS literal"""
-    msg, key = mt_bytes(96, 5), mt_bytes(16, 6)
-    pk, vk = api.synthesize_keys(96)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# the BASELINE.json workloads themselves
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def aes96(api):
+    """the bench's chunk key: 6 blocks per proof, |H| = 2^20, |K| = 2^22, the reference's universal-SRS literal"""
+    return api.synthesize_keys(96)
+
+
+def test_aes96_matches_the_committed_oracle_fixture(api, aes96):
+    """The bench configuration itself, without ten minutes of oracle time on the GPU box: tests/golden/oracle_aes96.json holds what the CPU oracle
+    produced for this (message, key) in the build container (tests/golden/make_oracle_aes96.py): the witness, all nine prover polynomials and the
+    proof bytes must be identical."""
+    import hashlib
+    import json
+    fx = json.load(open(os.path.join(GOLD, "oracle_aes96.json")))
+    pk, vk = aes96
+    msg, key = bytes.fromhex(fx["message"]), bytes.fromhex(fx["key"])
+    info = pk.info()
+    assert (info["h"], info["k"]) == (fx["index"]["h"], fx["index"]["k"]) == (1 << 20, 1 << 22)
+    assert (info["constraints"], info["joint_nnz"]) == (fx["index"]["num_constraints"], fx["index"]["num_non_zero"])
+    z = pk.witness(msg, key)
+    assert len(z) == fx["witness_len"] and hashlib.sha256(z).hexdigest() == fx["witness_sha256"]
     proof = api.encrypt(msg, key, pk)
-    cs, _ = zko.synth_aes(bytes(96), bytes(16))
-    ix = zko.Index(cs)
-    cs, _ = zko.synth_aes(msg, key)
-    ref = ix.prove(cs)
-    for poly in zko.POLY_NAMES:
-        assert pk.debug_fetch(poly) == ref.poly(poly), poly
-    assert proof == ref.to_bytes()
+    for name, want in fx["poly_sha256"].items():
+        got = pk.debug_fetch(name)
+        assert len(got) // 32 == fx["poly_len"][name], name
+        assert hashlib.sha256(got).hexdigest() == want, name
+    assert proof.hex() == fx["proof"] and hashlib.sha256(proof).hexdigest() == fx["proof_sha256"]
+    assert api.verify_encryption(vk, proof, bytes.fromhex(fx["ciphertext"])) is True
+    # and the oracle's own proof bytes (as committed) are accepted by the product verifier
+    assert api.verify_encryption(vk, bytes.fromhex(fx["proof"]), bytes.fromhex(fx["ciphertext"])) is True
+
+
+def _verify_all(api, jobs):
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 4)) as ex:     # ctypes releases the GIL inside the verifier
+        return sum(ex.map(lambda j: bool(api.verify_encryption(*j)), jobs))
+
+
+def test_config_64_block_message_as_10x6_plus_4(zko, api, aes96):
+    """BASELINE configs[1] shape: a 64-block (1 KiB) message = 10 chunk-proofs of 6 blocks + 1 of 4 on two keys; all 11 verify against the
+    byte-level ciphertext, a flipped byte is rejected, and chunk-proofs are position-bound (proof i does not verify chunk j's ciphertext)."""
+    pk, vk = aes96
+    pk4, vk4 = api.synthesize_keys(64)
+    key, msg = mt_bytes(16, 0x5EED), mt_bytes(1024, 0x5EED + 1)
+    ct = zko.aes_encrypt(msg, key)
+    proofs = pk.encrypt_chunked(msg[:960], key) + pk4.encrypt_chunked(msg[960:], key)
+    assert len(proofs) == 11 and all(len(p) == 855 for p in proofs)
+    jobs = [(vk, proofs[i], ct[96 * i:96 * i + 96]) for i in range(10)] + [(vk4, proofs[10], ct[960:])]
+    assert _verify_all(api, jobs) == 11
+    bad = bytearray(ct[:96]); bad[17] ^= 0x40
+    assert api.verify_encryption(vk, proofs[0], bytes(bad)) is False
+    assert api.verify_encryption(vk, proofs[0], ct[96:192]) is False
+    assert api.verify_encryption(vk4, proofs[10], ct[:64]) is False
+    # the concurrent contexts produce exactly the proof a lone call produces
+    assert proofs[7] == api.encrypt(msg[96 * 7:96 * 8], key, pk)
+
+
+def test_config_4096_block_message(zko, api, aes96):
+    """BASELINE configs[2], the headline workload: ONE 4096-block (64 KiB) message = 682 chunk-proofs of 6 blocks + 1 of 4 (about 70 s on one
+    MI355X); 683 / 683 verify, and a ciphertext with one flipped bit per sampled chunk is rejected."""
+    pk, vk = aes96
+    pk4, vk4 = api.synthesize_keys(64)
+    key, msg = mt_bytes(16, 0x5EED), mt_bytes(16 * 4096, 0x5EED + 1)
+    ct = zko.aes_encrypt(msg, key)
+    os.environ["ZKAES_CONTEXTS"] = "10"
+    n_full = 4096 // 6
+    proofs = pk.encrypt_chunked(msg[:96 * n_full], key) + pk4.encrypt_chunked(msg[96 * n_full:], key)
+    assert len(proofs) == 683
+    jobs = [(vk, proofs[i], ct[96 * i:96 * i + 96]) for i in range(n_full)] + [(vk4, proofs[n_full], ct[96 * n_full:])]
+    assert _verify_all(api, jobs) == 683
+    for i in (0, 341, 681):
+        bad = bytearray(ct[96 * i:96 * i + 96]); bad[i % 96] ^= 1
+        assert api.verify_encryption(vk, proofs[i], bytes(bad)) is False
+
+
+def test_config_1024_single_block_proofs_on_one_srs(zko, api, aes16):
+    """BASELINE configs[4] shape on one GPU: 1,024 independent (message, key) single-block proofs on one SRS / one index"""
+    pk, vk = aes16
+    msgs = [mt_bytes(16, 10_000 + i) for i in range(1024)]
+    keys = [mt_bytes(16, 20_000 + i) for i in range(1024)]
+    os.environ["ZKAES_CONTEXTS"] = "10"
+    proofs = pk.encrypt_batch(msgs, keys)
+    assert len(proofs) == 1024
+    assert _verify_all(api, [(vk, p, zko.aes_encrypt(m, k)) for m, k, p in zip(msgs, keys, proofs)]) == 1024
+    assert api.verify_encryption(vk, proofs[5], zko.aes_encrypt(msgs[5], keys[6])) is False
+
+
+def test_seeded_chunked_and_batch_calls_do_not_share_randomness(zko, api, aes16):
+    """zk_seed: proof i draws from StdRng(Blake2s(seed || i)); equal chunks then get different proofs (different blinding), the call is
+    reproducible, and the unseeded call keeps the reference's fixed-seed behaviour (equal chunks -> equal proofs)."""
+    pk, vk = aes16
+    key, blk = mt_bytes(16, 600), mt_bytes(16, 601)
+    msg = blk * 4                                                  # four identical chunks (the reference's own 64-byte test repeats one block)
+    ct = zko.aes_encrypt(blk, key)
+    plain = pk.encrypt_chunked(msg, key)
+    assert len(set(plain)) == 1                                    # parity mode: same randomness, same proof
+    seed = bytes(range(32))
+    seeded = pk.encrypt_chunked(msg, key, zk_seed=seed)
+    assert len(set(seeded)) == 4 and plain[0] not in seeded
+    assert seeded == pk.encrypt_chunked(msg, key, zk_seed=seed)
+    assert seeded != pk.encrypt_chunked(msg, key, zk_seed=bytes(32))
+    assert all(api.verify_encryption(vk, p, ct) for p in seeded)
+    # first commitment (w, hiding) differs between any two proofs: no shared blinding
+    assert len({p[16:64] for p in seeded}) == 4
+    b = pk.encrypt_batch([blk] * 3, [key] * 3, zk_seed=seed)
+    assert b == seeded[:3]                                         # same derivation for both entry points
+    with pytest.raises(api.ZkAesError, match="32 bytes"):
+        pk.encrypt_chunked(msg, key, zk_seed=b"short")
+    with pytest.raises(api.ZkAesError, match="bytes"):
+        pk.encrypt_batch([blk, blk[:15]], [key, key])
+    with pytest.raises(api.ZkAesError, match="16 bytes"):
+        pk.encrypt_batch([blk], [key[:8]])

@@ -82,6 +82,7 @@ def test_vk_transport_roundtrip(api, xor_setup):
 
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "gpu_aes16_proof.bin")), reason="GPU-made fixture not generated yet")
@@ -102,6 +103,78 @@ def test_gpu_made_ark_layout_key_verifies_on_the_host(api, vectors):
     proof = open(os.path.join(GOLD, "gpu_aes16_proof.bin"), "rb").read()
     assert api.verify_encryption(vk, proof, bytes(vectors["ciphertext"])) is True
     assert api.verify_encryption(vk, proof, bytes(vectors["wrong_ciphertext_16"])) is False
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "gpu_aes16_proof.bin")), reason="GPU-made fixture not generated yet")
+def test_deserialize_proof_rejects_what_ark_serialize_rejects(api, zko, vectors):
+    """ark-ec 0.3 GroupAffine::deserialize (behind the reference's deserialize_proof, src/lib.rs:52) rejects points outside the prime-order
+    subgroup and SWFlags::from_u8 rejects the flag byte with infinity and sign both set; a lax reader makes proofs malleable (a cofactor-order
+    component added to an opening witness survives the pairing check)."""
+    proof = open(os.path.join(GOLD, "gpu_aes16_proof.bin"), "rb").read()
+    vk = api.VerifyingKey.from_bytes(open(os.path.join(GOLD, "gpu_aes16_vk.bin"), "rb").read())
+    assert api.proof_roundtrip(proof) == proof
+    off = 8 + 8                                                   # Vec<Vec<Commitment>> length, first round length -> first commitment (48 B compressed G1)
+    q = zko.Q377
+
+    def with_point(xbytes):
+        return proof[:off] + bytes(xbytes) + proof[off + 48:]
+    # 1. on the curve, NOT in the subgroup: the smallest x with x^3 + 1 a square whose point has a cofactor component
+    x = 1
+    while True:
+        x += 1
+        rhs = (x * x * x + 1) % q
+        if pow(rhs, (q - 1) // 2, q) != 1:
+            continue
+        bad = with_point(x.to_bytes(48, "little"))
+        with pytest.raises(api.ZkAesError, match="subgroup"):
+            api.proof_roundtrip(bad)
+        with pytest.raises(api.ZkAesError, match="subgroup"):
+            api.verify_encryption(vk, bad, bytes(vectors["ciphertext"]))
+        break
+    # 2. flag byte with infinity AND sign set
+    b = bytearray(proof[off:off + 48]); b[47] |= 0xC0
+    with pytest.raises(api.ZkAesError, match="flags"):
+        api.proof_roundtrip(with_point(b))
+    # 3. infinity flag with non-zero x bits: one encoding per point
+    b = bytearray(proof[off:off + 48]); b[47] = (b[47] & 0x3f) | 0x40
+    with pytest.raises(api.ZkAesError, match="infinity"):
+        api.proof_roundtrip(with_point(b))
+    # the canonical infinity encoding still parses (and the proof then simply fails to verify)
+    inf = bytearray(48); inf[47] = 0x40
+    assert api.proof_roundtrip(with_point(inf)) == with_point(inf)
+    assert api.verify_encryption(vk, with_point(inf), bytes(vectors["ciphertext"])) is False
+    # 4. an opening witness shifted by a cofactor-order point used to verify; it no longer parses.  (x = 0, y = 1) has order 3 on y^2 = x^3 + 1
+    w_off = len(proof) - 1 - 1 - 48                               # ... w_gamma (48 B), Option tag, pc_proof.evals tag
+    zero_x = bytearray(48)
+    with pytest.raises(api.ZkAesError, match="subgroup"):
+        api.proof_roundtrip(proof[:w_off] + bytes(zero_x) + proof[w_off + 48:])
+
+
+def test_concurrent_first_use_of_point_decompression(api):
+    """the square-root constants behind point decompression are initialised on first use; the first callers may race (verifier-only process,
+    INTEGRATION.md: VkHandle is Sync).  Eight threads decompress at once in a FRESH process; all must agree with a later single-threaded call."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, threading
+sys.path.insert(0, %r)
+from aes_zero_knowledge_proof_circuit_amd import api
+import os
+gold = os.path.join(%r, "tests", "golden")
+raw = open(os.path.join(gold, "gpu_aes16_vk_ark.bin"), "rb").read()
+out = [None] * 8
+def run(i):
+    out[i] = api.VerifyingKey.from_ark_bytes(raw).to_ark_bytes()
+ts = [threading.Thread(target=run, args=(i,)) for i in range(8)]
+[t.start() for t in ts]; [t.join() for t in ts]
+assert all(o == raw for o in out), "racing first calls disagree"
+assert api.VerifyingKey.from_ark_bytes(raw).to_ark_bytes() == raw
+print("ok")
+""" % (ROOT_DIR, ROOT_DIR)
+    if not os.path.exists(os.path.join(GOLD, "gpu_aes16_vk_ark.bin")):
+        pytest.skip("GPU-made fixture not generated yet")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
 # ---------------- ark-serialize layout of the verifying key (SURVEY.md 8f item 1) ----------------
