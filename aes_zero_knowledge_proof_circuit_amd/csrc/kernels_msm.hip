@@ -339,7 +339,7 @@ struct MsmWorkspace {
     uint32_t *deferred = nullptr, *deferred_count = nullptr;
     void *buckets = nullptr, *seg_s = nullptr, *seg_w = nullptr, *partial = nullptr, *wsum = nullptr, *tmp = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, fence_a = nullptr, fence_b = nullptr;
-    hipStream_t low = nullptr;                                     // low-priority side stream for k_accumulate (ZKAES_STREAM_PRIORITY, default on)
+    hipStream_t low = nullptr;                                     // low-priority side stream for k_accumulate (ZKAES_STREAM_PRIORITY=1; default off)
 };
 static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t xyzz_bytes) {
     if (!S.ev0) {
@@ -368,7 +368,9 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
     (void)xyzz_bytes;
 }
 bool stream_priorities_enabled() {
-    static const bool on = [] { const char *e = getenv("ZKAES_STREAM_PRIORITY"); return !e || atoi(e) != 0; }();
+    // measured (profiles/r02_bench_stream_priority.md): 59.7 blocks/s with the side stream, 61.1 without -- the hardware queues already interleave the
+    // contexts' kernels and the two extra event waits per MSM cost more than the priority buys.  Off unless ZKAES_STREAM_PRIORITY=1.
+    static const bool on = [] { const char *e = getenv("ZKAES_STREAM_PRIORITY"); return e && atoi(e) != 0; }();
     return on;
 }
 MsmWorkspace *msm_workspace_create() {

@@ -21,8 +21,8 @@ void d2h(void *dst, const void *src, size_t bytes, stream_t s) { if (bytes) { HI
 void d2d(void *dst, const void *src, size_t bytes, stream_t s) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s)); }
 void dzero(void *dst, size_t bytes, stream_t s) { if (bytes) HIP_CHECK(hipMemsetAsync(dst, 0, bytes, (hipStream_t)s)); }
 void sync(stream_t s) { HIP_CHECK(hipStreamSynchronize((hipStream_t)s)); }
-// Prover streams are HIGH priority; the MSM workspace of the same context owns a LOW-priority side stream that carries only k_accumulate
-// (kernels_msm.hip run_buckets).  ZKAES_STREAM_PRIORITY=0 puts everything back on plain default-priority streams.
+// With ZKAES_STREAM_PRIORITY=1 prover streams are HIGH priority and the MSM workspace of the same context owns a LOW-priority side stream that
+// carries only k_accumulate (kernels_msm.hip run_buckets); measured neutral-to-worse on MI355X, so the default is plain streams.
 stream_t stream_create() {
     hipStream_t s;
     int lo = 0, hi = 0;

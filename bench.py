@@ -6,6 +6,8 @@ Default workload = BASELINE.json configs[2], the one the >=100x target is quoted
 that fits |H| = 2^20, |K| = 2^22 and the reference's SRS literal).  The --steps timed steps SLICE that one message: step i proves the i-th
 contiguous share of its chunk-proofs, witness generation -> serialized proof, SRS / index / circuit tables resident in HBM beforehand (the
 region criterion times in the reference: benches/benchmark_encrypt.rs:45-47).  value = blocks of the whole message(s) / timed region.
+The slices are issued through a 2-deep software pipeline (slice i+1 is submitted while slice i drains, as a streaming caller of the library would do), so
+the chip does not idle between steps; the timed region is still exactly the --steps slices between two barriers.
 Warm-up steps prove a separate short message.  Every timed proof is verified afterwards on the host (accept rate must be 100 %) together
 with the reference's negative case (a wrong ciphertext must be rejected).
 
@@ -89,6 +91,7 @@ def build_parser():
     ap.add_argument("--proofs", type=int, default=1024, help="batch mode: independent single-block proofs (whole job)")
     ap.add_argument("--chunk", type=int, default=6, help="blocks per chunk-proof (6 = the most that fits |H|=2^20, |K|=2^22 and the reference's SRS literal)")
     ap.add_argument("--contexts", type=int, default=10, help="chunk-proofs in flight per GPU (separate HIP streams)")
+    ap.add_argument("--pipeline", type=int, default=2, help="timed slices in flight (1 = strictly one after the other: the chip drains at every step boundary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chunk-samples", type=int, default=1, help="CPU-oracle samples at the bench's chunk size (0 = one-block samples only)")
     ap.add_argument("--serial-probe", type=int, default=2, help="chunk-proofs proven one at a time after the timed region for un-overlapped kernel durations (0 = off)")
@@ -196,11 +199,17 @@ def run(args, api, dist_env=None):
     proofs = []
     barrier()
     t0 = time.perf_counter()
-    for a, b in slices:
-        proofs.extend(prove_range(a, b))
-        if pk is not None and b > a:
-            for k, v in pk.timings().items():
-                phase[k] += v                                 # wall times of ONE chunk-proof of the step (sampled; several are in flight concurrently)
+    def timed_slice(ab):
+        api.set_device(local_rank)
+        r = prove_range(*ab)
+        t = pk.timings() if (pk is not None and ab[1] > ab[0]) else None      # wall times of ONE chunk-proof of the step (sampled; several are in flight concurrently)
+        return r, t
+    with ThreadPoolExecutor(max_workers=max(1, args.pipeline)) as ex:        # slice i+1 starts while slice i drains: both queue on the same prover contexts
+        for r, t in ex.map(timed_slice, slices):
+            proofs.extend(r)
+            if t:
+                for k, v in t.items():
+                    phase[k] += v
     gathered = None
     if mode != "headline":
         gathered = sharding.gather_proofs(proofs, device=coll_device)    # the job's one exchange: ~855 B per chunk-proof to every rank

@@ -4,6 +4,7 @@
  * /root/reference) -- SURVEY.md §A.4 "VariableBaseMSM::multi_scalar_mul".
  */
 #include "zko.h"
+#include <omp.h>
 #include "zko_consts.h"
 #include <math.h>
 #include <stdlib.h>
@@ -223,6 +224,13 @@ void zko_g1_rand(g1a_t *out, zko_chacha *rng, const zko_curve *C) {
     }
 }
 
+/* ark-ec 0.3.0 VariableBaseMSM::multi_scalar_mul restated: window c = ln(n) + 2 (3 below 32 points), windows at bit offsets 0, c, 2c, ...,
+ * 2^c - 1 buckets per window, scalar == 1 added directly in window 0, zero scalars skipped, running-sum bucket reduction, Horner over the
+ * window sums.  Upstream runs ONE rayon task per window (<= 17 useful threads); so that the CPU baseline uses all the cores of the box, each
+ * window's points are additionally cut into `slices` contiguous ranges with their own bucket arrays (merged bucket-wise afterwards) and the
+ * running sum is done in 4096-bucket segments (W_seg + lo * S_seg).  Group addition is associative and commutative: the resulting point -- and
+ * every serialized byte downstream -- is the same as the one-task-per-window order gives (tests/test_oracle_primitives.py compares against
+ * plain double-and-add). */
 void zko_msm(g1j_t *out, const g1a_t *bases, const fr_t *scalars, size_t n, const zko_curve *C) {
     const fr_params *F = C->fr;
     if (n == 0) { g1j_set_inf(out); return; }
@@ -238,34 +246,68 @@ void zko_msm(g1j_t *out, const g1a_t *bases, const fr_t *scalars, size_t n, cons
     for (size_t i = 0; i < n; i++) fr_to_raw(raw[i], &scalars[i], F);
     g1j_t *wsum = malloc(nwin * sizeof(g1j_t));
     size_t nb = ((size_t)1 << c) - 1;
-#pragma omp parallel for schedule(dynamic, 1)
+    int threads = omp_get_max_threads();
+    int slices = (threads + nwin - 1) / nwin;
+    while (slices > 1 && (n / slices < 8 * nb || (size_t)nwin * slices * nb * sizeof(g1j_t) > ((size_t)6 << 30))) slices--;   /* merging costs nb adds per extra slice */
+    g1j_t *bk = malloc((size_t)nwin * slices * nb * sizeof(g1j_t));
+    g1j_t *ones = malloc((size_t)slices * sizeof(g1j_t));           /* scalar == 1 terms (window 0 only) */
+    if (!bk || !ones) abort();
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int w = 0; w < nwin; w++) {
-        int w_start = w * c;
-        g1j_t res; g1j_set_inf(&res);
-        g1j_t *buckets = malloc(nb * sizeof(g1j_t));
-        for (size_t b = 0; b < nb; b++) g1j_set_inf(&buckets[b]);
-        for (size_t i = 0; i < n; i++) {
-            const uint64_t *s = raw[i];
-            if ((s[0] | s[1] | s[2] | s[3]) == 0) continue;
-            if (s[0] == 1 && (s[1] | s[2] | s[3]) == 0) {
-                if (w_start == 0) g1j_madd(&res, &res, &bases[i], C);
-                continue;
+        for (int sl = 0; sl < slices; sl++) {
+            int w_start = w * c;
+            g1j_t res; g1j_set_inf(&res);
+            g1j_t *buckets = bk + ((size_t)w * slices + sl) * nb;
+            for (size_t b = 0; b < nb; b++) g1j_set_inf(&buckets[b]);
+            size_t i0 = n * (size_t)sl / slices, i1 = n * (size_t)(sl + 1) / slices;
+            for (size_t i = i0; i < i1; i++) {
+                const uint64_t *s = raw[i];
+                if ((s[0] | s[1] | s[2] | s[3]) == 0) continue;
+                if (s[0] == 1 && (s[1] | s[2] | s[3]) == 0) {
+                    if (w_start == 0) g1j_madd(&res, &res, &bases[i], C);
+                    continue;
+                }
+                /* (scalar >> w_start) % 2^c */
+                int limb = w_start / 64, sh = w_start % 64;
+                uint64_t v = s[limb] >> sh;
+                if (sh && limb + 1 < 4) v |= s[limb + 1] << (64 - sh);
+                v &= ((uint64_t)1 << c) - 1;
+                if (v != 0) g1j_madd(&buckets[v - 1], &buckets[v - 1], &bases[i], C);
             }
-            /* (scalar >> w_start) % 2^c */
-            int limb = w_start / 64, sh = w_start % 64;
-            uint64_t v = s[limb] >> sh;
-            if (sh && limb + 1 < 4) v |= s[limb + 1] << (64 - sh);
-            v &= ((uint64_t)1 << c) - 1;
-            if (v != 0) g1j_madd(&buckets[v - 1], &buckets[v - 1], &bases[i], C);
+            if (w == 0) ones[sl] = res;
         }
-        g1j_t running; g1j_set_inf(&running);
-        for (size_t b = nb; b-- > 0;) {
-            g1j_add(&running, &running, &buckets[b], C);
-            g1j_add(&res, &res, &running, C);
+    }
+    /* running sum in segments: bucket b carries weight b + 1 = (b - lo + 1) + lo */
+    const size_t SEG = 4096;
+    size_t nseg = (nb + SEG - 1) / SEG;
+    g1j_t *segres = malloc((size_t)nwin * nseg * sizeof(g1j_t));
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int w = 0; w < nwin; w++) {
+        for (size_t sg = 0; sg < nseg; sg++) {
+            size_t lo = sg * SEG, hi = lo + SEG < nb ? lo + SEG : nb;
+            g1j_t running, acc; g1j_set_inf(&running); g1j_set_inf(&acc);
+            for (size_t b = hi; b-- > lo;) {
+                g1j_t tot = bk[((size_t)w * slices) * nb + b];
+                for (int sl = 1; sl < slices; sl++) g1j_add(&tot, &tot, &bk[((size_t)w * slices + sl) * nb + b], C);
+                g1j_add(&running, &running, &tot, C);
+                g1j_add(&acc, &acc, &running, C);
+            }
+            if (lo) {   /* + lo * S_seg (running == S_seg now) */
+                g1j_t m; g1j_set_inf(&m);
+                int top = 63; while (top > 0 && !((lo >> top) & 1)) top--;
+                for (int bit = top; bit >= 0; bit--) { g1j_dbl(&m, &m, C); if ((lo >> bit) & 1) g1j_add(&m, &m, &running, C); }
+                g1j_add(&acc, &acc, &m, C);
+            }
+            segres[(size_t)w * nseg + sg] = acc;
         }
-        free(buckets);
+    }
+    for (int w = 0; w < nwin; w++) {
+        g1j_t res; g1j_set_inf(&res);
+        if (w == 0) for (int sl = 0; sl < slices; sl++) g1j_add(&res, &res, &ones[sl], C);
+        for (size_t sg = 0; sg < nseg; sg++) g1j_add(&res, &res, &segres[(size_t)w * nseg + sg], C);
         wsum[w] = res;
     }
+    free(segres); free(ones); free(bk);
     /* lowest + sum_{w>=1 from high} (total + wsum[w]) doubled c times */
     g1j_t total; g1j_set_inf(&total);
     for (int w = nwin - 1; w >= 1; w--) {

@@ -11,6 +11,7 @@
  */
 #include "zko_marlin.h"
 #include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include "zko_consts.h"
 
@@ -297,7 +298,11 @@ static void sample_outside(fr_t *out, zko_fsrng *fs, const zko_domain *D) {
     do { zko_fr_rand(out, &fs->r, D->F); zko_domain_eval_vanishing(&v, D, out); } while (fr_is_zero(&v));
 }
 
+/* ZKO_TIMING=1: per-phase wall times of the prover on stderr (finding what does not scale with the thread count) */
+static double tm_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+#define TM(label) do { if (tm_on) { double t_ = tm_now(); fprintf(stderr, "zko timing %-28s %8.3f s\n", label, t_ - tm_last); tm_last = t_; } } while (0)
 zko_proof *zko_marlin_prove(const zko_index *ix, zko_cs *cs, const uint8_t *zk_seed) {
+    const int tm_on = getenv("ZKO_TIMING") != NULL; double tm_last = tm_now();
     const zko_curve *C = ix->ck.C;
     const fr_params *F = C->fr;
     const zko_ck *ck = &ix->ck;
@@ -328,6 +333,7 @@ zko_proof *zko_marlin_prove(const zko_index *ix, zko_cs *cs, const uint8_t *zk_s
             fr_from_i64(dst[q], (int64_t)s, F);
         }
     }
+    TM("pad + z_A z_B");
     /* ---- FS init: "MARLIN-2019" || index_vk || public_input (padded instance without the leading One) */
     zko_fsrng fs;
     {
@@ -365,11 +371,14 @@ zko_proof *zko_marlin_prove(const zko_index *ix, zko_cs *cs, const uint8_t *zk_s
     zko_fr_rand(&rho, &zk, F); fr_sub(&r1[1].p.c[0], &r1[1].p.c[0], &rho, F); r1[1].p.c[n] = rho;
     r1[2].p = poly_new(n + 1); memcpy(r1[2].p.c, zb, n * sizeof(fr_t)); zko_ifft(H, r1[2].p.c);
     zko_fr_rand(&rho, &zk, F); fr_sub(&r1[2].p.c[0], &r1[2].p.c[0], &rho, F); r1[2].p.c[n] = rho;
+    TM("round 1 polynomials");
     r1[3].p = poly_new(3 * n);                                  /* mask: degree 3|H| + 2 zk - 3 */
     for (size_t i = 0; i < 3 * n; i++) zko_fr_rand(&r1[3].p.c[i], &zk, F);
     { fr_t s = r1[3].p.c[0]; fr_add(&s, &s, &r1[3].p.c[n], F); fr_add(&s, &s, &r1[3].p.c[2 * n], F); fr_sub(&r1[3].p.c[0], &r1[3].p.c[0], &s, F); }
+    TM("mask draws");
     for (int i = 0; i < 4; i++) { r1[i].bound = -1; r1[i].hiding = i < 3; }
     for (int i = 0; i < 4; i++) mpc_commit(&r1[i], ck, &zk);
+    TM("round 1 commitments");
     fs_absorb_commitments(&fs, r1, 4, C);
     fr_t alpha, eta_a, eta_b, eta_c;
     sample_outside(&alpha, &fs, H);
@@ -383,6 +392,7 @@ zko_proof *zko_marlin_prove(const zko_index *ix, zko_cs *cs, const uint8_t *zk_s
     fr_batch_inv(r_alpha_evals, n, scr, F);
     for (size_t i = 0; i < n; i++) fr_mul(&r_alpha_evals[i], &r_alpha_evals[i], &vh_alpha, F);
     free(scr);
+    TM("r(alpha, .) on H");
     /* calculate_t (row-major accumulate, as the reference's upstream loop) */
     fr_t *t_evals = fr_alloc(n);
     {
@@ -398,6 +408,7 @@ zko_proof *zko_marlin_prove(const zko_index *ix, zko_cs *cs, const uint8_t *zk_s
                 }
             }
     }
+    TM("calculate_t");
     r2[0].p = poly_new(n); memcpy(r2[0].p.c, t_evals, n * sizeof(fr_t)); zko_ifft(H, r2[0].p.c);
     free(t_evals);
     zko_poly r_alpha_poly = poly_new(n); memcpy(r_alpha_poly.c, r_alpha_evals, n * sizeof(fr_t)); zko_ifft(H, r_alpha_poly.c);
@@ -432,7 +443,9 @@ zko_proof *zko_marlin_prove(const zko_index *ix, zko_cs *cs, const uint8_t *zk_s
     }
     free(e_za); free(e_zb); free(e_ra); free(e_t); free(e_z);
     r2[0].bound = -1; r2[0].hiding = 0; r2[1].bound = (long)(n - 2); r2[1].hiding = 1; r2[2].bound = -1; r2[2].hiding = 0;
+    TM("round 2 polynomials");
     for (int i = 0; i < 3; i++) mpc_commit(&r2[i], ck, &zk);
+    TM("round 2 commitments");
     fs_absorb_commitments(&fs, r2, 3, C);
     fr_t beta; sample_outside(&beta, &fs, H);
 
@@ -484,7 +497,9 @@ zko_proof *zko_marlin_prove(const zko_index *ix, zko_cs *cs, const uint8_t *zk_s
         free(rm); free(ea); free(eb); free(ef); poly_free(&a_poly); poly_free(&b_poly);
     }
     r3[0].bound = (long)(k - 2); r3[0].hiding = 0; r3[1].bound = -1; r3[1].hiding = 0;
+    TM("round 3 polynomials");
     for (int i = 0; i < 2; i++) mpc_commit(&r3[i], ck, &zk);
+    TM("round 3 commitments");
     fs_absorb_commitments(&fs, r3, 2, C);
     fr_t gamma; zko_fr_rand(&gamma, &fs.r, F);
 
@@ -588,6 +603,7 @@ zko_proof *zko_marlin_prove(const zko_index *ix, zko_cs *cs, const uint8_t *zk_s
     pf->alpha = alpha; pf->eta_a = eta_a; pf->eta_b = eta_b; pf->eta_c = eta_c; pf->beta = beta; pf->gamma = gamma; pf->opening_challenge = ch;
     free(za); free(zb); free(x_evals); free(r_alpha_evals); free(small);
     poly_free(&x_poly); poly_free(&r_alpha_poly); poly_free(&z_poly); poly_free(&f_poly);
+    TM("evaluations + openings");
     return pf;
 }
 void zko_proof_free(zko_proof *p) { if (!p) return; for (int i = 0; i < 9; i++) free(p->polys[i].c); free(p); }
