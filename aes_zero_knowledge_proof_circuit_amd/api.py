@@ -263,6 +263,26 @@ def g1_sum(curve_id, points):
     return out.raw, bool(oinf.value)
 
 
+def msm_sharded_plan(curve_id, n_total):
+    """(window_bits, n_windows, bytes_per_rank) of a point-range-sharded MSM over n_total points"""
+    c, w, b = C.c_int(), C.c_int(), C.c_size_t()
+    _check(lib().zkaes_msm_sharded_plan(int(curve_id), C.c_size_t(n_total), C.byref(c), C.byref(w), C.byref(b)))
+    return c.value, w.value, b.value
+
+
+def msm_window_sums_dev(curve_id, bases_bytes, scalars_bytes, n_total, dev_ptr, dev_bytes):
+    """Pippenger over this rank's slice; the window sums stay in device memory at dev_ptr (an int device address, e.g. tensor.data_ptr())"""
+    n = len(scalars_bytes) // 32
+    _check(lib().zkaes_msm_window_sums_dev(int(curve_id), bytes(bases_bytes), bytes(scalars_bytes), C.c_size_t(n), C.c_size_t(n_total), C.c_void_p(dev_ptr), C.c_size_t(dev_bytes)))
+
+
+def msm_fold_window_sums_dev(curve_id, dev_ptr, world, n_total):
+    out = C.create_string_buffer(96)
+    inf = C.c_int()
+    _check(lib().zkaes_msm_fold_window_sums_dev(int(curve_id), C.c_void_p(dev_ptr), int(world), C.c_size_t(n_total), out, C.byref(inf)))
+    return out.raw, bool(inf.value)
+
+
 def msm_table(curve_id, bases_bytes, scalars_bytes, window_bits):
     n = len(scalars_bytes) // 32
     out = C.create_string_buffer(96)

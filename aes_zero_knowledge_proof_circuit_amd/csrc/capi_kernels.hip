@@ -95,6 +95,34 @@ template <class Curve> void run_msm_table(const uint8_t *bases, const uint8_t *s
     zk::gpu::msm_workspace_destroy(ws);
     zk::gpu::dfree(tab); zk::gpu::dfree(ds); zk::gpu::stream_destroy(s);
 }
+template <class Curve> void run_msm_window_sums_dev(const uint8_t *bases, const uint8_t *scalars, size_t n_local, size_t n_total, void *dev_out, size_t dev_out_bytes) {
+    using Fq = typename Curve::Fq; using Fr = typename Curve::Fr;
+    zk::gpu::require_device();
+    int c = 0, nwin = 0;
+    zk::gpu::msm_sharded_plan<Curve>(n_total, &c, &nwin);
+    if (!dev_out || dev_out_bytes < (size_t)nwin * sizeof(zk::XYZZ<Fq>)) throw std::invalid_argument("zkaes_msm_window_sums_dev: device buffer too small for the window sums");
+    if (n_local > n_total) throw std::invalid_argument("zkaes_msm_window_sums_dev: n_local > n_total");
+    zk::gpu::stream_t s = zk::gpu::stream_create();
+    zk::Affine<Fq> *db = (zk::Affine<Fq> *)zk::gpu::dmalloc(n_local * 96);
+    Fr *ds = (Fr *)zk::gpu::dmalloc(n_local * 32);
+    zk::gpu::h2d(db, bases, n_local * 96, s); zk::gpu::h2d(ds, scalars, n_local * 32, s);
+    zk::Affine28<typename Curve::FqP> *db28 = (zk::Affine28<typename Curve::FqP> *)zk::gpu::dmalloc(n_local * sizeof(zk::Affine28<typename Curve::FqP>));
+    zk::gpu::convert_bases<Curve>(db28, db, n_local, s);
+    zk::gpu::MsmWorkspace *ws = zk::gpu::msm_workspace_create();
+    zk::gpu::msm_window_sums_device<Curve>(ws, db28, ds, n_local, n_total, (zk::XYZZ<Fq> *)dev_out, s);    // synchronizes the stream
+    zk::gpu::msm_workspace_destroy(ws);
+    zk::gpu::dfree(db28); zk::gpu::dfree(db); zk::gpu::dfree(ds); zk::gpu::stream_destroy(s);
+}
+template <class Curve> void run_msm_fold_dev(const void *dev_in, int world, size_t n_total, uint8_t *out_xy, int *out_inf) {
+    using Fq = typename Curve::Fq;
+    zk::gpu::require_device();
+    if (!dev_in || world < 1) throw std::invalid_argument("zkaes_msm_fold_window_sums_dev: bad arguments");
+    zk::gpu::stream_t s = zk::gpu::stream_create();
+    zk::Affine<Fq> a = zk::gpu::msm_fold_window_sums_device<Curve>((const zk::XYZZ<Fq> *)dev_in, world, n_total, s).to_affine();
+    zk::gpu::stream_destroy(s);
+    if (out_inf) *out_inf = a.is_inf() ? 1 : 0;
+    if (out_xy) { memcpy(out_xy, a.x.l, 48); memcpy(out_xy + 48, a.y.l, 48); }
+}
 // host-side sum of a handful of affine partial results: the "local EC add" after the all-gather of a point-range-sharded MSM
 template <class Curve> void run_g1_sum(const uint8_t *points_xy, const int *inf, size_t n, uint8_t *out_xy, int *out_inf) {
     using Fq = typename Curve::Fq;
@@ -112,6 +140,21 @@ template <class Curve> void run_g1_sum(const uint8_t *points_xy, const int *inf,
 }  // namespace
 
 extern "C" {
+int zkaes_msm_sharded_plan(int curve_id, size_t n_total, int *window_bits, int *n_windows, size_t *bytes_per_rank) {
+    return guardk([&] {
+        int c = 0, w = 0;
+        if (curve_id == 381) zk::gpu::msm_sharded_plan<zk::Bls381>(n_total, &c, &w); else if (curve_id == 377) zk::gpu::msm_sharded_plan<zk::Bls377>(n_total, &c, &w); else throw std::invalid_argument("curve_id must be 377 or 381");
+        if (window_bits) *window_bits = c;
+        if (n_windows) *n_windows = w;
+        if (bytes_per_rank) *bytes_per_rank = (size_t)w * 192;
+    });
+}
+int zkaes_msm_window_sums_dev(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n_local, size_t n_total, void *dev_out, size_t dev_out_bytes) {
+    return guardk([&] { if (curve_id == 381) run_msm_window_sums_dev<zk::Bls381>(bases, scalars, n_local, n_total, dev_out, dev_out_bytes); else if (curve_id == 377) run_msm_window_sums_dev<zk::Bls377>(bases, scalars, n_local, n_total, dev_out, dev_out_bytes); else throw std::invalid_argument("curve_id must be 377 or 381"); });
+}
+int zkaes_msm_fold_window_sums_dev(int curve_id, const void *dev_in, int world, size_t n_total, uint8_t *out_xy, int *out_inf) {
+    return guardk([&] { if (curve_id == 381) run_msm_fold_dev<zk::Bls381>(dev_in, world, n_total, out_xy, out_inf); else if (curve_id == 377) run_msm_fold_dev<zk::Bls377>(dev_in, world, n_total, out_xy, out_inf); else throw std::invalid_argument("curve_id must be 377 or 381"); });
+}
 int zkaes_g1_sum(int curve_id, const uint8_t *points_xy, const int *inf, size_t n, uint8_t *out_xy, int *out_inf) {
     return guardk([&] { if (curve_id == 381) run_g1_sum<zk::Bls381>(points_xy, inf, n, out_xy, out_inf); else if (curve_id == 377) run_g1_sum<zk::Bls377>(points_xy, inf, n, out_xy, out_inf); else throw std::invalid_argument("curve_id must be 377 or 381"); });
 }

@@ -53,14 +53,30 @@ XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws, const Affine28<typename Curve::Fq
 // of the same array) as ONE Pippenger instance; msm_finish: accumulate from `bases` + reduce.  msm_finish may be called several times on one
 // prepared state with different base arrays (the plain and the shifted commitment of a degree-bounded polynomial share their scalars).
 template <class Curve>
-void msm_prepare(MsmWorkspace *ws, const typename Curve::Fr *scal1, size_t n1, const typename Curve::Fr *scal2, size_t n2, size_t val_off2, stream_t s);
+void msm_prepare(MsmWorkspace *ws, const typename Curve::Fr *scal1, size_t n1, const typename Curve::Fr *scal2, size_t n2, size_t val_off2, stream_t s, int force_c = 0);
 template <class Curve>
 XYZZ<typename Curve::Fq> msm_finish(MsmWorkspace *ws, const Affine28<typename Curve::FqP> *bases, stream_t s);
-// Precomputed-window variant for FIXED bases (the SRS): tables[j * stride + i] = 2^(c j) * P_i for j < table_windows(c); with one
-// table copy per window all windows share ONE bucket set, so bucket reduction is paid once and c can grow (fewer windows = fewer adds).
-// build_window_tables fills copies 1.. from copy 0 (already in tables[0..stride)); msm_table sums scalars[i] * P_{off+i}, i < n.
+// ONE MSM sharded by point range over ranks: msm_sharded_plan gives the window plan of the whole MSM (all ranks agree on it);
+// msm_window_sums_device runs this rank's slice and leaves n_windows XYZZ window sums (192 B each, standard Montgomery form) at dev_out in HBM
+// -- the payload of the one all-gather; msm_fold_window_sums_device adds `world` such blocks (rank-major) per window on the device and finishes
+// with the Horner pass over the windows.
+template <class Curve> void msm_sharded_plan(size_t n_total, int *window_bits, int *n_windows);
+template <class Curve>
+void msm_window_sums_device(MsmWorkspace *ws, const Affine28<typename Curve::FqP> *bases, const typename Curve::Fr *scalars, size_t n_local, size_t n_total,
+                            XYZZ<typename Curve::Fq> *dev_out, stream_t s);
+template <class Curve>
+XYZZ<typename Curve::Fq> msm_fold_window_sums_device(const XYZZ<typename Curve::Fq> *dev_in, int world, size_t n_total, stream_t s);
+// Precomputed-window variant for FIXED bases (the SRS): tables[j * stride + i] = 2^(c j) * P_i for j < table_windows(c).  With one table copy
+// per window ALL windows share ONE set of 2^(c-1) signed-digit buckets, so the bucket reduction is paid once and c can grow to 20-22
+// (12-13 windows instead of 15): fewer (point, window) pairs = fewer mixed adds in k_accumulate.
+// build_window_tables fills copies 1.. from copy 0 (already in tables[0..stride)).
+// msm_prepare_table + msm_finish(ws, tables [+ constant index shift]) mirror msm_prepare / msm_finish: element i of scalar vector v names table
+// entry w * stride + off_v + i in window w, so two vectors over two index ranges (plain + shifted powers) share one Pippenger instance, and one
+// prepared state can be finished against two index shifts (the plain and the shifted commitment of a degree-bounded polynomial).
 template <class Curve> int table_windows(int c);
 template <class Curve> void build_window_tables(Affine<typename Curve::Fq> *tables, size_t stride, int c, stream_t s);
+template <class Curve>
+void msm_prepare_table(MsmWorkspace *ws, const typename Curve::Fr *scal1, size_t n1, size_t off1, const typename Curve::Fr *scal2, size_t n2, size_t off2, int c, size_t stride, stream_t s);
 template <class Curve>
 XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws, const Affine28<typename Curve::FqP> *tables, size_t stride, size_t off, int c, const typename Curve::Fr *scalars, size_t n, stream_t s);
 // out[i] = (beta^(from+i)) * base for i < count   (KZG powers; fixed-base windows)   -- device output

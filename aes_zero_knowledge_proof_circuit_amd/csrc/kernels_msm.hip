@@ -60,22 +60,28 @@ __global__ void k_digits(const Fr *__restrict__ scalars, uint32_t n, uint32_t i_
     }
 }
 
-// table mode: every window j reads its own precomputed copy T_j[i] = 2^(c j) * P_i, so all windows share ONE bucket set:
-// key = digit, value = absolute index j * stride + base_off + i into the table array
+// table mode: every window j reads its own precomputed copy T_j[i] = 2^(c j) * P_i, so ALL windows share ONE bucket set of 2^(c-1) signed-digit
+// buckets: key = |digit| - 1 (zero digits: bucket 0 + SKIP), value = absolute index j * stride + val_off + i into the table array (+ sign / skip bits).
+// With one set the running-sum reduction is paid once instead of once per window, so c can grow to 20-22 and the windows shrink to 12-13.
 template <class Fr>
-__global__ void k_digits_table(const Fr *__restrict__ scalars, uint32_t n, int c, int nwin, uint32_t stride, uint32_t base_off, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+__global__ void k_digits_table(const Fr *__restrict__ scalars, uint32_t n, uint32_t i_off, uint32_t ntot, uint32_t val_off, int c, int nwin, uint32_t stride,
+                               uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t raw[Fr::N + 1];
     scalars[i].to_raw(raw);
     raw[Fr::N] = 0;
-    uint32_t mask = (1u << c) - 1;
+    const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
+    uint32_t carry = 0;
     for (int w = 0; w < nwin; w++) {
         int bit = w * c, limb = bit >> 5, sh = bit & 31;
-        uint64_t two = (uint64_t)raw[limb] | ((uint64_t)raw[limb + 1] << 32);
-        uint32_t d = (uint32_t)(two >> sh) & mask;
-        keys[(size_t)w * n + i] = d ? d - 1 : (1u << c);                       // bucket index = digit - 1; zero digits sort past the buckets
-        vals[(size_t)w * n + i] = (uint32_t)w * stride + base_off + i;
+        uint64_t two = limb <= Fr::N - 1 ? ((uint64_t)raw[limb] | ((uint64_t)raw[limb + 1] << 32)) : 0;
+        uint32_t v = ((uint32_t)(two >> sh) & mask) + carry;
+        uint32_t neg = 0;
+        carry = 0;
+        if (v > half) { v = (1u << c) - v; neg = 1u << 31; carry = 1; }
+        keys[(size_t)w * ntot + i_off + i] = v ? v - 1 : 0u;
+        vals[(size_t)w * ntot + i_off + i] = v ? (((uint32_t)w * stride + val_off + i) | neg) : VAL_SKIP;
     }
 }
 // T_j = 2^c * T_{j-1}: 8 points per lane, c doublings each, ONE field inversion per lane (Montgomery's trick) back to affine
@@ -134,16 +140,16 @@ __global__ void k_convert_bases(const Affine<Fp<P>> *__restrict__ src, Affine28<
     if (i < n) dst[i] = Affine28<P>::from_std(src[i]);
 }
 
-// A bucket lane adds at most BUCKET_CAP points; the rest of an oversized bucket (skewed scalars: many equal digits) is cut into
-// BUCKET_CAP-point overflow segments that k_accumulate_tail sums in parallel and k_reduce_l1 folds back -- so no input can
-// serialise the whole MSM on one lane.
-constexpr uint32_t BUCKET_CAP = 2048;
-__global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, uint32_t nb, uint32_t *__restrict__ size_key,
+// A bucket lane adds at most `cap` points; the rest of an oversized bucket (skewed scalars: many equal digits; in table mode the 2^11 buckets the short
+// top window lands on) is cut into cap-point overflow segments that k_accumulate_tail sums in parallel and k_reduce_l1 folds back -- so no input can
+// serialise the whole MSM on one lane.  cap = 2048 for the per-window buckets (average bucket ~50 points), 256 in table mode (average ~25).
+constexpr uint32_t BUCKET_CAP = 2048, BUCKET_CAP_TABLE = 256;
+__global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, uint32_t nb, uint32_t cap, uint32_t *__restrict__ size_key,
                                uint32_t *__restrict__ ids, uint32_t *__restrict__ extra) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nb) return;
     uint32_t sz = end[k] - start[k];
-    extra[k] = sz > BUCKET_CAP ? (sz - 1) / BUCKET_CAP : 0;
+    extra[k] = sz > cap ? (sz - 1) / cap : 0;
     if (sz > 8191u) sz = 8191u;
     size_key[k] = 8191u - sz;             // ascending sort on this 13-bit key = descending bucket size (sizes above 8191 tie)
     ids[k] = k;
@@ -156,7 +162,7 @@ __global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_
 template <class P>
 __global__ void __launch_bounds__(64, 2) k_accumulate(const Affine28<P> *__restrict__ bases, const uint32_t *__restrict__ vals,
                                                        const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, const uint32_t *__restrict__ order,
-                                                       uint32_t nbuckets_total, Acc28<P> *__restrict__ buckets,
+                                                       uint32_t nbuckets_total, uint32_t cap, Acc28<P> *__restrict__ buckets,
                                                        uint32_t *__restrict__ deferred, uint32_t deferred_cap, uint32_t *__restrict__ deferred_count) {
     using G = Fp28<P>;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -166,7 +172,7 @@ __global__ void __launch_bounds__(64, 2) k_accumulate(const Affine28<P> *__restr
     bool acc_inf = true;
     {
         uint32_t s = start[k], e = end[k];
-        if (e - s > BUCKET_CAP) e = s + BUCKET_CAP;                        // the remainder goes through the overflow kernels
+        if (e - s > cap) e = s + cap;                                      // the remainder goes through the overflow segments of k_accumulate_tail
         if (s < e) {
             uint32_t idx = vals[s];
             Affine28<P> nxt = bases[idx & VAL_INDEX];
@@ -209,7 +215,7 @@ __device__ void accumulate_fixup(const Affine28<P> *__restrict__ bases, Acc28<P>
 // lane exits after two loads.
 template <class P>
 __global__ void __launch_bounds__(64, 2) k_accumulate_tail(const Affine28<P> *__restrict__ bases, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ start,
-                                                            const uint32_t *__restrict__ end, const uint32_t *__restrict__ extra_off, uint32_t nb, uint32_t max_segments,
+                                                            const uint32_t *__restrict__ end, const uint32_t *__restrict__ extra_off, uint32_t nb, uint32_t max_segments, uint32_t cap,
                                                             Acc28<P> *__restrict__ partial, Acc28<P> *__restrict__ buckets, uint32_t *__restrict__ deferred, uint32_t deferred_cap,
                                                             uint32_t *__restrict__ deferred_count) {
     using G = Fp28<P>;
@@ -220,7 +226,7 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_tail(const Affine28<P> *__
         uint32_t lo = 0, hi = nb;                         // largest k with extra_off[k] <= t
         while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (extra_off[mid] <= t) lo = mid; else hi = mid; }
         uint32_t k = lo, j = t - extra_off[k];
-        uint32_t s = start[k] + (j + 1) * BUCKET_CAP, e = s + BUCKET_CAP < end[k] ? s + BUCKET_CAP : end[k];
+        uint32_t s = start[k] + (j + 1) * cap, e = s + cap < end[k] ? s + cap : end[k];
         Acc28<P> acc;
         bool acc_inf = true;
         for (uint32_t i = s; i < e; i++) {
@@ -328,6 +334,8 @@ __global__ void __launch_bounds__(256) k_reduce_window(const Acc28<P> *__restric
     if (t == 0) out[w] = to_std_point<P>(sh[0]);
 }
 
+template <class P> __global__ void k_sum_tree(const Acc28<P> *__restrict__ in, uint32_t total, uint32_t per, Acc28<P> *__restrict__ out);
+
 constexpr uint32_t DEFERRED_CAP = 1u << 20;
 struct MsmWorkspace {
     size_t cap_pairs = 0, cap_buckets = 0, cap_tmp = 0;
@@ -336,17 +344,19 @@ struct MsmWorkspace {
     uint32_t *size_key = nullptr, *size_key2 = nullptr, *ids = nullptr, *order = nullptr, *extra = nullptr, *extra_off = nullptr;
     void *ovf_partial = nullptr; size_t cap_ovf = 0;
     size_t plan_n = 0, plan_pairs = 0; int plan_c = 0, plan_nwin = 0;     // state between msm_prepare and msm_finish
+    bool plan_table = false; uint32_t plan_cap = BUCKET_CAP;
     uint32_t *deferred = nullptr, *deferred_count = nullptr;
     void *buckets = nullptr, *seg_s = nullptr, *seg_w = nullptr, *partial = nullptr, *wsum = nullptr, *tmp = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, fence_a = nullptr, fence_b = nullptr;
     hipStream_t low = nullptr;                                     // low-priority side stream for k_accumulate (ZKAES_STREAM_PRIORITY=1; default off)
 };
-static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t xyzz_bytes) {
+static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t cap) {
+    if (cap == 0) cap = BUCKET_CAP;
     if (!S.ev0) {
         HIP_CHECK(hipEventCreate(&S.ev0)); HIP_CHECK(hipEventCreate(&S.ev1));
         S.deferred = (uint32_t *)dmalloc(2 * DEFERRED_CAP * 4); S.deferred_count = (uint32_t *)dmalloc(8);
     }
-    if (pairs / BUCKET_CAP + 64 > S.cap_ovf) { dfree(S.ovf_partial); S.cap_ovf = pairs / BUCKET_CAP + 64; S.ovf_partial = dmalloc(S.cap_ovf * 224); }
+    if (pairs / cap + 64 > S.cap_ovf) { dfree(S.ovf_partial); S.cap_ovf = pairs / cap + 64; S.ovf_partial = dmalloc(S.cap_ovf * 224); }
     if (pairs > S.cap_pairs) {
         dfree(S.keys_a); dfree(S.keys_b); dfree(S.vals_a); dfree(S.vals_b);
         S.cap_pairs = pairs;
@@ -365,7 +375,6 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
         S.partial = dmalloc((buckets / (RED_L1 * RED_L2) + 64 * 64) * 224); S.wsum = dmalloc(192 * 64);
         // (window sums: at most 64 sets)
     }
-    (void)xyzz_bytes;
 }
 bool stream_priorities_enabled() {
     // measured (profiles/r02_bench_stream_priority.md): 59.7 blocks/s with the side stream, 61.1 without -- the hardware queues already interleave the
@@ -397,7 +406,7 @@ void msm_workspace_destroy(MsmWorkspace *w) {
 
 // shared middle: sort the (key, value) pairs, find bucket ranges, order buckets by descending size, cut oversized buckets
 template <class P>
-static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int sort_bits, hipStream_t s) {
+static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int sort_bits, uint32_t cap, hipStream_t s) {
     // c here = log2(buckets per set); keys run over [0, nb) plus the out-of-range key nb for zero digits
     size_t nb = (size_t)nsets << c;
     int key_bits = 1;
@@ -416,7 +425,7 @@ static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int
     HIP_LAUNCH_CHECK();
     // size-balanced visiting order of the buckets
     HIP_CHECK(hipMemsetAsync(S.extra + nb, 0, 4, s));
-    hipLaunchKernelGGL(k_bucket_sizes, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, S.start, S.end, (uint32_t)nb, S.size_key, S.ids, S.extra);
+    hipLaunchKernelGGL(k_bucket_sizes, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, S.start, S.end, (uint32_t)nb, cap, S.size_key, S.ids, S.extra);
     HIP_LAUNCH_CHECK();
     {
         size_t tb = 0;
@@ -434,7 +443,8 @@ static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int
 // shared tail over prepared buckets: accumulate from `bases`, fold overflow segments and deferred degenerate additions, reduce; returns the
 // nsets window sums.  May be called several times on one prepared state with different base arrays (same scalars, e.g. plain + shifted powers).
 template <class P>
-static std::vector<XYZZ<Fp<P>>> run_buckets(MsmWorkspace &S, const Affine28<P> *bases, size_t pairs, int c, int nsets, size_t n_points, hipStream_t s, float *acc_ms) {
+static std::vector<XYZZ<Fp<P>>> run_buckets(MsmWorkspace &S, const Affine28<P> *bases, size_t pairs, int c, int nsets, size_t n_points, uint32_t cap, hipStream_t s, float *acc_ms,
+                                            XYZZ<Fp<P>> *dev_wsum_out = nullptr) {
     using Fq = Fp<P>;
     size_t nb = (size_t)nsets << c;
     HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 8, s));        // [0] deferred pairs, [1] the tail kernel's workgroup ticket
@@ -444,14 +454,14 @@ static std::vector<XYZZ<Fp<P>>> run_buckets(MsmWorkspace &S, const Affine28<P> *
     hipStream_t sa = S.low ? S.low : s;
     if (S.low) { HIP_CHECK(hipEventRecord(S.fence_a, s)); HIP_CHECK(hipStreamWaitEvent(S.low, S.fence_a, 0)); }
     HIP_CHECK(hipEventRecord(S.ev0, sa));
-    hipLaunchKernelGGL((k_accumulate<P>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, sa, bases, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb,
+    hipLaunchKernelGGL((k_accumulate<P>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, sa, bases, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb, cap,
                        (Acc28<P> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
     HIP_CHECK(hipEventRecord(S.ev1, sa));
     if (S.low) { HIP_CHECK(hipEventRecord(S.fence_b, S.low)); HIP_CHECK(hipStreamWaitEvent(s, S.fence_b, 0)); }
-    uint32_t max_seg = (uint32_t)(pairs / BUCKET_CAP + 1);
+    uint32_t max_seg = (uint32_t)(pairs / cap + 1);
     // oversized buckets + deferred degenerate additions (none for uniformly distributed digits: every lane exits at once)
-    hipLaunchKernelGGL((k_accumulate_tail<P>), dim3((max_seg + 63) / 64), dim3(64), 0, s, bases, S.sorted_vals, S.start, S.end, S.extra_off, (uint32_t)nb, max_seg,
+    hipLaunchKernelGGL((k_accumulate_tail<P>), dim3((max_seg + 63) / 64), dim3(64), 0, s, bases, S.sorted_vals, S.start, S.end, S.extra_off, (uint32_t)nb, max_seg, cap,
                        (Acc28<P> *)S.ovf_partial, (Acc28<P> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
     uint32_t segs = (1u << c) / RED_L1, groups = (segs + RED_L2 - 1) / RED_L2;
@@ -460,10 +470,19 @@ static std::vector<XYZZ<Fp<P>>> run_buckets(MsmWorkspace &S, const Affine28<P> *
     HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_reduce_l2<P>), dim3((unsigned)((groups * nsets + 63) / 64)), dim3(64), 0, s, (const Acc28<P> *)S.seg_s, (const Acc28<P> *)S.seg_w, c, nsets, (Acc28<P> *)S.partial);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_reduce_window<P>), dim3((unsigned)nsets), dim3(256), 0, s, (const Acc28<P> *)S.partial, groups, (XYZZ<Fq> *)S.wsum);
+    if (nsets == 1 && groups > 2048) {
+        // one big bucket set (table mode): 256-partial blocks first, so the final LDS tree does not walk tens of thousands of partials serially
+        uint32_t mid = (groups + 255) / 256;
+        hipLaunchKernelGGL((k_sum_tree<P>), dim3(mid), dim3(256), 0, s, (const Acc28<P> *)S.partial, groups, 256u, (Acc28<P> *)S.seg_s);
+        HIP_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_reduce_window<P>), dim3(1), dim3(256), 0, s, (const Acc28<P> *)S.seg_s, mid, (XYZZ<Fq> *)S.wsum);
+    } else {
+        hipLaunchKernelGGL((k_reduce_window<P>), dim3((unsigned)nsets), dim3(256), 0, s, (const Acc28<P> *)S.partial, groups, (XYZZ<Fq> *)S.wsum);
+    }
     HIP_LAUNCH_CHECK();
     std::vector<XYZZ<Fq>> ws(nsets);
     uint32_t n_deferred = 0;
+    if (dev_wsum_out) HIP_CHECK(hipMemcpyAsync(dev_wsum_out, S.wsum, sizeof(XYZZ<Fq>) * nsets, hipMemcpyDeviceToDevice, s));   // stays in HBM for a collective
     HIP_CHECK(hipMemcpyAsync(ws.data(), S.wsum, sizeof(XYZZ<Fq>) * nsets, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(&n_deferred, S.deferred_count, 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
@@ -492,7 +511,7 @@ void convert_bases(Affine28<typename Curve::FqP> *dst, const Affine<typename Cur
 //   msm_prepare : window digits of up to two scalar vectors (the second one naming bases `val_off2` further on), sort, bucket ranges
 //   msm_finish  : accumulate from `bases` + reduce + Horner on the host
 template <class Curve>
-void msm_prepare(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_t n1, const typename Curve::Fr *scal2, size_t n2, size_t val_off2, stream_t s_) {
+void msm_prepare(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_t n1, const typename Curve::Fr *scal2, size_t n2, size_t val_off2, stream_t s_, int force_c) {
     using Fr = typename Curve::Fr;
     hipStream_t s = (hipStream_t)s_;
     if (!ws_) throw GpuError("msm: null workspace");
@@ -507,15 +526,16 @@ void msm_prepare(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_t n1, 
     if (c < 7) c = 7;
     if (c > 17) c = 17;
     if (const char *e = getenv("ZKAES_MSM_C")) { int v = atoi(e); if (v >= 4 && v <= 22) c = v; }   // tuning knob (tools/ubench/msm_sweep.py)
+    if (force_c >= 4 && force_c <= 22) c = force_c;     // ranks sharing one MSM by point range must cut the scalars into the same windows
     const int nwin = (Fr::BITS + 1 + c - 1) / c;  // one extra bit for the recoding carry
     size_t pairs = n * (size_t)nwin;
     if (pairs >= ((size_t)1 << 31)) throw GpuError("msm: n x windows exceeds the 2^31 pairs the sort indexes with int");
     const size_t nb = (size_t)nwin << (c - 1);
-    S.plan_c = c; S.plan_nwin = nwin; S.plan_pairs = pairs;
-    ensure_scratch(S, pairs, nb, 0);
+    S.plan_c = c; S.plan_nwin = nwin; S.plan_pairs = pairs; S.plan_table = false; S.plan_cap = BUCKET_CAP;
+    ensure_scratch(S, pairs, nb, BUCKET_CAP);
     if (n1) { hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, scal1, (uint32_t)n1, 0u, (uint32_t)n, 0u, c, nwin, (uint32_t)nb, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
     if (n2) { hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, scal2, (uint32_t)n2, (uint32_t)n1, (uint32_t)n, (uint32_t)val_off2, c, nwin, (uint32_t)nb, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
-    prepare_buckets<typename Curve::FqP>(S, pairs, c - 1, nwin, c - 1, s);
+    prepare_buckets<typename Curve::FqP>(S, pairs, c - 1, nwin, c - 1, BUCKET_CAP, s);
 }
 template <class Curve>
 XYZZ<typename Curve::Fq> msm_finish(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *bases, stream_t s_) {
@@ -528,7 +548,12 @@ XYZZ<typename Curve::Fq> msm_finish(MsmWorkspace *ws_, const Affine28<typename C
     auto t_begin = std::chrono::steady_clock::now();
     const int c = S.plan_c, nwin = S.plan_nwin;
     float ms = 0;
-    std::vector<XYZZ<Fq>> ws = run_buckets<typename Curve::FqP>(S, bases, S.plan_pairs, c - 1, nwin, S.plan_n, s, &ms);
+    if (S.plan_table) {      // `bases` = table copy 0 (+ a constant index shift): the window weights live in the copies, ONE bucket set, no Horner
+        std::vector<XYZZ<Fq>> one = run_buckets<typename Curve::FqP>(S, bases, S.plan_pairs, c - 1, 1, S.plan_n, S.plan_cap, s, &ms);
+        add_stats(ms, S.plan_n, S.plan_pairs, t_begin);
+        return one[0];
+    }
+    std::vector<XYZZ<Fq>> ws = run_buckets<typename Curve::FqP>(S, bases, S.plan_pairs, c - 1, nwin, S.plan_n, S.plan_cap, s, &ms);
     if (getenv("ZKAES_MSM_DEBUG")) {
         for (int w = 0; w < nwin; w++) {
             Affine<Fq> a = ws[w].to_affine();
@@ -551,8 +576,70 @@ XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws_, const Affine28<typename Curve::F
     return msm_finish<Curve>(ws_, bases, s_);
 }
 
+// ---- ONE MSM sharded by point range over ranks (SURVEY.md 8e second row): every rank runs the buckets of its slice with the window plan of the WHOLE
+// MSM and leaves its window sums in device memory; after the all-gather (RCCL, HBM to HBM) k_fold_ranks adds the ranks' sums per window.
 template <class Curve>
-int table_windows(int c) { return (Curve::Fr::BITS + c - 1) / c; }
+void msm_sharded_plan(size_t n_total, int *c_out, int *nwin_out) {
+    int lg = 0;
+    while (((size_t)1 << lg) < n_total) lg++;
+    int c = lg - 2;
+    if (c < 7) c = 7;
+    if (c > 17) c = 17;
+    *c_out = c;
+    *nwin_out = (Curve::Fr::BITS + 1 + c - 1) / c;
+}
+template <class Curve>
+void msm_window_sums_device(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *bases, const typename Curve::Fr *scalars, size_t n_local, size_t n_total,
+                            XYZZ<typename Curve::Fq> *dev_out, stream_t s_) {
+    using Fq = typename Curve::Fq;
+    hipStream_t s = (hipStream_t)s_;
+    int c, nwin;
+    msm_sharded_plan<Curve>(n_total, &c, &nwin);
+    if (n_local == 0) {       // an empty share contributes the point at infinity in every window (zz = 0)
+        HIP_CHECK(hipMemsetAsync(dev_out, 0, sizeof(XYZZ<Fq>) * nwin, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        return;
+    }
+    msm_prepare<Curve>(ws_, scalars, n_local, nullptr, 0, 0, s_, c);
+    MsmWorkspace &S = *ws_;
+    if (S.plan_nwin != nwin) throw GpuError("msm_window_sums_device: window plan mismatch");
+    float ms = 0;
+    auto t_begin = std::chrono::steady_clock::now();
+    run_buckets<typename Curve::FqP>(S, bases, S.plan_pairs, c - 1, nwin, n_local, S.plan_cap, s, &ms, dev_out);
+    add_stats(ms, n_local, S.plan_pairs, t_begin);
+}
+template <class Fq>
+__global__ void k_fold_ranks(const XYZZ<Fq> *__restrict__ in, int world, int nwin, XYZZ<Fq> *__restrict__ out) {
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwin) return;
+    XYZZ<Fq> acc = in[w];
+    for (int r = 1; r < world; r++) acc.add(in[(size_t)r * nwin + w]);
+    out[w] = acc;
+}
+template <class Curve>
+XYZZ<typename Curve::Fq> msm_fold_window_sums_device(const XYZZ<typename Curve::Fq> *dev_in, int world, size_t n_total, stream_t s_) {
+    using Fq = typename Curve::Fq;
+    hipStream_t s = (hipStream_t)s_;
+    int c, nwin;
+    msm_sharded_plan<Curve>(n_total, &c, &nwin);
+    XYZZ<Fq> *d_out = (XYZZ<Fq> *)dmalloc(sizeof(XYZZ<Fq>) * nwin);
+    hipLaunchKernelGGL((k_fold_ranks<Fq>), dim3(1), dim3(64), 0, s, dev_in, world, nwin, d_out);
+    HIP_LAUNCH_CHECK();
+    std::vector<XYZZ<Fq>> ws(nwin);
+    HIP_CHECK(hipMemcpyAsync(ws.data(), d_out, sizeof(XYZZ<Fq>) * nwin, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    dfree(d_out);
+    XYZZ<Fq> total = XYZZ<Fq>::inf();
+    for (int w = nwin - 1; w >= 1; w--) {
+        total.add(ws[w]);
+        for (int k = 0; k < c; k++) total = total.dbl();
+    }
+    total.add(ws[0]);
+    return total;
+}
+
+template <class Curve>
+int table_windows(int c) { return (Curve::Fr::BITS + 1 + c - 1) / c; }      // signed digits: one extra bit for the recoding carry
 
 template <class Curve>
 void build_window_tables(Affine<typename Curve::Fq> *tables, size_t stride, int c, stream_t s_) {
@@ -567,27 +654,36 @@ void build_window_tables(Affine<typename Curve::Fq> *tables, size_t stride, int 
     HIP_CHECK(hipStreamSynchronize(s));
 }
 
+// Table-mode Pippenger in the same two steps as the per-window variant.  msm_prepare_table: signed c-bit digits of up to two scalar vectors
+// (element i of vector v names table entry w * stride + off_v + i in window w), sort on the c - 1 bucket bits, bucket ranges;
+// msm_finish (above) with `tables` = copy 0 (optionally shifted by a constant index, e.g. to the shifted-powers part of every copy).
 template <class Curve>
-XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *tables, size_t stride, size_t off, int c, const typename Curve::Fr *scalars, size_t n, stream_t s_) {
-    using Fq = typename Curve::Fq;
+void msm_prepare_table(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_t n1, size_t off1, const typename Curve::Fr *scal2, size_t n2, size_t off2, int c, size_t stride,
+                       stream_t s_) {
     using Fr = typename Curve::Fr;
     hipStream_t s = (hipStream_t)s_;
-    if (n == 0) return XYZZ<Fq>::inf();
     if (!ws_) throw GpuError("msm: null workspace");
-    const int nwin = table_windows<Curve>(c);
-    if (off + n > stride) throw GpuError("msm_table: range exceeds the table");
-    if ((uint64_t)nwin * stride >= (1ull << 32) || (uint64_t)n * nwin >= (1ull << 31)) throw GpuError("msm_table: index range too large");
-    auto t_begin = std::chrono::steady_clock::now();
-    size_t pairs = n * (size_t)nwin;
     MsmWorkspace &S = *ws_;
-    ensure_scratch(S, pairs, (size_t)1 << c, sizeof(XYZZ<Fq>));
-    hipLaunchKernelGGL((k_digits_table<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scalars, (uint32_t)n, c, nwin, (uint32_t)stride, (uint32_t)off, S.keys_a, S.vals_a);
-    HIP_LAUNCH_CHECK();
-    float ms = 0;
-    prepare_buckets<typename Curve::FqP>(S, pairs, c, 1, 0, s);
-    std::vector<XYZZ<Fq>> ws = run_buckets<typename Curve::FqP>(S, tables, pairs, c, 1, n, s, &ms);
-    add_stats(ms, n, pairs, t_begin);
-    return ws[0];
+    size_t n = n1 + n2;
+    S.plan_n = n;
+    if (n == 0) return;
+    if (c < 4 || c > 24) throw GpuError("msm_table: window bits out of range");
+    const int nwin = table_windows<Curve>(c);
+    if (off1 + n1 > stride || off2 + n2 > stride) throw GpuError("msm_table: range exceeds the table");
+    if ((uint64_t)nwin * stride >= (1ull << 30) || (uint64_t)n * nwin >= (1ull << 31)) throw GpuError("msm_table: index range too large");
+    size_t pairs = n * (size_t)nwin;
+    const size_t nb = (size_t)1 << (c - 1);
+    S.plan_c = c; S.plan_nwin = nwin; S.plan_pairs = pairs; S.plan_table = true; S.plan_cap = BUCKET_CAP_TABLE;
+    ensure_scratch(S, pairs, nb, BUCKET_CAP_TABLE);
+    if (n1) { hipLaunchKernelGGL((k_digits_table<Fr>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, scal1, (uint32_t)n1, 0u, (uint32_t)n, (uint32_t)off1, c, nwin, (uint32_t)stride, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
+    if (n2) { hipLaunchKernelGGL((k_digits_table<Fr>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, scal2, (uint32_t)n2, (uint32_t)n1, (uint32_t)n, (uint32_t)off2, c, nwin, (uint32_t)stride, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
+    prepare_buckets<typename Curve::FqP>(S, pairs, c - 1, 1, c - 1, BUCKET_CAP_TABLE, s);
+}
+template <class Curve>
+XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *tables, size_t stride, size_t off, int c, const typename Curve::Fr *scalars, size_t n, stream_t s_) {
+    if (n == 0) return XYZZ<typename Curve::Fq>::inf();
+    msm_prepare_table<Curve>(ws_, scalars, n, off, nullptr, 0, 0, c, stride, s_);
+    return msm_finish<Curve>(ws_, tables, s_);
 }
 
 // ---- fixed-base powers: out[i] = beta^(from + i) * base
@@ -753,6 +849,14 @@ bool class_sum(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *bases, co
     return true;
 }
 
+template void msm_sharded_plan<Bls377>(size_t, int *, int *);
+template void msm_sharded_plan<Bls381>(size_t, int *, int *);
+template void msm_window_sums_device<Bls377>(MsmWorkspace *, const Affine28<Fq377P> *, const Fr377 *, size_t, size_t, XYZZ<Fq377> *, stream_t);
+template void msm_window_sums_device<Bls381>(MsmWorkspace *, const Affine28<Fq381P> *, const Fr381 *, size_t, size_t, XYZZ<Fq381> *, stream_t);
+template XYZZ<Fq377> msm_fold_window_sums_device<Bls377>(const XYZZ<Fq377> *, int, size_t, stream_t);
+template XYZZ<Fq381> msm_fold_window_sums_device<Bls381>(const XYZZ<Fq381> *, int, size_t, stream_t);
+template void msm_prepare_table<Bls377>(MsmWorkspace *, const Fr377 *, size_t, size_t, const Fr377 *, size_t, size_t, int, size_t, stream_t);
+template void msm_prepare_table<Bls381>(MsmWorkspace *, const Fr381 *, size_t, size_t, const Fr381 *, size_t, size_t, int, size_t, stream_t);
 template XYZZ<Fq377> msm_table<Bls377>(MsmWorkspace *, const Affine28<Fq377P> *, size_t, size_t, int, const Fr377 *, size_t, stream_t);
 template XYZZ<Fq381> msm_table<Bls381>(MsmWorkspace *, const Affine28<Fq381P> *, size_t, size_t, int, const Fr381 *, size_t, stream_t);
 template void convert_bases<Bls377>(Affine28<Fq377P> *, const Affine<Fq377> *, size_t, stream_t);
@@ -761,8 +865,8 @@ template void build_window_tables<Bls377>(Affine<Fq377> *, size_t, int, stream_t
 template void build_window_tables<Bls381>(Affine<Fq381> *, size_t, int, stream_t);
 template int table_windows<Bls377>(int);
 template int table_windows<Bls381>(int);
-template void msm_prepare<Bls377>(MsmWorkspace *, const Fr377 *, size_t, const Fr377 *, size_t, size_t, stream_t);
-template void msm_prepare<Bls381>(MsmWorkspace *, const Fr381 *, size_t, const Fr381 *, size_t, size_t, stream_t);
+template void msm_prepare<Bls377>(MsmWorkspace *, const Fr377 *, size_t, const Fr377 *, size_t, size_t, stream_t, int);
+template void msm_prepare<Bls381>(MsmWorkspace *, const Fr381 *, size_t, const Fr381 *, size_t, size_t, stream_t, int);
 template XYZZ<Fq377> msm_finish<Bls377>(MsmWorkspace *, const Affine28<Fq377P> *, stream_t);
 template XYZZ<Fq381> msm_finish<Bls381>(MsmWorkspace *, const Affine28<Fq381P> *, stream_t);
 template XYZZ<Fq377> msm<Bls377>(MsmWorkspace *, const Affine28<Fq377P> *, const Fr377 *, size_t, stream_t);

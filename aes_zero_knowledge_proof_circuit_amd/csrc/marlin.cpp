@@ -403,16 +403,20 @@ class ProvingKeyImpl {
     int device = 0;                            // the HIP device this key (SRS, index, contexts) lives on; every entry point re-selects it,
                                                // because HIP's current device is per thread and callers may arrive on fresh threads
     G1A gamma_powers[3];
-    // device: SRS as precomputed window tables: copy j holds 2^(table_c * j) * powers_of_g[i] (gpu.hpp msm_table)
-    Affine28<Fq377P> *d_powers = nullptr, *d_shifted = nullptr;   // reduced-radix copies (ff28.cuh) -- what k_accumulate gathers
+    // device SRS, reduced-radix copies (ff28.cuh) -- what k_accumulate gathers.  Copy 0 = powers_of_g[0..=supported_degree] followed by the shifted
+    // range (one index space: merged openings name bases of both); with window tables (use_tables) copies j = 1.. follow at j * srs_stride and hold
+    // 2^(table_c * j) * copy 0 (gpu.hpp msm_prepare_table).  d_shifted = d_powers + n_plain (copy 0's shifted part).
+    Affine28<Fq377P> *d_powers = nullptr, *d_shifted = nullptr;
+    size_t srs_stride = 0, n_plain = 0;
+    size_t table_min_n = 500000;    // MSMs below this many points keep the per-window buckets (their own, smaller c)
     // Lagrange-basis SRS over H (ZKAES_LAGRANGE=0 disables): L_k(beta) G for z_A, z_B; L_k(beta)/v_X(beta) G (zero on X) for w;
     // P_j for the public-input part of w; v_H(beta) G and (v_H/v_X)(beta) G for the blinding terms
     bool use_lagrange = true;
     Affine28<Fq377P> *d_lag_h = nullptr, *d_lag_w = nullptr;
     std::vector<G1A> lag_pj;
     G1A lag_vh, lag_vw;
-    int table_c = 16;
-    bool use_tables = false;   // ZKAES_MSM_TABLES=1: precomputed-window path (measured slower than per-window buckets on MI355X today: DESIGN.md §3)
+    int table_c = 22;
+    bool use_tables = false;   // window tables for the large MSMs (default on when |K| >= 2^21: ZKAES_MSM_TABLES=0/1 overrides)
     // device: circuit
     uint32_t *d_desc = nullptr, *d_sbox_in = nullptr, *d_sbox_tmpl = nullptr;
     uint32_t *d_a_rowptr = nullptr, *d_a_col = nullptr, *d_b_rowptr = nullptr, *d_b_col = nullptr;
@@ -426,7 +430,7 @@ class ProvingKeyImpl {
     ProverTimings last_timings;
 
     ~ProvingKeyImpl() {
-        gpu::dfree(d_powers); if (use_tables) gpu::dfree(d_shifted); gpu::dfree(d_lag_h); gpu::dfree(d_lag_w); gpu::dfree(d_desc); gpu::dfree(d_sbox_in); gpu::dfree(d_sbox_tmpl);
+        gpu::dfree(d_powers); gpu::dfree(d_lag_h); gpu::dfree(d_lag_w); gpu::dfree(d_desc); gpu::dfree(d_sbox_in); gpu::dfree(d_sbox_tmpl);
         gpu::dfree(d_a_rowptr); gpu::dfree(d_a_col); gpu::dfree(d_b_rowptr); gpu::dfree(d_b_col); gpu::dfree(d_a_coeff); gpu::dfree(d_b_coeff);
         gpu::dfree(d_t_heavy); gpu::dfree(d_t_colptr); gpu::dfree(d_t_seg_start); gpu::dfree(d_t_seg_end); gpu::dfree(d_t_row); gpu::dfree(d_t_mat); gpu::dfree(d_t_coeff);
         for (auto &b : ix_ev) b.release();
@@ -468,12 +472,13 @@ class ProvingKeyImpl {
         return d;
     }
 
-    // MSM against powers_of_g starting at `off` (plain or shifted table); device scalars
+    bool table_ok(size_t len) const { return use_tables && len >= table_min_n; }
+    // MSM against powers_of_g starting at `off` (plain or shifted range); device scalars
     XYZZ<Fq377> msm_powers(ProverContext &cx, bool shifted, size_t off, const F *scalars, size_t len) {
         if (len == 0) return XYZZ<Fq377>::inf();
         size_t avail = shifted ? (bounds[1] + 1) : (supported_degree + 1);
         if (off + len > avail) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
-        if (use_tables) return gpu::msm_table<Bls377>(cx.msm_ws, shifted ? d_shifted : d_powers, shifted ? bounds[1] + 1 : supported_degree + 1, off, table_c, scalars, len, cx.stream);
+        if (table_ok(len)) return gpu::msm_table<Bls377>(cx.msm_ws, d_powers, srs_stride, (shifted ? n_plain : 0) + off, table_c, scalars, len, cx.stream);
         return gpu::msm<Bls377>(cx.msm_ws, (shifted ? d_shifted : d_powers) + off, scalars, len, cx.stream);
     }
     // KZG10::commit: MSM(powers, coeffs) [+ MSM(powers_of_gamma_g, blinding) when hiding]
@@ -513,30 +518,26 @@ class ProvingKeyImpl {
         const F *coeffs = cx.poly[lp.idx].p;
         size_t len = cx.poly_len[lp.idx];
         lp.comm.has_shifted = false;
-        if (lp.bound < 0 || use_tables) {
+        if (lp.bound < 0) {
             lp.comm.comm = kzg_commit(cx, false, 0, coeffs, len, lp.hiding, lp.rand, zk);
-            if (lp.bound >= 0) {
-                size_t off = (max_degree - (size_t)lp.bound) - lowest_shift;
-                lp.comm.shifted = kzg_commit(cx, true, off, coeffs, len, lp.hiding, lp.shifted_rand, zk);
-                lp.comm.has_shifted = true;
-            }
             return;
         }
         // degree-bounded polynomial: the plain and the shifted commitment have the same scalars -> one digit / sort pass, two accumulations
         size_t off = (max_degree - (size_t)lp.bound) - lowest_shift;
         if (len > supported_degree + 1 || off + len > bounds[1] + 1) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
-        gpu::msm_prepare<Bls377>(cx.msm_ws, coeffs, len, nullptr, 0, 0, cx.stream);
+        if (table_ok(len)) gpu::msm_prepare_table<Bls377>(cx.msm_ws, coeffs, len, 0, nullptr, 0, 0, table_c, srs_stride, cx.stream);
+        else gpu::msm_prepare<Bls377>(cx.msm_ws, coeffs, len, nullptr, 0, 0, cx.stream);
         XYZZ<Fq377> c1 = gpu::msm_finish<Bls377>(cx.msm_ws, d_powers, cx.stream);
         add_hiding(c1, lp.hiding, lp.rand, zk);
-        XYZZ<Fq377> c2 = gpu::msm_finish<Bls377>(cx.msm_ws, d_shifted + off, cx.stream);
+        XYZZ<Fq377> c2 = gpu::msm_finish<Bls377>(cx.msm_ws, d_shifted + off, cx.stream);     // table mode: every copy's index shifts by n_plain + off
         add_hiding(c2, lp.hiding, lp.shifted_rand, zk);
         lp.comm.comm = c1.to_affine(); lp.comm.shifted = c2.to_affine(); lp.comm.has_shifted = true;
     }
     // opening witness = MSM(powers, wit) + MSM(shifted powers from shift_off, swit) as ONE Pippenger instance over the contiguous SRS array
     XYZZ<Fq377> msm_opening(ProverContext &cx, const F *wit, size_t wlen, const F *swit, size_t slen, size_t shift_off) {
         if (wlen > supported_degree + 1 || shift_off + slen > bounds[1] + 1) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
-        if (use_tables) { XYZZ<Fq377> w = msm_powers(cx, false, 0, wit, wlen); w.add(msm_powers(cx, true, shift_off, swit, slen)); return w; }
-        gpu::msm_prepare<Bls377>(cx.msm_ws, wit, wlen, swit, slen, (supported_degree + 1) + shift_off, cx.stream);
+        if (table_ok(wlen + slen)) gpu::msm_prepare_table<Bls377>(cx.msm_ws, wit, wlen, 0, swit, slen, n_plain + shift_off, table_c, srs_stride, cx.stream);
+        else gpu::msm_prepare<Bls377>(cx.msm_ws, wit, wlen, swit, slen, n_plain + shift_off, cx.stream);
         return gpu::msm_finish<Bls377>(cx.msm_ws, d_powers, cx.stream);
     }
 
@@ -589,30 +590,38 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
     G1A g, gamma_g;
     pairing::G2Affine srs_h;
     kzg_setup_points(srs_beta, g, gamma_g, srs_h);
+    // window tables pay for the |K|-scale MSMs of the 4- to 6-block keys; small keys keep per-window buckets only
+    use_tables = lg_k >= 21;
     if (const char *e = getenv("ZKAES_MSM_TABLES")) use_tables = atoi(e) != 0;
-    // window bits of the table path: the top window must keep enough significant bits or a handful of buckets receive most points
-    table_c = lg_k >= 22 ? 20 : (lg_k >= 19 ? 17 : 8);
+    // c = 20: 13 signed windows instead of 15 and 2^19 buckets in ONE set (the 15 x 2^16 per-window buckets cost more to reduce).  c = 22 saves one more
+    // window but its 2^21 buckets triple k_reduce_l1 (1.95 ms vs 0.67 ms per MSM): measured slower (profiles/r02_msm_tables.md)
+    table_c = 20;
+    if (const char *e = getenv("ZKAES_MSM_TABLE_C")) { int v = atoi(e); if (v >= 8 && v <= 24) table_c = v; }
+    if (const char *e = getenv("ZKAES_MSM_TABLE_MIN")) table_min_n = (size_t)atoll(e);
+    {   // the short top window lands on 2^(top bits - 1) buckets only; with fewer than ~12 bits those buckets hold n / 2^11 and more points each and
+        // their overflow segments are folded serially (c = 19: 7 bits -> 56 blocks/s, c = 21: 2 bits -> 29 blocks/s against 64.7 at c = 20)
+        const int nw = gpu::table_windows<Bls377>(table_c), top_bits = (Fr::BITS + 1) - (nw - 1) * table_c;
+        if (use_tables && top_bits < 12 && !getenv("ZKAES_MSM_TABLE_C")) use_tables = false;
+    }
     const size_t n_tab = use_tables ? (size_t)gpu::table_windows<Bls377>(table_c) : 1;
     // powers_of_g[0..=supported_degree] and the shifted range live in ONE reduced-radix array (shifted part right after the plain part), so
-    // an MSM may name bases of both through one index space (merged openings).  Table mode keeps two separate multi-copy arrays.
-    const size_t n_plain = supported_degree + 1, n_shift = bounds[1] + 1;
-    auto make_srs = [&](Affine28<Fq377P> *dst, size_t from, size_t count) {
-        G1A *tmp = (G1A *)gpu::dmalloc(n_tab * count * sizeof(G1A));
-        gpu::fixed_base_powers<Bls377>(tmp, g, srs_beta, from, count, stream);
-        if (use_tables) gpu::build_window_tables<Bls377>(tmp, count, table_c, stream);
-        gpu::convert_bases<Bls377>(dst, tmp, n_tab * count, stream);
+    // an MSM may name bases of both through one index space (merged openings); table copies repeat that layout at multiples of srs_stride.
+    n_plain = supported_degree + 1;
+    const size_t n_shift = bounds[1] + 1;
+    srs_stride = n_plain + n_shift;
+    if (use_tables && (uint64_t)n_tab * srs_stride >= (1ull << 30)) { use_tables = false; }
+    {
+        const size_t copies = use_tables ? n_tab : 1;
+        G1A *tmp = (G1A *)gpu::dmalloc(copies * srs_stride * sizeof(G1A));
+        gpu::fixed_base_powers<Bls377>(tmp, g, srs_beta, 0, n_plain, stream);
+        gpu::fixed_base_powers<Bls377>(tmp + n_plain, g, srs_beta, lowest_shift, n_shift, stream);
+        if (use_tables) gpu::build_window_tables<Bls377>(tmp, srs_stride, table_c, stream);
+        d_powers = (Affine28<Fq377P> *)gpu::dmalloc(copies * srs_stride * sizeof(Affine28<Fq377P>));
+        gpu::convert_bases<Bls377>(d_powers, tmp, copies * srs_stride, stream);
         gpu::sync(stream);
         gpu::dfree(tmp);
-    };
-    if (use_tables) {
-        d_powers = (Affine28<Fq377P> *)gpu::dmalloc(n_tab * n_plain * sizeof(Affine28<Fq377P>));
-        d_shifted = (Affine28<Fq377P> *)gpu::dmalloc(n_tab * n_shift * sizeof(Affine28<Fq377P>));
-    } else {
-        d_powers = (Affine28<Fq377P> *)gpu::dmalloc((n_plain + n_shift) * sizeof(Affine28<Fq377P>));
         d_shifted = d_powers + n_plain;
     }
-    make_srs(d_powers, 0, n_plain);
-    make_srs(d_shifted, lowest_shift, n_shift);
     if (const char *e = getenv("ZKAES_LAGRANGE")) use_lagrange = atoi(e) != 0;
     if (use_lagrange) {
         // With the (public, test_rng-derived) trapdoor the Lagrange-basis points are direct fixed-base products; a trapdoor-free universal SRS

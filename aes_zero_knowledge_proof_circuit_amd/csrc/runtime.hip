@@ -1,8 +1,20 @@
 // csrc/runtime.hip -- thin HIP runtime plumbing (allocation, copies, streams, events)
+#include <cstdlib>
 #include "hip_util.hpp"
 
 namespace zk {
 namespace gpu {
+
+// ROCclr multiplexes all HIP streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4): with 10-16 prover contexts several
+// streams share a queue and a 10 ms k_accumulate of one context blocks the sort / reduction / NTT kernels of the contexts behind it.
+// One hardware queue per prover context keeps them independent (measured +1.5 % without window tables, +4.7 % with: profiles/r02_msm_tables.md).
+// The variable is read when the HIP runtime initialises, i.e. at the first HIP call of the process: libzkaes sets it (without overriding a value
+// the caller exported) when the library is loaded; a process that initialised HIP earlier must export it itself.
+namespace {
+struct HwQueueDefault {
+    HwQueueDefault() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+} g_hw_queue_default;
+}  // namespace
 
 int device_count() {
     int n = 0;

@@ -88,6 +88,31 @@ def point_range(n, rank, world):
     return split_chunks(n, rank, world)
 
 
+def msm_sharded_device(curve_id, bases_bytes, scalars_bytes, device):
+    """The same point-range sharding with a DEVICE-RESIDENT exchange: every rank leaves the window sums of its slice (n_windows x 192 B XYZZ points,
+    window plan of the whole MSM) in row `rank` of a [world, bytes] CUDA tensor, ONE torch.distributed.all_gather_into_tensor moves the rows
+    HBM to HBM over RCCL / xGMI, and a device kernel adds the ranks' sums per window before the Horner pass (include/zkaes.h,
+    zkaes_msm_window_sums_dev / zkaes_msm_fold_window_sums_dev).  Nothing of the data path is staged through host memory.
+    """
+    import torch
+    import torch.distributed as dist
+    from . import api
+    n = len(scalars_bytes) // 32
+    if len(bases_bytes) != 96 * n:
+        raise ValueError("bases must be n x 96 bytes and scalars n x 32 bytes")
+    rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+    lo, hi = point_range(n, rank, world)
+    _, _, nbytes = api.msm_sharded_plan(curve_id, n)
+    buf = torch.zeros((world, nbytes), dtype=torch.uint8, device=device)
+    torch.cuda.synchronize(device)                                   # libzkaes writes from its own stream: the zero-fill must have landed
+    api.msm_window_sums_dev(curve_id, bases_bytes[96 * lo:96 * hi], scalars_bytes[32 * lo:32 * hi], n, buf[rank].data_ptr(), nbytes)   # returns after its stream has drained
+    if dist.is_available() and dist.is_initialized():
+        mine = buf[rank].clone()
+        dist.all_gather_into_tensor(buf.view(-1), mine)              # RCCL: HBM -> HBM (also exercised with one rank)
+        torch.cuda.synchronize(device)
+    return api.msm_fold_window_sums_dev(curve_id, buf.data_ptr(), world, n)
+
+
 def msm_sharded(curve_id, bases_bytes, scalars_bytes, local_msm=None, device=None):
     """ONE multi-scalar multiplication sharded by point range over the ranks of the default process group (second row).
 

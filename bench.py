@@ -30,6 +30,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# one hardware queue per prover context (ROCclr default: 4 for all streams of the process); must be in the environment before the first HIP call,
+# which under torchrun is torch's, not libzkaes' (csrc/runtime.hip sets the same default when the library is loaded first)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 CIRCUIT_MODEL_NOTE = ("R1CS of the restated ark-r1cs-std 0.3.1 gadget semantics: 629,856 constraints / 3,002,900 non-zeros at 64 bytes; the reference's own SRS literal "
@@ -90,7 +93,7 @@ def build_parser():
     ap.add_argument("--blocks", type=int, default=None, help="ECB blocks of the message (headline: per rank, default 4096; strong: whole job, default 65536)")
     ap.add_argument("--proofs", type=int, default=1024, help="batch mode: independent single-block proofs (whole job)")
     ap.add_argument("--chunk", type=int, default=6, help="blocks per chunk-proof (6 = the most that fits |H|=2^20, |K|=2^22 and the reference's SRS literal)")
-    ap.add_argument("--contexts", type=int, default=10, help="chunk-proofs in flight per GPU (separate HIP streams)")
+    ap.add_argument("--contexts", type=int, default=16, help="chunk-proofs in flight per GPU (separate HIP streams)")
     ap.add_argument("--pipeline", type=int, default=2, help="timed slices in flight (1 = strictly one after the other: the chip drains at every step boundary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chunk-samples", type=int, default=1, help="CPU-oracle samples at the bench's chunk size (0 = one-block samples only)")

@@ -71,7 +71,7 @@ int zkaes_encrypt_chunked(const uint8_t *message, size_t message_len, const uint
  * length bytes, secret_keys = n x 16 bytes.  Up to ZKAES_CONTEXTS (environment; default ZKAES_DEFAULT_CONTEXTS, the configuration bench.py
  * measures) proofs are in flight per call, each on its own pair of HIP streams.  This entry point cannot check its buffer lengths: prefer
  * zkaes_encrypt_batch_seeded. */
-#define ZKAES_DEFAULT_CONTEXTS 10
+#define ZKAES_DEFAULT_CONTEXTS 16
 int zkaes_encrypt_batch(size_t n, const uint8_t *messages, const uint8_t *secret_keys, const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens);
 /* the chunked / batch calls with explicit buffer lengths (checked: messages_len == n x plaintext length, secret_keys_len == n x 16) and a
  * 32-byte seed for the provers' zero-knowledge randomness.  Proof i draws from StdRng(Blake2s(zk_seed32 || i as u64 LE)), so no two proofs of a
@@ -131,6 +131,17 @@ int zkaes_msm(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t
  * all-gather when ONE MSM is sharded by point range over ranks (SURVEY.md 8e "inside one proof"; the upstream analogue is the final fold of the
  * per-window sums in ark-ec's VariableBaseMSM::multi_scalar_mul).  Runs on the host: a few hundred field products. */
 int zkaes_g1_sum(int curve_id, const uint8_t *points_xy, const int *inf, size_t n, uint8_t *out_xy, int *out_inf);
+/* ---- ONE MSM sharded by point range over the GPUs of a node with a device-resident exchange (SURVEY.md 8e "inside one proof"; north_star's "single RCCL
+ * all-reduce of bucket partials over xGMI" -- EC addition is not an RCCL reduction operator, hence all-gather + local fold).  Every rank:
+ *   1. zkaes_msm_sharded_plan(curve, n_total, ...)           -> window plan of the WHOLE MSM + bytes of one rank's payload (n_windows x 192 B)
+ *   2. zkaes_msm_window_sums_dev(curve, bases, scalars of ITS slice, n_local, n_total, dev_out, bytes): Pippenger over the slice, the n_windows
+ *      XYZZ window sums are left IN DEVICE MEMORY at dev_out (e.g. row `rank` of a [world, bytes] torch.uint8 CUDA tensor)
+ *   3. one all-gather of those rows over RCCL (HBM to HBM over xGMI; torch.distributed.all_gather_into_tensor)
+ *   4. zkaes_msm_fold_window_sums_dev(curve, dev_in = the gathered [world, bytes] block, world, n_total, out): per-window sum over ranks on the
+ *      device, Horner over the windows -> the MSM result.  aes_zero_knowledge_proof_circuit_amd/sharding.py msm_sharded(device_resident=True) is this sequence. */
+int zkaes_msm_sharded_plan(int curve_id, size_t n_total, int *window_bits, int *n_windows, size_t *bytes_per_rank);
+int zkaes_msm_window_sums_dev(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n_local, size_t n_total, void *dev_out, size_t dev_out_bytes);
+int zkaes_msm_fold_window_sums_dev(int curve_id, const void *dev_in, int world, size_t n_total, uint8_t *out_xy, int *out_inf);
 /* same sum through the precomputed-window path the prover uses for the SRS (tables 2^(c j) P_i built on the fly here; one bucket set) */
 int zkaes_msm_table(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, int window_bits, uint8_t *out_xy, int *out_inf);
 /* device-resident variant for benchmarking: repeats the MSM `reps` times over device copies, returns ms per MSM of the whole pipeline and of

@@ -250,3 +250,47 @@ def test_point_range_sharded_msm_two_gpu_processes():
     mp.spawn(_msm_worker, args=(world, port, cid, n, True, out), nprocs=world, join=True)
     bases, scalars = _msm_inputs(cid, n, 4000 + n)
     assert out[0] == out[1] == _oracle_msm(cid)(bases, scalars)
+
+
+def _msm_device_worker(rank, world, port, cid, n, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    bases, scalars = _msm_inputs(cid, n, 4000 + n)
+    out[rank] = sharding.msm_sharded_device(cid, bases, scalars, torch.device("cuda", 0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cid,n", [(377, 5000), (381, 333)])
+def test_point_range_sharded_msm_device_resident_exchange_rccl(cid, n):
+    """the device-resident variant: window sums stay in HBM, torch.distributed.all_gather_into_tensor over RCCL, per-window fold on the device.
+    One rank here (a one-GPU box; RCCL refuses two ranks on one device) -- the collective and both C-ABI calls still run."""
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_msm_device_worker, args=(1, port, cid, n, out), nprocs=1, join=True)
+    bases, scalars = _msm_inputs(cid, n, 4000 + n)
+    assert out[0] == _oracle_msm(cid)(bases, scalars)
+
+
+@pytest.mark.gpu
+def test_window_sum_fold_of_two_slices_equals_the_whole_msm():
+    """the fold itself with world = 2 on one GPU (no process group): slice A and slice B -> rows 0 and 1 of one device buffer -> per-window sum"""
+    from aes_zero_knowledge_proof_circuit_amd import api
+    cid, n = 377, 4097
+    bases, scalars = _msm_inputs(cid, n, 77)
+    c, nwin, nbytes = api.msm_sharded_plan(cid, n)
+    assert nbytes == nwin * 192 and (253 + 1 + c - 1) // c == nwin
+    buf = torch.zeros((2, nbytes), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    cut = 1500
+    api.msm_window_sums_dev(cid, bases[:96 * cut], scalars[:32 * cut], n, buf[0].data_ptr(), nbytes)
+    api.msm_window_sums_dev(cid, bases[96 * cut:], scalars[32 * cut:], n, buf[1].data_ptr(), nbytes)
+    assert api.msm_fold_window_sums_dev(cid, buf.data_ptr(), 2, n) == _oracle_msm(cid)(bases, scalars)
+    # an empty share is the point at infinity in every window
+    api.msm_window_sums_dev(cid, b"", b"", n, buf[1].data_ptr(), nbytes)
+    api.msm_window_sums_dev(cid, bases, scalars, n, buf[0].data_ptr(), nbytes)
+    assert api.msm_fold_window_sums_dev(cid, buf.data_ptr(), 2, n) == _oracle_msm(cid)(bases, scalars)
+    with pytest.raises(api.ZkAesError, match="too small"):
+        api.msm_window_sums_dev(cid, bases, scalars, n, buf[0].data_ptr(), 100)

@@ -1,0 +1,16 @@
+set -x
+mkdir -p gpurun_out
+run() { name=$1; ctx=$2; shift; shift; env "$@" timeout 600 python bench.py --steps 4 --warmup 1 --contexts $ctx --serial-probe 0 --no-cpu-baseline > gpurun_out/r02_bench_$name.json 2> gpurun_out/r02_bench_$name.err; python - <<PY
+import json
+try:
+    d=json.loads(open("gpurun_out/r02_bench_$name.json").read().strip().splitlines()[-1])
+    print("$name", d["value"], d["proofs_verified"], "acc avg", d["roofline"]["avg_launch_ms"], "overlap", d["roofline"]["launch_overlap"], d["phase_ms_last_proof_avg"]["total_ms"])
+except Exception as e:
+    print("$name ERR", e); print(open("gpurun_out/r02_bench_$name.err").read()[-1500:])
+PY
+}
+run q8_notab_c10 10 GPU_MAX_HW_QUEUES=8 ZKAES_MSM_TABLES=0
+run q16_notab_c16 16 GPU_MAX_HW_QUEUES=16 ZKAES_MSM_TABLES=0
+run q32_notab_c24 24 GPU_MAX_HW_QUEUES=32 ZKAES_MSM_TABLES=0
+run q16_tab22_c16 16 GPU_MAX_HW_QUEUES=16
+run q16_tab20_c16 16 GPU_MAX_HW_QUEUES=16 ZKAES_MSM_TABLE_C=20
