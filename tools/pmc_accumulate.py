@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """PMC passes for the MSM bucket-accumulation kernel (run ON THE GPU BOX, from the repo root):
 
-    python tools/pmc_accumulate.py [lg_n=22] [tag=v11]   ->  gpurun_out/r01_pmc_k_accumulate_<tag>.json
+    python tools/pmc_accumulate.py [lg_n=22] [tag=r02]   ->  gpurun_out/<tag>_pmc_k_accumulate.json
 
 Three separate rocprofv3 runs of `tools/ubench/msm_one.py <lg_n>` (FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ counters in a third), each with
 `--pmc ... --kernel-trace --output-format csv` only (MI355X_MICROARCH.md, HBM / rocprofv3 sections).  The absolute FETCH_SIZE scale is calibrated on
@@ -15,14 +15,14 @@ import subprocess
 import sys
 
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 22
-tag = sys.argv[2] if len(sys.argv) > 2 else "v11"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 n = 1 << lg
 out_dir = os.path.join("gpurun_out", "pmc_" + tag)
 os.makedirs(out_dir, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
 PASSES = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"],
           "sq": ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"],
-          "valu": ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"]}
+          "valu": ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"]}
 
 
 def collect(name, counters):
@@ -65,15 +65,21 @@ res = {
     "kernel": "k_accumulate (%s), n = 2^%d points, %d signed-digit windows of 17 bits, averages over %d launches" % (tag, lg, nwin, counts[("k_accumulate", "FETCH_SIZE")]),
     "command": "rocprofv3 --pmc <one counter group> --kernel-trace --output-format csv -- python tools/ubench/msm_one.py %d 0   (three separate passes: %s)" % (lg, PASSES),
     "counters": {c: vals[("k_accumulate", c)] for grp in PASSES.values() for c in grp},
-    # rocprofv3's derived VALUBusy = 100 * SQ_ACTIVE_INST_VALU * 4 / SIMD_NUM / GRBM_GUI_ACTIVE with GRBM_GUI_ACTIVE per XCD (the raw counter is the
-    # sum over the 8 XCDs) and 1024 SIMDs: share of cycles in which a SIMD is executing a VALU instruction
-    "valu_busy_percent": 100.0 * vals[("k_accumulate", "SQ_ACTIVE_INST_VALU")] * 4 / 1024 / (vals[("k_accumulate", "GRBM_GUI_ACTIVE")] / 8),
+    # wave-cycle accounting (MI355X_MICROARCH.md "rocprofv3 PMC slots": SQ_WAIT_ANY + SQ_WAIT_INST_ANY + SQ_ACTIVE_INST_ANY ~ SQ_WAVE_CYCLES, all in
+    # quad-cycles).  rocprofv3's derived VALUBusy falls back to a gfx94x formula on gfx950 and SQ_ACTIVE_INST_VALU reads identical to SQ_INSTS_VALU
+    # here (an instruction count, not busy cycles), so no "VALU busy %" is derived from it: the issue-bound argument rests on the disassembly + rates.hip.
+    "wave_cycle_shares": {
+        "active_inst_any": vals[("k_accumulate", "SQ_ACTIVE_INST_ANY")] / vals[("k_accumulate", "SQ_WAVE_CYCLES")],
+        "wait_inst_any_issue_stall": vals[("k_accumulate", "SQ_WAIT_INST_ANY")] / vals[("k_accumulate", "SQ_WAVE_CYCLES")],
+        "wait_any_parked": vals[("k_accumulate", "SQ_WAIT_ANY")] / vals[("k_accumulate", "SQ_WAVE_CYCLES")],
+    },
+    "valu_instructions_per_point_window": vals[("k_accumulate", "SQ_INSTS_VALU")] * 64 / (n * nwin),
     "units": "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them",
     "calibration": cal,
     "algorithmic_bytes_per_launch": 128 * n,
     "hbm_bytes_per_launch": hbm,
     "hbm_bytes_per_point_window": hbm / (n * nwin),
 }
-dst = os.path.join("gpurun_out", "r01_pmc_k_accumulate_%s.json" % tag)
+dst = os.path.join("gpurun_out", "%s_pmc_k_accumulate.json" % tag)
 json.dump(res, open(dst, "w"), indent=1)
 print(json.dumps(res, indent=1))
