@@ -5,24 +5,21 @@
 
 namespace zk {
 
-// Bucket accumulator in the reduced-radix form (ff28.cuh).  Values are NOT kept below p: the bounds are tracked statically --
-//   x < 6.2 p, y < 3.2 p, zz, zzz < 1.2 p (products) -- and every subtraction adds the multiple of p that keeps it non-negative.
+// Bucket accumulator in the reduced-radix form (FpMsm: ff30.cuh, or ff28.cuh with -DZK_MSM_RADIX=28).  Values are NOT kept below p: the bounds are
+// tracked statically.  The bound comments below are ff28's (unsigned limbs: every subtraction adds the multiple of p named in sub<K> that keeps it
+// non-negative: x < 6.2 p, y < 3.2 p, zz, zzz < 1.2 p); with ff30 the limbs are signed, sub<K> is a plain subtraction, products lie in (-0.51 p, 0.51 p)
+// and every intermediate stays below 3 p in magnitude (|x3| <= |r^2| + |ppp| + 2 |qq| < 2.1 p, |pd|, |t| < 2.6 p) -- far inside the 8 p the product accepts.
 template <class P>
-struct Acc28 { Fp28<P> x, y, zz, zzz; };
+struct Acc28 { FpMsm<P> x, y, zz, zzz; };
 
 // mixed add, every product inlined, no carry chains (hot path of k_accumulate).  Returns false for P == +-Q (left to the fix-up pass).
 template <class P>
 ZK_HD bool madd28(Acc28<P> &a, const Affine28<P> &q) {
-    using G = Fp28<P>;
+    using G = FpMsm<P>;
     G u2 = q.x * a.zz, s2 = q.y * a.zzz;                        // < 1.2 p
     G pd = u2.template sub<7>(a.x), r = s2.template sub<4>(a.y); // < 8.2 p, < 5.2 p
-    G pp = pd.sqr();                                            // < 1.2 p ; pd == 0 (mod p)  <=>  pp in {0, p}
-    {
-        uint32_t z0 = 0, zp = 0;
-#pragma unroll
-        for (int i = 0; i < G::N; i++) { z0 |= pp.l[i]; zp |= pp.l[i] ^ G::mod28(i); }
-        if (z0 == 0 || zp == 0) return false;
-    }
+    G pp = pd.sqr();                                            // pd == 0 (mod p)  <=>  pp == 0 (mod p)
+    if (G::product_is_zero(pp)) return false;
     G ppp = pd * pp, qq = a.x * pp;
     G x3 = (r.sqr().template sub<2>(ppp)).template sub<3>(qq.dbl());   // r^2 - ppp - 2 qq + 5p  < 6.2 p
     G t = qq.template sub<7>(x3);                                      // < 8.2 p
@@ -36,15 +33,10 @@ ZK_HD bool madd28(Acc28<P> &a, const Affine28<P> &q) {
 // ---- complete group law on reduced-radix XYZZ points (bucket reduction kernels).  Infinity <=> zz limbs all zero.
 // Coordinate bounds maintained by every routine: x < 6.2 p, y < 4 p, zz, zzz < 1.2 p.
 template <class P>
-ZK_HD bool is_zero_product(const Fp28<P> &v) {     // v is a product (< 1.2 p): v == 0 (mod p)  <=>  v in {0, p}
-    uint32_t z0 = 0, zp = 0;
-#pragma unroll
-    for (int i = 0; i < Fp28<P>::N; i++) { z0 |= v.l[i]; zp |= v.l[i] ^ Fp28<P>::mod28(i); }
-    return z0 == 0 || zp == 0;
-}
+ZK_HD bool is_zero_product(const FpMsm<P> &v) { return FpMsm<P>::product_is_zero(v); }
 template <class P>
 ZK_EC_FN void dbl28(Acc28<P> &a) {                        // dbl-2008-s-1
-    using G = Fp28<P>;
+    using G = FpMsm<P>;
     if (a.zz.limbs_zero()) return;
     G u = a.y.dbl(), v = u.sqr(), w = u * v, s = a.x * v;                // u < 8 p
     G xx = a.x.sqr(), m = xx.dbl() + xx;                                 // m < 3.6 p
@@ -54,7 +46,7 @@ ZK_EC_FN void dbl28(Acc28<P> &a) {                        // dbl-2008-s-1
 }
 template <class P>
 ZK_EC_FN void add28(Acc28<P> &a, const Acc28<P> &b) {     // add-2008-s, complete
-    using G = Fp28<P>;
+    using G = FpMsm<P>;
     if (b.zz.limbs_zero()) return;
     if (a.zz.limbs_zero()) { a = b; return; }
     G u1 = a.x * b.zz, u2 = b.x * a.zz, s1 = a.y * b.zzz, s2 = b.y * a.zzz;
@@ -73,9 +65,9 @@ ZK_EC_FN void add28(Acc28<P> &a, const Acc28<P> &b) {     // add-2008-s, complet
     a.zzz = a.zzz * b.zzz * ppp;
 }
 template <class P>
-ZK_HD Acc28<P> neg28(const Acc28<P> &a) { Acc28<P> r = a; r.y = Fp28<P>::zero().template sub<4>(a.y); return r; }
+ZK_HD Acc28<P> neg28(const Acc28<P> &a) { Acc28<P> r = a; r.y = FpMsm<P>::zero().template sub<4>(a.y); return r; }
 template <class P>
-ZK_HD Acc28<P> inf28() { Acc28<P> r; r.x = Fp28<P>::zero(); r.y = r.x; r.zz = r.x; r.zzz = r.x; return r; }
+ZK_HD Acc28<P> inf28() { Acc28<P> r; r.x = FpMsm<P>::zero(); r.y = r.x; r.zz = r.x; r.zzz = r.x; return r; }
 template <class P>
 ZK_HD XYZZ<Fp<P>> to_std_point(const Acc28<P> &a) {
     XYZZ<Fp<P>> o;
@@ -86,7 +78,7 @@ ZK_HD XYZZ<Fp<P>> to_std_point(const Acc28<P> &a) {
 template <class P>
 ZK_HD Acc28<P> from_std_point(const XYZZ<Fp<P>> &a) {
     if (a.is_inf()) return inf28<P>();
-    Acc28<P> o; o.x = Fp28<P>::from_std(a.x); o.y = Fp28<P>::from_std(a.y); o.zz = Fp28<P>::from_std(a.zz); o.zzz = Fp28<P>::from_std(a.zzz);
+    Acc28<P> o; o.x = FpMsm<P>::from_std(a.x); o.y = FpMsm<P>::from_std(a.y); o.zz = FpMsm<P>::from_std(a.zz); o.zzz = FpMsm<P>::from_std(a.zzz);
     return o;
 }
 

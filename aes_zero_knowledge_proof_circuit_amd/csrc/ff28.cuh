@@ -31,6 +31,13 @@ struct Fp28 {
 
     ZK_HD static Fp28 zero() { Fp28 r; for (int i = 0; i < N; i++) r.l[i] = 0; return r; }
     ZK_HD bool limbs_zero() const { uint32_t o = 0; for (int i = 0; i < N; i++) o |= l[i]; return o == 0; }
+    // v is a product (< 1.2 p): v == 0 (mod p)  <=>  v in {0, p}
+    ZK_HD static bool product_is_zero(const Fp28 &v) {
+        uint32_t z0 = 0, zp = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) { z0 |= v.l[i]; zp |= v.l[i] ^ mod28(i); }
+        return z0 == 0 || zp == 0;
+    }
 
     // split a 12x32 little-endian integer into 28-bit limbs (no arithmetic)
     ZK_HD static Fp28 split(const uint32_t *w) {
@@ -215,6 +222,7 @@ struct Fp28 {
     }
     // 2^400 mod p and 2^384 mod p as 28-bit limb integers, computed from Fp<P> (R = 2^384: one() = 2^384 mod p)
     ZK_HD static Fp28 k_2_384() { Fp<P> o = Fp<P>::one(); return split(o.l); }
+    ZK_HD static Fp28 k_one() { return k_2_392(); }
     ZK_HD static Fp28 k_2_392() {               // the Montgomery one of this representation (R' mod p)
         Fp<P> v = Fp<P>::one();
         for (int i = 0; i < 8; i++) v = v.dbl();

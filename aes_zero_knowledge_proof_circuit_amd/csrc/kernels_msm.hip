@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(64, 2) k_accumulate(const Affine28<P> *__restr
                                                        const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, const uint32_t *__restrict__ order,
                                                        uint32_t nbuckets_total, uint32_t cap, Acc28<P> *__restrict__ buckets,
                                                        uint32_t *__restrict__ deferred, uint32_t deferred_cap, uint32_t *__restrict__ deferred_count) {
-    using G = Fp28<P>;
+    using G = FpMsm<P>;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nbuckets_total) return;
     uint32_t k = order[t];
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(64, 2) k_accumulate(const Affine28<P> *__restr
                 if (i + 1 < e) { idx = vals[i + 1]; nxt = bases[idx & VAL_INDEX]; }   // prefetch the next gather under this add's ALU work
                 if ((cur & VAL_SKIP) || p.is_inf()) continue;
                 if (cur >> 31) p.y = G::zero().template sub<2>(p.y);                 // negative digit: add -P  (y < 1.2 p as a product, so 2p - y > 0)
-                if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_2_392(); acc.zzz = acc.zz; acc_inf = false; continue; }
+                if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_one(); acc.zzz = acc.zz; acc_inf = false; continue; }
                 if (!madd28(acc, p)) {
                     uint32_t slot = atomicAdd(deferred_count, 1u);
                     if (slot < deferred_cap) { deferred[2 * slot] = k; deferred[2 * slot + 1] = cur; }
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_tail(const Affine28<P> *__
                                                             const uint32_t *__restrict__ end, const uint32_t *__restrict__ extra_off, uint32_t nb, uint32_t max_segments, uint32_t cap,
                                                             Acc28<P> *__restrict__ partial, Acc28<P> *__restrict__ buckets, uint32_t *__restrict__ deferred, uint32_t deferred_cap,
                                                             uint32_t *__restrict__ deferred_count) {
-    using G = Fp28<P>;
+    using G = FpMsm<P>;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t total = extra_off[nb];                   // exclusive scan has nb + 1 entries
     if (total > max_segments) total = max_segments;
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_tail(const Affine28<P> *__
             Affine28<P> p = bases[cur & VAL_INDEX];
             if ((cur & VAL_SKIP) || p.is_inf()) continue;
             if (cur >> 31) p.y = G::zero().template sub<2>(p.y);
-            if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_2_392(); acc.zzz = acc.zz; acc_inf = false; continue; }
+            if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_one(); acc.zzz = acc.zz; acc_inf = false; continue; }
             if (!madd28(acc, p)) {
                 uint32_t slot = atomicAdd(deferred_count, 1u);
                 if (slot < deferred_cap) { deferred[2 * slot] = k; deferred[2 * slot + 1] = cur; }
@@ -337,6 +337,8 @@ __global__ void __launch_bounds__(256) k_reduce_window(const Acc28<P> *__restric
 template <class P> __global__ void k_sum_tree(const Acc28<P> *__restrict__ in, uint32_t total, uint32_t per, Acc28<P> *__restrict__ out);
 
 constexpr uint32_t DEFERRED_CAP = 1u << 20;
+constexpr size_t ACC_BYTES = sizeof(Acc28<Fq377P>);          // one XYZZ bucket in the reduced-radix form (208 B with ff30, 224 B with ff28; same for both curves)
+static_assert(sizeof(Acc28<Fq381P>) == ACC_BYTES, "bucket size differs between the curves");
 struct MsmWorkspace {
     size_t cap_pairs = 0, cap_buckets = 0, cap_tmp = 0;
     uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr, *start = nullptr, *end = nullptr;
@@ -356,7 +358,7 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
         HIP_CHECK(hipEventCreate(&S.ev0)); HIP_CHECK(hipEventCreate(&S.ev1));
         S.deferred = (uint32_t *)dmalloc(2 * DEFERRED_CAP * 4); S.deferred_count = (uint32_t *)dmalloc(8);
     }
-    if (pairs / cap + 64 > S.cap_ovf) { dfree(S.ovf_partial); S.cap_ovf = pairs / cap + 64; S.ovf_partial = dmalloc(S.cap_ovf * 224); }
+    if (pairs / cap + 64 > S.cap_ovf) { dfree(S.ovf_partial); S.cap_ovf = pairs / cap + 64; S.ovf_partial = dmalloc(S.cap_ovf * ACC_BYTES); }
     if (pairs > S.cap_pairs) {
         dfree(S.keys_a); dfree(S.keys_b); dfree(S.vals_a); dfree(S.vals_b);
         S.cap_pairs = pairs;
@@ -370,9 +372,9 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
         S.cap_buckets = buckets;
         S.start = (uint32_t *)dmalloc(buckets * 4); S.end = (uint32_t *)dmalloc(buckets * 4);
         S.size_key = (uint32_t *)dmalloc(buckets * 4); S.size_key2 = (uint32_t *)dmalloc(buckets * 4); S.ids = (uint32_t *)dmalloc(buckets * 4); S.order = (uint32_t *)dmalloc(buckets * 4);
-        S.buckets = dmalloc(buckets * 224);
-        S.seg_s = dmalloc((buckets / RED_L1 + 64) * 224); S.seg_w = dmalloc((buckets / RED_L1 + 64) * 224);
-        S.partial = dmalloc((buckets / (RED_L1 * RED_L2) + 64 * 64) * 224); S.wsum = dmalloc(192 * 64);
+        S.buckets = dmalloc(buckets * ACC_BYTES);
+        S.seg_s = dmalloc((buckets / RED_L1 + 64) * ACC_BYTES); S.seg_w = dmalloc((buckets / RED_L1 + 64) * ACC_BYTES);
+        S.partial = dmalloc((buckets / (RED_L1 * RED_L2) + 64 * 64) * ACC_BYTES); S.wsum = dmalloc(192 * 64);
         // (window sums: at most 64 sets)
     }
 }
@@ -769,7 +771,7 @@ constexpr int CLS_CHUNK = 16;
 template <class P>
 __global__ void __launch_bounds__(64, 2) k_class_partials(const Affine28<P> *__restrict__ bases, const int8_t *__restrict__ vals, uint32_t n, Acc28<P> *__restrict__ part1,
                                                            Acc28<P> *__restrict__ part2, uint32_t *__restrict__ flags) {
-    using G = Fp28<P>;
+    using G = FpMsm<P>;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t s0 = t * CLS_CHUNK;
     if (s0 >= n) return;
@@ -783,10 +785,10 @@ __global__ void __launch_bounds__(64, 2) k_class_partials(const Affine28<P> *__r
         if (p.is_inf()) continue;
         if (v < 0) { p.y = G::zero().template sub<2>(p.y); v = -v; }
         if (v == 1) {
-            if (inf1) { a1.x = p.x; a1.y = p.y; a1.zz = G::k_2_392(); a1.zzz = a1.zz; inf1 = false; }
+            if (inf1) { a1.x = p.x; a1.y = p.y; a1.zz = G::k_one(); a1.zzz = a1.zz; inf1 = false; }
             else if (!madd28(a1, p)) atomicOr(flags, 1u);
         } else if (v == 2) {
-            if (inf2) { a2.x = p.x; a2.y = p.y; a2.zz = G::k_2_392(); a2.zzz = a2.zz; inf2 = false; }
+            if (inf2) { a2.x = p.x; a2.y = p.y; a2.zz = G::k_one(); a2.zzz = a2.zz; inf2 = false; }
             else if (!madd28(a2, p)) atomicOr(flags, 1u);
         } else atomicOr(flags, 2u);
     }

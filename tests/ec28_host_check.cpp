@@ -3,8 +3,10 @@
 #include <cstdio>
 #include <cstdlib>
 using namespace zk;
+// p itself as a field value (a non-canonical representative of 0): built from the parameter pack through the 12x32 split
+template <class P> FpMsm<P> mod_as_field() { uint32_t w[12]; for (int i = 0; i < 12; i++) w[i] = P::mod(i); return FpMsm<P>::split(w); }
 template <class Curve, class P> int run(const char *name, const uint32_t *gx, const uint32_t *gy) {
-    using Fq = Fp<P>; using G = Fp28<P>;
+    using Fq = Fp<P>; using G = FpMsm<P>;
     Affine<Fq> g; for (int k = 0; k < 12; k++) { g.x.l[k] = gx[k]; g.y.l[k] = gy[k]; }
     XYZZ<Fq> Gs = XYZZ<Fq>::from_affine(g);
     srand(3);
@@ -22,9 +24,9 @@ template <class Curve, class P> int run(const char *name, const uint32_t *gx, co
             if (variant & 1) { a1.y = G::zero().template sub<2>(a1.y); s1 = s1.neg(); }
             if (variant & 2) { a2.y = G::zero().template sub<2>(a2.y); s2 = s2.neg(); }
             // non-canonical representatives: add p to the coordinates (still < 2.2 p)
-            if (it % 3 == 0) { G pp; for (int i = 0; i < 14; i++) pp.l[i] = G::mod28(i); a1.y = a1.y + pp; }
+            if (it % 3 == 0) a1.y = a1.y + mod_as_field<P>();
             // accumulate: first = a1, then madd a2, then madd a1 again, a2 again ...
-            Acc28<P> acc; acc.x = a1.x; acc.y = a1.y; acc.zz = G::k_2_392(); acc.zzz = acc.zz;
+            Acc28<P> acc; acc.x = a1.x; acc.y = a1.y; acc.zz = G::k_one(); acc.zzz = acc.zz;
             XYZZ<Fq> ref = XYZZ<Fq>::from_affine(s1);
             for (int r = 0; r < 5; r++) {
                 const Affine28<P> &q = (r & 1) ? a1 : a2; const Affine<Fq> &sq = (r & 1) ? s1 : s2;

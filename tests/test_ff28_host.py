@@ -10,11 +10,12 @@ CSRC = os.path.join(ROOT, "aes_zero_knowledge_proof_circuit_amd", "csrc")
 
 SRC = r'''
 #include "ff28.cuh"
+#include "ff30.cuh"
 #include <cstdio>
 #include <cstdlib>
 using namespace zk;
-template <class P> int run(const char *name) {
-    using F = Fp<P>; using G = Fp28<P>;
+template <class P, class G> int run(const char *name) {
+    using F = Fp<P>;
     srand(7);
     int bad = 0;
     for (int it = 0; it < 3000; it++) {
@@ -35,11 +36,22 @@ template <class P> int run(const char *name) {
         bad += !(w.to_std() == ws);
         bad += (a8.template sub<2>(a8)).is_zero_mod_p() != true;
         bad += a8.is_zero_mod_p() != a.is_zero();
+        // a two-product sum with one reduction, on grown operands; a product that is 0 mod p must test as zero
+        bad += !(G::fma2(u, v, a8.template sub<2>(b8), b8.dbl()).to_std() == ((a + b).dbl()) * (a - b) + (a - b) * b.dbl());
+        bad += G::product_is_zero(a8 * b8) != (a * b).is_zero();
+        bad += G::product_is_zero((a8.template sub<2>(a8)) * b8) != true;
+        bad += G::product_is_zero((u.template sub<8>(u)).sqr()) != true;
+        // long lazy chain: values may be negative (ff30) or many multiples of p (ff28) before the next product
+        G acc = a8; F racc = a;
+        for (int k = 0; k < 6; k++) { acc = (acc * b8).template sub<7>(a8.dbl()) + v; racc = racc * b - a.dbl() + (a - b); }
+        bad += !(acc.to_std() == racc);
     }
     printf("%s %d\n", name, bad);
     return bad;
 }
-int main() { return run<Fq377P>("fq377") + run<Fq381P>("fq381"); }
+int main() {
+    return run<Fq377P, Fp28<Fq377P>>("fq377x28") + run<Fq381P, Fp28<Fq381P>>("fq381x28") + run<Fq377P, Fp30<Fq377P>>("fq377x30") + run<Fq381P, Fp30<Fq381P>>("fq381x30");
+}
 '''
 
 
@@ -50,7 +62,7 @@ def test_reduced_radix_field_matches_montgomery_reference():
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", CSRC, src, "-o", exe])
         out = subprocess.run([exe], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout + out.stderr
-        assert out.stdout.split() == ["fq377", "0", "fq381", "0"]
+        assert out.stdout.split() == ["fq377x28", "0", "fq381x28", "0", "fq377x30", "0", "fq381x30", "0"]
 
 
 
@@ -58,12 +70,13 @@ def test_reduced_radix_group_law_matches_xyzz_reference():
     """madd28 / add28 / dbl28 / neg28 (csrc/ec28.cuh) against XYZZ<Fq> on random points of both curves: accumulation chains with negated and
     non-canonical (value >= p) coordinates, the running-sum pattern of the bucket reduction (P + P through the complete law), P - P = infinity."""
     src_path = os.path.join(ROOT, "tests", "ec28_host_check.cpp")
-    with tempfile.TemporaryDirectory() as d:
-        exe = os.path.join(d, "t")
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", CSRC, src_path, "-o", exe])
-        out = subprocess.run([exe], capture_output=True, text=True)
-        assert out.returncode == 0, out.stdout + out.stderr
-        assert out.stdout.split() == ["bls377", "0", "bls381", "0"]
+    for radix in (28, 30):                      # the product builds with ZK_MSM_RADIX=28 (ff28.cuh); 30 = the signed 13 x 30-bit alternative (ff30.cuh)
+        with tempfile.TemporaryDirectory() as d:
+            exe = os.path.join(d, "t")
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-DZK_MSM_RADIX=%d" % radix, "-I", CSRC, src_path, "-o", exe])
+            out = subprocess.run([exe], capture_output=True, text=True)
+            assert out.returncode == 0, out.stdout + out.stderr
+            assert out.stdout.split() == ["bls377", "0", "bls381", "0"], (radix, out.stdout)
 
 
 SRC29 = r'''

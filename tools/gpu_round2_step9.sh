@@ -1,0 +1,20 @@
+set -x
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_marlin.py -m gpu -x -q -k "not 4096 and not 1024 and not aes32 and not aes16_proof" > gpurun_out/r02_gputest_9.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r02_gputest_9.log
+tail -6 gpurun_out/r02_gputest_9.log
+run() { name=$1; shift; env "$@" timeout 600 python bench.py --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/r02_bench_$name.json 2> gpurun_out/r02_bench_$name.err; python - <<PY
+import json
+try:
+    d=json.loads(open("gpurun_out/r02_bench_$name.json").read().strip().splitlines()[-1])
+    print("$name", d["value"], d["proofs_verified"], "acc avg", d["roofline"]["avg_launch_ms"], "overlap", d["roofline"]["launch_overlap"], d["roofline"]["one_context_probe"])
+except Exception as e:
+    print("$name ERR", e); print(open("gpurun_out/r02_bench_$name.err").read()[-1500:])
+PY
+}
+run radix30 A=1
+python tools/ubench/msm_one.py 22 0; python tools/ubench/msm_one.py 22 20
+ZK_MSM_RADIX=28 python -m aes_zero_knowledge_proof_circuit_amd.build --force > /dev/null 2>&1
+run radix28 A=1
+python tools/ubench/msm_one.py 22 0; python tools/ubench/msm_one.py 22 20
+python -m aes_zero_knowledge_proof_circuit_amd.build --force > /dev/null 2>&1
+run radix30_again A=1
