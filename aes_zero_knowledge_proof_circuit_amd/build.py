@@ -19,8 +19,10 @@ CXX_SOURCES = ["circuit.cpp", "marlin.cpp", "capi.cpp"]
 HEADERS = ["ff.cuh", "ff28.cuh", "ff29.cuh", "ff30.cuh", "ec.cuh", "ec28.cuh", "gpu.hpp", "hip_util.hpp", "consts32.h", "trace_layout.h", "circuit.hpp", "marlin.hpp", "pairing.hpp", "transcript.hpp",
            os.path.join("..", "..", "include", "zkaes.h")]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-I", CSRC, "-Wno-unused-result"]
-if os.environ.get("ZK_MSM_RADIX"):          # 28 = round 1's 14 x 28-bit field for the MSM (A/B measurements); default 30 (csrc/ec.cuh)
+if os.environ.get("ZK_MSM_RADIX"):          # 30 = the 13 x 30-bit signed-limb field for the MSM (csrc/ff30.cuh; A/B measurements); default 28 (csrc/ec.cuh)
     COMMON.append("-DZK_MSM_RADIX=" + os.environ["ZK_MSM_RADIX"])
+if os.environ.get("ZK_EXTRA_DEFINES"):      # e.g. "-DZK_CHEAP_PRETEST=0" for A/B builds on the GPU box
+    COMMON += os.environ["ZK_EXTRA_DEFINES"].split()
 
 
 def _newer(target, deps):

@@ -137,7 +137,11 @@ ZK_HD bool on_curve(const Affine<Fq> &a, const Fq &b) {
 template <class P>
 struct Affine28 {
     FpMsm<P> x, y;
+#if ZK_CHEAP_PRETEST
+    ZK_HD bool is_inf() const { return (x.l[0] | y.l[0]) == 0 && x.limbs_zero() && y.limbs_zero(); }      // one-word pre-test: the full OR only when both low limbs are zero
+#else
     ZK_HD bool is_inf() const { return x.limbs_zero() && y.limbs_zero(); }
+#endif
     ZK_HD static Affine28 from_std(const Affine<Fp<P>> &a) { Affine28 r; r.x = FpMsm<P>::from_std(a.x); r.y = FpMsm<P>::from_std(a.y); return r; }
     ZK_HD Affine<Fp<P>> to_std() const { Affine<Fp<P>> r; r.x = x.to_std(); r.y = y.to_std(); return r; }
 };

@@ -222,26 +222,41 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_tail(const Affine28<P> *__
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t total = extra_off[nb];                   // exclusive scan has nb + 1 entries
     if (total > max_segments) total = max_segments;
-    if (t < total) {
-        uint32_t lo = 0, hi = nb;                         // largest k with extra_off[k] <= t
-        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (extra_off[mid] <= t) lo = mid; else hi = mid; }
-        uint32_t k = lo, j = t - extra_off[k];
-        uint32_t s = start[k] + (j + 1) * cap, e = s + cap < end[k] ? s + cap : end[k];
+    // workgroups whose 64 segment slots are all beyond `total` (every workgroup, for uniform digits) skip the segment work and its LDS fold
+    if (blockIdx.x * blockDim.x < total) {
+        __shared__ Acc28<P> sh[64];
+        __shared__ uint32_t key[64];
+        uint32_t k = 0xffffffffu;
         Acc28<P> acc;
-        bool acc_inf = true;
-        for (uint32_t i = s; i < e; i++) {
-            uint32_t cur = vals[i];
-            Affine28<P> p = bases[cur & VAL_INDEX];
-            if ((cur & VAL_SKIP) || p.is_inf()) continue;
-            if (cur >> 31) p.y = G::zero().template sub<2>(p.y);
-            if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_one(); acc.zzz = acc.zz; acc_inf = false; continue; }
-            if (!madd28(acc, p)) {
-                uint32_t slot = atomicAdd(deferred_count, 1u);
-                if (slot < deferred_cap) { deferred[2 * slot] = k; deferred[2 * slot + 1] = cur; }
+        if (t < total) {
+            uint32_t lo = 0, hi = nb;                         // largest k with extra_off[k] <= t
+            while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (extra_off[mid] <= t) lo = mid; else hi = mid; }
+            k = lo;
+            uint32_t j = t - extra_off[k];
+            uint32_t s = start[k] + (j + 1) * cap, e = s + cap < end[k] ? s + cap : end[k];
+            bool acc_inf = true;
+            for (uint32_t i = s; i < e; i++) {
+                uint32_t cur = vals[i];
+                Affine28<P> p = bases[cur & VAL_INDEX];
+                if ((cur & VAL_SKIP) || p.is_inf()) continue;
+                if (cur >> 31) p.y = G::zero().template sub<2>(p.y);
+                if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_one(); acc.zzz = acc.zz; acc_inf = false; continue; }
+                if (!madd28(acc, p)) {
+                    uint32_t slot = atomicAdd(deferred_count, 1u);
+                    if (slot < deferred_cap) { deferred[2 * slot] = k; deferred[2 * slot + 1] = cur; }
+                }
             }
+            if (acc_inf) acc = inf28<P>();
+            sh[threadIdx.x] = acc;
         }
-        if (acc_inf) acc = inf28<P>();
-        partial[t] = acc;
+        key[threadIdx.x] = k;
+        __syncthreads();
+        // the segments of one bucket are consecutive t: the first lane of every (workgroup, bucket) run folds its run (<= 63 additions) and stores ONE
+        // partial at its own slot; k_reduce_l1's load_bucket then visits one slot per workgroup the bucket's segments span, not one per segment
+        if (t < total && (threadIdx.x == 0 || key[threadIdx.x - 1] != k)) {
+            for (uint32_t q = threadIdx.x + 1; q < 64 && key[q] == k; q++) add28<P>(acc, sh[q]);
+            partial[t] = acc;
+        }
     }
     __shared__ uint32_t ticket;
     __threadfence();
@@ -260,7 +275,8 @@ __device__ __forceinline__ Acc28<P> load_bucket(const Acc28<P> *__restrict__ buc
     uint32_t a = extra_off[k], b = extra_off[k + 1];
     if (a != b) {
         if (b > max_segments) b = max_segments;
-        for (uint32_t i = a; i < b; i++) add28<P>(acc, partial[i]);
+        // one folded partial per 64-segment workgroup of k_accumulate_tail that the bucket's segments [a, b) span, stored at the run's first slot
+        for (uint32_t w = a / 64; w * 64 < b; w++) { uint32_t i = w * 64 > a ? w * 64 : a; if (i < b) add28<P>(acc, partial[i]); }
     }
     return acc;
 }

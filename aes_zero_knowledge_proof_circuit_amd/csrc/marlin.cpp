@@ -416,7 +416,7 @@ class ProvingKeyImpl {
     std::vector<G1A> lag_pj;
     G1A lag_vh, lag_vw;
     int table_c = 22;
-    bool use_tables = false;   // window tables for the large MSMs (default on when |K| >= 2^21: ZKAES_MSM_TABLES=0/1 overrides)
+    bool use_tables = false;   // window tables for the large MSMs (default on when |K| >= 2^20: ZKAES_MSM_TABLES=0/1 overrides)
     // device: circuit
     uint32_t *d_desc = nullptr, *d_sbox_in = nullptr, *d_sbox_tmpl = nullptr;
     uint32_t *d_a_rowptr = nullptr, *d_a_col = nullptr, *d_b_rowptr = nullptr, *d_b_col = nullptr;
@@ -590,8 +590,8 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
     G1A g, gamma_g;
     pairing::G2Affine srs_h;
     kzg_setup_points(srs_beta, g, gamma_g, srs_h);
-    // window tables pay for the |K|-scale MSMs of the 4- to 6-block keys; small keys keep per-window buckets only
-    use_tables = lg_k >= 21;
+    // window tables pay from the one-block key (|K| = 2^20: 35.5 -> 38.2 proofs/s in batch mode) upwards; tiny circuits keep per-window buckets only
+    use_tables = lg_k >= 20;
     if (const char *e = getenv("ZKAES_MSM_TABLES")) use_tables = atoi(e) != 0;
     // c = 20: 13 signed windows instead of 15 and 2^19 buckets in ONE set (the 15 x 2^16 per-window buckets cost more to reduce).  c = 22 saves one more
     // window but its 2^21 buckets triple k_reduce_l1 (1.95 ms vs 0.67 ms per MSM): measured slower (profiles/r02_msm_tables.md)

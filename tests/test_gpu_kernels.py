@@ -135,6 +135,19 @@ def test_msm_skewed_scalars_use_the_overflow_path(zko, api, distinct):
     assert not inf and not ref_inf and got == ref.raw
 
 
+@pytest.mark.parametrize("distinct,n,c", [(1, 20_000, 12), (3, 20_000, 16), (2, 70_000, 9)])
+def test_msm_table_skewed_scalars_fold_overflow_runs_across_workgroups(zko, api, distinct, n, c):
+    """table mode cuts buckets above 256 points into overflow segments; with one to three distinct scalars a bucket has 26 ... 270 segments, so its
+    runs span several 64-segment workgroups of k_accumulate_tail (LDS fold per workgroup) and k_reduce_l1 picks up one partial per workgroup"""
+    bases = oracle_points(zko, 377, n, 515 + n)
+    vals = [int.from_bytes(np.random.RandomState(900 + i).bytes(31), "little") for i in range(distinct)]
+    scalars = zko.fr_pack([vals[i % distinct] for i in range(n)])
+    ref = C.create_string_buffer(96)
+    ref_inf = zko.lib().zko_api_msm(377, bases, scalars, C.c_size_t(n), ref)
+    got, inf = api.msm_table(377, bases, scalars, c)
+    assert not inf and not ref_inf and got == ref.raw
+
+
 def test_msm_full_size_two_independent_paths_agree(api):
     """BASELINE-size MSM (2^20 points = |H| of a 6-block proof; the oracle would need minutes): the signed-digit per-window path and the
     precomputed-table single-bucket-set path are different algorithms over different table copies -- their sums must be identical."""
