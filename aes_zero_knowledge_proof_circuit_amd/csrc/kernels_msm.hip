@@ -159,8 +159,14 @@ __global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_
 // The loop body has no function call: the (cryptographically negligible, but reachable with repeated bases) P == +-Q case is
 // appended to a deferred list and replayed by the last workgroup of k_accumulate_tail with the complete addition law.  Buckets stay in the
 // reduced-radix form through the reduction kernels; only the per-window sums are converted back for the host.
+#ifndef ZK_ACC_WAVES
+#define ZK_ACC_WAVES 2          // waves per SIMD the compiler must fit k_accumulate into (A/B knob: 3 spills with ff28, tools/gpu_round2_occupancy.sh)
+#endif
+#ifndef ZK_ACC_PREFETCH
+#define ZK_ACC_PREFETCH 1       // software prefetch of the next gathered point (28 registers)
+#endif
 template <class P>
-__global__ void __launch_bounds__(64, 2) k_accumulate(const Affine28<P> *__restrict__ bases, const uint32_t *__restrict__ vals,
+__global__ void __launch_bounds__(64, ZK_ACC_WAVES) k_accumulate(const Affine28<P> *__restrict__ bases, const uint32_t *__restrict__ vals,
                                                        const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, const uint32_t *__restrict__ order,
                                                        uint32_t nbuckets_total, uint32_t cap, Acc28<P> *__restrict__ buckets,
                                                        uint32_t *__restrict__ deferred, uint32_t deferred_cap, uint32_t *__restrict__ deferred_count) {
@@ -174,12 +180,19 @@ __global__ void __launch_bounds__(64, 2) k_accumulate(const Affine28<P> *__restr
         uint32_t s = start[k], e = end[k];
         if (e - s > cap) e = s + cap;                                      // the remainder goes through the overflow segments of k_accumulate_tail
         if (s < e) {
+#if ZK_ACC_PREFETCH
             uint32_t idx = vals[s];
             Affine28<P> nxt = bases[idx & VAL_INDEX];
+#endif
             for (uint32_t i = s; i < e; i++) {
+#if ZK_ACC_PREFETCH
                 Affine28<P> p = nxt;
                 uint32_t cur = idx;
                 if (i + 1 < e) { idx = vals[i + 1]; nxt = bases[idx & VAL_INDEX]; }   // prefetch the next gather under this add's ALU work
+#else
+                uint32_t cur = vals[i];
+                Affine28<P> p = bases[cur & VAL_INDEX];
+#endif
                 if ((cur & VAL_SKIP) || p.is_inf()) continue;
                 if (cur >> 31) p.y = G::zero().template sub<2>(p.y);                 // negative digit: add -P  (y < 1.2 p as a product, so 2p - y > 0)
                 if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_one(); acc.zzz = acc.zz; acc_inf = false; continue; }

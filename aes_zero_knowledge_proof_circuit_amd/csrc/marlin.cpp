@@ -376,6 +376,7 @@ struct ProverContext {
     size_t poly_len[9] = {0};
     DevBuf e[5], big_tmp, f_poly, acc, wit, wit2, scratch;
     ProverTimings timings;
+    bool throughput = false;           // set per proof: several proofs in flight (chunked / batch calls) -> window tables; a lone encrypt() call -> per-window buckets
     ProverContext() { stream = gpu::stream_create(); msm_ws = gpu::msm_workspace_create(); }
     ~ProverContext() {
         gpu::dfree(d_trace); gpu::dfree(d_z); gpu::dfree(d_msg); gpu::dfree(d_key);
@@ -472,13 +473,17 @@ class ProvingKeyImpl {
         return d;
     }
 
-    bool table_ok(size_t len) const { return use_tables && len >= table_min_n; }
+    // Window tables trade latency for throughput: 13 instead of 15 windows of mixed additions, but the short top window's buckets cost ~2 ms of
+    // serial segment chains per MSM (k_accumulate_tail).  With several proofs in flight that latency hides behind other contexts' kernels (+9 % blocks/s);
+    // a lone encrypt() call -- what the reference's criterion bench times -- would just get slower (16 B: 62.6 vs 54 ms), so it keeps the per-window buckets.
+    bool table_ok(const ProverContext &cx, size_t len) const { return use_tables && (cx.throughput || force_tables) && len >= table_min_n; }
+    bool force_tables = false;         // ZKAES_MSM_TABLES=2: tables for lone calls too (measurements)
     // MSM against powers_of_g starting at `off` (plain or shifted range); device scalars
     XYZZ<Fq377> msm_powers(ProverContext &cx, bool shifted, size_t off, const F *scalars, size_t len) {
         if (len == 0) return XYZZ<Fq377>::inf();
         size_t avail = shifted ? (bounds[1] + 1) : (supported_degree + 1);
         if (off + len > avail) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
-        if (table_ok(len)) return gpu::msm_table<Bls377>(cx.msm_ws, d_powers, srs_stride, (shifted ? n_plain : 0) + off, table_c, scalars, len, cx.stream);
+        if (table_ok(cx, len)) return gpu::msm_table<Bls377>(cx.msm_ws, d_powers, srs_stride, (shifted ? n_plain : 0) + off, table_c, scalars, len, cx.stream);
         return gpu::msm<Bls377>(cx.msm_ws, (shifted ? d_shifted : d_powers) + off, scalars, len, cx.stream);
     }
     // KZG10::commit: MSM(powers, coeffs) [+ MSM(powers_of_gamma_g, blinding) when hiding]
@@ -525,7 +530,7 @@ class ProvingKeyImpl {
         // degree-bounded polynomial: the plain and the shifted commitment have the same scalars -> one digit / sort pass, two accumulations
         size_t off = (max_degree - (size_t)lp.bound) - lowest_shift;
         if (len > supported_degree + 1 || off + len > bounds[1] + 1) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
-        if (table_ok(len)) gpu::msm_prepare_table<Bls377>(cx.msm_ws, coeffs, len, 0, nullptr, 0, 0, table_c, srs_stride, cx.stream);
+        if (table_ok(cx, len)) gpu::msm_prepare_table<Bls377>(cx.msm_ws, coeffs, len, 0, nullptr, 0, 0, table_c, srs_stride, cx.stream);
         else gpu::msm_prepare<Bls377>(cx.msm_ws, coeffs, len, nullptr, 0, 0, cx.stream);
         XYZZ<Fq377> c1 = gpu::msm_finish<Bls377>(cx.msm_ws, d_powers, cx.stream);
         add_hiding(c1, lp.hiding, lp.rand, zk);
@@ -536,13 +541,13 @@ class ProvingKeyImpl {
     // opening witness = MSM(powers, wit) + MSM(shifted powers from shift_off, swit) as ONE Pippenger instance over the contiguous SRS array
     XYZZ<Fq377> msm_opening(ProverContext &cx, const F *wit, size_t wlen, const F *swit, size_t slen, size_t shift_off) {
         if (wlen > supported_degree + 1 || shift_off + slen > bounds[1] + 1) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
-        if (table_ok(wlen + slen)) gpu::msm_prepare_table<Bls377>(cx.msm_ws, wit, wlen, 0, swit, slen, n_plain + shift_off, table_c, srs_stride, cx.stream);
+        if (table_ok(cx, wlen + slen)) gpu::msm_prepare_table<Bls377>(cx.msm_ws, wit, wlen, 0, swit, slen, n_plain + shift_off, table_c, srs_stride, cx.stream);
         else gpu::msm_prepare<Bls377>(cx.msm_ws, wit, wlen, swit, slen, n_plain + shift_off, cx.stream);
         return gpu::msm_finish<Bls377>(cx.msm_ws, d_powers, cx.stream);
     }
 
     void setup(int kind, size_t message_len, const SrsLiterals &srs);
-    Proof prove(ProverContext &cx, const uint8_t *trace_or_null, const uint8_t *msg, size_t len, const uint8_t *key, const uint8_t *zk_seed);
+    Proof prove(ProverContext &cx, const uint8_t *trace_or_null, const uint8_t *msg, size_t len, const uint8_t *key, const uint8_t *zk_seed, bool throughput = false);
 };
 
 void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs) {
@@ -592,7 +597,7 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
     kzg_setup_points(srs_beta, g, gamma_g, srs_h);
     // window tables pay from the one-block key (|K| = 2^20: 35.5 -> 38.2 proofs/s in batch mode) upwards; tiny circuits keep per-window buckets only
     use_tables = lg_k >= 20;
-    if (const char *e = getenv("ZKAES_MSM_TABLES")) use_tables = atoi(e) != 0;
+    if (const char *e = getenv("ZKAES_MSM_TABLES")) { use_tables = atoi(e) != 0; force_tables = atoi(e) == 2; }
     // c = 20: 13 signed windows instead of 15 and 2^19 buckets in ONE set (the 15 x 2^16 per-window buckets cost more to reduce).  c = 22 saves one more
     // window but its 2^21 buckets triple k_reduce_l1 (1.95 ms vs 0.67 ms per MSM): measured slower (profiles/r02_msm_tables.md)
     table_c = 20;
@@ -740,9 +745,10 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
     gpu::sync(stream);
 }
 
-Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const uint8_t *msg, size_t len, const uint8_t *key, const uint8_t *zk_seed) {
+Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const uint8_t *msg, size_t len, const uint8_t *key, const uint8_t *zk_seed, bool throughput) {
     gpu::set_device(device);
     std::lock_guard<std::mutex> busy(cx.in_use);
+    cx.throughput = throughput;
     const Circuit &c = circuit;
     gpu::stream_t s = cx.stream;
     auto &d_trace = cx.d_trace; auto &d_z = cx.d_z; auto &d_msg = cx.d_msg; auto &d_key = cx.d_key;
@@ -978,7 +984,7 @@ static std::vector<Proof> prove_many(ProvingKeyImpl *impl, const uint8_t *messag
                 if (i >= n_chunks) break;
                 uint8_t seed_i[32];
                 if (zk_seed) derive_zk_seed(seed_i, zk_seed, (uint64_t)i);
-                proofs[i] = impl->prove(cx, nullptr, messages + i * chunk, chunk, keys + i * key_stride, zk_seed ? seed_i : nullptr);
+                proofs[i] = impl->prove(cx, nullptr, messages + i * chunk, chunk, keys + i * key_stride, zk_seed ? seed_i : nullptr, n_chunks > 1);   // a multi-proof call is a throughput call
             }
         } catch (const std::exception &e) { errors[ci] = e.what(); }
     };
