@@ -160,7 +160,7 @@ __global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_
 // appended to a deferred list and replayed by the last workgroup of k_accumulate_tail with the complete addition law.  Buckets stay in the
 // reduced-radix form through the reduction kernels; only the per-window sums are converted back for the host.
 #ifndef ZK_ACC_WAVES
-#define ZK_ACC_WAVES 2          // waves per SIMD the compiler must fit k_accumulate into (A/B knob: 3 spills with ff28, tools/gpu_round2_occupancy.sh)
+#define ZK_ACC_WAVES 2          // waves per SIMD the compiler must fit k_accumulate into (A/B knob: 3 spills with ff28, tools/gpu_runs/gpu_round2_occupancy.sh)
 #endif
 #ifndef ZK_ACC_PREFETCH
 #define ZK_ACC_PREFETCH 1       // software prefetch of the next gathered point (28 registers)

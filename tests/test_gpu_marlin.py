@@ -233,6 +233,12 @@ def test_aes96_matches_the_committed_oracle_fixture(api, aes96):
         assert hashlib.sha256(got).hexdigest() == want, name
     assert proof.hex() == fx["proof"] and hashlib.sha256(proof).hexdigest() == fx["proof_sha256"]
     assert api.verify_encryption(vk, proof, bytes.fromhex(fx["ciphertext"])) is True
+    # a lone encrypt() call runs its MSMs over per-window buckets; a multi-proof call runs them through the fixed-base window tables (13 signed windows,
+    # one bucket set): the same group elements, so the same bytes -- the bench's code path against the oracle fixture
+    two = pk.encrypt_chunked(msg + msg, key)
+    assert two[0] == proof and two[1] == proof
+    for name, want in fx["poly_sha256"].items():
+        assert hashlib.sha256(pk.debug_fetch(name)).hexdigest() == want, name
     # and the oracle's own proof bytes (as committed) are accepted by the product verifier
     assert api.verify_encryption(vk, bytes.fromhex(fx["proof"]), bytes.fromhex(fx["ciphertext"])) is True
 
