@@ -8,6 +8,7 @@
 #include <map>
 #include <mutex>
 #include <thread>
+#include <functional>
 #include <stdexcept>
 #include "gpu.hpp"
 #include "trace_layout.h"
@@ -417,8 +418,14 @@ struct ProverContext {
     size_t poly_len[9] = {0};
     DevBuf e[5], big_tmp, f_poly, acc, wit, wit2, scratch;
     ProverTimings timings;
+    // MSM lanes: lane 0 = (stream, msm_ws) above; lanes 1..3 (own stream + MSM scratch, created on first use) let a LONE encrypt() call run the independent
+    // commitments of a round side by side (latency path only: with several proofs in flight the chip is already full)
+    struct Lane { gpu::stream_t stream = nullptr; gpu::MsmWorkspace *ws = nullptr; };
+    Lane lane[4];
+    DevBuf acc_b, wit_b, wit2_b, scratch_b;             // second set of opening buffers (the two openings run side by side on the latency path)
     bool throughput = false;           // set per proof: several proofs in flight (chunked / batch calls) -> window tables; a lone encrypt() call -> per-window buckets
-    ProverContext() { stream = gpu::stream_create(); msm_ws = gpu::msm_workspace_create(); }
+    ProverContext() { stream = gpu::stream_create(); msm_ws = gpu::msm_workspace_create(); lane[0].stream = stream; lane[0].ws = msm_ws; }
+    void ensure_lanes() { for (int i = 1; i < 4; i++) if (!lane[i].stream) { lane[i].stream = gpu::stream_create(); lane[i].ws = gpu::msm_workspace_create(); } }
     ~ProverContext() {
         gpu::dfree(d_trace); gpu::dfree(d_z); gpu::dfree(d_msg); gpu::dfree(d_key);
         for (auto p : d_cls) gpu::dfree(p);
@@ -426,6 +433,8 @@ struct ProverContext {
         for (DevBuf *b : {&za_ev, &zb_ev, &x_poly, &x_tmp, &x_evals, &tmp_n, &ra_ev, &ra_poly, &zpoly, &t_partial, &big_tmp, &f_poly, &acc, &wit, &wit2, &scratch}) b->release();
         for (auto &b : poly) b.release();
         for (auto &b : e) b.release();
+        for (DevBuf *b : {&acc_b, &wit_b, &wit2_b, &scratch_b}) b->release();
+        for (int i = 1; i < 4; i++) if (lane[i].stream) { gpu::msm_workspace_destroy(lane[i].ws); gpu::stream_destroy(lane[i].stream); }
         gpu::msm_workspace_destroy(msm_ws);
         gpu::stream_destroy(stream);
     }
@@ -520,72 +529,81 @@ class ProvingKeyImpl {
     // a lone encrypt() call -- what the reference's criterion bench times -- would just get slower (16 B: 62.6 vs 54 ms), so it keeps the per-window buckets.
     bool table_ok(const ProverContext &cx, size_t len) const { return use_tables && (cx.throughput || force_tables) && len >= table_min_n; }
     bool force_tables = false;         // ZKAES_MSM_TABLES=2: tables for lone calls too (measurements)
+    using Lane = ProverContext::Lane;
     // MSM against powers_of_g starting at `off` (plain or shifted range); device scalars
-    XYZZ<Fq377> msm_powers(ProverContext &cx, bool shifted, size_t off, const F *scalars, size_t len) {
+    XYZZ<Fq377> msm_powers(ProverContext &cx, Lane &ln, bool shifted, size_t off, const F *scalars, size_t len) {
         if (len == 0) return XYZZ<Fq377>::inf();
         size_t avail = shifted ? (bounds[1] + 1) : (supported_degree + 1);
         if (off + len > avail) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
-        if (table_ok(cx, len)) return gpu::msm_table<Bls377>(cx.msm_ws, d_powers, srs_stride, (shifted ? n_plain : 0) + off, table_c, scalars, len, cx.stream);
-        return gpu::msm<Bls377>(cx.msm_ws, (shifted ? d_shifted : d_powers) + off, scalars, len, cx.stream);
+        if (table_ok(cx, len)) return gpu::msm_table<Bls377>(ln.ws, d_powers, srs_stride, (shifted ? n_plain : 0) + off, table_c, scalars, len, ln.stream);
+        return gpu::msm<Bls377>(ln.ws, (shifted ? d_shifted : d_powers) + off, scalars, len, ln.stream);
     }
-    // KZG10::commit: MSM(powers, coeffs) [+ MSM(powers_of_gamma_g, blinding) when hiding]
-    G1A kzg_commit(ProverContext &cx, bool shifted, size_t off, const F *coeffs, size_t len, bool hiding, KzgRand &rnd, ChaChaRng &zk) {
-        XYZZ<Fq377> c = msm_powers(cx, shifted, off, coeffs, len);
-        rnd.hiding = hiding;
-        for (auto &x : rnd.b) x = Fr::zero();
-        if (hiding) {
-            for (int i = 0; i < 3; i++) rnd.b[i] = zk.rand_field<Fr>();
-            for (int i = 0; i < 3; i++) c.add(gamma_tab[i].mul(rnd.b[i]));
-        }
-        return c.to_affine();
+    struct Labeled { int idx; long bound; bool hiding; KzgRand rand, shifted_rand; Commitment comm; };
+    // The prover RNG is consumed in label order BEFORE the commitments are computed (three blinding coefficients per hiding commitment, the shifted
+    // commitment of a degree-bounded polynomial draws its own three): the same stream positions as upstream's commit loop, and the commitments
+    // themselves no longer touch the RNG, so independent ones may run concurrently.
+    static void draw_rand(Labeled &lp, ChaChaRng &zk) {
+        auto draw = [&](KzgRand &r) { r.hiding = lp.hiding; for (auto &x : r.b) x = Fr::zero(); if (lp.hiding) for (int i = 0; i < 3; i++) r.b[i] = zk.rand_field<Fr>(); };
+        draw(lp.rand);
+        if (lp.bound >= 0) draw(lp.shifted_rand);
     }
+    void hide(XYZZ<Fq377> &c, const KzgRand &rnd) const { if (rnd.hiding) for (int i = 0; i < 3; i++) c.add(gamma_tab[i].mul(rnd.b[i])); }
     // commitment of w / z_A / z_B through the Lagrange-basis SRS: sum of the bases whose evaluation is non-zero (+-1, 2) + the blinding term
     // rho * V + the hiding part.  Same group element as MSM(powers, coefficients); falls back to the MSM if the class sum declines.
-    bool lagrange_commit(ProverContext &cx, int which, const std::vector<uint8_t> &inst, const Fr &rho, KzgRand &rnd, ChaChaRng &zk, G1A &out) {
+    bool lagrange_commit(ProverContext &cx, Lane &ln, int which, const std::vector<uint8_t> &inst, const Fr &rho, const KzgRand &rnd, G1A &out) {
         XYZZ<Fq377> c;
-        if (!gpu::class_sum<Bls377>(cx.msm_ws, which == 0 ? d_lag_w : d_lag_h, cx.d_cls[which], n, &c, cx.stream)) return false;
+        if (!gpu::class_sum<Bls377>(ln.ws, which == 0 ? d_lag_w : d_lag_h, cx.d_cls[which], n, &c, ln.stream)) return false;
         if (which == 0) for (size_t j = 0; j < m; j++) if (inst[j]) c.madd(lag_pj[j].neg());
         c.add((which == 0 ? lag_vw_tab : lag_vh_tab).mul(rho));
-        rnd.hiding = true;
-        for (int i = 0; i < 3; i++) rnd.b[i] = zk.rand_field<Fr>();
-        for (int i = 0; i < 3; i++) c.add(gamma_tab[i].mul(rnd.b[i]));
+        hide(c, rnd);
         out = c.to_affine();
         return true;
     }
-    struct Labeled { int idx; long bound; bool hiding; KzgRand rand, shifted_rand; Commitment comm; };
-    void add_hiding(XYZZ<Fq377> &c, bool hiding, KzgRand &rnd, ChaChaRng &zk) {
-        rnd.hiding = hiding;
-        for (auto &x : rnd.b) x = Fr::zero();
-        if (hiding) {
-            for (int i = 0; i < 3; i++) rnd.b[i] = zk.rand_field<Fr>();
-            for (int i = 0; i < 3; i++) c.add(gamma_tab[i].mul(rnd.b[i]));
-        }
-    }
-    void mpc_commit(ProverContext &cx, Labeled &lp, ChaChaRng &zk) {
+    // marlin_pc commit of one labeled polynomial (randomness already drawn): KZG10::commit = MSM(powers, coeffs) [+ hiding terms]
+    void mpc_commit(ProverContext &cx, Lane &ln, Labeled &lp) {
         const F *coeffs = cx.poly[lp.idx].p;
         size_t len = cx.poly_len[lp.idx];
         lp.comm.has_shifted = false;
         if (lp.bound < 0) {
-            lp.comm.comm = kzg_commit(cx, false, 0, coeffs, len, lp.hiding, lp.rand, zk);
+            XYZZ<Fq377> c = msm_powers(cx, ln, false, 0, coeffs, len);
+            hide(c, lp.rand);
+            lp.comm.comm = c.to_affine();
             return;
         }
         // degree-bounded polynomial: the plain and the shifted commitment have the same scalars -> one digit / sort pass, two accumulations
         size_t off = (max_degree - (size_t)lp.bound) - lowest_shift;
         if (len > supported_degree + 1 || off + len > bounds[1] + 1) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
-        if (table_ok(cx, len)) gpu::msm_prepare_table<Bls377>(cx.msm_ws, coeffs, len, 0, nullptr, 0, 0, table_c, srs_stride, cx.stream);
-        else gpu::msm_prepare<Bls377>(cx.msm_ws, coeffs, len, nullptr, 0, 0, cx.stream);
-        XYZZ<Fq377> c1 = gpu::msm_finish<Bls377>(cx.msm_ws, d_powers, cx.stream);
-        add_hiding(c1, lp.hiding, lp.rand, zk);
-        XYZZ<Fq377> c2 = gpu::msm_finish<Bls377>(cx.msm_ws, d_shifted + off, cx.stream);     // table mode: every copy's index shifts by n_plain + off
-        add_hiding(c2, lp.hiding, lp.shifted_rand, zk);
+        if (table_ok(cx, len)) gpu::msm_prepare_table<Bls377>(ln.ws, coeffs, len, 0, nullptr, 0, 0, table_c, srs_stride, ln.stream);
+        else gpu::msm_prepare<Bls377>(ln.ws, coeffs, len, nullptr, 0, 0, ln.stream);
+        XYZZ<Fq377> c1 = gpu::msm_finish<Bls377>(ln.ws, d_powers, ln.stream);
+        hide(c1, lp.rand);
+        XYZZ<Fq377> c2 = gpu::msm_finish<Bls377>(ln.ws, d_shifted + off, ln.stream);     // table mode: every copy's index shifts by n_plain + off
+        hide(c2, lp.shifted_rand);
         lp.comm.comm = c1.to_affine(); lp.comm.shifted = c2.to_affine(); lp.comm.has_shifted = true;
     }
     // opening witness = MSM(powers, wit) + MSM(shifted powers from shift_off, swit) as ONE Pippenger instance over the contiguous SRS array
-    XYZZ<Fq377> msm_opening(ProverContext &cx, const F *wit, size_t wlen, const F *swit, size_t slen, size_t shift_off) {
+    XYZZ<Fq377> msm_opening(ProverContext &cx, Lane &ln, const F *wit, size_t wlen, const F *swit, size_t slen, size_t shift_off) {
         if (wlen > supported_degree + 1 || shift_off + slen > bounds[1] + 1) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
-        if (table_ok(cx, wlen + slen)) gpu::msm_prepare_table<Bls377>(cx.msm_ws, wit, wlen, 0, swit, slen, n_plain + shift_off, table_c, srs_stride, cx.stream);
-        else gpu::msm_prepare<Bls377>(cx.msm_ws, wit, wlen, swit, slen, n_plain + shift_off, cx.stream);
-        return gpu::msm_finish<Bls377>(cx.msm_ws, d_powers, cx.stream);
+        if (table_ok(cx, wlen + slen)) gpu::msm_prepare_table<Bls377>(ln.ws, wit, wlen, 0, swit, slen, n_plain + shift_off, table_c, srs_stride, ln.stream);
+        else gpu::msm_prepare<Bls377>(ln.ws, wit, wlen, swit, slen, n_plain + shift_off, ln.stream);
+        return gpu::msm_finish<Bls377>(ln.ws, d_powers, ln.stream);
+    }
+    // Run the independent jobs of one prover step.  Throughput calls (several proofs in flight) and ZKAES_LANES=0 run them one after the other on lane 0;
+    // a lone encrypt() call gives each job its own lane (stream + MSM scratch) and a host thread, after the main stream has produced their inputs.
+    bool use_lanes = true;
+    void run_jobs(ProverContext &cx, std::vector<std::function<void(Lane &)>> &jobs) {
+        if (cx.throughput || !use_lanes || jobs.size() < 2) { for (auto &j : jobs) j(cx.lane[0]); return; }
+        if (jobs.size() > 4) throw std::logic_error("run_jobs: more jobs than lanes");
+        cx.ensure_lanes();
+        gpu::sync(cx.stream);
+        std::vector<std::string> errs(jobs.size());
+        std::vector<std::thread> th;
+        const int dev = device;
+        for (size_t i = 1; i < jobs.size(); i++)
+            th.emplace_back([&, i] { try { gpu::set_device(dev); jobs[i](cx.lane[i]); } catch (const std::exception &e) { errs[i] = e.what(); if (errs[i].empty()) errs[i] = "error"; } });
+        try { jobs[0](cx.lane[0]); } catch (const std::exception &e) { errs[0] = e.what(); if (errs[0].empty()) errs[0] = "error"; }
+        for (auto &t : th) t.join();
+        for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
     }
 
     void setup(int kind, size_t message_len, const SrsLiterals &srs);
@@ -670,6 +688,7 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
         d_shifted = d_powers + n_plain;
     }
     if (const char *e = getenv("ZKAES_LAGRANGE")) use_lagrange = atoi(e) != 0;
+    if (const char *e = getenv("ZKAES_LANES")) use_lanes = atoi(e) != 0;
     if (use_lagrange) {
         // With the (public, test_rng-derived) trapdoor the Lagrange-basis points are direct fixed-base products; a trapdoor-free universal SRS
         // yields the same points through an inverse FFT over the group elements powers_of_g[0..|H|) (one time per key).
@@ -768,7 +787,7 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
         gpu::sync(stream);
         gpu::dfree(d_ci); gpu::dfree(d_ri); gpu::dfree(d_ja); gpu::dfree(d_jb); gpu::dfree(d_jc);
     }
-    for (int i = 0; i < 6; i++) vk.index_comms[i] = msm_powers(*cx0, false, 0, ix_co[i].p, k).to_affine();
+    for (int i = 0; i < 6; i++) vk.index_comms[i] = msm_powers(*cx0, cx0->lane[0], false, 0, ix_co[i].p, k).to_affine();
     {   // values of the index polynomials on the coset g K, once per key: round 3 then needs no transform for a(X) and b(X)
         for (int i = 0; i < 8; i++) coset_g.l[i] = FR377_GEN_MONT[i];
         coset_g_inv = coset_g.inverse();
@@ -851,9 +870,18 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
         gpu::mask_fixup(poly[3].p, n, s);
         poly_len[3] = 3 * n;
     }
-    for (auto &lp : r1) {
-        if (use_lagrange && lp.idx < 3 && lagrange_commit(cx, lp.idx, inst, rhos[lp.idx], lp.rand, zk, lp.comm.comm)) { lp.comm.has_shifted = false; continue; }
-        mpc_commit(cx, lp, zk);
+    using Jobs = std::vector<std::function<void(Lane &)>>;
+    for (auto &lp : r1) draw_rand(lp, zk);
+    {
+        Jobs jobs;
+        for (auto &lp_ : r1) {
+            Labeled *lp = &lp_;
+            jobs.push_back([&, lp](Lane &ln) {
+                if (use_lagrange && lp->idx < 3 && lagrange_commit(cx, ln, lp->idx, inst, rhos[lp->idx], lp->rand, lp->comm.comm)) { lp->comm.has_shifted = false; return; }
+                mpc_commit(cx, ln, *lp);
+            });
+        }
+        run_jobs(cx, jobs);
     }
     { Bytes o; for (auto &lp : r1) o.commitment_tobytes(lp.comm); fs.absorb(o.b); }
     auto sample_outside_h = [&]() { Fr t; do { t = fs.rng().rand_field<Fr>(); } while (eval_vanishing(n, t).is_zero()); return t; };
@@ -881,7 +909,12 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     gpu::divide_by_vanishing(poly[6].p, e[0].p, big_tmp.p, 3 * n, n, s);     // h_1 (2|H| coeffs), remainder = x * g_1
     poly_len[6] = 2 * n;
     gpu::d2d(poly[5].p, e[0].p + 1, (n - 1) * sizeof(F), s); poly_len[5] = n - 1;
-    for (auto &lp : r2) mpc_commit(cx, lp, zk);
+    for (auto &lp : r2) draw_rand(lp, zk);
+    {
+        Jobs jobs;
+        for (auto &lp_ : r2) { Labeled *lp = &lp_; jobs.push_back([&, lp](Lane &ln) { mpc_commit(cx, ln, *lp); }); }
+        run_jobs(cx, jobs);
+    }
     { Bytes o; for (auto &lp : r2) o.commitment_tobytes(lp.comm); fs.absorb(o.b); }
     Fr beta = sample_outside_h();
     timings.round2_ms = ms_since(t0); t0 = Clock::now();
@@ -903,7 +936,12 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     gpu::ntt<F>(big_tmp.p, e[0].p, k, lg_k, true, s);                         // coefficients of h_2(g X)
     gpu::coset_scale(poly[8].p, big_tmp.p, coset_g_inv, k - 1, k - 1, s);     // h_2 (the coefficient of X^(|K|-1) is zero for a satisfied instance)
     poly_len[8] = k - 1;
-    for (auto &lp : r3) mpc_commit(cx, lp, zk);
+    for (auto &lp : r3) draw_rand(lp, zk);
+    {
+        Jobs jobs;
+        for (auto &lp_ : r3) { Labeled *lp = &lp_; jobs.push_back([&, lp](Lane &ln) { mpc_commit(cx, ln, *lp); }); }
+        run_jobs(cx, jobs);
+    }
     { Bytes o; for (auto &lp : r3) o.commitment_tobytes(lp.comm); fs.absorb(o.b); }
     Fr gamma = fs.rng().rand_field<Fr>();
     timings.round3_ms = ms_since(t0); t0 = Clock::now();
@@ -928,21 +966,28 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     auto rand_axpy = [](Fr out[3], const Fr &sc, const KzgRand &r) { if (r.hiding) for (int i = 0; i < 3; i++) out[i] = out[i] + sc * r.b[i]; };
     auto host_divide_by_linear = [](Fr q[2], const Fr p[3], const Fr &z) { q[1] = p[2]; q[0] = p[1] + z * p[2]; };
     auto host_eval3 = [](const Fr p[3], const Fr &z) { return p[0] + z * (p[1] + z * p[2]); };
-    {   // open at beta: g_1 (ch^0; shifted ch^1), outer_sumcheck (ch^2), t (ch^3), z_b (ch^4)
+    // the two openings are independent: on the latency path they run side by side, the second one on its own buffers
+    if (!cx.throughput && use_lanes && !cx.acc_b.p) {
+        cx.acc_b.alloc(acc.n); cx.wit_b.alloc(wit.n); cx.wit2_b.alloc(wit2.n); cx.scratch_b.alloc(scratch.n);
+    }
+    const bool two_sets = cx.acc_b.p != nullptr && !cx.throughput && use_lanes;
+    Jobs open_jobs;
+    open_jobs.push_back([&](Lane &ln) {   // open at beta: g_1 (ch^0; shifted ch^1), outer_sumcheck (ch^2), t (ch^3), z_b (ch^4)
+        gpu::stream_t ls_ = ln.stream;
         size_t plen = 3 * n;
         Fr rb[3] = {Fr::zero(), Fr::zero(), Fr::zero()};
         {
             const F *ps[7] = {poly[5].p, poly[3].p, poly[1].p, poly[0].p, poly[6].p, poly[4].p, poly[2].p};
             size_t ls[7] = {poly_len[5], poly_len[3], poly_len[1], poly_len[0], poly_len[6], poly_len[4], poly_len[2]};
             Fr sc[7] = {chp[0], chp[2], chp[2] * c_za, chp[2] * c_w, chp[2] * c_h1, chp[3], chp[4]};
-            gpu::poly_lincomb_n(acc.p, plen, ps, ls, sc, 7, s);
+            gpu::poly_lincomb_n(acc.p, plen, ps, ls, sc, 7, ls_);
         }
         rand_axpy(rb, chp[0], r2[1].rand); rand_axpy(rb, chp[2] * c_za, r1[1].rand); rand_axpy(rb, chp[2] * c_w, r1[0].rand); rand_axpy(rb, chp[4], r1[2].rand);
-        gpu::divide_by_linear(wit.p, acc.p, plen, beta, scratch.p, scratch.n, s);
+        gpu::divide_by_linear(wit.p, acc.p, plen, beta, scratch.p, scratch.n, ls_);
         // shifted part (g_1, degree bound |H| - 2) rides in the same Pippenger instance
-        gpu::divide_by_linear(wit2.p, poly[5].p, poly_len[5], beta, scratch.p, scratch.n, s);
-        gpu::poly_scale(wit2.p, chp[1], poly_len[5] - 1, s);
-        XYZZ<Fq377> w = msm_opening(cx, wit.p, plen - 1, wit2.p, poly_len[5] - 1, bounds[1] - (n - 2));
+        gpu::divide_by_linear(wit2.p, poly[5].p, poly_len[5], beta, scratch.p, scratch.n, ls_);
+        gpu::poly_scale(wit2.p, chp[1], poly_len[5] - 1, ls_);
+        XYZZ<Fq377> w = msm_opening(cx, ln, wit.p, plen - 1, wit2.p, poly_len[5] - 1, bounds[1] - (n - 2));
         Fr rq[2]; host_divide_by_linear(rq, rb, beta);
         for (int i = 0; i < 2; i++) w.add(gamma_tab[i].mul(rq[i]));
         Fr rv = host_eval3(rb, beta);
@@ -951,21 +996,24 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
         for (int i = 0; i < 2; i++) w.add(gamma_tab[i].mul(rq[i]));
         rv = rv + host_eval3(srb, beta);
         pf.w_beta = w.to_affine(); pf.random_v_beta = rv;
-    }
-    {   // open at gamma: g_2 (ch^0; shifted ch^1), inner_sumcheck (ch^2)
+    });
+    open_jobs.push_back([&](Lane &ln) {   // open at gamma: g_2 (ch^0; shifted ch^1), inner_sumcheck (ch^2)
+        gpu::stream_t ls_ = ln.stream;
+        DevBuf &acc_ = two_sets ? cx.acc_b : acc, &wit_ = two_sets ? cx.wit_b : wit, &wit2_ = two_sets ? cx.wit2_b : wit2, &scr_ = two_sets ? cx.scratch_b : scratch;
         size_t plen = k;
         {
             const F *ps[8] = {poly[7].p, ix_co[2].p, ix_co[3].p, ix_co[4].p, ix_co[0].p, ix_co[1].p, ix_co[5].p, poly[8].p};
             size_t ls[8] = {poly_len[7], k, k, k, k, k, k, poly_len[8]};
             Fr sc[8] = {chp[0], chp[2] * ea_vv, chp[2] * eb_vv, chp[2] * ec_vv, chp[2] * c_row, chp[2] * c_col, chp[2] * c_rc, chp[2] * c_h2};
-            gpu::poly_lincomb_n(acc.p, plen, ps, ls, sc, 8, s);
+            gpu::poly_lincomb_n(acc_.p, plen, ps, ls, sc, 8, ls_);
         }
-        gpu::divide_by_linear(wit.p, acc.p, plen, gamma, scratch.p, scratch.n, s);
-        gpu::divide_by_linear(wit2.p, poly[7].p, poly_len[7], gamma, scratch.p, scratch.n, s);
-        gpu::poly_scale(wit2.p, chp[1], poly_len[7] - 1, s);
-        XYZZ<Fq377> w = msm_opening(cx, wit.p, plen - 1, wit2.p, poly_len[7] - 1, bounds[1] - (k - 2));
+        gpu::divide_by_linear(wit_.p, acc_.p, plen, gamma, scr_.p, scr_.n, ls_);
+        gpu::divide_by_linear(wit2_.p, poly[7].p, poly_len[7], gamma, scr_.p, scr_.n, ls_);
+        gpu::poly_scale(wit2_.p, chp[1], poly_len[7] - 1, ls_);
+        XYZZ<Fq377> w = msm_opening(cx, ln, wit_.p, plen - 1, wit2_.p, poly_len[7] - 1, bounds[1] - (k - 2));
         pf.w_gamma = w.to_affine();
-    }
+    });
+    run_jobs(cx, open_jobs);
     for (int i = 0; i < 4; i++) pf.comms[i] = r1[i].comm;
     for (int i = 0; i < 3; i++) pf.comms[4 + i] = r2[i].comm;
     for (int i = 0; i < 2; i++) pf.comms[7 + i] = r3[i].comm;

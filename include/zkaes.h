@@ -13,7 +13,8 @@
  *   - byte buffers returned through `uint8_t**` are owned by the library: release with zkaes_bytes_free.
  *   - a key for a plaintext of 16 bytes or more also holds fixed-base window tables of the SRS (13 copies, ~6 GB for the one-block key, ~24 GB for the
  *     4- to 6-block keys): multi-proof calls (zkaes_encrypt_chunked / _batch) run their large MSMs through them (13 instead of 15 windows of bucket additions),
- *     a lone zkaes_encrypt call keeps the per-window buckets, which have the lower latency;
+ *     a lone zkaes_encrypt call keeps the per-window buckets, which have the lower latency, and runs the independent commitments of each round on four
+ *     MSM lanes (streams + host threads) side by side;
  *   - when the library is loaded it exports GPU_MAX_HW_QUEUES=16 unless the variable is already set (one hardware queue per prover context; the ROCm default of 4
  *     lets the contexts' kernels queue behind each other).  It is read at the first HIP call of the process: export it yourself if HIP is initialised earlier;
  *   - the library needs a HIP device (gfx950) for key synthesis and proving and FAILS (non-zero + message) when
