@@ -21,6 +21,8 @@ extern "C" {
     fn zkaes_synthesize_keys(plaintext_length: usize, pk: *mut *mut zkaes_pk, vk: *mut *mut zkaes_vk) -> c_int;
     fn zkaes_encrypt(message: *const u8, message_len: usize, secret_key: *const u8, pk: *const zkaes_pk, proof: *mut *mut u8, proof_len: *mut usize) -> c_int;
     fn zkaes_verify_encryption(vk: *const zkaes_vk, proof: *const u8, proof_len: usize, ciphertext: *const u8, ciphertext_len: usize, accepted: *mut c_int) -> c_int;
+    fn zkaes_encrypt_chunked_seeded(message: *const u8, message_len: usize, secret_key: *const u8, pk: *const zkaes_pk, zk_seed32: *const u8, proofs: *mut *mut u8,
+                                    proofs_len: *mut usize, proof_lens: *mut usize, n_chunks: usize) -> c_int;
     fn zkaes_vk_serialize_ark(vk: *const zkaes_vk, out: *mut *mut u8, out_len: *mut usize) -> c_int;
     fn zkaes_vk_deserialize_ark(bytes: *const u8, len: usize, vk: *mut *mut zkaes_vk) -> c_int;
 }
@@ -85,4 +87,21 @@ pub fn verify_encryption(verifying_key: &VerifyingKey, proof: &[u8], ciphertext:
     let mut accepted: c_int = 0;
     if unsafe { zkaes_verify_encryption((verifying_key.0).0, proof.as_ptr(), proof.len(), ciphertext.as_ptr(), ciphertext.len(), &mut accepted) } != 0 { return Err(last_error()); }
     Ok(accepted != 0)
+}
+
+/// Long ECB messages (not in the reference API: its SRS literal caps one proof at 96 bytes): ceil(len / chunk) independent chunk-proofs on the key of
+/// `chunk` bytes, many in flight on the GPU (ECB blocks are independent, src/lib.rs:194).  `zk_seed`: 32 bytes of fresh randomness; proof i draws its
+/// blinding from StdRng(Blake2s(seed || i)).  `None` reproduces the reference's fixed `test_rng` seed in every proof -- byte-parity, not zero-knowledge.
+pub fn encrypt_chunked(message: &[u8], secret_key: &[u8; 16], proving_key: &ProvingKey, chunk_len: usize, zk_seed: Option<&[u8; 32]>) -> Result<Vec<Vec<u8>>> {
+    if chunk_len == 0 || message.len() % chunk_len != 0 { return Err(anyhow!("message length must be a multiple of the key's plaintext length")); }
+    let n = message.len() / chunk_len;
+    let (mut p, mut total) = (std::ptr::null_mut(), 0usize);
+    let mut lens = vec![0usize; n.max(1)];
+    let seed = zk_seed.map_or(std::ptr::null(), |s| s.as_ptr());
+    if unsafe { zkaes_encrypt_chunked_seeded(message.as_ptr(), message.len(), secret_key.as_ptr(), (proving_key.0).0, seed, &mut p, &mut total, lens.as_mut_ptr(), n) } != 0 { return Err(last_error()); }
+    let blob = take_bytes(p, total);
+    let mut out = Vec::with_capacity(n);
+    let mut off = 0;
+    for l in lens.iter().take(n) { out.push(blob[off..off + l].to_vec()); off += l; }
+    Ok(out)
 }
