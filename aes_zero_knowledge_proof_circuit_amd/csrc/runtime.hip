@@ -25,6 +25,8 @@ void require_device() {
     if (device_count() <= 0) throw GpuError("no HIP device available: libzkaes proves on an AMD GPU (gfx950) and has no CPU fallback");
 }
 int current_device() { int d = 0; HIP_CHECK(hipGetDevice(&d)); return d; }
+// (hipDeviceScheduleBlockingSync was tried for the 16 waiting prover threads per GPU: the bench hangs with it on ROCm 7.2 -- profiles/r02_msm_tables.md section 6 -- so waits keep
+// the runtime's default policy; a saturated run keeps ~13 host cores busy per GPU.)
 void set_device(int ordinal) { HIP_CHECK(hipSetDevice(ordinal)); }
 void *dmalloc(size_t bytes) { void *p = nullptr; HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16)); return p; }
 void dfree(void *p) { if (p) (void)hipFree(p); }
