@@ -284,7 +284,7 @@ def run(args, api, dist_env=None):
         acc_ms, pts, launches = stats["accumulate_ms"], stats["points"], stats["launches"]
         achieved = (128.0 * pts / 1e9) / (acc_ms / 1e3) if acc_ms > 0 else 0.0
         traffic = traffic_src = None
-        for name in ("r02_pmc_k_accumulate.json", "r01_pmc_k_accumulate_v12.json"):
+        for name in ("r02_pmc_k_accumulate_tables.json", "r02_pmc_k_accumulate.json", "r01_pmc_k_accumulate_v12.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 traffic = round(pmc["hbm_bytes_per_point_window"] * stats["pairs"] / max(launches, 1))

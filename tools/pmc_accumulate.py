@@ -16,6 +16,7 @@ import sys
 
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+wbits = int(sys.argv[3]) if len(sys.argv) > 3 else 0        # 0 = per-window buckets (15 windows of 17 bits), 20 = window tables (13 windows, one bucket set)
 n = 1 << lg
 out_dir = os.path.join("gpurun_out", "pmc_" + tag)
 os.makedirs(out_dir, exist_ok=True)
@@ -27,7 +28,7 @@ PASSES = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"],
 
 def collect(name, counters):
     cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", out_dir, "-o", "pmc_" + name, "--",
-           sys.executable, "tools/ubench/msm_one.py", str(lg), "0"]
+           sys.executable, "tools/ubench/msm_one.py", str(lg), str(wbits)]
     subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
     path = None
     for root, _, files in os.walk(out_dir):
@@ -49,7 +50,7 @@ for name, ctrs in PASSES.items():
     vals.update(v); counts.update(c)
 
 KIB = 1024.0
-nwin = 15
+nwin = 15 if wbits == 0 else (253 + 1 + wbits - 1) // wbits
 fetch = vals[("k_accumulate", "FETCH_SIZE")] * KIB
 write = vals[("k_accumulate", "WRITE_SIZE")] * KIB
 cal = {
@@ -62,8 +63,8 @@ cal["fetch_scale_coalesced_stream"] = cal["k_digits_FETCH_SIZE_bytes"] / cal["k_
 cal["write_scale"] = cal["k_convert_bases_WRITE_SIZE_bytes"] / cal["k_convert_bases_known_write_bytes"]
 hbm = fetch / cal["fetch_scale_aos_16B_per_lane"] + write / cal["write_scale"]
 res = {
-    "kernel": "k_accumulate (%s), n = 2^%d points, %d signed-digit windows of 17 bits, averages over %d launches" % (tag, lg, nwin, counts[("k_accumulate", "FETCH_SIZE")]),
-    "command": "rocprofv3 --pmc <one counter group> --kernel-trace --output-format csv -- python tools/ubench/msm_one.py %d 0   (three separate passes: %s)" % (lg, PASSES),
+    "kernel": "k_accumulate (%s), n = 2^%d points, %d signed-digit windows of %d bits%s, averages over %d launches" % (tag, lg, nwin, wbits or 17, " through window tables (one bucket set)" if wbits else "", counts[("k_accumulate", "FETCH_SIZE")]),
+    "command": "rocprofv3 --pmc <one counter group> --kernel-trace --output-format csv -- python tools/ubench/msm_one.py %d %d   (separate passes: %s)" % (lg, wbits, PASSES),
     "counters": {c: vals[("k_accumulate", c)] for grp in PASSES.values() for c in grp},
     # wave-cycle accounting (MI355X_MICROARCH.md "rocprofv3 PMC slots": SQ_WAIT_ANY + SQ_WAIT_INST_ANY + SQ_ACTIVE_INST_ANY ~ SQ_WAVE_CYCLES, all in
     # quad-cycles).  rocprofv3's derived VALUBusy falls back to a gfx94x formula on gfx950 and SQ_ACTIVE_INST_VALU reads identical to SQ_INSTS_VALU
