@@ -1,4 +1,16 @@
-import sys, itertools; sys.path.insert(0,'tools')
+#!/usr/bin/env python3
+"""tools/circuit_variants_sweep.py -- the wider sweep behind DESIGN.md section 2a (output: profiles/r02_circuit_variants_sweep.txt).
+
+On top of tools/circuit_variants.py's shift / rotate variants it varies (i) Boolean::conditionally_select: A = as restated, B = general case with a
+booleanity check on the result, C = constant folding only when both branches are constant, Cb = C + booleanity; (ii) MixColumns also in round 10;
+(iii) the key schedule re-derived per block.  One line per variant: select shift rotate mc10 key_per_block constraints nnz (delta to the literal).
+
+    python tools/circuit_variants_sweep.py > profiles/r02_circuit_variants_sweep.txt      # ~7 minutes
+"""
+import itertools
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import circuit_variants as cv
 T = cv.TARGET
 orig_select = cv.b_select
