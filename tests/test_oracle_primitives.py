@@ -172,3 +172,16 @@ def test_fr_rand_is_montgomery_rejection_sampling(zko):
         if v < zko.R377:
             got.append(v)
     assert [int.from_bytes(out.raw[32 * k:32 * k + 32], "little") for k in range(n)] == got
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """the CPU oracle built with -fsanitize=address,undefined walks every layer once at small sizes (byte-level AES KAT, one-block
+    circuit satisfied / corrupted, NTT round trip on both fields, Pippenger MSM vs double-and-add, a complete Marlin index + proof of the ops xor gate):
+    oracle/zko_selftest.c.  Any sanitizer report (or leak) fails the run."""
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.check_call(["make", "-s", "-C", here, "selftest_asan"])
+    env = dict(os.environ, OMP_NUM_THREADS="4", ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    out = subprocess.run([os.path.join(here, "selftest_asan")], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and "selftest ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
