@@ -6,6 +6,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CIRCUIT_AES, CIRCUIT_OPS_XOR, CIRCUIT_OPS_ADD = 0, 1, 2
+KEY_NO_TABLES = 1                  # zkaes_synthesize_keys_ex2 flag: no fixed-base window tables (saves 6-24 GB per key)
+PARITY = "parity"                  # zk_seed=PARITY: the reference's fixed ark_std::test_rng() stream for every proof (byte-parity tests only)
 
 
 class ZkAesError(RuntimeError):
@@ -141,16 +143,30 @@ class ProvingKey:
         _check(lib().zkaes_prove_ops(self._p, C.c_uint32(x), C.c_uint32(y), zk_seed, C.byref(out), C.byref(n)))
         return _take(out, n)
 
-    def encrypt_chunked(self, message, secret_key, zk_seed=None):
+    @staticmethod
+    def _seed_arg(zk_seed):
+        """None -> fresh OS seed per call (the unseeded C entry points); PARITY -> NULL seed = fixed test_rng stream; else 32 bytes"""
+        if zk_seed is None or zk_seed == PARITY:
+            return None
+        if len(zk_seed) != 32:
+            raise ZkAesError("zk_seed must be 32 bytes")
+        return bytes(zk_seed)
+
+    def encrypt_chunked(self, message, secret_key, zk_seed=None, first_proof_index=0):
+        """chunk-proofs of a long ECB message.  zk_seed: None = a fresh OS seed per call, 32 bytes = caller's seed (proof i uses index first_proof_index + i),
+        PARITY = the reference's fixed prover randomness for every proof"""
         if len(secret_key) != 16:
             raise ZkAesError("secret_key must be 16 bytes")
-        if zk_seed is not None and len(zk_seed) != 32:
-            raise ZkAesError("zk_seed must be 32 bytes")
+        seed = self._seed_arg(zk_seed)
         chunk = (self.info()["raw_instance"] - 1) // 8          # 8 public-input bits per ciphertext byte
         n_chunks = len(message) // chunk
         lens = (C.c_size_t * max(n_chunks, 1))()
         out, n = C.c_void_p(), C.c_size_t()
-        _check(lib().zkaes_encrypt_chunked_seeded(bytes(message), C.c_size_t(len(message)), bytes(secret_key), self._p, zk_seed, C.byref(out), C.byref(n), lens, C.c_size_t(n_chunks)))
+        if zk_seed is None:
+            _check(lib().zkaes_encrypt_chunked(bytes(message), C.c_size_t(len(message)), bytes(secret_key), self._p, C.byref(out), C.byref(n), lens, C.c_size_t(n_chunks)))
+        else:
+            _check(lib().zkaes_encrypt_chunked_seeded_at(bytes(message), C.c_size_t(len(message)), bytes(secret_key), self._p, seed, C.c_uint64(first_proof_index), C.byref(out), C.byref(n), lens,
+                                                         C.c_size_t(n_chunks)))
         blob = _take(out, n)
         proofs, off = [], 0
         for i in range(n_chunks):
@@ -158,8 +174,8 @@ class ProvingKey:
             off += lens[i]
         return proofs
 
-    def encrypt_batch(self, messages, secret_keys, zk_seed=None):
-        """n independent proofs: messages = list of equal-length byte strings (the key's plaintext length), secret_keys = list of 16-byte keys"""
+    def encrypt_batch(self, messages, secret_keys, zk_seed=None, first_proof_index=0):
+        """n independent proofs: messages = list of equal-length byte strings (the key's plaintext length), secret_keys = list of 16-byte keys; zk_seed as encrypt_chunked"""
         n = len(messages)
         chunk = (self.info()["raw_instance"] - 1) // 8
         if len(secret_keys) != n:
@@ -168,12 +184,14 @@ class ProvingKey:
             raise ZkAesError("every message must be %d bytes (the key's plaintext length)" % chunk)
         if any(len(k) != 16 for k in secret_keys):
             raise ZkAesError("secret_key must be 16 bytes")
-        if zk_seed is not None and len(zk_seed) != 32:
-            raise ZkAesError("zk_seed must be 32 bytes")
+        seed = self._seed_arg(zk_seed)
         lens = (C.c_size_t * max(n, 1))()
         out, total = C.c_void_p(), C.c_size_t()
         mb, kb = b"".join(bytes(m) for m in messages), b"".join(bytes(k) for k in secret_keys)
-        _check(lib().zkaes_encrypt_batch_seeded(C.c_size_t(n), mb, C.c_size_t(len(mb)), kb, C.c_size_t(len(kb)), self._p, zk_seed, C.byref(out), C.byref(total), lens))
+        if zk_seed is None:
+            _check(lib().zkaes_encrypt_batch(C.c_size_t(n), mb, kb, self._p, C.byref(out), C.byref(total), lens))
+        else:
+            _check(lib().zkaes_encrypt_batch_seeded_at(C.c_size_t(n), mb, C.c_size_t(len(mb)), kb, C.c_size_t(len(kb)), self._p, seed, C.c_uint64(first_proof_index), C.byref(out), C.byref(total), lens))
         blob = _take(out, total)
         proofs, off = [], 0
         for i in range(n):
@@ -190,10 +208,10 @@ class ProvingKey:
             pass
 
 
-def synthesize_keys(plaintext_length, circuit=CIRCUIT_AES, srs=(866_944, 513, 4_062_064)):
-    """zk_aes::synthesize_keys (src/lib.rs:138-174) -> (ProvingKey, VerifyingKey)."""
+def synthesize_keys(plaintext_length, circuit=CIRCUIT_AES, srs=(866_944, 513, 4_062_064), flags=0):
+    """zk_aes::synthesize_keys (src/lib.rs:138-174) -> (ProvingKey, VerifyingKey).  flags: KEY_NO_TABLES"""
     pk, vk = C.c_void_p(), C.c_void_p()
-    _check(lib().zkaes_synthesize_keys_ex(int(circuit), C.c_size_t(plaintext_length), C.c_size_t(srs[0]), C.c_size_t(srs[1]), C.c_size_t(srs[2]), C.byref(pk), C.byref(vk)))
+    _check(lib().zkaes_synthesize_keys_ex2(int(circuit), C.c_size_t(plaintext_length), C.c_size_t(srs[0]), C.c_size_t(srs[1]), C.c_size_t(srs[2]), C.c_uint(flags), C.byref(pk), C.byref(vk)))
     return ProvingKey(pk.value), VerifyingKey(vk.value)
 
 

@@ -43,15 +43,19 @@ void zkaes_vk_free(zkaes_vk *vk) { delete vk; }
 int zkaes_device_count(void) { return zk::gpu::device_count(); }
 int zkaes_set_device(int ordinal);   // defined in runtime glue below
 
-int zkaes_synthesize_keys_ex(int kind, size_t len, size_t nc, size_t nv, size_t nnz, zkaes_pk **pk, zkaes_vk **vk) {
+int zkaes_synthesize_keys_ex2(int kind, size_t len, size_t nc, size_t nv, size_t nnz, unsigned flags, zkaes_pk **pk, zkaes_vk **vk) {
     return guard([&] {
+        if (flags & ~(unsigned)ZKAES_KEY_NO_TABLES) throw std::invalid_argument("synthesize_keys: unknown flag bits");
         zk::SrsLiterals srs; srs.num_constraints = nc; srs.num_variables = nv; srs.num_non_zero = nnz;
-        auto k = zk::synthesize_keys(kind, len, srs);
+        auto k = zk::synthesize_keys(kind, len, srs, (flags & ZKAES_KEY_NO_TABLES) ? (unsigned)zk::KEY_NO_TABLES : 0u);
         zkaes_vk *v = new zkaes_vk{k->vk()};
         zkaes_pk *p = new zkaes_pk{std::move(k)};
         if (pk) *pk = p; else delete p;
         if (vk) *vk = v; else delete v;
     });
+}
+int zkaes_synthesize_keys_ex(int kind, size_t len, size_t nc, size_t nv, size_t nnz, zkaes_pk **pk, zkaes_vk **vk) {
+    return zkaes_synthesize_keys_ex2(kind, len, nc, nv, nnz, 0u, pk, vk);
 }
 int zkaes_synthesize_keys(size_t len, zkaes_pk **pk, zkaes_vk **vk) {
     zk::SrsLiterals d;
@@ -82,31 +86,48 @@ static void pack_proofs(const std::vector<zk::Proof> &ps, uint8_t **proofs, size
     }
     *proofs = give(all); *proofs_len = all.size();
 }
-int zkaes_encrypt_chunked_seeded(const uint8_t *msg, size_t len, const uint8_t key[16], const zkaes_pk *pk, const uint8_t *zk_seed32, uint8_t **proofs, size_t *proofs_len,
-                                 size_t *proof_lens, size_t n_chunks) {
+// the unseeded multi-proof entry points draw a fresh seed from the OS per call; ZKAES_PARITY_RNG=1 (tests, byte-parity with the oracle) keeps the
+// reference's fixed ark_std::test_rng() stream for every proof instead
+static bool parity_rng() { const char *e = getenv("ZKAES_PARITY_RNG"); return e && atoi(e) != 0; }
+int zkaes_encrypt_chunked_seeded_at(const uint8_t *msg, size_t len, const uint8_t key[16], const zkaes_pk *pk, const uint8_t *zk_seed32, uint64_t first_proof_index, uint8_t **proofs,
+                                    size_t *proofs_len, size_t *proof_lens, size_t n_chunks) {
     return guard([&] {
         if (!pk || !proofs || !proofs_len || !key || (!msg && len)) throw std::invalid_argument("null argument");
         size_t chunk = pk->pk->circuit().n_blocks * 16;
         if (chunk == 0 || len % chunk || len / chunk != n_chunks) throw std::invalid_argument("message length must be n_chunks * the key's plaintext length");
-        pack_proofs(pk->pk->prove_aes_chunked(msg, len, key, default_contexts(), zk_seed32), proofs, proofs_len, proof_lens);
+        pack_proofs(pk->pk->prove_aes_chunked(msg, len, key, default_contexts(), zk_seed32, first_proof_index), proofs, proofs_len, proof_lens);
     });
 }
-int zkaes_encrypt_chunked(const uint8_t *msg, size_t len, const uint8_t key[16], const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens, size_t n_chunks) {
-    return zkaes_encrypt_chunked_seeded(msg, len, key, pk, nullptr, proofs, proofs_len, proof_lens, n_chunks);
+int zkaes_encrypt_chunked_seeded(const uint8_t *msg, size_t len, const uint8_t key[16], const zkaes_pk *pk, const uint8_t *zk_seed32, uint8_t **proofs, size_t *proofs_len,
+                                 size_t *proof_lens, size_t n_chunks) {
+    return zkaes_encrypt_chunked_seeded_at(msg, len, key, pk, zk_seed32, 0, proofs, proofs_len, proof_lens, n_chunks);
 }
-int zkaes_encrypt_batch_seeded(size_t n, const uint8_t *messages, size_t messages_len, const uint8_t *secret_keys, size_t secret_keys_len, const zkaes_pk *pk,
-                               const uint8_t *zk_seed32, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens) {
+int zkaes_encrypt_chunked(const uint8_t *msg, size_t len, const uint8_t key[16], const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens, size_t n_chunks) {
+    uint8_t seed[32];
+    const bool parity = parity_rng();
+    if (!parity) { int rc = guard([&] { zk::os_random_seed(seed); }); if (rc) return rc; }
+    return zkaes_encrypt_chunked_seeded_at(msg, len, key, pk, parity ? nullptr : seed, 0, proofs, proofs_len, proof_lens, n_chunks);
+}
+int zkaes_encrypt_batch_seeded_at(size_t n, const uint8_t *messages, size_t messages_len, const uint8_t *secret_keys, size_t secret_keys_len, const zkaes_pk *pk,
+                                  const uint8_t *zk_seed32, uint64_t first_proof_index, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens) {
     return guard([&] {
         if (!pk || !proofs || !proofs_len || (n && (!messages || !secret_keys))) throw std::invalid_argument("null argument");
         size_t chunk = pk->pk->circuit().n_blocks * 16;
         if (messages_len != n * chunk) throw std::invalid_argument("messages must hold n x " + std::to_string(chunk) + " bytes (the key's plaintext length)");
         if (secret_keys_len != n * 16) throw std::invalid_argument("secret_keys must hold n x 16 bytes");
-        pack_proofs(pk->pk->prove_aes_batch(messages, secret_keys, n, default_contexts(), zk_seed32), proofs, proofs_len, proof_lens);
+        pack_proofs(pk->pk->prove_aes_batch(messages, secret_keys, n, default_contexts(), zk_seed32, first_proof_index), proofs, proofs_len, proof_lens);
     });
+}
+int zkaes_encrypt_batch_seeded(size_t n, const uint8_t *messages, size_t messages_len, const uint8_t *secret_keys, size_t secret_keys_len, const zkaes_pk *pk,
+                               const uint8_t *zk_seed32, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens) {
+    return zkaes_encrypt_batch_seeded_at(n, messages, messages_len, secret_keys, secret_keys_len, pk, zk_seed32, 0, proofs, proofs_len, proof_lens);
 }
 int zkaes_encrypt_batch(size_t n, const uint8_t *messages, const uint8_t *secret_keys, const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens) {
     size_t chunk = pk ? pk->pk->circuit().n_blocks * 16 : 0;
-    return zkaes_encrypt_batch_seeded(n, messages, n * chunk, secret_keys, n * 16, pk, nullptr, proofs, proofs_len, proof_lens);
+    uint8_t seed[32];
+    const bool parity = parity_rng();
+    if (!parity) { int rc = guard([&] { zk::os_random_seed(seed); }); if (rc) return rc; }
+    return zkaes_encrypt_batch_seeded_at(n, messages, n * chunk, secret_keys, n * 16, pk, parity ? nullptr : seed, 0, proofs, proofs_len, proof_lens);
 }
 int zkaes_prove_ops(const zkaes_pk *pk, uint32_t x, uint32_t y, const uint8_t *seed, uint8_t **proof, size_t *proof_len) {
     return guard([&] {

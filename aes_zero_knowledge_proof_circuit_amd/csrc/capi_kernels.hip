@@ -85,11 +85,22 @@ template <class Curve> void run_msm_table(const uint8_t *bases, const uint8_t *s
     Fr *ds = (Fr *)zk::gpu::dmalloc(n * 32);
     zk::gpu::h2d(tab, bases, n * 96, s); zk::gpu::h2d(ds, scalars, n * 32, s);
     zk::gpu::build_window_tables<Curve>(tab, n, c, s);
-    zk::Affine28<typename Curve::FqP> *tab28 = (zk::Affine28<typename Curve::FqP> *)zk::gpu::dmalloc(nt * n * sizeof(zk::Affine28<typename Curve::FqP>));
-    zk::gpu::convert_bases<Curve>(tab28, tab, nt * n, s);
     zk::gpu::MsmWorkspace *ws = zk::gpu::msm_workspace_create();
-    zk::Affine<Fq> a = zk::gpu::msm_table<Curve>(ws, tab28, n, 0, c, ds, n, s).to_affine();
-    zk::gpu::dfree(tab28);
+    zk::Affine<Fq> a;
+#if ZK_MSM_EDWARDS
+    if constexpr (Curve::ID == 377) {        // the prover's SRS path: tables on the twisted Edwards model (bases must lie in the prime-order subgroup)
+        zk::Niels28<typename Curve::FqP> *tabte = (zk::Niels28<typename Curve::FqP> *)zk::gpu::dmalloc(nt * n * sizeof(zk::Niels28<typename Curve::FqP>));
+        zk::gpu::convert_bases_te<Curve>(tabte, tab, nt * n, s);
+        a = zk::gpu::msm_table<Curve>(ws, tabte, n, 0, c, ds, n, s).to_affine();
+        zk::gpu::dfree(tabte);
+    } else
+#endif
+    {
+        zk::Affine28<typename Curve::FqP> *tab28 = (zk::Affine28<typename Curve::FqP> *)zk::gpu::dmalloc(nt * n * sizeof(zk::Affine28<typename Curve::FqP>));
+        zk::gpu::convert_bases<Curve>(tab28, tab, nt * n, s);
+        a = zk::gpu::msm_table<Curve>(ws, tab28, n, 0, c, ds, n, s).to_affine();
+        zk::gpu::dfree(tab28);
+    }
     if (out_inf) *out_inf = a.is_inf() ? 1 : 0;
     if (out_xy) { memcpy(out_xy, a.x.l, 48); memcpy(out_xy + 48, a.y.l, 48); }
     zk::gpu::msm_workspace_destroy(ws);
@@ -172,20 +183,27 @@ int zkaes_msm_bench(int curve_id, const uint8_t *bases, const uint8_t *scalars, 
     return guardk([&] { if (curve_id == 381) run_msm<zk::Bls381>(bases, scalars, n, nullptr, nullptr, reps, ms_total, ms_accumulate); else run_msm<zk::Bls377>(bases, scalars, n, nullptr, nullptr, reps, ms_total, ms_accumulate); });
 }
 // BLS12-377 only: n_points synthetic bases (powers of a fixed scalar times the generator, made on the device) and pseudo-random scalars;
-// window_bits = 0 -> classic per-window buckets, else the precomputed-table path.  Returns ms per MSM (whole pipeline / accumulate kernel).
+// window_bits = 0 -> per-window buckets on the Weierstrass model (the generic path), < 0 -> per-window buckets on the twisted Edwards model (the prover's lone-call
+// path), > 0 -> the precomputed-table path (Edwards).  Returns ms per MSM (whole pipeline / accumulate kernel).
 int zkaes_msm_bench_synth(size_t n, int window_bits, int reps, double *ms_total, double *ms_accumulate, uint8_t *out_xy) {
     return guardk([&] {
         using Fq = zk::Fq377; using Fr = zk::Fr377;
         zk::gpu::require_device();
         zk::gpu::stream_t s = zk::gpu::stream_create();
-        const size_t nt = window_bits ? (size_t)zk::gpu::table_windows<zk::Bls377>(window_bits) : 1;
+        const size_t nt = window_bits > 0 ? (size_t)zk::gpu::table_windows<zk::Bls377>(window_bits) : 1;
         zk::Affine<Fq> *tab = (zk::Affine<Fq> *)zk::gpu::dmalloc(nt * n * 96);
         zk::Affine<Fq> g; for (int i = 0; i < 12; i++) { g.x.l[i] = G1_377_X_MONT[i]; g.y.l[i] = G1_377_Y_MONT[i]; }
         Fr beta = Fr::from_u64(0x9e3779b97f4a7c15ull) * Fr::from_u64(0xc2b2ae3d27d4eb4full);
         zk::gpu::fixed_base_powers<zk::Bls377>(tab, g, beta, 1, n, s);
-        if (window_bits) zk::gpu::build_window_tables<zk::Bls377>(tab, n, window_bits, s);
-        zk::Affine28<zk::Fq377P> *tab28 = (zk::Affine28<zk::Fq377P> *)zk::gpu::dmalloc(nt * n * sizeof(zk::Affine28<zk::Fq377P>));
-        zk::gpu::convert_bases<zk::Bls377>(tab28, tab, nt * n, s);
+        if (window_bits > 0) zk::gpu::build_window_tables<zk::Bls377>(tab, n, window_bits, s);
+        // window_bits == 0: the generic path (Weierstrass model, XYZZ buckets, 112-byte bases); < 0 or > 0: the prover's SRS path on the twisted Edwards model
+        const bool edwards = ZK_MSM_EDWARDS && window_bits != 0;
+        zk::Affine28<zk::Fq377P> *tab28 = nullptr;
+#if ZK_MSM_EDWARDS
+        zk::Niels28<zk::Fq377P> *tabte = nullptr;
+        if (edwards) { tabte = (zk::Niels28<zk::Fq377P> *)zk::gpu::dmalloc(nt * n * sizeof(zk::Niels28<zk::Fq377P>)); zk::gpu::convert_bases_te<zk::Bls377>(tabte, tab, nt * n, s); }
+#endif
+        if (!edwards) { tab28 = (zk::Affine28<zk::Fq377P> *)zk::gpu::dmalloc(nt * n * sizeof(zk::Affine28<zk::Fq377P>)); zk::gpu::convert_bases<zk::Bls377>(tab28, tab, nt * n, s); }
         std::vector<Fr> sc(n);
         uint64_t x = 88172645463325252ull;
         for (size_t i = 0; i < n; i++) { for (int k = 0; k < 8; k += 2) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; sc[i].l[k] = (uint32_t)x; sc[i].l[k + 1] = (uint32_t)(x >> 32); } sc[i].l[7] &= 0x0fffffffu; }
@@ -193,7 +211,12 @@ int zkaes_msm_bench_synth(size_t n, int window_bits, int reps, double *ms_total,
         zk::gpu::h2d(ds, sc.data(), n * 32, s);
         zk::gpu::sync(s);
         zk::gpu::MsmWorkspace *ws = zk::gpu::msm_workspace_create();
-        auto run = [&] { return window_bits ? zk::gpu::msm_table<zk::Bls377>(ws, tab28, n, 0, window_bits, ds, n, s) : zk::gpu::msm<zk::Bls377>(ws, tab28, ds, n, s); };
+        auto run = [&]() -> zk::XYZZ<Fq> {
+#if ZK_MSM_EDWARDS
+            if (edwards) return window_bits > 0 ? zk::gpu::msm_table<zk::Bls377>(ws, tabte, n, 0, window_bits, ds, n, s) : zk::gpu::msm<zk::Bls377>(ws, tabte, ds, n, s);
+#endif
+            return window_bits > 0 ? zk::gpu::msm_table<zk::Bls377>(ws, tab28, n, 0, window_bits, ds, n, s) : zk::gpu::msm<zk::Bls377>(ws, tab28, ds, n, s);
+        };
         {
             zk::Affine<Fq> a = run().to_affine();
             if (out_xy) { memcpy(out_xy, a.x.l, 48); memcpy(out_xy + 48, a.y.l, 48); }
@@ -209,6 +232,9 @@ int zkaes_msm_bench_synth(size_t n, int window_bits, int reps, double *ms_total,
         zk::gpu::event_destroy(e0); zk::gpu::event_destroy(e1);
         zk::gpu::msm_workspace_destroy(ws);
         zk::gpu::dfree(tab28);
+#if ZK_MSM_EDWARDS
+        zk::gpu::dfree(tabte);
+#endif
         zk::gpu::dfree(tab); zk::gpu::dfree(ds); zk::gpu::stream_destroy(s);
     });
 }

@@ -6,6 +6,7 @@
 #include <stdexcept>
 #include <string>
 #include "ec.cuh"
+#include "te28.cuh"
 
 namespace zk {
 namespace gpu {
@@ -19,12 +20,15 @@ void require_device();
 int current_device();
 void set_device(int ordinal);                    // throws GpuError("no HIP device ...") -- the product never falls back to the CPU
 void *dmalloc(size_t bytes);
+size_t mem_free_bytes();                         // free device memory right now (hipMemGetInfo)
 void dfree(void *p);
 void h2d(void *dst, const void *src, size_t bytes, stream_t s);
 void d2h(void *dst, const void *src, size_t bytes, stream_t s);
 void d2d(void *dst, const void *src, size_t bytes, stream_t s);
 void dzero(void *dst, size_t bytes, stream_t s);
-void sync(stream_t s);
+void sync(stream_t s);                    // wait for the stream: spins (lone calls) or polls with sleeps while a ThroughputWaits scope is alive
+// RAII marker of a multi-proof call: host threads of its prover contexts wait by polling + nanosleep instead of spinning (runtime.hip)
+struct ThroughputWaits { explicit ThroughputWaits(bool on); ~ThroughputWaits(); ThroughputWaits(const ThroughputWaits &) = delete; ThroughputWaits &operator=(const ThroughputWaits &) = delete; private: bool on_; };
 stream_t stream_create();                 // high priority unless ZKAES_STREAM_PRIORITY=0
 bool stream_priorities_enabled();
 void stream_destroy(stream_t s);
@@ -56,6 +60,21 @@ template <class Curve>
 void msm_prepare(MsmWorkspace *ws, const typename Curve::Fr *scal1, size_t n1, const typename Curve::Fr *scal2, size_t n2, size_t val_off2, stream_t s, int force_c = 0);
 template <class Curve>
 XYZZ<typename Curve::Fq> msm_finish(MsmWorkspace *ws, const Affine28<typename Curve::FqP> *bases, stream_t s);
+#if ZK_MSM_EDWARDS
+// BLS12-377 only -- the prover's path over its fixed SRS: bases precomputed on the curve's twisted Edwards model (te28.cuh: Niels28 = (y - x, y + x, 2 d x y),
+// 168 B), bucket additions of 7 field products instead of 10 and no special cases.  convert_bases_te maps Weierstrass affine points (which MUST lie in the
+// prime-order subgroup; a point of order 2 or 4 is refused) to that form; msm / msm_finish / msm_table / class_sum are overloaded on the base type and
+// return the same Weierstrass XYZZ results as their Affine28 versions.
+template <class Curve> void convert_bases_te(Niels28<typename Curve::FqP> *dst, const Affine<typename Curve::Fq> *src, size_t n, stream_t s);
+template <class Curve>
+XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws, const Niels28<typename Curve::FqP> *bases, const typename Curve::Fr *scalars, size_t n, stream_t s);
+template <class Curve>
+XYZZ<typename Curve::Fq> msm_finish(MsmWorkspace *ws, const Niels28<typename Curve::FqP> *bases, stream_t s);
+template <class Curve>
+XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws, const Niels28<typename Curve::FqP> *tables, size_t stride, size_t off, int c, const typename Curve::Fr *scalars, size_t n, stream_t s);
+template <class Curve>
+bool class_sum(MsmWorkspace *ws, const Niels28<typename Curve::FqP> *bases, const int8_t *vals, size_t n, XYZZ<typename Curve::Fq> *out, stream_t s);
+#endif
 // ONE MSM sharded by point range over ranks: msm_sharded_plan gives the window plan of the whole MSM (all ranks agree on it);
 // msm_window_sums_device runs this rank's slice and leaves n_windows XYZZ window sums (192 B each, standard Montgomery form) at dev_out in HBM
 // -- the payload of the one all-gather; msm_fold_window_sums_device adds `world` such blocks (rank-major) per window on the device and finishes
@@ -75,6 +94,8 @@ XYZZ<typename Curve::Fq> msm_fold_window_sums_device(const XYZZ<typename Curve::
 // prepared state can be finished against two index shifts (the plain and the shifted commitment of a degree-bounded polynomial).
 template <class Curve> int table_windows(int c);
 template <class Curve> void build_window_tables(Affine<typename Curve::Fq> *tables, size_t stride, int c, stream_t s);
+// one step of the same: next = 2^(width of window j-1) * prev = table copy j from copy j-1 (`count` points; asynchronous on s)
+template <class Curve> void table_next(Affine<typename Curve::Fq> *next, const Affine<typename Curve::Fq> *prev, size_t count, int c, int j, stream_t s);
 template <class Curve>
 void msm_prepare_table(MsmWorkspace *ws, const typename Curve::Fr *scal1, size_t n1, size_t off1, const typename Curve::Fr *scal2, size_t n2, size_t off2, int c, size_t stride, stream_t s);
 template <class Curve>

@@ -16,11 +16,23 @@
 #include <mutex>
 #include <vector>
 #include "hip_util.hpp"
-#include "ec28.cuh"
+#include "te28.cuh"
 
 namespace zk {
 namespace gpu {
 
+// The bucket kernels are written once over a "law": the Weierstrass model with XYZZ accumulators and 112-byte affine bases (both curves, any points), or
+// BLS12-377's twisted Edwards model with extended accumulators and 168-byte precomputed (y - x, y + x, 2 d x y) bases (te28.cuh: 7 products per
+// bucket addition instead of 10, no special cases) -- what the prover runs over its fixed SRS.
+template <class P> struct WeierLaw { using Params = P; using Base = Affine28<P>; using Acc = Acc28<P>; static constexpr bool edwards = false; };
+#if ZK_MSM_EDWARDS
+template <class P> struct EdwardsLaw { using Params = P; using Base = Niels28<P>; using Acc = AccTE<P>; static constexpr bool edwards = true; };
+#endif
+
+// measurement knob (tools/gpu_runs/knockin.sh): ZKAES_KNOCKIN is a bit mask of pipeline parts to run TWICE (all idempotent, so proofs stay valid) --
+// 1 sort, 2 bucket reductions, 4 tail, 8 accumulate, 16 digits + bounds.  The drop in blocks/s of a saturated bench run is that part's real cost beside
+// the other contexts' kernels, which the one-context profile cannot show.
+static int knockin() { static const int v = [] { const char *e = getenv("ZKAES_KNOCKIN"); return e ? atoi(e) : 0; }(); return v; }
 static MsmStats g_stats;
 static std::mutex g_stats_mu;
 MsmStats msm_stats(bool reset) {
@@ -60,21 +72,38 @@ __global__ void k_digits(const Fr *__restrict__ scalars, uint32_t n, uint32_t i_
     }
 }
 
-// table mode: every window j reads its own precomputed copy T_j[i] = 2^(c j) * P_i, so ALL windows share ONE bucket set of 2^(c-1) signed-digit
+// table mode: every window j reads its own precomputed copy T_j[i] = 2^(off_j) * P_i, so ALL windows share ONE bucket set of 2^(c-1) signed-digit
 // buckets: key = |digit| - 1 (zero digits: bucket 0 + SKIP), value = absolute index j * stride + val_off + i into the table array (+ sign / skip bits).
 // With one set the running-sum reduction is paid once instead of once per window, so c can grow to 20-22 and the windows shrink to 12-13.
+// The windows are BALANCED (TableLayout): the BITS + 1 bits (one for the recoding carry) are spread over the nwin windows as evenly as possible --
+// 254 = 7 x 20 + 6 x 19 for c = 20 -- instead of 12 x 20 + a 14-bit top window whose digits all land on 2^13 buckets (n / 2^13 extra points each:
+// serial overflow-segment chains, 2.3 ms of k_accumulate_tail per launch in round 2).  The top window's spare bit is always zero, so it never recodes
+// and the carry dies there.
+struct TableLayout {
+    int nwin, c_hi, n_hi;                         // windows j < n_hi are c_hi bits wide, the others c_hi - 1
+    __host__ __device__ int width(int j) const { return j < n_hi ? c_hi : c_hi - 1; }
+    __host__ __device__ int offset(int j) const { return j < n_hi ? j * c_hi : n_hi * c_hi + (j - n_hi) * (c_hi - 1); }
+};
+static TableLayout table_layout(int total_bits, int c) {
+    TableLayout L;
+    L.nwin = (total_bits + c - 1) / c;
+    int base = total_bits / L.nwin, rem = total_bits % L.nwin;
+    L.c_hi = base + (rem ? 1 : 0);
+    L.n_hi = rem ? rem : L.nwin;
+    return L;
+}
 template <class Fr>
-__global__ void k_digits_table(const Fr *__restrict__ scalars, uint32_t n, uint32_t i_off, uint32_t ntot, uint32_t val_off, int c, int nwin, uint32_t stride,
+__global__ void k_digits_table(const Fr *__restrict__ scalars, uint32_t n, uint32_t i_off, uint32_t ntot, uint32_t val_off, TableLayout L, uint32_t stride,
                                uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t raw[Fr::N + 1];
     scalars[i].to_raw(raw);
     raw[Fr::N] = 0;
-    const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
     uint32_t carry = 0;
-    for (int w = 0; w < nwin; w++) {
-        int bit = w * c, limb = bit >> 5, sh = bit & 31;
+    for (int w = 0; w < L.nwin; w++) {
+        const int c = L.width(w), bit = L.offset(w), limb = bit >> 5, sh = bit & 31;
+        const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
         uint64_t two = limb <= Fr::N - 1 ? ((uint64_t)raw[limb] | ((uint64_t)raw[limb + 1] << 32)) : 0;
         uint32_t v = ((uint32_t)(two >> sh) & mask) + carry;
         uint32_t neg = 0;
@@ -140,10 +169,11 @@ __global__ void k_convert_bases(const Affine<Fp<P>> *__restrict__ src, Affine28<
     if (i < n) dst[i] = Affine28<P>::from_std(src[i]);
 }
 
-// A bucket lane adds at most `cap` points; the rest of an oversized bucket (skewed scalars: many equal digits; in table mode the 2^11 buckets the short
-// top window lands on) is cut into cap-point overflow segments that k_accumulate_tail sums in parallel and k_reduce_l1 folds back -- so no input can
-// serialise the whole MSM on one lane.  cap = 2048 for the per-window buckets (average bucket ~50 points), 256 in table mode (average ~25).
-constexpr uint32_t BUCKET_CAP = 2048, BUCKET_CAP_TABLE = 256;
+// A bucket lane adds at most `cap` points; the rest of an oversized bucket (skewed scalars: many equal digits) is cut into cap-point overflow
+// segments that k_accumulate_tail sums in parallel and k_reduce_l1 folds back -- so no input can serialise the whole MSM on one lane.
+// cap = 2048 for the per-window buckets (average bucket ~50 points), 512 in table mode (balanced windows: the 2^18 buckets every window reaches hold
+// ~20 n / 2^19 points, ~330 for the largest MSM of a 6-block proof; uniform digits therefore never overflow).
+constexpr uint32_t BUCKET_CAP = 2048, BUCKET_CAP_TABLE = 512;
 __global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, uint32_t nb, uint32_t cap, uint32_t *__restrict__ size_key,
                                uint32_t *__restrict__ ids, uint32_t *__restrict__ extra) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,20 +195,42 @@ __global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_
 #ifndef ZK_ACC_PREFETCH
 #define ZK_ACC_PREFETCH 1       // software prefetch of the next gathered point (28 registers)
 #endif
-template <class P>
-__global__ void __launch_bounds__(64, ZK_ACC_WAVES) k_accumulate(const Affine28<P> *__restrict__ bases, const uint32_t *__restrict__ vals,
+template <class Law>
+__global__ void __launch_bounds__(64, ZK_ACC_WAVES) k_accumulate(const typename Law::Base *__restrict__ bases, const uint32_t *__restrict__ vals,
                                                        const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, const uint32_t *__restrict__ order,
-                                                       uint32_t nbuckets_total, uint32_t cap, Acc28<P> *__restrict__ buckets,
+                                                       uint32_t nbuckets_total, uint32_t cap, typename Law::Acc *__restrict__ buckets,
                                                        uint32_t *__restrict__ deferred, uint32_t deferred_cap, uint32_t *__restrict__ deferred_count) {
+    using P = typename Law::Params;
     using G = FpMsm<P>;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nbuckets_total) return;
     uint32_t k = order[t];
+    uint32_t s = start[k], e = end[k];
+    if (e - s > cap) e = s + cap;                                          // the remainder goes through the overflow segments of k_accumulate_tail
+#if ZK_MSM_EDWARDS
+    if constexpr (Law::edwards) {
+        // unified law: the accumulator starts at the identity, P = +-Q and identity bases need no branch, nothing is deferred
+        AccTE<P> acc = te_identity<P>();
+        if (s < e) {
+            uint32_t idx = vals[s];
+            Niels28<P> nxt = bases[idx & VAL_INDEX];
+            for (uint32_t i = s; i < e; i++) {
+                Niels28<P> p = nxt;
+                uint32_t cur = idx;
+                if (i + 1 < e) { idx = vals[i + 1]; nxt = bases[idx & VAL_INDEX]; }   // prefetch the next gather under this add's ALU work
+                if (cur & VAL_SKIP) continue;
+                if (cur >> 31) p = niels_neg<P>(p);                                    // negative digit: add -P
+                te_madd<P>(acc, p);
+            }
+        }
+        buckets[k] = acc;
+        return;
+    } else
+#endif
+    {
     Acc28<P> acc;
     bool acc_inf = true;
     {
-        uint32_t s = start[k], e = end[k];
-        if (e - s > cap) e = s + cap;                                      // the remainder goes through the overflow segments of k_accumulate_tail
         if (s < e) {
 #if ZK_ACC_PREFETCH
             uint32_t idx = vals[s];
@@ -205,6 +257,7 @@ __global__ void __launch_bounds__(64, ZK_ACC_WAVES) k_accumulate(const Affine28<
     }
     if (acc_inf) acc = inf28<P>();
     buckets[k] = acc;
+    }
 }
 // replay of the deferred (bucket, point) pairs with the complete formulas; one lane, sequential (the list is empty in practice)
 template <class P>
@@ -226,40 +279,56 @@ __device__ void accumulate_fixup(const Affine28<P> *__restrict__ bases, Acc28<P>
 // deferred_count[1]) -- the replay of the deferred degenerate additions of this kernel and of k_accumulate.  The overflow partials are folded
 // into their buckets by k_reduce_l1 when it loads them.  For uniformly distributed digits there are no segments and no deferred pairs: every
 // lane exits after two loads.
-template <class P>
-__global__ void __launch_bounds__(64, 2) k_accumulate_tail(const Affine28<P> *__restrict__ bases, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ start,
+template <class Law>
+__global__ void __launch_bounds__(64, 2) k_accumulate_tail(const typename Law::Base *__restrict__ bases, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ start,
                                                             const uint32_t *__restrict__ end, const uint32_t *__restrict__ extra_off, uint32_t nb, uint32_t max_segments, uint32_t cap,
-                                                            Acc28<P> *__restrict__ partial, Acc28<P> *__restrict__ buckets, uint32_t *__restrict__ deferred, uint32_t deferred_cap,
+                                                            typename Law::Acc *__restrict__ partial, typename Law::Acc *__restrict__ buckets, uint32_t *__restrict__ deferred, uint32_t deferred_cap,
                                                             uint32_t *__restrict__ deferred_count) {
+    using P = typename Law::Params;
+    using A = typename Law::Acc;
     using G = FpMsm<P>;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t total = extra_off[nb];                   // exclusive scan has nb + 1 entries
     if (total > max_segments) total = max_segments;
     // workgroups whose 64 segment slots are all beyond `total` (every workgroup, for uniform digits) skip the segment work and its LDS fold
     if (blockIdx.x * blockDim.x < total) {
-        __shared__ Acc28<P> sh[64];
+        __shared__ A sh[64];
         __shared__ uint32_t key[64];
         uint32_t k = 0xffffffffu;
-        Acc28<P> acc;
+        A acc;
         if (t < total) {
             uint32_t lo = 0, hi = nb;                         // largest k with extra_off[k] <= t
             while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (extra_off[mid] <= t) lo = mid; else hi = mid; }
             k = lo;
             uint32_t j = t - extra_off[k];
             uint32_t s = start[k] + (j + 1) * cap, e = s + cap < end[k] ? s + cap : end[k];
-            bool acc_inf = true;
-            for (uint32_t i = s; i < e; i++) {
-                uint32_t cur = vals[i];
-                Affine28<P> p = bases[cur & VAL_INDEX];
-                if ((cur & VAL_SKIP) || p.is_inf()) continue;
-                if (cur >> 31) p.y = G::zero().template sub<2>(p.y);
-                if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_one(); acc.zzz = acc.zz; acc_inf = false; continue; }
-                if (!madd28(acc, p)) {
-                    uint32_t slot = atomicAdd(deferred_count, 1u);
-                    if (slot < deferred_cap) { deferred[2 * slot] = k; deferred[2 * slot + 1] = cur; }
+#if ZK_MSM_EDWARDS
+            if constexpr (Law::edwards) {
+                acc = te_identity<P>();
+                for (uint32_t i = s; i < e; i++) {
+                    uint32_t cur = vals[i];
+                    if (cur & VAL_SKIP) continue;
+                    Niels28<P> p = bases[cur & VAL_INDEX];
+                    if (cur >> 31) p = niels_neg<P>(p);
+                    te_madd<P>(acc, p);
                 }
+            } else
+#endif
+            {
+                bool acc_inf = true;
+                for (uint32_t i = s; i < e; i++) {
+                    uint32_t cur = vals[i];
+                    Affine28<P> p = bases[cur & VAL_INDEX];
+                    if ((cur & VAL_SKIP) || p.is_inf()) continue;
+                    if (cur >> 31) p.y = G::zero().template sub<2>(p.y);
+                    if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_one(); acc.zzz = acc.zz; acc_inf = false; continue; }
+                    if (!madd28(acc, p)) {
+                        uint32_t slot = atomicAdd(deferred_count, 1u);
+                        if (slot < deferred_cap) { deferred[2 * slot] = k; deferred[2 * slot + 1] = cur; }
+                    }
+                }
+                if (acc_inf) acc = inf28<P>();
             }
-            if (acc_inf) acc = inf28<P>();
             sh[threadIdx.x] = acc;
         }
         key[threadIdx.x] = k;
@@ -267,29 +336,30 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_tail(const Affine28<P> *__
         // the segments of one bucket are consecutive t: the first lane of every (workgroup, bucket) run folds its run (<= 63 additions) and stores ONE
         // partial at its own slot; k_reduce_l1's load_bucket then visits one slot per workgroup the bucket's segments span, not one per segment
         if (t < total && (threadIdx.x == 0 || key[threadIdx.x - 1] != k)) {
-            for (uint32_t q = threadIdx.x + 1; q < 64 && key[q] == k; q++) add28<P>(acc, sh[q]);
+            for (uint32_t q = threadIdx.x + 1; q < 64 && key[q] == k; q++) PtOps<A>::add(acc, sh[q]);
             partial[t] = acc;
         }
     }
-    __shared__ uint32_t ticket;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) ticket = atomicAdd(deferred_count + 1, 1u);
-    __syncthreads();
-    if (ticket != gridDim.x - 1 || threadIdx.x != 0) return;
-    __threadfence();
-    accumulate_fixup<P>(bases, buckets, deferred, deferred_cap, deferred_count);
+    if constexpr (!Law::edwards) {       // the Weierstrass law defers P = +-Q additions: whichever workgroup finishes last replays them with the complete formulas
+        __shared__ uint32_t ticket;
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) ticket = atomicAdd(deferred_count + 1, 1u);
+        __syncthreads();
+        if (ticket != gridDim.x - 1 || threadIdx.x != 0) return;
+        __threadfence();
+        accumulate_fixup<P>(bases, buckets, deferred, deferred_cap, deferred_count);
+    }
 }
 // bucket k with its overflow partials folded in (k_reduce_l1's load)
-template <class P>
-__device__ __forceinline__ Acc28<P> load_bucket(const Acc28<P> *__restrict__ buckets, size_t k, const uint32_t *__restrict__ extra_off, uint32_t max_segments,
-                                                const Acc28<P> *__restrict__ partial) {
-    Acc28<P> acc = buckets[k];
+template <class A>
+__device__ __forceinline__ A load_bucket(const A *__restrict__ buckets, size_t k, const uint32_t *__restrict__ extra_off, uint32_t max_segments, const A *__restrict__ partial) {
+    A acc = buckets[k];
     uint32_t a = extra_off[k], b = extra_off[k + 1];
     if (a != b) {
         if (b > max_segments) b = max_segments;
         // one folded partial per 64-segment workgroup of k_accumulate_tail that the bucket's segments [a, b) span, stored at the run's first slot
-        for (uint32_t w = a / 64; w * 64 < b; w++) { uint32_t i = w * 64 > a ? w * 64 : a; if (i < b) add28<P>(acc, partial[i]); }
+        for (uint32_t w = a / 64; w * 64 < b; w++) { uint32_t i = w * 64 > a ? w * 64 : a; if (i < b) PtOps<A>::add(acc, partial[i]); }
     }
     return acc;
 }
@@ -298,76 +368,80 @@ __device__ __forceinline__ Acc28<P> load_bucket(const Acc28<P> *__restrict__ buc
 //   k_reduce_l1: lane (w, g) over the 8 buckets j0 = 8 g ..: S_g = sum B_j, W_g = sum (j - j0 + 1) B_j             (running sums only)
 //   k_reduce_l2: lane (w, h) over 8 segments: sum_g [W_g + 8 g S_g] via a second running sum + ONE small scalar product
 //   k_reduce_window: LDS tree over the group partials of a window
+// A = the accumulator type (Acc28: XYZZ on the Weierstrass model, AccTE: extended twisted Edwards); PtOps<A> is the group law.
 constexpr int RED_L1 = 8, RED_L2 = 8;
-template <class P>
-__global__ void __launch_bounds__(64) k_reduce_l1(const Acc28<P> *__restrict__ buckets, int c, int nwin, Acc28<P> *__restrict__ seg_s, Acc28<P> *__restrict__ seg_w,
-                                                   const uint32_t *__restrict__ extra_off, uint32_t max_segments, const Acc28<P> *__restrict__ ovf_partial) {
+template <class A>
+__global__ void __launch_bounds__(64) k_reduce_l1(const A *__restrict__ buckets, int c, int nwin, A *__restrict__ seg_s, A *__restrict__ seg_w,
+                                                   const uint32_t *__restrict__ extra_off, uint32_t max_segments, const A *__restrict__ ovf_partial) {
     uint32_t segs = (1u << c) / RED_L1;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= segs * (uint32_t)nwin) return;
     uint32_t w = t / segs, g = t % segs;
     const size_t k0 = ((size_t)w << c) + (size_t)g * RED_L1;
-    Acc28<P> run = inf28<P>(), tot = inf28<P>();
+    A run = PtOps<A>::identity(), tot = PtOps<A>::identity();
     for (int d = RED_L1 - 1; d >= 0; d--) {
-        Acc28<P> b = load_bucket<P>(buckets, k0 + d, extra_off, max_segments, ovf_partial);
-        add28<P>(run, b);
-        add28<P>(tot, run);
+        A b = load_bucket<A>(buckets, k0 + d, extra_off, max_segments, ovf_partial);
+        PtOps<A>::add(run, b);
+        PtOps<A>::add(tot, run);
     }
     seg_s[t] = run;
     seg_w[t] = tot;
 }
-template <class P>
-__global__ void __launch_bounds__(64) k_reduce_l2(const Acc28<P> *__restrict__ seg_s, const Acc28<P> *__restrict__ seg_w, int c, int nwin, Acc28<P> *__restrict__ partial) {
+template <class A>
+__global__ void __launch_bounds__(64) k_reduce_l2(const A *__restrict__ seg_s, const A *__restrict__ seg_w, int c, int nwin, A *__restrict__ partial) {
     uint32_t segs = (1u << c) / RED_L1, groups = (segs + RED_L2 - 1) / RED_L2;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= groups * (uint32_t)nwin) return;
     uint32_t w = t / groups, h = t % groups;
     uint32_t g0 = h * RED_L2, g1 = g0 + RED_L2 < segs ? g0 + RED_L2 : segs;
-    const Acc28<P> *S = seg_s + (size_t)w * segs, *W = seg_w + (size_t)w * segs;
-    Acc28<P> run = inf28<P>(), tot2 = inf28<P>(), sw = inf28<P>();
+    const A *S = seg_s + (size_t)w * segs, *W = seg_w + (size_t)w * segs;
+    A run = PtOps<A>::identity(), tot2 = PtOps<A>::identity(), sw = PtOps<A>::identity();
     for (int g = (int)g1 - 1; g >= (int)g0; g--) {
-        add28<P>(run, S[g]);
-        add28<P>(tot2, run);           // tot2 = sum (g - g0 + 1) S_g
-        add28<P>(sw, W[g]);
+        PtOps<A>::add(run, S[g]);
+        PtOps<A>::add(tot2, run);           // tot2 = sum (g - g0 + 1) S_g
+        PtOps<A>::add(sw, W[g]);
     }
     // bucket j carries weight j + 1:  sum_g [W_g + L1 g S_g] = sw + L1 (tot2 - run) + (L1 g0) run     (run = sum S_g, L1 = 8)
-    Acc28<P> a = tot2;
-    add28<P>(a, neg28<P>(run));
-    for (int i = 0; i < 3; i++) dbl28<P>(a);      // * RED_L1
-    add28<P>(sw, a);
+    A a = tot2;
+    PtOps<A>::add(a, PtOps<A>::neg(run));
+    for (int i = 0; i < 3; i++) PtOps<A>::dbl(a);      // * RED_L1
+    PtOps<A>::add(sw, a);
     if (g0 != 0) {
         uint32_t m = RED_L1 * g0;
-        Acc28<P> acc = inf28<P>();
+        A acc = PtOps<A>::identity();
         int top = 31 - __clz(m);
         for (int bit = top; bit >= 0; bit--) {
-            dbl28<P>(acc);
-            if ((m >> bit) & 1) add28<P>(acc, run);
+            PtOps<A>::dbl(acc);
+            if ((m >> bit) & 1) PtOps<A>::add(acc, run);
         }
-        add28<P>(sw, acc);
+        PtOps<A>::add(sw, acc);
     }
     partial[t] = sw;
 }
 
-template <class P>
-__global__ void __launch_bounds__(256) k_reduce_window(const Acc28<P> *__restrict__ partial, uint32_t per_window, XYZZ<Fp<P>> *__restrict__ out) {
-    __shared__ Acc28<P> sh[256];
+template <class A>
+__global__ void __launch_bounds__(256) k_reduce_window(const A *__restrict__ partial, uint32_t per_window, XYZZ<Fp<typename PtOps<A>::Params>> *__restrict__ out) {
+    __shared__ A sh[256];
     uint32_t w = blockIdx.x, t = threadIdx.x;
-    Acc28<P> acc = inf28<P>();
-    for (uint32_t i = t; i < per_window; i += 256) add28<P>(acc, partial[(size_t)w * per_window + i]);
+    A acc = PtOps<A>::identity();
+    for (uint32_t i = t; i < per_window; i += 256) PtOps<A>::add(acc, partial[(size_t)w * per_window + i]);
     sh[t] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if ((int)t < s) { Acc28<P> a = sh[t]; add28<P>(a, sh[t + s]); sh[t] = a; }
+        if ((int)t < s) { A a = sh[t]; PtOps<A>::add(a, sh[t + s]); sh[t] = a; }
         __syncthreads();
     }
-    if (t == 0) out[w] = to_std_point<P>(sh[0]);
+    if (t == 0) out[w] = PtOps<A>::to_std(sh[0]);     // always the Weierstrass XYZZ form in the library-wide Montgomery representation
 }
 
-template <class P> __global__ void k_sum_tree(const Acc28<P> *__restrict__ in, uint32_t total, uint32_t per, Acc28<P> *__restrict__ out);
+template <class A> __global__ void k_sum_tree(const A *__restrict__ in, uint32_t total, uint32_t per, A *__restrict__ out);
 
 constexpr uint32_t DEFERRED_CAP = 1u << 20;
 constexpr size_t ACC_BYTES = sizeof(Acc28<Fq377P>);          // one XYZZ bucket in the reduced-radix form (208 B with ff30, 224 B with ff28; same for both curves)
 static_assert(sizeof(Acc28<Fq381P>) == ACC_BYTES, "bucket size differs between the curves");
+#if ZK_MSM_EDWARDS
+static_assert(sizeof(AccTE<Fq377P>) == ACC_BYTES, "the Edwards accumulator must fit the XYZZ bucket slots");
+#endif
 struct MsmWorkspace {
     size_t cap_pairs = 0, cap_buckets = 0, cap_tmp = 0;
     uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr, *start = nullptr, *end = nullptr;
@@ -449,6 +523,7 @@ static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int
     HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, dk, dv, (int)pairs, 0, key_bits, s));
     if (tmp_bytes > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tmp_bytes); S.cap_tmp = tmp_bytes; }
     HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp, tmp_bytes, dk, dv, (int)pairs, 0, key_bits, s));
+    if (knockin() & 1) HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp, tmp_bytes, dk, dv, (int)pairs, 0, key_bits, s));
     S.sorted_keys = dk.Current(); S.sorted_vals = dv.Current();
     HIP_CHECK(hipMemsetAsync(S.start, 0, nb * 4, s));
     HIP_CHECK(hipMemsetAsync(S.end, 0, nb * 4, s));
@@ -473,9 +548,11 @@ static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int
 }
 // shared tail over prepared buckets: accumulate from `bases`, fold overflow segments and deferred degenerate additions, reduce; returns the
 // nsets window sums.  May be called several times on one prepared state with different base arrays (same scalars, e.g. plain + shifted powers).
-template <class P>
-static std::vector<XYZZ<Fp<P>>> run_buckets(MsmWorkspace &S, const Affine28<P> *bases, size_t pairs, int c, int nsets, size_t n_points, uint32_t cap, hipStream_t s, float *acc_ms,
-                                            XYZZ<Fp<P>> *dev_wsum_out = nullptr) {
+template <class Law>
+static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, const typename Law::Base *bases, size_t pairs, int c, int nsets, size_t n_points, uint32_t cap, hipStream_t s, float *acc_ms,
+                                            XYZZ<Fp<typename Law::Params>> *dev_wsum_out = nullptr) {
+    using P = typename Law::Params;
+    using A = typename Law::Acc;
     using Fq = Fp<P>;
     size_t nb = (size_t)nsets << c;
     HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 8, s));        // [0] deferred pairs, [1] the tail kernel's workgroup ticket
@@ -484,39 +561,50 @@ static std::vector<XYZZ<Fp<P>>> run_buckets(MsmWorkspace &S, const Affine28<P> *
     // queue behind its waves
     hipStream_t sa = S.low ? S.low : s;
     if (S.low) { HIP_CHECK(hipEventRecord(S.fence_a, s)); HIP_CHECK(hipStreamWaitEvent(S.low, S.fence_a, 0)); }
+    if (knockin() & 8) {        // (measurement only) one extra, untimed launch
+        hipLaunchKernelGGL((k_accumulate<Law>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, sa, bases, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb, cap,
+                           (A *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
+        HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 8, sa));
+    }
     HIP_CHECK(hipEventRecord(S.ev0, sa));
-    hipLaunchKernelGGL((k_accumulate<P>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, sa, bases, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb, cap,
-                       (Acc28<P> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
+    hipLaunchKernelGGL((k_accumulate<Law>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, sa, bases, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb, cap,
+                       (A *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
     HIP_CHECK(hipEventRecord(S.ev1, sa));
     if (S.low) { HIP_CHECK(hipEventRecord(S.fence_b, S.low)); HIP_CHECK(hipStreamWaitEvent(s, S.fence_b, 0)); }
     uint32_t max_seg = (uint32_t)(pairs / cap + 1);
     // oversized buckets + deferred degenerate additions (none for uniformly distributed digits: every lane exits at once)
-    hipLaunchKernelGGL((k_accumulate_tail<P>), dim3((max_seg + 63) / 64), dim3(64), 0, s, bases, S.sorted_vals, S.start, S.end, S.extra_off, (uint32_t)nb, max_seg, cap,
-                       (Acc28<P> *)S.ovf_partial, (Acc28<P> *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
+    hipLaunchKernelGGL((k_accumulate_tail<Law>), dim3((max_seg + 63) / 64), dim3(64), 0, s, bases, S.sorted_vals, S.start, S.end, S.extra_off, (uint32_t)nb, max_seg, cap,
+                       (A *)S.ovf_partial, (A *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
+    if (knockin() & 4) {        // (measurement only) the tail kernel once more: its ticket never reaches gridDim - 1 again, so the deferred replay runs once
+        hipLaunchKernelGGL((k_accumulate_tail<Law>), dim3((max_seg + 63) / 64), dim3(64), 0, s, bases, S.sorted_vals, S.start, S.end, S.extra_off, (uint32_t)nb, max_seg, cap,
+                           (A *)S.ovf_partial, (A *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
+    }
     uint32_t segs = (1u << c) / RED_L1, groups = (segs + RED_L2 - 1) / RED_L2;
-    hipLaunchKernelGGL((k_reduce_l1<P>), dim3((unsigned)((segs * nsets + 63) / 64)), dim3(64), 0, s, (const Acc28<P> *)S.buckets, c, nsets, (Acc28<P> *)S.seg_s, (Acc28<P> *)S.seg_w,
-                       S.extra_off, max_seg, (const Acc28<P> *)S.ovf_partial);
+    for (int rep = (knockin() & 2) ? 0 : 1; rep < 2; rep++) {
+    hipLaunchKernelGGL((k_reduce_l1<A>), dim3((unsigned)((segs * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.buckets, c, nsets, (A *)S.seg_s, (A *)S.seg_w,
+                       S.extra_off, max_seg, (const A *)S.ovf_partial);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_reduce_l2<P>), dim3((unsigned)((groups * nsets + 63) / 64)), dim3(64), 0, s, (const Acc28<P> *)S.seg_s, (const Acc28<P> *)S.seg_w, c, nsets, (Acc28<P> *)S.partial);
+    hipLaunchKernelGGL((k_reduce_l2<A>), dim3((unsigned)((groups * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.seg_s, (const A *)S.seg_w, c, nsets, (A *)S.partial);
     HIP_LAUNCH_CHECK();
     if (nsets == 1 && groups > 2048) {
         // one big bucket set (table mode): 256-partial blocks first, so the final LDS tree does not walk tens of thousands of partials serially
         uint32_t mid = (groups + 255) / 256;
-        hipLaunchKernelGGL((k_sum_tree<P>), dim3(mid), dim3(256), 0, s, (const Acc28<P> *)S.partial, groups, 256u, (Acc28<P> *)S.seg_s);
+        hipLaunchKernelGGL((k_sum_tree<A>), dim3(mid), dim3(256), 0, s, (const A *)S.partial, groups, 256u, (A *)S.seg_s);
         HIP_LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_reduce_window<P>), dim3(1), dim3(256), 0, s, (const Acc28<P> *)S.seg_s, mid, (XYZZ<Fq> *)S.wsum);
+        hipLaunchKernelGGL((k_reduce_window<A>), dim3(1), dim3(256), 0, s, (const A *)S.seg_s, mid, (XYZZ<Fq> *)S.wsum);
     } else {
-        hipLaunchKernelGGL((k_reduce_window<P>), dim3((unsigned)nsets), dim3(256), 0, s, (const Acc28<P> *)S.partial, groups, (XYZZ<Fq> *)S.wsum);
+        hipLaunchKernelGGL((k_reduce_window<A>), dim3((unsigned)nsets), dim3(256), 0, s, (const A *)S.partial, groups, (XYZZ<Fq> *)S.wsum);
     }
     HIP_LAUNCH_CHECK();
+    }
     std::vector<XYZZ<Fq>> ws(nsets);
     uint32_t n_deferred = 0;
     if (dev_wsum_out) HIP_CHECK(hipMemcpyAsync(dev_wsum_out, S.wsum, sizeof(XYZZ<Fq>) * nsets, hipMemcpyDeviceToDevice, s));   // stays in HBM for a collective
     HIP_CHECK(hipMemcpyAsync(ws.data(), S.wsum, sizeof(XYZZ<Fq>) * nsets, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(&n_deferred, S.deferred_count, 4, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    sync((stream_t)s);
     if (n_deferred > DEFERRED_CAP) throw GpuError("msm: more than 2^20 degenerate additions (repeated base points); refusing to return a wrong sum");
     HIP_CHECK(hipEventElapsedTime(acc_ms, S.ev0, S.ev1));
     (void)n_points;
@@ -530,6 +618,56 @@ static void add_stats(float acc_ms, size_t n, size_t pairs, std::chrono::steady_
     g_stats.launches += 1;
     g_stats.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 }
+
+#if ZK_MSM_EDWARDS
+// Weierstrass affine (library-wide form) -> precomputed Edwards form (y - x, y + x, 2 d x y), 8 points per lane sharing ONE field inversion
+// (Montgomery's trick) for the two divisions of the map.  A point of order 2 or 4 (den = 0; never in the prime-order subgroup) raises *bad.
+__global__ void __launch_bounds__(64) k_convert_bases_te(const Affine<Fq377> *__restrict__ src, Niels28<Fq377P> *__restrict__ dst, size_t n, uint32_t *__restrict__ bad) {
+    constexpr int B = 8;
+    size_t s0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * B;
+    if (s0 >= n) return;
+    size_t e = s0 + B < n ? s0 + B : n;
+    TeMapParts m[B];
+    Fq377 pre[B];
+    bool skip[B];
+    Fq377 acc = Fq377::one();
+    for (size_t i = s0; i < e; i++) {
+        Affine<Fq377> p = src[i];
+        int q = (int)(i - s0);
+        skip[q] = p.is_inf();
+        if (!skip[q]) {
+            m[q] = te_map_parts(p);
+            if (m[q].den.is_zero()) { skip[q] = true; atomicOr(bad, 1u); }
+        }
+        pre[q] = acc;
+        if (!skip[q]) acc = acc * m[q].den;
+    }
+    acc = acc.inverse();
+    for (size_t i = e; i-- > s0;) {
+        int q = (int)(i - s0);
+        if (skip[q]) { dst[i] = niels_identity<Fq377P>(); continue; }
+        Fq377 inv = acc * pre[q];
+        acc = acc * m[q].den;
+        dst[i] = te_niels_finish(m[q], inv);
+    }
+}
+template <class Curve>
+void convert_bases_te(Niels28<typename Curve::FqP> *dst, const Affine<typename Curve::Fq> *src, size_t n, stream_t s_) {
+    static_assert(Curve::ID == 377, "only BLS12-377's G1 has a twisted Edwards model");
+    if (!n) return;
+    hipStream_t s = (hipStream_t)s_;
+    uint32_t *d_bad = (uint32_t *)dmalloc(4), h_bad = 0;
+    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, s));
+    size_t lanes = (n + 7) / 8;
+    hipLaunchKernelGGL(k_convert_bases_te, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, src, dst, n, d_bad);
+    HIP_LAUNCH_CHECK();
+    HIP_CHECK(hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, s));
+    sync((stream_t)s);
+    dfree(d_bad);
+    if (h_bad) throw GpuError("convert_bases_te: a base point has order 2 or 4 -- the Edwards path needs points of the prime-order subgroup");
+}
+template void convert_bases_te<Bls377>(Niels28<Fq377P> *, const Affine<Fq377> *, size_t, stream_t);
+#endif
 
 template <class Curve>
 void convert_bases(Affine28<typename Curve::FqP> *dst, const Affine<typename Curve::Fq> *src, size_t n, stream_t s_) {
@@ -568,8 +706,8 @@ void msm_prepare(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_t n1, 
     if (n2) { hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, scal2, (uint32_t)n2, (uint32_t)n1, (uint32_t)n, (uint32_t)val_off2, c, nwin, (uint32_t)nb, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
     prepare_buckets<typename Curve::FqP>(S, pairs, c - 1, nwin, c - 1, BUCKET_CAP, s);
 }
-template <class Curve>
-XYZZ<typename Curve::Fq> msm_finish(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *bases, stream_t s_) {
+template <class Curve, class Law>
+static XYZZ<typename Curve::Fq> msm_finish_impl(MsmWorkspace *ws_, const typename Law::Base *bases, stream_t s_) {
     using Fq = typename Curve::Fq;
     static_assert(sizeof(XYZZ<Fq>) == 192, "XYZZ layout");
     hipStream_t s = (hipStream_t)s_;
@@ -580,11 +718,11 @@ XYZZ<typename Curve::Fq> msm_finish(MsmWorkspace *ws_, const Affine28<typename C
     const int c = S.plan_c, nwin = S.plan_nwin;
     float ms = 0;
     if (S.plan_table) {      // `bases` = table copy 0 (+ a constant index shift): the window weights live in the copies, ONE bucket set, no Horner
-        std::vector<XYZZ<Fq>> one = run_buckets<typename Curve::FqP>(S, bases, S.plan_pairs, c - 1, 1, S.plan_n, S.plan_cap, s, &ms);
+        std::vector<XYZZ<Fq>> one = run_buckets<Law>(S, bases, S.plan_pairs, c - 1, 1, S.plan_n, S.plan_cap, s, &ms);
         add_stats(ms, S.plan_n, S.plan_pairs, t_begin);
         return one[0];
     }
-    std::vector<XYZZ<Fq>> ws = run_buckets<typename Curve::FqP>(S, bases, S.plan_pairs, c - 1, nwin, S.plan_n, S.plan_cap, s, &ms);
+    std::vector<XYZZ<Fq>> ws = run_buckets<Law>(S, bases, S.plan_pairs, c - 1, nwin, S.plan_n, S.plan_cap, s, &ms);
     if (getenv("ZKAES_MSM_DEBUG")) {
         for (int w = 0; w < nwin; w++) {
             Affine<Fq> a = ws[w].to_affine();
@@ -601,11 +739,23 @@ XYZZ<typename Curve::Fq> msm_finish(MsmWorkspace *ws_, const Affine28<typename C
     return total;
 }
 template <class Curve>
+XYZZ<typename Curve::Fq> msm_finish(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *bases, stream_t s_) { return msm_finish_impl<Curve, WeierLaw<typename Curve::FqP>>(ws_, bases, s_); }
+template <class Curve>
 XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *bases, const typename Curve::Fr *scalars, size_t n, stream_t s_) {
     if (n == 0) return XYZZ<typename Curve::Fq>::inf();
     msm_prepare<Curve>(ws_, scalars, n, nullptr, 0, 0, s_);
     return msm_finish<Curve>(ws_, bases, s_);
 }
+#if ZK_MSM_EDWARDS
+template <class Curve>
+XYZZ<typename Curve::Fq> msm_finish(MsmWorkspace *ws_, const Niels28<typename Curve::FqP> *bases, stream_t s_) { return msm_finish_impl<Curve, EdwardsLaw<typename Curve::FqP>>(ws_, bases, s_); }
+template <class Curve>
+XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws_, const Niels28<typename Curve::FqP> *bases, const typename Curve::Fr *scalars, size_t n, stream_t s_) {
+    if (n == 0) return XYZZ<typename Curve::Fq>::inf();
+    msm_prepare<Curve>(ws_, scalars, n, nullptr, 0, 0, s_);
+    return msm_finish<Curve>(ws_, bases, s_);
+}
+#endif
 
 // ---- ONE MSM sharded by point range over ranks (SURVEY.md 8e second row): every rank runs the buckets of its slice with the window plan of the WHOLE
 // MSM and leaves its window sums in device memory; after the all-gather (RCCL, HBM to HBM) k_fold_ranks adds the ranks' sums per window.
@@ -628,7 +778,7 @@ void msm_window_sums_device(MsmWorkspace *ws_, const Affine28<typename Curve::Fq
     msm_sharded_plan<Curve>(n_total, &c, &nwin);
     if (n_local == 0) {       // an empty share contributes the point at infinity in every window (zz = 0)
         HIP_CHECK(hipMemsetAsync(dev_out, 0, sizeof(XYZZ<Fq>) * nwin, s));
-        HIP_CHECK(hipStreamSynchronize(s));
+        sync((stream_t)s);
         return;
     }
     msm_prepare<Curve>(ws_, scalars, n_local, nullptr, 0, 0, s_, c);
@@ -636,7 +786,7 @@ void msm_window_sums_device(MsmWorkspace *ws_, const Affine28<typename Curve::Fq
     if (S.plan_nwin != nwin) throw GpuError("msm_window_sums_device: window plan mismatch");
     float ms = 0;
     auto t_begin = std::chrono::steady_clock::now();
-    run_buckets<typename Curve::FqP>(S, bases, S.plan_pairs, c - 1, nwin, n_local, S.plan_cap, s, &ms, dev_out);
+    run_buckets<WeierLaw<typename Curve::FqP>>(S, bases, S.plan_pairs, c - 1, nwin, n_local, S.plan_cap, s, &ms, dev_out);
     add_stats(ms, n_local, S.plan_pairs, t_begin);
 }
 template <class Fq>
@@ -658,7 +808,7 @@ XYZZ<typename Curve::Fq> msm_fold_window_sums_device(const XYZZ<typename Curve::
     HIP_LAUNCH_CHECK();
     std::vector<XYZZ<Fq>> ws(nwin);
     HIP_CHECK(hipMemcpyAsync(ws.data(), d_out, sizeof(XYZZ<Fq>) * nwin, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    sync((stream_t)s);
     dfree(d_out);
     XYZZ<Fq> total = XYZZ<Fq>::inf();
     for (int w = nwin - 1; w >= 1; w--) {
@@ -670,19 +820,28 @@ XYZZ<typename Curve::Fq> msm_fold_window_sums_device(const XYZZ<typename Curve::
 }
 
 template <class Curve>
-int table_windows(int c) { return (Curve::Fr::BITS + 1 + c - 1) / c; }      // signed digits: one extra bit for the recoding carry
+int table_windows(int c) { return table_layout(Curve::Fr::BITS + 1, c).nwin; }      // signed digits: one extra bit for the recoding carry
 
 template <class Curve>
 void build_window_tables(Affine<typename Curve::Fq> *tables, size_t stride, int c, stream_t s_) {
     using Fq = typename Curve::Fq;
     hipStream_t s = (hipStream_t)s_;
-    const int nwin = table_windows<Curve>(c);
-    for (int j = 1; j < nwin; j++) {
+    const TableLayout L = table_layout(Curve::Fr::BITS + 1, c);
+    for (int j = 1; j < L.nwin; j++) {          // copy j = 2^(width of window j-1) * copy j-1 = 2^(offset of window j) * copy 0
         uint32_t lanes = (uint32_t)((stride + 7) / 8);
-        hipLaunchKernelGGL((k_table_next<Fq>), dim3((lanes + 63) / 64), dim3(64), 0, s, tables + (size_t)(j - 1) * stride, tables + (size_t)j * stride, (uint32_t)stride, c);
+        hipLaunchKernelGGL((k_table_next<Fq>), dim3((lanes + 63) / 64), dim3(64), 0, s, tables + (size_t)(j - 1) * stride, tables + (size_t)j * stride, (uint32_t)stride, L.width(j - 1));
         HIP_LAUNCH_CHECK();
     }
-    HIP_CHECK(hipStreamSynchronize(s));
+    sync((stream_t)s);
+}
+
+template <class Curve>
+void table_next(Affine<typename Curve::Fq> *next, const Affine<typename Curve::Fq> *prev, size_t count, int c, int j, stream_t s_) {
+    const TableLayout L = table_layout(Curve::Fr::BITS + 1, c);
+    if (j < 1 || j >= L.nwin) throw GpuError("table_next: window index out of range");
+    uint32_t lanes = (uint32_t)((count + 7) / 8);
+    hipLaunchKernelGGL((k_table_next<typename Curve::Fq>), dim3((lanes + 63) / 64), dim3(64), 0, (hipStream_t)s_, prev, next, (uint32_t)count, L.width(j - 1));
+    HIP_LAUNCH_CHECK();
 }
 
 // Table-mode Pippenger in the same two steps as the per-window variant.  msm_prepare_table: signed c-bit digits of up to two scalar vectors
@@ -699,16 +858,17 @@ void msm_prepare_table(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_
     S.plan_n = n;
     if (n == 0) return;
     if (c < 4 || c > 24) throw GpuError("msm_table: window bits out of range");
-    const int nwin = table_windows<Curve>(c);
+    const TableLayout L = table_layout(Fr::BITS + 1, c);
+    const int nwin = L.nwin;
     if (off1 + n1 > stride || off2 + n2 > stride) throw GpuError("msm_table: range exceeds the table");
     if ((uint64_t)nwin * stride >= (1ull << 30) || (uint64_t)n * nwin >= (1ull << 31)) throw GpuError("msm_table: index range too large");
     size_t pairs = n * (size_t)nwin;
-    const size_t nb = (size_t)1 << (c - 1);
-    S.plan_c = c; S.plan_nwin = nwin; S.plan_pairs = pairs; S.plan_table = true; S.plan_cap = BUCKET_CAP_TABLE;
+    const size_t nb = (size_t)1 << (L.c_hi - 1);
+    S.plan_c = L.c_hi; S.plan_nwin = nwin; S.plan_pairs = pairs; S.plan_table = true; S.plan_cap = BUCKET_CAP_TABLE;
     ensure_scratch(S, pairs, nb, BUCKET_CAP_TABLE);
-    if (n1) { hipLaunchKernelGGL((k_digits_table<Fr>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, scal1, (uint32_t)n1, 0u, (uint32_t)n, (uint32_t)off1, c, nwin, (uint32_t)stride, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
-    if (n2) { hipLaunchKernelGGL((k_digits_table<Fr>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, scal2, (uint32_t)n2, (uint32_t)n1, (uint32_t)n, (uint32_t)off2, c, nwin, (uint32_t)stride, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
-    prepare_buckets<typename Curve::FqP>(S, pairs, c - 1, 1, c - 1, BUCKET_CAP_TABLE, s);
+    if (n1) { hipLaunchKernelGGL((k_digits_table<Fr>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, scal1, (uint32_t)n1, 0u, (uint32_t)n, (uint32_t)off1, L, (uint32_t)stride, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
+    if (n2) { hipLaunchKernelGGL((k_digits_table<Fr>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, scal2, (uint32_t)n2, (uint32_t)n1, (uint32_t)n, (uint32_t)off2, L, (uint32_t)stride, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
+    prepare_buckets<typename Curve::FqP>(S, pairs, L.c_hi - 1, 1, L.c_hi - 1, BUCKET_CAP_TABLE, s);
 }
 template <class Curve>
 XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *tables, size_t stride, size_t off, int c, const typename Curve::Fr *scalars, size_t n, stream_t s_) {
@@ -716,6 +876,14 @@ XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws_, const Affine28<typename Cu
     msm_prepare_table<Curve>(ws_, scalars, n, off, nullptr, 0, 0, c, stride, s_);
     return msm_finish<Curve>(ws_, tables, s_);
 }
+#if ZK_MSM_EDWARDS
+template <class Curve>
+XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws_, const Niels28<typename Curve::FqP> *tables, size_t stride, size_t off, int c, const typename Curve::Fr *scalars, size_t n, stream_t s_) {
+    if (n == 0) return XYZZ<typename Curve::Fq>::inf();
+    msm_prepare_table<Curve>(ws_, scalars, n, off, nullptr, 0, 0, c, stride, s_);
+    return msm_finish<Curve>(ws_, tables, s_);
+}
+#endif
 
 // ---- fixed-base powers: out[i] = beta^(from + i) * base
 template <class Fr>
@@ -752,7 +920,7 @@ Affine<typename Curve::Fq> *upload_fixed_base_table(const Affine<typename Curve:
     }
     Affine<Fq> *d_table = (Affine<Fq> *)dmalloc(table.size() * sizeof(Affine<Fq>));
     HIP_CHECK(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(Affine<Fq>), hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    sync((stream_t)s);
     return d_table;
 }
 }  // namespace
@@ -773,7 +941,7 @@ void fixed_base_powers(Affine<typename Curve::Fq> *out, const Affine<typename Cu
         hipLaunchKernelGGL((k_fixed_base<Fq, Fr>), dim3((m + 63) / 64), dim3(64), 0, s, d_table, d_sc, m, out + off);
         HIP_LAUNCH_CHECK();
     }
-    HIP_CHECK(hipStreamSynchronize(s));
+    sync((stream_t)s);
     dfree(d_table); dfree(d_sc);
 }
 // out[i] = scalars[i] * base for device-resident scalars (Lagrange-basis SRS points)
@@ -790,21 +958,40 @@ void fixed_base_scalars(Affine<typename Curve::Fq> *out, const Affine<typename C
         hipLaunchKernelGGL((k_fixed_base<Fq, Fr>), dim3((m + 63) / 64), dim3(64), 0, s, d_table, scalars + off, m, out + off);
         HIP_LAUNCH_CHECK();
     }
-    HIP_CHECK(hipStreamSynchronize(s));
+    sync((stream_t)s);
     dfree(d_table);
 }
 
 // ---- sum of bases weighted by SMALL integers (|v| <= 2): the Lagrange-basis commitments of 0/1-valued evaluation vectors.
 // One lane per 16 consecutive bases (short chains: the lanes of a wave diverge between the two classes) keeps two accumulators (|v| = 1, |v| = 2; the sign negates y); a two-level tree sums the partials.
 constexpr int CLS_CHUNK = 16;
-template <class P>
-__global__ void __launch_bounds__(64, 2) k_class_partials(const Affine28<P> *__restrict__ bases, const int8_t *__restrict__ vals, uint32_t n, Acc28<P> *__restrict__ part1,
-                                                           Acc28<P> *__restrict__ part2, uint32_t *__restrict__ flags) {
+template <class Law>
+__global__ void __launch_bounds__(64, 2) k_class_partials(const typename Law::Base *__restrict__ bases, const int8_t *__restrict__ vals, uint32_t n, typename Law::Acc *__restrict__ part1,
+                                                           typename Law::Acc *__restrict__ part2, uint32_t *__restrict__ flags) {
+    using P = typename Law::Params;
     using G = FpMsm<P>;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t s0 = t * CLS_CHUNK;
     if (s0 >= n) return;
     uint32_t e = s0 + CLS_CHUNK < n ? s0 + CLS_CHUNK : n;
+#if ZK_MSM_EDWARDS
+    if constexpr (Law::edwards) {
+        AccTE<P> a1 = te_identity<P>(), a2 = a1;
+        for (uint32_t i = s0; i < e; i++) {
+            int v = vals[i];
+            if (v == 0) continue;
+            Niels28<P> p = bases[i];
+            if (v < 0) { p = niels_neg<P>(p); v = -v; }
+            if (v == 1) te_madd<P>(a1, p);
+            else if (v == 2) te_madd<P>(a2, p);
+            else atomicOr(flags, 2u);
+        }
+        part1[t] = a1;
+        part2[t] = a2;
+        return;
+    } else
+#endif
+    {
     Acc28<P> a1, a2;
     bool inf1 = true, inf2 = true;
     for (uint32_t i = s0; i < e; i++) {
@@ -823,32 +1010,33 @@ __global__ void __launch_bounds__(64, 2) k_class_partials(const Affine28<P> *__r
     }
     part1[t] = inf1 ? inf28<P>() : a1;
     part2[t] = inf2 ? inf28<P>() : a2;
+    }
 }
 // out[b] = sum of in[b * per .. (b+1) * per)   (one block of 256 lanes per output)
-template <class P>
-__global__ void __launch_bounds__(256) k_sum_tree(const Acc28<P> *__restrict__ in, uint32_t total, uint32_t per, Acc28<P> *__restrict__ out) {
-    __shared__ Acc28<P> sh[256];
+template <class A>
+__global__ void __launch_bounds__(256) k_sum_tree(const A *__restrict__ in, uint32_t total, uint32_t per, A *__restrict__ out) {
+    __shared__ A sh[256];
     uint32_t b = blockIdx.x, t = threadIdx.x;
     uint32_t lo = b * per, hi = lo + per < total ? lo + per : total;
-    Acc28<P> acc = inf28<P>();
-    for (uint32_t i = lo + t; i < hi; i += 256) add28<P>(acc, in[i]);
+    A acc = PtOps<A>::identity();
+    for (uint32_t i = lo + t; i < hi; i += 256) PtOps<A>::add(acc, in[i]);
     sh[t] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if ((int)t < s) { Acc28<P> a = sh[t]; add28<P>(a, sh[t + s]); sh[t] = a; }
+        if ((int)t < s) { A a = sh[t]; PtOps<A>::add(a, sh[t + s]); sh[t] = a; }
         __syncthreads();
     }
     if (t == 0) out[b] = sh[0];
 }
-template <class P>
-__global__ void k_points_to_std(const Acc28<P> *__restrict__ in, uint32_t n, XYZZ<Fp<P>> *__restrict__ out) {
+template <class A>
+__global__ void k_points_to_std(const A *__restrict__ in, uint32_t n, XYZZ<Fp<typename PtOps<A>::Params>> *__restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = to_std_point<P>(in[i]);
+    if (i < n) out[i] = PtOps<A>::to_std(in[i]);
 }
 
-template <class Curve>
-bool class_sum(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *bases, const int8_t *vals, size_t n, XYZZ<typename Curve::Fq> *out, stream_t s_) {
-    using P = typename Curve::FqP;
+template <class Curve, class Law>
+static bool class_sum_impl(MsmWorkspace *ws_, const typename Law::Base *bases, const int8_t *vals, size_t n, XYZZ<typename Curve::Fq> *out, stream_t s_) {
+    using A = typename Law::Acc;
     using Fq = typename Curve::Fq;
     hipStream_t s = (hipStream_t)s_;
     *out = XYZZ<Fq>::inf();
@@ -859,26 +1047,40 @@ bool class_sum(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *bases, co
     // scratch carved from the bucket array (sized for >= 2 * chunks + 2 * mid + 2 points by any prior msm of this context, else grown here)
     size_t need_buckets = 2 * (size_t)chunks + 2 * mid + 8;
     ensure_scratch(S, 1, need_buckets, 0);
-    Acc28<P> *p1 = (Acc28<P> *)S.buckets, *p2 = p1 + chunks, *m1 = p2 + chunks, *m2 = m1 + mid, *fin = m2 + mid;
+    A *p1 = (A *)S.buckets, *p2 = p1 + chunks, *m1 = p2 + chunks, *m2 = m1 + mid, *fin = m2 + mid;
     HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 4, s));
-    hipLaunchKernelGGL((k_class_partials<P>), dim3((chunks + 63) / 64), dim3(64), 0, s, bases, vals, (uint32_t)n, p1, p2, S.deferred_count);
+    hipLaunchKernelGGL((k_class_partials<Law>), dim3((chunks + 63) / 64), dim3(64), 0, s, bases, vals, (uint32_t)n, p1, p2, S.deferred_count);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_sum_tree<P>), dim3(mid), dim3(256), 0, s, (const Acc28<P> *)p1, chunks, 256u, m1); HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_sum_tree<P>), dim3(mid), dim3(256), 0, s, (const Acc28<P> *)p2, chunks, 256u, m2); HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_sum_tree<P>), dim3(1), dim3(256), 0, s, (const Acc28<P> *)m1, mid, mid, fin); HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_sum_tree<P>), dim3(1), dim3(256), 0, s, (const Acc28<P> *)m2, mid, mid, fin + 1); HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_points_to_std<P>), dim3(1), dim3(64), 0, s, (const Acc28<P> *)fin, 2u, (XYZZ<Fq> *)S.wsum); HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_sum_tree<A>), dim3(mid), dim3(256), 0, s, (const A *)p1, chunks, 256u, m1); HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_sum_tree<A>), dim3(mid), dim3(256), 0, s, (const A *)p2, chunks, 256u, m2); HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_sum_tree<A>), dim3(1), dim3(256), 0, s, (const A *)m1, mid, mid, fin); HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_sum_tree<A>), dim3(1), dim3(256), 0, s, (const A *)m2, mid, mid, fin + 1); HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_points_to_std<A>), dim3(1), dim3(64), 0, s, (const A *)fin, 2u, (XYZZ<Fq> *)S.wsum); HIP_LAUNCH_CHECK();
     XYZZ<Fq> r[2];
     uint32_t flags = 0;
     HIP_CHECK(hipMemcpyAsync(r, S.wsum, sizeof r, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(&flags, S.deferred_count, 4, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    sync((stream_t)s);
     if (flags) return false;          // a value outside [-2, 2] or a degenerate addition: the caller falls back to the generic MSM
     XYZZ<Fq> t = r[1].dbl();
     t.add(r[0]);
     *out = t;
     return true;
 }
+template <class Curve>
+bool class_sum(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *bases, const int8_t *vals, size_t n, XYZZ<typename Curve::Fq> *out, stream_t s_) {
+    return class_sum_impl<Curve, WeierLaw<typename Curve::FqP>>(ws_, bases, vals, n, out, s_);
+}
+#if ZK_MSM_EDWARDS
+template <class Curve>
+bool class_sum(MsmWorkspace *ws_, const Niels28<typename Curve::FqP> *bases, const int8_t *vals, size_t n, XYZZ<typename Curve::Fq> *out, stream_t s_) {
+    return class_sum_impl<Curve, EdwardsLaw<typename Curve::FqP>>(ws_, bases, vals, n, out, s_);
+}
+template XYZZ<Fq377> msm_finish<Bls377>(MsmWorkspace *, const Niels28<Fq377P> *, stream_t);
+template XYZZ<Fq377> msm<Bls377>(MsmWorkspace *, const Niels28<Fq377P> *, const Fr377 *, size_t, stream_t);
+template XYZZ<Fq377> msm_table<Bls377>(MsmWorkspace *, const Niels28<Fq377P> *, size_t, size_t, int, const Fr377 *, size_t, stream_t);
+template bool class_sum<Bls377>(MsmWorkspace *, const Niels28<Fq377P> *, const int8_t *, size_t, XYZZ<Fq377> *, stream_t);
+#endif
 
 template void msm_sharded_plan<Bls377>(size_t, int *, int *);
 template void msm_sharded_plan<Bls381>(size_t, int *, int *);
@@ -893,6 +1095,8 @@ template XYZZ<Fq381> msm_table<Bls381>(MsmWorkspace *, const Affine28<Fq381P> *,
 template void convert_bases<Bls377>(Affine28<Fq377P> *, const Affine<Fq377> *, size_t, stream_t);
 template void convert_bases<Bls381>(Affine28<Fq381P> *, const Affine<Fq381> *, size_t, stream_t);
 template void build_window_tables<Bls377>(Affine<Fq377> *, size_t, int, stream_t);
+template void table_next<Bls377>(Affine<Fq377> *, const Affine<Fq377> *, size_t, int, int, stream_t);
+template void table_next<Bls381>(Affine<Fq381> *, const Affine<Fq381> *, size_t, int, int, stream_t);
 template void build_window_tables<Bls381>(Affine<Fq381> *, size_t, int, stream_t);
 template int table_windows<Bls377>(int);
 template int table_windows<Bls381>(int);

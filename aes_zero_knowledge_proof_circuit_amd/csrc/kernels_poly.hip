@@ -163,7 +163,7 @@ F poly_eval(const F *p, size_t len, const F &x, F *scratch, stream_t s_) {
     hipLaunchKernelGGL(k_eval_combine, dim3(1), dim3(256), 0, s, scratch, nch, x.pow_u64(64), scratch + nch); HIP_LAUNCH_CHECK();
     F out;
     HIP_CHECK(hipMemcpyAsync(&out, scratch + nch, sizeof(F), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    sync((stream_t)s);
     return out;
 }
 
@@ -223,7 +223,7 @@ size_t count_nonzero(const F *p, size_t n, stream_t s_) {
     HIP_CHECK(hipMemsetAsync(d, 0, 8, s));
     if (n) { hipLaunchKernelGGL(k_count_nonzero, GRID(n), 0, s, p, n, d); HIP_LAUNCH_CHECK(); }
     HIP_CHECK(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    sync((stream_t)s);
     dfree(d);
     return (size_t)h;
 }
@@ -363,7 +363,7 @@ uint64_t chacha_field_stream(F *out, size_t count, const uint32_t key[8], int ro
         HIP_CHECK(hipMemcpyAsync(&h_last, last, 4, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipMemcpyAsync(&h_tail[0], pos + ncand - 1, 4, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipMemcpyAsync(&h_tail[1], flags + ncand - 1, 4, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
+        sync((stream_t)s);
         if (h_last != 0xffffffffu) { pos_words += 8ull * ((uint64_t)h_last + 1); done = count; }
         else { done += (size_t)h_tail[0] + h_tail[1]; pos_words += 8ull * ncand; }   // every accepted candidate of the batch was used
     }

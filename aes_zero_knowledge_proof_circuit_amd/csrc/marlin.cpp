@@ -10,6 +10,8 @@
 #include <thread>
 #include <functional>
 #include <stdexcept>
+#include <cerrno>
+#include <sys/random.h>
 #include "gpu.hpp"
 #include "trace_layout.h"
 #include "transcript.hpp"
@@ -396,6 +398,16 @@ std::vector<Fr> ciphertext_to_public_input(const uint8_t *ct, size_t len) {
 
 // =====================================================================================================================
 // proving key
+// the SRS in the form k_accumulate gathers: BLS12-377's twisted Edwards model (te28.cuh, 168 B per point, 7 products per bucket addition) in the default
+// build, the reduced-radix Weierstrass affine form (112 B, 10 products) with -DZK_MSM_RADIX=30
+#if ZK_MSM_EDWARDS
+using SrsPoint = Niels28<Fq377P>;
+static void srs_convert(SrsPoint *dst, const G1A *src, size_t n, gpu::stream_t s) { gpu::convert_bases_te<Bls377>(dst, src, n, s); }
+#else
+using SrsPoint = Affine28<Fq377P>;
+static void srs_convert(SrsPoint *dst, const G1A *src, size_t n, gpu::stream_t s) { gpu::convert_bases<Bls377>(dst, src, n, s); }
+#endif
+
 struct DevBuf {
     F *p = nullptr; size_t n = 0;
     void alloc(size_t count) { n = count; p = (F *)gpu::dmalloc(count * sizeof(F)); }
@@ -458,13 +470,13 @@ class ProvingKeyImpl {
     // device SRS, reduced-radix copies (ff28.cuh) -- what k_accumulate gathers.  Copy 0 = powers_of_g[0..=supported_degree] followed by the shifted
     // range (one index space: merged openings name bases of both); with window tables (use_tables) copies j = 1.. follow at j * srs_stride and hold
     // 2^(table_c * j) * copy 0 (gpu.hpp msm_prepare_table).  d_shifted = d_powers + n_plain (copy 0's shifted part).
-    Affine28<Fq377P> *d_powers = nullptr, *d_shifted = nullptr;
+    SrsPoint *d_powers = nullptr, *d_shifted = nullptr;
     size_t srs_stride = 0, n_plain = 0;
     size_t table_min_n = 500000;    // MSMs below this many points keep the per-window buckets (their own, smaller c)
     // Lagrange-basis SRS over H (ZKAES_LAGRANGE=0 disables): L_k(beta) G for z_A, z_B; L_k(beta)/v_X(beta) G (zero on X) for w;
     // P_j for the public-input part of w; v_H(beta) G and (v_H/v_X)(beta) G for the blinding terms
     bool use_lagrange = true;
-    Affine28<Fq377P> *d_lag_h = nullptr, *d_lag_w = nullptr;
+    SrsPoint *d_lag_h = nullptr, *d_lag_w = nullptr;
     std::vector<G1A> lag_pj;
     G1A lag_vh, lag_vw;
     int table_c = 22;
@@ -606,11 +618,11 @@ class ProvingKeyImpl {
         for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
     }
 
-    void setup(int kind, size_t message_len, const SrsLiterals &srs);
+    void setup(int kind, size_t message_len, const SrsLiterals &srs, unsigned flags);
     Proof prove(ProverContext &cx, const uint8_t *trace_or_null, const uint8_t *msg, size_t len, const uint8_t *key, const uint8_t *zk_seed, bool throughput = false);
 };
 
-void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs) {
+void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs, unsigned flags) {
     gpu::require_device();
     device = gpu::current_device();
     message_len = message_len_;
@@ -656,35 +668,42 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
     pairing::G2Affine srs_h;
     kzg_setup_points(srs_beta, g, gamma_g, srs_h);
     // window tables pay from the one-block key (|K| = 2^20: 35.5 -> 38.2 proofs/s in batch mode) upwards; tiny circuits keep per-window buckets only
-    use_tables = lg_k >= 20;
-    if (const char *e = getenv("ZKAES_MSM_TABLES")) { use_tables = atoi(e) != 0; force_tables = atoi(e) == 2; }
+    use_tables = lg_k >= 20 && !(flags & KEY_NO_TABLES);
+    if (const char *e = getenv("ZKAES_MSM_TABLES")) { use_tables = atoi(e) != 0 && !(flags & KEY_NO_TABLES); force_tables = atoi(e) == 2; }
     // c = 20: 13 signed windows instead of 15 and 2^19 buckets in ONE set (the 15 x 2^16 per-window buckets cost more to reduce).  c = 22 saves one more
     // window but its 2^21 buckets triple k_reduce_l1 (1.95 ms vs 0.67 ms per MSM): measured slower (profiles/r02_msm_tables.md)
     table_c = 20;
     if (const char *e = getenv("ZKAES_MSM_TABLE_C")) { int v = atoi(e); if (v >= 8 && v <= 24) table_c = v; }
     if (const char *e = getenv("ZKAES_MSM_TABLE_MIN")) table_min_n = (size_t)atoll(e);
-    {   // the short top window lands on 2^(top bits - 1) buckets only; with fewer than ~12 bits those buckets hold n / 2^11 and more points each and
-        // their overflow segments are folded serially (c = 19: 7 bits -> 56 blocks/s, c = 21: 2 bits -> 29 blocks/s against 64.7 at c = 20)
-        const int nw = gpu::table_windows<Bls377>(table_c), top_bits = (Fr::BITS + 1) - (nw - 1) * table_c;
-        if (use_tables && top_bits < 12 && !getenv("ZKAES_MSM_TABLE_C")) use_tables = false;
-    }
-    const size_t n_tab = use_tables ? (size_t)gpu::table_windows<Bls377>(table_c) : 1;
+    // (the windows are balanced since round 3 -- 254 = 7 x 20 + 6 x 19 bits at c = 20, kernels_msm.hip TableLayout -- so no window is short and any c is safe)
+    size_t n_tab = use_tables ? (size_t)gpu::table_windows<Bls377>(table_c) : 1;
     // powers_of_g[0..=supported_degree] and the shifted range live in ONE reduced-radix array (shifted part right after the plain part), so
     // an MSM may name bases of both through one index space (merged openings); table copies repeat that layout at multiples of srs_stride.
     n_plain = supported_degree + 1;
     const size_t n_shift = bounds[1] + 1;
     srs_stride = n_plain + n_shift;
     if (use_tables && (uint64_t)n_tab * srs_stride >= (1ull << 30)) { use_tables = false; }
+    if (use_tables) {
+        // the tables are an optimisation, not a requirement: skip them when the device is short of memory (copies in the reduced-radix form + two staging
+        // copies in the standard form + ~5 GB per prover context a caller may still create) instead of failing key synthesis
+        const size_t need = n_tab * srs_stride * sizeof(SrsPoint) + 2 * srs_stride * sizeof(G1A) + ((size_t)8 << 30);
+        if (gpu::mem_free_bytes() < need) use_tables = false;
+    }
+    if (!use_tables) n_tab = 1;
     {
-        const size_t copies = use_tables ? n_tab : 1;
-        G1A *tmp = (G1A *)gpu::dmalloc(copies * srs_stride * sizeof(G1A));
-        gpu::fixed_base_powers<Bls377>(tmp, g, srs_beta, 0, n_plain, stream);
-        gpu::fixed_base_powers<Bls377>(tmp + n_plain, g, srs_beta, lowest_shift, n_shift, stream);
-        if (use_tables) gpu::build_window_tables<Bls377>(tmp, srs_stride, table_c, stream);
-        d_powers = (Affine28<Fq377P> *)gpu::dmalloc(copies * srs_stride * sizeof(Affine28<Fq377P>));
-        gpu::convert_bases<Bls377>(d_powers, tmp, copies * srs_stride, stream);
+        // copy j is made from copy j - 1 in a two-slot staging buffer (standard form) and converted into its place: the setup peak is the final array
+        // + two staging copies, not twice the final array
+        G1A *stage[2] = {(G1A *)gpu::dmalloc(srs_stride * sizeof(G1A)), use_tables ? (G1A *)gpu::dmalloc(srs_stride * sizeof(G1A)) : nullptr};
+        gpu::fixed_base_powers<Bls377>(stage[0], g, srs_beta, 0, n_plain, stream);
+        gpu::fixed_base_powers<Bls377>(stage[0] + n_plain, g, srs_beta, lowest_shift, n_shift, stream);
+        d_powers = (SrsPoint *)gpu::dmalloc(n_tab * srs_stride * sizeof(SrsPoint));
+        srs_convert(d_powers, stage[0], srs_stride, stream);
+        for (size_t j = 1; j < n_tab; j++) {
+            gpu::table_next<Bls377>(stage[j & 1], stage[(j - 1) & 1], srs_stride, table_c, (int)j, stream);
+            srs_convert(d_powers + j * srs_stride, stage[j & 1], srs_stride, stream);
+        }
         gpu::sync(stream);
-        gpu::dfree(tmp);
+        gpu::dfree(stage[0]); gpu::dfree(stage[1]);
         d_shifted = d_powers + n_plain;
     }
     if (const char *e = getenv("ZKAES_LAGRANGE")) use_lagrange = atoi(e) != 0;
@@ -697,8 +716,8 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
         G1A *tmp = (G1A *)gpu::dmalloc(n * sizeof(G1A));
         auto to28 = [&](const F *sc) {
             gpu::fixed_base_scalars<Bls377>(tmp, g, sc, n, stream);
-            Affine28<Fq377P> *dst = (Affine28<Fq377P> *)gpu::dmalloc(n * sizeof(Affine28<Fq377P>));
-            gpu::convert_bases<Bls377>(dst, tmp, n, stream);
+            SrsPoint *dst = (SrsPoint *)gpu::dmalloc(n * sizeof(SrsPoint));
+            srs_convert(dst, tmp, n, stream);
             gpu::sync(stream);
             return dst;
         };
@@ -1048,16 +1067,25 @@ std::vector<uint8_t> ProvingKey::aes_witness(const uint8_t *message, size_t len,
     gpu::d2h(z.data(), cx.d_z, z.size(), s);
     return z;
 }
-// zero-knowledge randomness of proof i of a chunked / batch call: the caller's seed is domain-separated per proof, Blake2s(seed || i as u64 LE), so no two
-// proofs share rho, the KZG hiding coefficients or the mask polynomial.  seed == nullptr keeps the reference's behaviour (every encrypt() call
-// draws from ark_std::test_rng(), src/lib.rs:65): bit-parity mode for tests, NOT zero-knowledge across proofs.
+// zero-knowledge randomness of proof i of a chunked / batch call: the caller's seed is domain-separated per proof, Blake2s(seed || (offset + i) as u64 LE),
+// so no two proofs share rho, the KZG hiding coefficients or the mask polynomial -- across calls and ranks too when they pass job-global offsets.
+// seed == nullptr keeps the reference's behaviour (every encrypt() call draws from ark_std::test_rng(), src/lib.rs:65): bit-parity mode for tests,
+// NOT zero-knowledge across proofs; the C ABI only reaches it with ZKAES_PARITY_RNG=1 or the explicit *_seeded(NULL) calls.
+void os_random_seed(uint8_t out[32]) {
+    size_t got = 0;
+    while (got < 32) {
+        ssize_t r = getrandom(out + got, 32 - got, 0);
+        if (r < 0) { if (errno == EINTR) continue; throw std::runtime_error("getrandom failed: no entropy for the prover's zero-knowledge seed"); }
+        got += (size_t)r;
+    }
+}
 static void derive_zk_seed(uint8_t out[32], const uint8_t *seed32, uint64_t index) {
     uint8_t buf[40];
     memcpy(buf, seed32, 32);
     for (int i = 0; i < 8; i++) buf[32 + i] = (uint8_t)(index >> (8 * i));
     Blake2s::digest(out, buf, sizeof buf);
 }
-static std::vector<Proof> prove_many(ProvingKeyImpl *impl, const uint8_t *messages, const uint8_t *keys, size_t key_stride, size_t n_chunks, size_t n_contexts, const uint8_t *zk_seed) {
+static std::vector<Proof> prove_many(ProvingKeyImpl *impl, const uint8_t *messages, const uint8_t *keys, size_t key_stride, size_t n_chunks, size_t n_contexts, const uint8_t *zk_seed, uint64_t index_offset) {
     size_t chunk = impl->circuit.n_blocks * 16;
     if (n_contexts == 0) n_contexts = 1;
     n_contexts = std::min(n_contexts, std::max<size_t>(n_chunks, 1));
@@ -1074,11 +1102,12 @@ static std::vector<Proof> prove_many(ProvingKeyImpl *impl, const uint8_t *messag
                 size_t i = next.fetch_add(1);
                 if (i >= n_chunks) break;
                 uint8_t seed_i[32];
-                if (zk_seed) derive_zk_seed(seed_i, zk_seed, (uint64_t)i);
+                if (zk_seed) derive_zk_seed(seed_i, zk_seed, index_offset + (uint64_t)i);
                 proofs[i] = impl->prove(cx, nullptr, messages + i * chunk, chunk, keys + i * key_stride, zk_seed ? seed_i : nullptr, n_chunks > 1);   // a multi-proof call is a throughput call
             }
         } catch (const std::exception &e) { errors[ci] = e.what(); }
     };
+    gpu::ThroughputWaits waits(n_contexts > 1);     // the context threads sleep-poll their streams instead of spinning (runtime.hip)
     std::vector<std::thread> threads;
     for (size_t ci = 1; ci < n_contexts; ci++) threads.emplace_back(worker, ci);
     worker(0);
@@ -1086,16 +1115,16 @@ static std::vector<Proof> prove_many(ProvingKeyImpl *impl, const uint8_t *messag
     for (auto &e : errors) if (!e.empty()) throw std::runtime_error(e);
     return proofs;
 }
-std::vector<Proof> ProvingKey::prove_aes_chunked(const uint8_t *message, size_t len, const uint8_t key[16], size_t n_contexts, const uint8_t *zk_seed) {
+std::vector<Proof> ProvingKey::prove_aes_chunked(const uint8_t *message, size_t len, const uint8_t key[16], size_t n_contexts, const uint8_t *zk_seed, uint64_t index_offset) {
     if (impl->circuit.kind != CIRCUIT_AES) throw std::invalid_argument("proving key was not synthesized for the AES circuit");
     size_t chunk = impl->circuit.n_blocks * 16;
     if (chunk == 0 || len % chunk) throw std::invalid_argument("message length must be a multiple of the key's plaintext length (" + std::to_string(chunk) + " bytes)");
-    return prove_many(impl, message, key, 0, len / chunk, n_contexts, zk_seed);
+    return prove_many(impl, message, key, 0, len / chunk, n_contexts, zk_seed, index_offset);
 }
-std::vector<Proof> ProvingKey::prove_aes_batch(const uint8_t *messages, const uint8_t *keys, size_t n, size_t n_contexts, const uint8_t *zk_seed) {
+std::vector<Proof> ProvingKey::prove_aes_batch(const uint8_t *messages, const uint8_t *keys, size_t n, size_t n_contexts, const uint8_t *zk_seed, uint64_t index_offset) {
     if (impl->circuit.kind != CIRCUIT_AES) throw std::invalid_argument("proving key was not synthesized for the AES circuit");
     if (impl->circuit.n_blocks == 0) throw std::invalid_argument("proving key has an empty plaintext");
-    return prove_many(impl, messages, keys, 16, n, n_contexts, zk_seed);
+    return prove_many(impl, messages, keys, 16, n, n_contexts, zk_seed, index_offset);
 }
 Proof ProvingKey::prove_ops(uint32_t x, uint32_t y, const uint8_t *zk_seed) {
     if (impl->circuit.kind == CIRCUIT_AES) throw std::invalid_argument("proving key was synthesized for the AES circuit");
@@ -1123,10 +1152,10 @@ std::vector<uint8_t> ProvingKey::debug_fetch(const std::string &name) const {
     throw std::invalid_argument("debug_fetch: unknown buffer " + name);
 }
 
-std::unique_ptr<ProvingKey> synthesize_keys(int circuit_kind, size_t message_len, const SrsLiterals &srs) {
+std::unique_ptr<ProvingKey> synthesize_keys(int circuit_kind, size_t message_len, const SrsLiterals &srs, unsigned flags) {
     std::unique_ptr<ProvingKey> pk(new ProvingKey());
     pk->impl = new ProvingKeyImpl();
-    pk->impl->setup(circuit_kind, message_len, srs);
+    pk->impl->setup(circuit_kind, message_len, srs, flags);
     return pk;
 }
 

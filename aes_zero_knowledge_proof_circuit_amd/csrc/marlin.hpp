@@ -65,10 +65,12 @@ class ProvingKey {
     // ark_std::test_rng()'s (what simpleworks::marlin::generate_rand() returns)
     Proof prove_aes(const uint8_t *message, size_t len, const uint8_t key[16], const uint8_t *zk_seed);
     // ceil(len / chunk) independent chunk-proofs of a long ECB message, `n_contexts` proofs in flight on separate HIP streams
-    // zk_seed: 32-byte seed, domain-separated per proof (Blake2s(seed || index)); nullptr = the reference's fixed test_rng seed for every proof (parity mode)
-    std::vector<Proof> prove_aes_chunked(const uint8_t *message, size_t len, const uint8_t key[16], size_t n_contexts, const uint8_t *zk_seed = nullptr);
+    // zk_seed: 32-byte seed, domain-separated per proof: proof i of the call draws from StdRng(Blake2s(seed || (index_offset + i) as u64 LE)), so callers that
+    // split one job over several calls / ranks pass the job-global index of their first proof and reuse one seed.  nullptr = the reference's fixed
+    // test_rng seed for every proof (byte-parity mode for tests; NOT zero-knowledge across proofs)
+    std::vector<Proof> prove_aes_chunked(const uint8_t *message, size_t len, const uint8_t key[16], size_t n_contexts, const uint8_t *zk_seed = nullptr, uint64_t index_offset = 0);
     // n independent (message_i, key_i) pairs, each message of the key's plaintext length; keys = n x 16 bytes
-    std::vector<Proof> prove_aes_batch(const uint8_t *messages, const uint8_t *keys, size_t n, size_t n_contexts, const uint8_t *zk_seed = nullptr);
+    std::vector<Proof> prove_aes_batch(const uint8_t *messages, const uint8_t *keys, size_t n, size_t n_contexts, const uint8_t *zk_seed = nullptr, uint64_t index_offset = 0);
     Proof prove_ops(uint32_t x, uint32_t y, const uint8_t *zk_seed);
     // witness generation only (kernels aes_trace + witness_expand): z = padded instance || witness, one byte per variable
     std::vector<uint8_t> aes_witness(const uint8_t *message, size_t len, const uint8_t key[16]);
@@ -79,8 +81,13 @@ class ProvingKey {
     ProvingKeyImpl *impl;
 };
 
-// universal_setup(literals) + index; GPU required
-std::unique_ptr<ProvingKey> synthesize_keys(int circuit_kind, size_t message_len, const SrsLiterals &srs);
+// universal_setup(literals) + index; GPU required.  flags: KEY_NO_TABLES = do not build the fixed-base window tables of the SRS (13 copies, 6-24 GB per key):
+// multi-proof calls then run 15 per-window-bucket windows instead of 13 table windows (~9 % fewer blocks/s), and the key fits a GPU that is short of memory.
+// Without the flag the tables are built when memory allows (hipMemGetInfo) and silently skipped otherwise.
+enum : unsigned { KEY_NO_TABLES = 1u };
+std::unique_ptr<ProvingKey> synthesize_keys(int circuit_kind, size_t message_len, const SrsLiterals &srs, unsigned flags = 0);
+// 32 bytes from the operating system (getrandom): the default zero-knowledge seed of the multi-proof entry points
+void os_random_seed(uint8_t out[32]);
 
 // public_input: the instance values WITHOUT the leading One (0/1 as field elements), e.g. ciphertext bits LSB-first per byte
 bool verify(const VerifyingKey &vk, const std::vector<Fr> &public_input, const Proof &proof);

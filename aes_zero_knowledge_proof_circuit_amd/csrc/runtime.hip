@@ -1,5 +1,8 @@
 // csrc/runtime.hip -- thin HIP runtime plumbing (allocation, copies, streams, events)
+#include <atomic>
 #include <cstdlib>
+#include <cstring>
+#include <time.h>
 #include "hip_util.hpp"
 
 namespace zk {
@@ -25,16 +28,41 @@ void require_device() {
     if (device_count() <= 0) throw GpuError("no HIP device available: libzkaes proves on an AMD GPU (gfx950) and has no CPU fallback");
 }
 int current_device() { int d = 0; HIP_CHECK(hipGetDevice(&d)); return d; }
-// (hipDeviceScheduleBlockingSync was tried for the 16 waiting prover threads per GPU: the bench hangs with it on ROCm 7.2 -- profiles/r02_msm_tables.md section 6 -- so waits keep
-// the runtime's default policy; a saturated run keeps ~13 host cores busy per GPU.)
+// ---- how a host thread waits for its stream.  hipStreamSynchronize spins (ROCclr's default "active wait"): right for a lone encrypt() call, whose waits are
+// short and on the critical path, but a throughput call keeps one host thread per prover context waiting most of the time -- 16 spinning threads per GPU
+// were ~13 busy cores per rank in round 2, 104 of a node's 128 cores at 8 ranks.  (hipDeviceScheduleBlockingSync hangs the bench on ROCm 7.2,
+// profiles/r02_msm_tables.md section 6, so the interrupt path is not used.)  While a ThroughputWaits scope is alive, sync() polls hipStreamQuery with
+// nanosleep back-off instead: 50 -> 200 us quanta, i.e. at most a few hundred microseconds of added latency per wait, hidden behind the other contexts' kernels.
+// ZKAES_WAIT=spin / sleep forces one policy.
+namespace {
+std::atomic<int> g_throughput_waits{0};
+int wait_override() { static const int v = [] { const char *e = getenv("ZKAES_WAIT"); return !e ? 0 : !strcmp(e, "spin") ? 1 : !strcmp(e, "sleep") ? 2 : 0; }(); return v; }
+}  // namespace
+ThroughputWaits::ThroughputWaits(bool on) : on_(on) { if (on_) g_throughput_waits.fetch_add(1); }
+ThroughputWaits::~ThroughputWaits() { if (on_) g_throughput_waits.fetch_sub(1); }
+void sync(stream_t s_) {
+    hipStream_t s = (hipStream_t)s_;
+    const int ov = wait_override();
+    if (ov == 1 || (ov == 0 && g_throughput_waits.load(std::memory_order_relaxed) == 0)) { HIP_CHECK(hipStreamSynchronize(s)); return; }
+    long ns = 50000;
+    for (int spins = 0;; spins++) {
+        hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotReady) HIP_CHECK(e);
+        if (spins < 4) continue;                       // a few immediate re-queries catch the short waits
+        struct timespec ts = {0, ns};
+        nanosleep(&ts, nullptr);
+        if (ns < 200000) ns += 50000;
+    }
+}
 void set_device(int ordinal) { HIP_CHECK(hipSetDevice(ordinal)); }
 void *dmalloc(size_t bytes) { void *p = nullptr; HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16)); return p; }
+size_t mem_free_bytes() { size_t f = 0, t = 0; HIP_CHECK(hipMemGetInfo(&f, &t)); return f; }
 void dfree(void *p) { if (p) (void)hipFree(p); }
 void h2d(void *dst, const void *src, size_t bytes, stream_t s) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)s)); }
-void d2h(void *dst, const void *src, size_t bytes, stream_t s) { if (bytes) { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)s)); HIP_CHECK(hipStreamSynchronize((hipStream_t)s)); } }
+void d2h(void *dst, const void *src, size_t bytes, stream_t s) { if (bytes) { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)s)); sync(s); } }
 void d2d(void *dst, const void *src, size_t bytes, stream_t s) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s)); }
 void dzero(void *dst, size_t bytes, stream_t s) { if (bytes) HIP_CHECK(hipMemsetAsync(dst, 0, bytes, (hipStream_t)s)); }
-void sync(stream_t s) { HIP_CHECK(hipStreamSynchronize((hipStream_t)s)); }
 // With ZKAES_STREAM_PRIORITY=1 prover streams are HIGH priority and the MSM workspace of the same context owns a LOW-priority side stream that
 // carries only k_accumulate (kernels_msm.hip run_buckets); measured neutral-to-worse on MI355X, so the default is plain streams.
 stream_t stream_create() {

@@ -49,12 +49,13 @@ def gather_proofs(proofs, device=None):
 
     ONE all-gather of a [rows x stride] uint8 tensor per rank (rows = the largest share, stride = 4-byte length prefix + the longest proof;
     a Marlin proof here is 855 B), preceded by one all-reduce(MAX) that agrees on rows / stride.  ~0.9 KB per chunk-proof: latency-bound on xGMI.
-    Without an initialized process group (single process) the list is returned unchanged.
+    Without an initialized process group (single process) the list is returned unchanged; with one, the collective runs even for a 1-rank group
+    (a 1-rank torchrun / the -m gpu test of one rank's configs[3] share still move their bytes through RCCL).
     """
     import torch
     import torch.distributed as dist
     proofs = [bytes(p) for p in proofs]
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return proofs
     world = dist.get_world_size()
     shape = torch.tensor([len(proofs), max((len(p) for p in proofs), default=0)], dtype=torch.int64, device=device)

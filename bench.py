@@ -11,14 +11,17 @@ the chip does not idle between steps; the timed region is still exactly the --st
 Warm-up steps prove a separate short message.  Every timed proof is verified afterwards on the host (accept rate must be 100 %) together
 with the reference's negative case (a wrong ciphertext must be rejected).
 
-modes (all one process per GPU, torch.distributed over RCCL when launched under torchrun):
-  headline (default)  every rank proves its own --blocks message                         -> "scaling": "weak", no data-path collective
-  strong              ONE --blocks message (default 65536 = BASELINE configs[3]); rank r proves the contiguous chunk range
-                      split_chunks(n, r, world); proofs are all-gathered and rank 0 verifies every one -> "scaling": "strong"
-  batch               --proofs independent single-block proofs on one SRS (configs[4]), sharded the same way -> "scaling": "strong"
+modes (all one process per GPU, torch.distributed over RCCL):
+  headline (default at 1 GPU)   every rank proves its own --blocks message (default 4096)    -> "scaling": "weak", no data-path collective
+  strong   (default at N > 1)   ONE --blocks message sharded over the ranks: rank r proves the contiguous chunk range split_chunks(n, r, world), the
+                                proofs are all-gathered (the job's one exchange, inside the timed region) and rank 0 verifies every one.  Default size =
+                                8192 blocks per rank, i.e. at 8 GPUs exactly BASELINE configs[3]'s 65,536-block (1 MiB) message (~130 s timed at every N;
+                                "scaling": "weak" because the per-GPU share is what stays fixed).  An explicit --blocks fixes the whole job -> "strong".
+  batch                         --proofs independent single-block proofs on one SRS (configs[4]), sharded the same way -> "scaling": "strong"
 
     python bench.py --gpus 1 --steps 4 --warmup 1
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus 8                      # starts 8 ranks itself (re-executes under torch.distributed.run, rank r on GPU r)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...   # what the driver does
 """
 import argparse
 import json
@@ -35,6 +38,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MADS_PER_ADD = 2649.0   # v_mad_u64_u32 per bucket addition of k_accumulate<EdwardsLaw> (7 Fq products x 378 + 3; disassembly of the gfx950 code object)
 CIRCUIT_MODEL_NOTE = ("R1CS of the restated ark-r1cs-std 0.3.1 gadget semantics: 629,856 constraints / 3,002,900 non-zeros at 64 bytes; the reference's own SRS literal "
                       "(src/lib.rs:141) records 866,944 / 4,062,064 for that size and no variant of the source-less simpleworks shift/rotate calls reproduces it "
                       "(tools/circuit_variants.py, DESIGN.md section 2a) -- at the literal's density a 2^20 domain holds 4 blocks per chunk-proof, not 6")
@@ -74,7 +78,9 @@ def cpu_baseline(samples_small=3, samples_chunk=1, chunk_blocks=6, budget_s=150.
     best_chunk = max(out["by_chunk"], key=lambda b: out["by_chunk"][b]["blocks_per_s"])
     out["value"] = out["by_chunk"][best_chunk]["blocks_per_s"]
     out["sample"] = "best of %s: %s" % (", ".join("%sx %s-block chunk-proof" % (len(v["samples_s"]), b) for b, v in out["by_chunk"].items()),
-                                        "%s-block chunk, %.1f s per proof" % (best_chunk, out["by_chunk"][best_chunk]["best_s"]))
+                                        "%s-block chunk, %.1f s per proof (%d sample%s at that size; --cpu-chunk-samples N takes more, ~60 s each)" % (
+                                            best_chunk, out["by_chunk"][best_chunk]["best_s"], len(out["by_chunk"][best_chunk]["samples_s"]),
+                                            "" if len(out["by_chunk"][best_chunk]["samples_s"]) == 1 else "s"))
     out["threads_effective"] = "MSM: windows x point-slices tasks (all %d threads); NTT / polynomial loops: OpenMP static; synthesis + transcript: 1 thread" % nthreads
     return out
 
@@ -89,14 +95,14 @@ def build_parser():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mode", choices=["headline", "strong", "batch"], default="headline")
-    ap.add_argument("--blocks", type=int, default=None, help="ECB blocks of the message (headline: per rank, default 4096; strong: whole job, default 65536)")
+    ap.add_argument("--mode", choices=["headline", "strong", "batch"], default=None, help="default: headline on one rank, strong on several")
+    ap.add_argument("--blocks", type=int, default=None, help="ECB blocks of the message (headline: per rank, default 4096; strong: whole job, default 8192 per rank = 65536 at 8 ranks)")
     ap.add_argument("--proofs", type=int, default=1024, help="batch mode: independent single-block proofs (whole job)")
     ap.add_argument("--chunk", type=int, default=6, help="blocks per chunk-proof (6 = the most that fits |H|=2^20, |K|=2^22 and the reference's SRS literal)")
     ap.add_argument("--contexts", type=int, default=16, help="chunk-proofs in flight per GPU (separate HIP streams)")
     ap.add_argument("--pipeline", type=int, default=2, help="timed slices in flight (1 = strictly one after the other: the chip drains at every step boundary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-chunk-samples", type=int, default=1, help="CPU-oracle samples at the bench's chunk size (0 = one-block samples only)")
+    ap.add_argument("--cpu-chunk-samples", type=int, default=1, help="CPU-oracle samples at the bench's chunk size, ~60 s each (0 = one-block samples only; profiles/ holds a 3-sample run)")
     ap.add_argument("--serial-probe", type=int, default=2, help="chunk-proofs proven one at a time after the timed region for un-overlapped kernel durations (0 = off)")
     return ap
 
@@ -125,9 +131,11 @@ def run(args, api, dist_env=None):
         raise SystemExit("bench.py needs a HIP device: libzkaes has no CPU fallback")
     api.set_device(local_rank)
 
-    mode = args.mode
+    mode = args.mode or ("headline" if world == 1 else "strong")
     chunk = 1 if mode == "batch" else args.chunk
-    total_blocks = args.proofs if mode == "batch" else (args.blocks or (65536 if mode == "strong" else 4096))
+    STRONG_BLOCKS_PER_RANK = 8192                            # x 8 ranks = BASELINE configs[3]'s 65,536-block message
+    total_blocks = args.proofs if mode == "batch" else (args.blocks or (STRONG_BLOCKS_PER_RANK * world if mode == "strong" else 4096))
+    scaling = "weak" if (mode == "headline" or (mode == "strong" and not args.blocks)) else "strong"
     n_full, rem = divmod(total_blocks, chunk)
     n_chunks = n_full + (1 if rem else 0)                    # chunk-proof i < n_full has `chunk` blocks, the last one (if rem) has `rem`
     # ---- this rank's share of the chunk-proof list
@@ -233,8 +241,9 @@ def run(args, api, dist_env=None):
         if s1["launches"]:
             serial = {"proofs": min(args.serial_probe, warm_n), "ms_per_proof": round(1e3 * t_serial / min(args.serial_probe, warm_n), 2),
                       "avg_launch_ms": round(s1["accumulate_ms"] / s1["launches"], 4), "launches": s1["launches"],
+                      "algorithmic_bytes_per_launch": round(128.0 * s1["points"] / s1["launches"]), "pairs_per_launch": round(s1["pairs"] / s1["launches"]),
                       "achieved_GBs": round(128.0 * s1["points"] / 1e9 / (s1["accumulate_ms"] / 1e3), 2),
-                      "int_multiplier_frac": round(3416.0 * s1["pairs"] / 1e12 / (s1["accumulate_ms"] / 1e3) / 28.1, 4)}
+                      "int_multiplier_frac": round(MADS_PER_ADD * s1["pairs"] / 1e12 / (s1["accumulate_ms"] / 1e3) / 28.1, 4)}
 
     # ---- acceptance: every timed proof must verify (host), the wrong-ciphertext negative must be rejected
     from oracle import zko   # checker only: byte-level AES for the expected ciphertext
@@ -279,15 +288,29 @@ def run(args, api, dist_env=None):
         job_blocks = total_blocks * (world if mode == "headline" else 1)
         value = job_blocks / elapsed
         # roofline of the dominant kernel (MSM bucket accumulation, kernels_msm.hip k_accumulate): algorithmic bytes per launch =
-        # 128 B per point (96 B affine base + 32 B scalar) x points in the launch; duration from HIP events on the
-        # kernel's own stream, accumulated over every launch of the timed region (rank 0's launches).
+        # 128 B per point (96 B affine base + 32 B scalar) x points in the launch, divided by the kernel's CHIP time per launch.
+        # HIP events on the kernel's own stream bracket every launch of the timed region, but 16 prover contexts overlap their launches (launch_overlap =
+        # sum of in-situ durations / wall ~ 1.9), so an in-situ duration is stretched by whatever shares the chip with it and summing them counts the chip
+        # twice (round 2's line did that).  Chip time = the un-overlapped duration: the one-context probe right after the timed region (same key, same
+        # kernel, same launch shapes; this is what the one-context rocprof summary under profiles/ must agree with).  Self-check: launches per step x chip
+        # time per launch must fit into a step.
         acc_ms, pts, launches = stats["accumulate_ms"], stats["points"], stats["launches"]
-        achieved = (128.0 * pts / 1e9) / (acc_ms / 1e3) if acc_ms > 0 else 0.0
+        in_situ_ms = acc_ms / max(launches, 1)
+        overlap = acc_ms / (1e3 * elapsed) if elapsed > 0 else 0.0
+        if serial:
+            chip_ms, bytes_per_launch, chip_src = serial["avg_launch_ms"], serial["algorithmic_bytes_per_launch"], "one_context_probe (un-overlapped HIP-event duration, %d launches)" % serial["launches"]
+            pairs_per_launch = serial["pairs_per_launch"]
+        else:
+            chip_ms, bytes_per_launch = in_situ_ms / max(1.0, overlap), 128.0 * pts / max(launches, 1)
+            chip_src = "in-situ duration / launch_overlap (no one-context probe in this mode)"
+            pairs_per_launch = stats["pairs"] / max(launches, 1)
+        achieved = (bytes_per_launch / 1e9) / (chip_ms / 1e3) if chip_ms > 0 else 0.0
+        kernel_ms_per_step = launches / max(args.steps, 1) * chip_ms
         traffic = traffic_src = None
-        for name in ("r02_pmc_k_accumulate_tables.json", "r02_pmc_k_accumulate.json", "r01_pmc_k_accumulate_v12.json"):
+        for name in ("r03_pmc_k_accumulate_tables.json", "r02_pmc_k_accumulate_tables.json", "r02_pmc_k_accumulate.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
-                traffic = round(pmc["hbm_bytes_per_point_window"] * stats["pairs"] / max(launches, 1))
+                traffic = round(pmc["hbm_bytes_per_point_window"] * pairs_per_launch)
                 traffic_src = "separate PMC run of the isolated kernel (profiles/%s: rocprofv3 --pmc bytes per (point, window) gather), scaled by this run's pairs per launch -- not counters of this run" % name
                 break
             except Exception:
@@ -296,16 +319,19 @@ def run(args, api, dist_env=None):
             copy_gbs = round(api.stream_copy_bench(1 << 30, 20), 1)
         except Exception:
             copy_gbs = None
-        mads = 3416.0 * stats["pairs"] / 1e12
+        mads = MADS_PER_ADD * stats["pairs"] / 1e12
+        mads_per_launch = MADS_PER_ADD * pairs_per_launch / 1e12
         workload = {
             "headline": "%d-block (%d B) ECB message per GPU as %d chunk-proofs of %d block(s)%s, sliced over the %d timed steps" % (total_blocks, 16 * total_blocks, n_full, chunk, (" + 1 of %d" % rem) if rem else "", args.steps),
-            "strong": "ONE %d-block (%d B) ECB message as %d chunk-proofs of %d block(s)%s, chunk ranges sharded over %d rank(s), proofs all-gathered, rank 0 verifies all" % (total_blocks, 16 * total_blocks, n_full, chunk, (" + 1 of %d" % rem) if rem else "", world),
+            "strong": "ONE %d-block (%d B) ECB message%s as %d chunk-proofs of %d block(s)%s, chunk ranges sharded over %d rank(s), proofs all-gathered, rank 0 verifies all" % (
+                total_blocks, 16 * total_blocks, " (BASELINE configs[3])" if total_blocks == 65536 else (" (%d blocks per rank: configs[3]'s per-GPU share)" % STRONG_BLOCKS_PER_RANK if not args.blocks else ""),
+                n_full, chunk, (" + 1 of %d" % rem) if rem else "", world),
             "batch": "%d independent single-block proofs on one SRS (own key each), sharded over %d rank(s), proofs all-gathered, rank 0 verifies all" % (total_blocks, world),
         }[mode] + "; BLS12-377 Marlin, |H|=%d |K|=%d, universal SRS literals (866944,513,4062064)" % (info["h"], info["k"])
         out = {
             "metric": "AES-ECB blocks proven/sec (Marlin), proof verifies", "value": round(value, 4), "unit": "blocks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
-            "higher_is_better": True, "scaling": "weak" if mode == "headline" else "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u32 limbs (253-bit Fr / 377-bit Fq modular integers)",
             "data": "synthetic (numpy MT19937 bytes, seed 0x5EED; key fixed, message per rank)" if mode == "headline" else "synthetic (numpy MT19937 bytes, seed 0x5EED; one job shared by all ranks)",
             "config": {"workload": workload, "mode": mode, "blocks_total": job_blocks, "chunk_blocks": chunk, "proofs_total": n_chunks * (world if mode == "headline" else 1),
@@ -318,22 +344,24 @@ def run(args, api, dist_env=None):
             "roofline": {"bound": "hbm", "kernel": "k_accumulate (Pippenger bucket accumulation)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "peak_measured_stream_copy": copy_gbs,
-                         "launches": launches, "avg_launch_ms": round(acc_ms / max(launches, 1), 4), "algorithmic_bytes_per_launch": round(128.0 * pts / max(launches, 1)),
-                         "launch_overlap": round(acc_ms / (1e3 * elapsed), 3),
+                         "avg_launch_ms": round(chip_ms, 4), "avg_launch_ms_source": chip_src, "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                         "launches": launches, "kernel_ms_per_step": round(kernel_ms_per_step, 1), "kernel_share_of_step": round(kernel_ms_per_step / (1e3 * elapsed / args.steps), 3) if elapsed > 0 else None,
+                         "avg_launch_ms_in_situ": round(in_situ_ms, 4), "launch_overlap": round(overlap, 3),
                          "one_context_probe": serial,
-                         "int_multiplier": {"unit": "T v_mad_u64_u32/s", "achieved": round(mads / (acc_ms / 1e3), 2) if acc_ms > 0 else 0.0, "peak": 28.1,
-                                            "frac": round(mads / (acc_ms / 1e3) / 28.1, 4) if acc_ms > 0 else 0.0, "frac_of_wall": round(mads / elapsed / 28.1, 4),
-                                            "note": "the kernel's real roof: 3416 v_mad_u64_u32 per mixed add (6 products x 378 + 2 squarings x 287 + one two-product sum with a shared reduction, 574), one mixed add per "
-                                                    "(point, window) pair; peak = rate of the same Fq product stream in isolation (tools/ubench/rates.hip: 74.4 G products/s x 378). frac divides by the SUM of in-situ "
-                                                    "launch durations: launches of concurrent prover contexts overlap (launch_overlap = that sum / wall), so in-situ durations are stretched -- one_context_probe has the "
-                                                    "un-overlapped figure; frac_of_wall divides by the whole timed region."},
-                         "note": "integer-ALU bound (10 Fq limb products, 9 Montgomery reductions = 3416 v_mad_u64_u32 per mixed add); HBM fraction of O(1%) is the expected regime (BASELINE.md §3); traffic is ~16x the "
-                                 "algorithmic bytes by construction: Pippenger gathers every 112-byte base once per window (15 windows), ~0.9 TB/s, not the limiter"},
+                         "int_multiplier": {"unit": "T v_mad_u64_u32/s", "achieved": round(mads_per_launch / (chip_ms / 1e3), 2) if chip_ms > 0 else 0.0, "peak": 28.1,
+                                            "frac": round(mads_per_launch / (chip_ms / 1e3) / 28.1, 4) if chip_ms > 0 else 0.0, "frac_of_wall": round(mads / elapsed / 28.1, 4),
+                                            "note": "the kernel's real roof: 2649 v_mad_u64_u32 per bucket addition (7 Fq products x 378 on the curve's twisted Edwards model; round 2's XYZZ mixed add needed 3416), one addition per "
+                                                    "(point, window) pair; peak = rate of the same Fq product stream in isolation (tools/ubench/rates.hip: 74.4 G products/s x 378). frac uses the same chip time "
+                                                    "per launch as roofline.frac; frac_of_wall = all multiplies of the timed region / whole timed region."},
+                         "note": "integer-ALU bound (7 Fq limb products with their Montgomery reductions = 2649 v_mad_u64_u32 per bucket addition); HBM fraction of O(1%) is the expected regime (BASELINE.md §3); traffic is ~17x the "
+                                 "algorithmic bytes by construction: every window gathers its own 168-byte precomputed copy of the base (13 windows), ~1.7 TB/s, not the limiter"},
         }
+        if kernel_ms_per_step > 1e3 * elapsed / args.steps * 1.02:
+            out["roofline"]["inconsistent"] = "kernel chip time per step exceeds the step itself"
         if acc_sum != tot_sum or neg_sum != world or tot_sum != out["config"]["proofs_total"]:
             out["error"] = "verification failure"
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(samples_chunk=args.cpu_chunk_samples, chunk_blocks=chunk if chunk > 1 else 6)
+            cb = cpu_baseline(samples_chunk=args.cpu_chunk_samples, chunk_blocks=chunk if chunk > 1 else 6, budget_s=150.0 + 75.0 * max(0, args.cpu_chunk_samples - 1))
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = round(value / cb["value"], 2)
         print(json.dumps(out), flush=True)
@@ -344,8 +372,30 @@ def run(args, api, dist_env=None):
     return out
 
 
+def launch_ranks(argv, n):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run with N ranks on this node (rank r binds GPU r in run()).
+    The driver's own `python -m torch.distributed.run ... bench.py --gpus N` sets WORLD_SIZE and never comes through here."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver only supports dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    return subprocess.call(cmd, env=env)
+
+
 def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
     args = build_parser().parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(argv, args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and int(os.environ.get("RANK", "0")) == 0:
+        print("bench.py: --gpus %d but %d rank(s) were launched; n_gpus reports the ranks that joined" % (args.gpus, world), file=sys.stderr)
     from aes_zero_knowledge_proof_circuit_amd import api
     run(args, api)
 

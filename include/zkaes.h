@@ -12,9 +12,11 @@
  *     (what simpleworks' (de)serialize_proof reads/writes, re-exported at src/lib.rs:52);
  *   - byte buffers returned through `uint8_t**` are owned by the library: release with zkaes_bytes_free.
  *   - a key for a plaintext of 16 bytes or more also holds fixed-base window tables of the SRS (13 copies, ~6 GB for the one-block key, ~24 GB for the
- *     4- to 6-block keys): multi-proof calls (zkaes_encrypt_chunked / _batch) run their large MSMs through them (13 instead of 15 windows of bucket additions),
- *     a lone zkaes_encrypt call keeps the per-window buckets, which have the lower latency, and runs the independent commitments of each round on four
- *     MSM lanes (streams + host threads) side by side;
+ *     4- to 6-block keys; skipped when the device is short of memory or with ZKAES_KEY_NO_TABLES): multi-proof calls (zkaes_encrypt_chunked / _batch) run their
+ *     large MSMs through them (13 balanced windows of 19-20 bits over ONE bucket set instead of 15 windows with their own buckets), a lone zkaes_encrypt call
+ *     keeps the per-window buckets and runs the independent commitments of each round on four MSM lanes (streams + host threads) side by side;
+ *   - host threads of a multi-proof call wait for the GPU by polling with short sleeps (a fraction of a core per prover context); a lone zkaes_encrypt call
+ *     spins, for latency.  ZKAES_WAIT=spin|sleep forces one policy;
  *   - when the library is loaded it exports GPU_MAX_HW_QUEUES=16 unless the variable is already set (one hardware queue per prover context; the ROCm default of 4
  *     lets the contexts' kernels queue behind each other).  It is read at the first HIP call of the process: export it yourself if HIP is initialised earlier;
  *   - the library needs a HIP device (gfx950) for key synthesis and proving and FAILS (non-zero + message) when
@@ -66,28 +68,41 @@ int zkaes_proof_roundtrip(const uint8_t *proof, size_t proof_len, uint8_t **out,
 /* as zkaes_synthesize_keys with an explicit circuit kind and universal-SRS literals (generate_universal_srs arguments) */
 int zkaes_synthesize_keys_ex(int circuit_kind, size_t plaintext_length, size_t srs_num_constraints, size_t srs_num_variables, size_t srs_num_non_zero, zkaes_pk **pk,
                              zkaes_vk **vk);
+/* the same with option flags.  ZKAES_KEY_NO_TABLES: do not build the fixed-base window tables of the SRS (saves 6-24 GB of device memory per key; multi-proof
+ * calls then use 15 per-window-bucket windows instead of 13 table windows, ~9 % fewer proofs per second).  Unknown flag bits are an error. */
+#define ZKAES_KEY_NO_TABLES 1u
+int zkaes_synthesize_keys_ex2(int circuit_kind, size_t plaintext_length, size_t srs_num_constraints, size_t srs_num_variables, size_t srs_num_non_zero, unsigned flags,
+                              zkaes_pk **pk, zkaes_vk **vk);
 /* as zkaes_encrypt with an explicit 32-byte StdRng seed for the prover's zero-knowledge randomness (NULL = test_rng seed) */
 int zkaes_encrypt_seeded(const uint8_t *message, size_t message_len, const uint8_t secret_key[16], const zkaes_pk *pk, const uint8_t *zk_seed32, uint8_t **proof,
                          size_t *proof_len);
 /* chunked proving of a long ECB message: ceil(message_len / chunk_len) independent proofs with one key for chunk_len bytes
- * (the last chunk must be full).  proofs = concatenation, proof_lens[i] = length of proof i (caller array of n_chunks). */
+ * (the last chunk must be full).  proofs = concatenation, proof_lens[i] = length of proof i (caller array of n_chunks).
+ * Zero-knowledge randomness: a FRESH 32-byte seed from the operating system per call (getrandom), proof i drawing from
+ * StdRng(Blake2s(seed || i as u64 LE)) -- unlike the reference's encrypt(), whose every call draws from the fixed ark_std::test_rng() seed
+ * (src/lib.rs:65), these extensions put hundreds of proofs under one AES key and must not share blinding factors.  ZKAES_PARITY_RNG=1 in the environment
+ * restores the fixed stream for every proof (byte-parity with the CPU oracle in tests; not zero-knowledge across proofs). */
 int zkaes_encrypt_chunked(const uint8_t *message, size_t message_len, const uint8_t secret_key[16], const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len,
                           size_t *proof_lens, size_t n_chunks);
 /* n independent (message_i, secret_key_i) pairs on one key / one SRS (BASELINE config 5: many small proofs): messages = n x plaintext
  * length bytes, secret_keys = n x 16 bytes.  Up to ZKAES_CONTEXTS (environment; default ZKAES_DEFAULT_CONTEXTS, the configuration bench.py
- * measures) proofs are in flight per call, each on its own pair of HIP streams.  This entry point cannot check its buffer lengths: prefer
- * zkaes_encrypt_batch_seeded. */
+ * measures) proofs are in flight per call, each on its own pair of HIP streams.  Randomness as zkaes_encrypt_chunked.  This entry point cannot
+ * check its buffer lengths: prefer zkaes_encrypt_batch_seeded. */
 #define ZKAES_DEFAULT_CONTEXTS 16
 int zkaes_encrypt_batch(size_t n, const uint8_t *messages, const uint8_t *secret_keys, const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens);
 /* the chunked / batch calls with explicit buffer lengths (checked: messages_len == n x plaintext length, secret_keys_len == n x 16) and a
- * 32-byte seed for the provers' zero-knowledge randomness.  Proof i draws from StdRng(Blake2s(zk_seed32 || i as u64 LE)), so no two proofs of a
- * call share blinding factors or the mask polynomial.  zk_seed32 == NULL (and the unseeded entry points above) reproduce the reference, where EVERY
- * encrypt() call draws from the fixed ark_std::test_rng() seed (src/lib.rs:65): byte-parity with the reference, but differences of hiding
- * commitments across proofs are then unblinded -- not zero-knowledge; use a fresh random seed per call in production. */
+ * caller-supplied 32-byte seed.  Proof i draws from StdRng(Blake2s(zk_seed32 || (first_proof_index + i) as u64 LE)): a caller that splits ONE job over
+ * several calls or ranks under one seed passes the job-global index of the call's first proof (the *_at variants; the plain ones use 0), so that no
+ * two proofs of the job share blinding factors or the mask polynomial.  zk_seed32 == NULL selects the reference's fixed test_rng() stream for every
+ * proof (explicit byte-parity mode: differences of hiding commitments across proofs are then unblinded -- tests only). */
 int zkaes_encrypt_chunked_seeded(const uint8_t *message, size_t message_len, const uint8_t secret_key[16], const zkaes_pk *pk, const uint8_t *zk_seed32, uint8_t **proofs,
                                  size_t *proofs_len, size_t *proof_lens, size_t n_chunks);
+int zkaes_encrypt_chunked_seeded_at(const uint8_t *message, size_t message_len, const uint8_t secret_key[16], const zkaes_pk *pk, const uint8_t *zk_seed32,
+                                    uint64_t first_proof_index, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens, size_t n_chunks);
 int zkaes_encrypt_batch_seeded(size_t n, const uint8_t *messages, size_t messages_len, const uint8_t *secret_keys, size_t secret_keys_len, const zkaes_pk *pk,
                                const uint8_t *zk_seed32, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens);
+int zkaes_encrypt_batch_seeded_at(size_t n, const uint8_t *messages, size_t messages_len, const uint8_t *secret_keys, size_t secret_keys_len, const zkaes_pk *pk,
+                                  const uint8_t *zk_seed32, uint64_t first_proof_index, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens);
 /* src/ops.rs toy gates proven with Marlin (public input: none) */
 int zkaes_prove_ops(const zkaes_pk *pk, uint32_t x, uint32_t y, const uint8_t *zk_seed32, uint8_t **proof, size_t *proof_len);
 /* generic verify: public_input_bits = instance assignment without the leading One, one byte (0/1) per variable */
@@ -144,17 +159,20 @@ int zkaes_g1_sum(int curve_id, const uint8_t *points_xy, const int *inf, size_t 
  *      XYZZ window sums are left IN DEVICE MEMORY at dev_out (e.g. row `rank` of a [world, bytes] torch.uint8 CUDA tensor)
  *   3. one all-gather of those rows over RCCL (HBM to HBM over xGMI; torch.distributed.all_gather_into_tensor)
  *   4. zkaes_msm_fold_window_sums_dev(curve, dev_in = the gathered [world, bytes] block, world, n_total, out): per-window sum over ranks on the
- *      device, Horner over the windows -> the MSM result.  aes_zero_knowledge_proof_circuit_amd/sharding.py msm_sharded(device_resident=True) is this sequence. */
+ *      device, Horner over the windows -> the MSM result.  aes_zero_knowledge_proof_circuit_amd/sharding.py msm_sharded_device is this sequence. */
 int zkaes_msm_sharded_plan(int curve_id, size_t n_total, int *window_bits, int *n_windows, size_t *bytes_per_rank);
 int zkaes_msm_window_sums_dev(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n_local, size_t n_total, void *dev_out, size_t dev_out_bytes);
 int zkaes_msm_fold_window_sums_dev(int curve_id, const void *dev_in, int world, size_t n_total, uint8_t *out_xy, int *out_inf);
-/* same sum through the precomputed-window path the prover uses for the SRS (tables 2^(c j) P_i built on the fly here; one bucket set) */
+/* same sum through the precomputed-window path the prover uses for the SRS (tables 2^(window offset j) P_i built on the fly here; one bucket set).  For curve 377
+ * this runs on the curve's twisted Edwards model (7-product bucket additions), which requires bases in the prime-order subgroup (as every KZG SRS point is):
+ * a base of order 2 or 4 is refused, other points outside the subgroup are the caller's responsibility.  Curve 381 has no such model and stays on XYZZ. */
 int zkaes_msm_table(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, int window_bits, uint8_t *out_xy, int *out_inf);
 /* device-resident variant for benchmarking: repeats the MSM `reps` times over device copies, returns ms per MSM of the whole pipeline and of
  * the bucket-accumulation kernel alone */
 int zkaes_msm_bench(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, int reps, double *ms_total, double *ms_accumulate);
 /* BLS12-377, synthetic device-made bases (powers of a fixed scalar times the generator) and xorshift scalars: window_bits = 0 per-window
- * signed-digit buckets, else the precomputed-table path.  out_xy (96 B, may be NULL) receives the sum: the two paths must agree. */
+ * signed-digit buckets on the Weierstrass model (the generic zkaes_msm path), < 0 the same buckets on the curve's twisted Edwards model (the prover's
+ * lone-call SRS path), > 0 the precomputed-table path (Edwards).  out_xy (96 B, may be NULL) receives the sum: all paths must agree. */
 int zkaes_msm_bench_synth(size_t n, int window_bits, int reps, double *ms_total, double *ms_accumulate, uint8_t *out_xy);
 /* stream-copy probe: copies `bytes` device-to-device `reps` times with a plain 16 B/lane kernel and returns read+write GB/s -- the measured
  * HBM peak bench.py prints beside the nominal 8 TB/s (SURVEY.md 8d "measure achievable with a stream-copy kernel and report both") */

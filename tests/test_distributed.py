@@ -151,11 +151,39 @@ def test_bench_batch_mode_two_ranks():
 
 
 def test_bench_headline_mode_two_ranks_is_weak_scaling():
-    out = _run_bench(["--gpus", "2", "--blocks", "10", "--chunk", "4", "--steps", "3", "--warmup", "1", "--contexts", "2", "--no-cpu-baseline"])
+    out = _run_bench(["--gpus", "2", "--mode", "headline", "--blocks", "10", "--chunk", "4", "--steps", "3", "--warmup", "1", "--contexts", "2", "--no-cpu-baseline"])
     res = out[0][0]
     assert res["scaling"] == "weak" and res["proofs_verified"] == "6/6" and "error" not in res       # 2 ranks x (2 chunks of 4 + 1 of 2)
     assert res["config"]["blocks_total"] == 20
     assert abs(res["value"] * res["ms_per_step"] * 3 / 1e3 - 20) < 0.5                               # value = all ranks' blocks / timed region (ms_per_step is rounded)
+
+
+def test_bench_default_on_several_ranks_is_the_sharded_configs3_message():
+    """no --mode / --blocks on N > 1 ranks: ONE message of 8192 blocks per rank (65,536 at 8 ranks = BASELINE configs[3]) sharded by chunk range, proofs
+    all-gathered, rank 0 verifies all; the per-GPU share is fixed, so the line says "weak" """
+    out = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "0", "--contexts", "2", "--no-cpu-baseline", "--serial-probe", "0"])
+    res = out[0][0]
+    assert res["config"]["mode"] == "strong" and res["scaling"] == "weak" and res["n_gpus"] == 2 and "error" not in res
+    assert res["config"]["blocks_total"] == 2 * 8192 and res["config"]["proofs_total"] == 2731 and res["proofs_verified"] == "2731/2731"
+    n0 = sum(e[2] for e in out[0][1] if e[0] == "chunked" and e[1] == 96)
+    n1 = sum(e[2] for e in out[1][1] if e[0] == "chunked" and e[1] == 96)
+    assert (n0, n1) == (1366, 1364) and ("chunked", 64, 1) in out[1][1]          # 2730 full chunks + the 4-block remainder on the last rank
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-executes under torch.distributed.run with N ranks (the driver's own torchrun command sets
+    WORLD_SIZE and is left alone)"""
+    import bench
+    calls = []
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr("subprocess.call", lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "4", "--steps", "2"])
+    assert e.value.code == 0 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
 def _gather_worker(rank, world, port, out):
@@ -254,10 +282,14 @@ def test_point_range_sharded_msm_two_gpu_processes():
 
 def _msm_device_worker(rank, world, port, cid, n, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    dev = rank if world > 1 else 0                  # one GPU per rank (RCCL refuses two ranks on one device)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    if world > 1:
+        from aes_zero_knowledge_proof_circuit_amd import api
+        api.set_device(dev)
     bases, scalars = _msm_inputs(cid, n, 4000 + n)
-    out[rank] = sharding.msm_sharded_device(cid, bases, scalars, torch.device("cuda", 0))
+    out[rank] = sharding.msm_sharded_device(cid, bases, scalars, torch.device("cuda", dev))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -272,6 +304,18 @@ def test_point_range_sharded_msm_device_resident_exchange_rccl(cid, n):
     mp.spawn(_msm_device_worker, args=(1, port, cid, n, out), nprocs=1, join=True)
     bases, scalars = _msm_inputs(cid, n, 4000 + n)
     assert out[0] == _oracle_msm(cid)(bases, scalars)
+
+
+@pytest.mark.gpu
+def test_point_range_sharded_msm_device_resident_exchange_two_gpus():
+    """the same over TWO RCCL ranks on two GPUs (skipped on a one-GPU box): rank-major rows of the all-gather, stream ordering between libzkaes and RCCL"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    cid, n, port = 377, 5000, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_msm_device_worker, args=(2, port, cid, n, out), nprocs=2, join=True)
+    bases, scalars = _msm_inputs(cid, n, 4000 + n)
+    assert out[0] == out[1] == _oracle_msm(cid)(bases, scalars)
 
 
 @pytest.mark.gpu

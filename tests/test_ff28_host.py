@@ -79,6 +79,19 @@ def test_reduced_radix_group_law_matches_xyzz_reference():
             assert out.stdout.split() == ["bls377", "0", "bls381", "0"], (radix, out.stdout)
 
 
+def test_twisted_edwards_group_law_matches_xyzz_reference():
+    """csrc/te28.cuh (BLS12-377 G1 on its twisted Edwards model: the 7-product precomputed-point addition of k_accumulate, the unified full addition and
+    doubling of the bucket reduction, negation, both maps) against XYZZ<Fq> on random points of the prime-order subgroup: accumulation chains from the
+    identity incl. P + P and P - P through the unified law, running sums, double-and-add, infinity <-> identity, a 2-torsion point is refused."""
+    src_path = os.path.join(ROOT, "tests", "te28_host_check.cpp")
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", CSRC, src_path, "-o", exe])
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert out.stdout.split() == ["te377", "0"], out.stdout
+
+
 SRC29 = r'''
 #include "ff29.cuh"
 #include <cstdio>

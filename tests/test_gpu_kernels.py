@@ -107,7 +107,8 @@ def test_msm_2_16_matches_oracle(zko, api):
 @pytest.mark.parametrize("cid", [377, 381])
 @pytest.mark.parametrize("n,c", [(1, 8), (33, 5), (1000, 11), (1 << 12, 13), ((1 << 13) + 3, 20)])
 def test_msm_precomputed_window_tables_match_oracle(zko, api, cid, n, c):
-    """the prover's SRS path: tables 2^(c j) P_i, one shared bucket set (kernels_msm.hip msm_table)"""
+    """the prover's SRS path: tables 2^(offset of window j) P_i over balanced windows (254 or 256 bits spread evenly: widths c and c - 1), one shared
+    bucket set (kernels_msm.hip msm_table, TableLayout)"""
     bases = oracle_points(zko, cid, n, 3 * n + c)
     scalars = bytearray(rand_fr_mont(n, zko.FR[cid], 5 * n + c))
     if n >= 33:
@@ -135,10 +136,10 @@ def test_msm_skewed_scalars_use_the_overflow_path(zko, api, distinct):
     assert not inf and not ref_inf and got == ref.raw
 
 
-@pytest.mark.parametrize("distinct,n,c", [(1, 20_000, 12), (3, 20_000, 16), (2, 70_000, 9)])
+@pytest.mark.parametrize("distinct,n,c", [(1, 40_000, 12), (3, 20_000, 16), (2, 140_000, 9)])
 def test_msm_table_skewed_scalars_fold_overflow_runs_across_workgroups(zko, api, distinct, n, c):
-    """table mode cuts buckets above 256 points into overflow segments; with one to three distinct scalars a bucket has 26 ... 270 segments, so its
-    runs span several 64-segment workgroups of k_accumulate_tail (LDS fold per workgroup) and k_reduce_l1 picks up one partial per workgroup"""
+    """table mode cuts buckets above 512 points into overflow segments; with one to three distinct scalars a bucket has 13 ... 136 segments, so its
+    runs span up to three 64-segment workgroups of k_accumulate_tail (LDS fold per workgroup) and k_reduce_l1 picks up one partial per workgroup"""
     bases = oracle_points(zko, 377, n, 515 + n)
     vals = [int.from_bytes(np.random.RandomState(900 + i).bytes(31), "little") for i in range(distinct)]
     scalars = zko.fr_pack([vals[i % distinct] for i in range(n)])
@@ -148,10 +149,13 @@ def test_msm_table_skewed_scalars_fold_overflow_runs_across_workgroups(zko, api,
     assert not inf and not ref_inf and got == ref.raw
 
 
-def test_msm_full_size_two_independent_paths_agree(api):
-    """BASELINE-size MSM (2^20 points = |H| of a 6-block proof; the oracle would need minutes): the signed-digit per-window path and the
-    precomputed-table single-bucket-set path are different algorithms over different table copies -- their sums must be identical."""
+def test_msm_full_size_independent_paths_agree(api):
+    """BASELINE-size MSM (2^20 points = |H| of a 6-block proof; the oracle would need minutes): per-window buckets on the Weierstrass model (XYZZ, the
+    generic path), the same buckets on the twisted Edwards model (the prover's lone-call SRS path), and the precomputed-table single-bucket-set path
+    (Edwards, 13 balanced windows) are different algorithms, group laws and table copies -- their sums must be identical."""
     n = 1 << 20
     _, _, p_classic = api.msm_bench_synth(n, 0, 1, want_point=True)
-    _, _, p_table = api.msm_bench_synth(n, 17, 1, want_point=True)
-    assert p_classic == p_table and p_classic != bytes(96)
+    _, _, p_edwards = api.msm_bench_synth(n, -1, 1, want_point=True)
+    _, _, p_table17 = api.msm_bench_synth(n, 17, 1, want_point=True)
+    _, _, p_table20 = api.msm_bench_synth(n, 20, 1, want_point=True)
+    assert p_classic == p_edwards == p_table17 == p_table20 and p_classic != bytes(96)

@@ -151,7 +151,7 @@ def test_batch_of_independent_single_block_proofs(zko, api, aes16):
     pk, vk = aes16
     msgs = [mt_bytes(16, 300 + i) for i in range(12)]
     keys = [mt_bytes(16, 400 + i) for i in range(12)]
-    proofs = pk.encrypt_batch(msgs, keys)
+    proofs = pk.encrypt_batch(msgs, keys, zk_seed=api.PARITY)
     assert len(proofs) == 12
     for i, (m, k, p) in enumerate(zip(msgs, keys, proofs)):
         assert api.verify_encryption(vk, p, zko.aes_encrypt(m, k))
@@ -163,7 +163,7 @@ def test_batch_of_independent_single_block_proofs(zko, api, aes16):
 def test_chunked_message_equals_individual_proofs(api, aes16):
     pk, vk = aes16
     key, msg = mt_bytes(16, 500), mt_bytes(16 * 5, 501)
-    proofs = pk.encrypt_chunked(msg, key)
+    proofs = pk.encrypt_chunked(msg, key, zk_seed=api.PARITY)
     assert proofs == [api.encrypt(msg[16 * i:16 * i + 16], key, pk) for i in range(5)]
 
 
@@ -233,9 +233,9 @@ def test_aes96_matches_the_committed_oracle_fixture(api, aes96):
         assert hashlib.sha256(got).hexdigest() == want, name
     assert proof.hex() == fx["proof"] and hashlib.sha256(proof).hexdigest() == fx["proof_sha256"]
     assert api.verify_encryption(vk, proof, bytes.fromhex(fx["ciphertext"])) is True
-    # a lone encrypt() call runs its MSMs over per-window buckets; a multi-proof call runs them through the fixed-base window tables (13 signed windows,
-    # one bucket set): the same group elements, so the same bytes -- the bench's code path against the oracle fixture
-    two = pk.encrypt_chunked(msg + msg, key)
+    # a lone encrypt() call runs its MSMs over per-window buckets; a multi-proof call runs them through the fixed-base window tables (13 balanced signed
+    # windows of 19-20 bits, one bucket set): the same group elements, so the same bytes -- the bench's code path against the oracle fixture
+    two = pk.encrypt_chunked(msg + msg, key, zk_seed=api.PARITY)
     assert two[0] == proof and two[1] == proof
     for name, want in fx["poly_sha256"].items():
         assert hashlib.sha256(pk.debug_fetch(name)).hexdigest() == want, name
@@ -256,7 +256,7 @@ def test_config_64_block_message_as_10x6_plus_4(zko, api, aes96):
     pk4, vk4 = api.synthesize_keys(64)
     key, msg = mt_bytes(16, 0x5EED), mt_bytes(1024, 0x5EED + 1)
     ct = zko.aes_encrypt(msg, key)
-    proofs = pk.encrypt_chunked(msg[:960], key) + pk4.encrypt_chunked(msg[960:], key)
+    proofs = pk.encrypt_chunked(msg[:960], key, zk_seed=api.PARITY) + pk4.encrypt_chunked(msg[960:], key, zk_seed=api.PARITY)
     assert len(proofs) == 11 and all(len(p) == 855 for p in proofs)
     jobs = [(vk, proofs[i], ct[96 * i:96 * i + 96]) for i in range(10)] + [(vk4, proofs[10], ct[960:])]
     assert _verify_all(api, jobs) == 11
@@ -268,16 +268,26 @@ def test_config_64_block_message_as_10x6_plus_4(zko, api, aes96):
     assert proofs[7] == api.encrypt(msg[96 * 7:96 * 8], key, pk)
 
 
-def test_config_4096_block_message(zko, api, aes96):
-    """BASELINE configs[2], the headline workload: ONE 4096-block (64 KiB) message = 682 chunk-proofs of 6 blocks + 1 of 4 (about 70 s on one
-    MI355X); 683 / 683 verify, and a ciphertext with one flipped bit per sampled chunk is rejected."""
+def _two_slices_in_flight(pk, msg, key, n_full):
+    """the bench's own concurrency: ZKAES_CONTEXTS=16 prover contexts and TWO encrypt_chunked calls in flight on the same key (bench.py --pipeline 2)"""
+    from concurrent.futures import ThreadPoolExecutor
+    half = n_full // 2
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        a, b = ex.map(lambda r: pk.encrypt_chunked(msg[96 * r[0]:96 * r[1]], key), [(0, half), (half, n_full)])
+    return a + b
+
+
+def test_config_4096_block_message(zko, api, aes96, monkeypatch):
+    """BASELINE configs[2], the headline workload: ONE 4096-block (64 KiB) message = 682 chunk-proofs of 6 blocks + 1 of 4 (about 65 s on one
+    MI355X) at the bench's own concurrency (16 contexts, two slices in flight, fresh OS-seeded prover randomness); 683 / 683 verify, and a
+    ciphertext with one flipped bit per sampled chunk is rejected."""
     pk, vk = aes96
     pk4, vk4 = api.synthesize_keys(64)
     key, msg = mt_bytes(16, 0x5EED), mt_bytes(16 * 4096, 0x5EED + 1)
     ct = zko.aes_encrypt(msg, key)
-    os.environ["ZKAES_CONTEXTS"] = "10"
+    monkeypatch.setenv("ZKAES_CONTEXTS", "16")
     n_full = 4096 // 6
-    proofs = pk.encrypt_chunked(msg[:96 * n_full], key) + pk4.encrypt_chunked(msg[96 * n_full:], key)
+    proofs = _two_slices_in_flight(pk, msg, key, n_full) + pk4.encrypt_chunked(msg[96 * n_full:], key)
     assert len(proofs) == 683
     jobs = [(vk, proofs[i], ct[96 * i:96 * i + 96]) for i in range(n_full)] + [(vk4, proofs[n_full], ct[96 * n_full:])]
     assert _verify_all(api, jobs) == 683
@@ -286,12 +296,56 @@ def test_config_4096_block_message(zko, api, aes96):
         assert api.verify_encryption(vk, proofs[i], bytes(bad)) is False
 
 
-def test_config_1024_single_block_proofs_on_one_srs(zko, api, aes16):
-    """BASELINE configs[4] shape on one GPU: 1,024 independent (message, key) single-block proofs on one SRS / one index"""
+def test_config_65536_block_message_one_ranks_share(zko, api, aes96, monkeypatch):
+    """BASELINE configs[3] (65,536-block = 1 MiB message over 8 GPUs), ONE rank's share on one GPU: rank 3 of 8 proves its contiguous chunk range of the
+    10,923 chunk-proofs (1,365 proofs = 8,190 blocks, ~130 s) exactly as `bench.py --mode strong` does -- same message, same split, per-job seed with
+    job-global proof indices -- then the share goes through the job's one exchange (sharding.gather_proofs over a 1-rank RCCL group) and every
+    gathered proof is verified against the byte-level ciphertext of its position."""
+    import torch
+    import torch.distributed as dist
+    from aes_zero_knowledge_proof_circuit_amd import sharding
+    pk, vk = aes96
+    total_blocks, chunk, world, rank = 65536, 6, 8, 3
+    n_chunks = -(-total_blocks // chunk)
+    lo, hi = sharding.split_chunks(n_chunks, rank, world)
+    assert (n_chunks, hi - lo) == (10923, 1365)
+    key = sharding.synthetic_bytes(16, 0x5EED)
+    msg = sharding.synthetic_bytes(16 * total_blocks, 0x5EED + 1)
+    share = msg[96 * lo:96 * hi]
+    monkeypatch.setenv("ZKAES_CONTEXTS", "16")
+    seed = bytes(range(100, 132))
+    from concurrent.futures import ThreadPoolExecutor
+    mid = (hi - lo) // 2
+    with ThreadPoolExecutor(max_workers=2) as ex:                 # two slices in flight, as the bench issues them
+        a, b = ex.map(lambda r: pk.encrypt_chunked(share[96 * r[0]:96 * r[1]], key, zk_seed=seed, first_proof_index=lo + r[0]), [(0, mid), (mid, hi - lo)])
+    proofs = a + b
+    assert len(proofs) == hi - lo and len(set(proofs)) == hi - lo
+    own_group = not dist.is_initialized()
+    if own_group:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        gathered = sharding.gather_proofs(proofs, device="cuda")
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+    assert gathered == proofs
+    ct = zko.aes_encrypt(share, key)
+    assert _verify_all(api, [(vk, p, ct[96 * i:96 * i + 96]) for i, p in enumerate(gathered)]) == hi - lo
+    assert api.verify_encryption(vk, gathered[0], ct[96:192]) is False
+
+
+def test_config_1024_single_block_proofs_on_one_srs(zko, api, aes16, monkeypatch):
+    """BASELINE configs[4] shape on one GPU: 1,024 independent (message, key) single-block proofs on one SRS / one index, 16 contexts"""
     pk, vk = aes16
     msgs = [mt_bytes(16, 10_000 + i) for i in range(1024)]
     keys = [mt_bytes(16, 20_000 + i) for i in range(1024)]
-    os.environ["ZKAES_CONTEXTS"] = "10"
+    monkeypatch.setenv("ZKAES_CONTEXTS", "16")
     proofs = pk.encrypt_batch(msgs, keys)
     assert len(proofs) == 1024
     assert _verify_all(api, [(vk, p, zko.aes_encrypt(m, k)) for m, k, p in zip(msgs, keys, proofs)]) == 1024
@@ -299,19 +353,25 @@ def test_config_1024_single_block_proofs_on_one_srs(zko, api, aes16):
 
 
 def test_seeded_chunked_and_batch_calls_do_not_share_randomness(zko, api, aes16):
-    """zk_seed: proof i draws from StdRng(Blake2s(seed || i)); equal chunks then get different proofs (different blinding), the call is
-    reproducible, and the unseeded call keeps the reference's fixed-seed behaviour (equal chunks -> equal proofs)."""
+    """zk_seed: proof i draws from StdRng(Blake2s(seed || first_proof_index + i)); equal chunks then get different proofs (different blinding), the call
+    is reproducible, splitting a job over calls with job-global indices gives the same proofs, the DEFAULT (no seed) draws a fresh OS seed per call, and
+    only the explicit parity mode keeps the reference's fixed-seed behaviour (equal chunks -> equal proofs)."""
     pk, vk = aes16
     key, blk = mt_bytes(16, 600), mt_bytes(16, 601)
     msg = blk * 4                                                  # four identical chunks (the reference's own 64-byte test repeats one block)
     ct = zko.aes_encrypt(blk, key)
-    plain = pk.encrypt_chunked(msg, key)
+    plain = pk.encrypt_chunked(msg, key, zk_seed=api.PARITY)
     assert len(set(plain)) == 1                                    # parity mode: same randomness, same proof
+    fresh = pk.encrypt_chunked(msg, key)                           # default: a fresh OS seed per call
+    assert len(set(fresh)) == 4 and plain[0] not in fresh and fresh != pk.encrypt_chunked(msg, key)
+    assert all(api.verify_encryption(vk, p, ct) for p in fresh)
     seed = bytes(range(32))
     seeded = pk.encrypt_chunked(msg, key, zk_seed=seed)
     assert len(set(seeded)) == 4 and plain[0] not in seeded
     assert seeded == pk.encrypt_chunked(msg, key, zk_seed=seed)
     assert seeded != pk.encrypt_chunked(msg, key, zk_seed=bytes(32))
+    # one job split over two calls (ranks) under one seed: job-global indices reproduce the one-call proofs, and index ranges never collide
+    assert pk.encrypt_chunked(msg[:32], key, zk_seed=seed) + pk.encrypt_chunked(msg[32:], key, zk_seed=seed, first_proof_index=2) == seeded
     assert all(api.verify_encryption(vk, p, ct) for p in seeded)
     # first commitment (w, hiding) differs between any two proofs: no shared blinding
     assert len({p[16:64] for p in seeded}) == 4

@@ -349,3 +349,79 @@ def ark_kzg10_setup_points():
         h = ec2_mul(F, cof, (x, y))
         break
     return beta, g, gamma_g, h
+
+
+# ---------------- twisted Edwards model of BLS12-377 G1 (MSM kernels, csrc/te28.cuh) -------------------------------------------------
+# y^2 = x^3 + 1 has the 2-torsion point (-1, 0) and 3 is a square mod q, so the curve has a Montgomery model B v^2 = u^3 + A u^2 + u
+# (u, v) = (s (x + 1), s y), s = 1 / sqrt(3), A = -3 s, B = s, hence the twisted Edwards model a' X^2 + Y^2 = 1 + d' X^2 Y^2 with a' = (A + 2) / B,
+# d' = (A - 2) / B, (X, Y) = (u / v, (u - 1) / (u + 1)); -a' is a square, so X -> f X with f = sqrt(-a') gives a = -1:
+#       -x^2 + y^2 = 1 + d x^2 y^2,   d = -d' / a'.
+# With a = -1 the unified extended-coordinate addition (Hisil-Wong-Carter-Dawson 2008) costs 7 field products when the second operand is a precomputed
+# affine point (y - x, y + x, 2 d x y), against 10 for the XYZZ mixed addition on the Weierstrass model.  d is a square here, so the law is not
+# complete on the whole curve; its exceptional cases need operands whose sum or difference has even order, which cannot happen inside the
+# prime-order subgroup the KZG SRS lives in.
+def edwards_377():
+    q = Q377
+    inv = lambda a: pow(a % q, -1, q)
+    s3 = fp_sqrt(3, q)
+    s3 = min(s3, q - s3)                              # canonical choice of the root
+    s = inv(s3)
+    A, B = (-3 * s) % q, s
+    ap, dp = (A + 2) * inv(B) % q, (A - 2) * inv(B) % q
+    f = fp_sqrt(-ap % q, q)
+    f = min(f, q - f)
+    d = (-dp * inv(ap)) % q
+    return dict(s=s, si=s3, f=f, fi=inv(f), d=d, k2d=2 * d % q, sif=s3 * f % q)
+
+
+def te_from_weierstrass(P, te=None):
+    """affine Weierstrass point (or None) -> affine twisted Edwards point of the a = -1 model"""
+    te = te or edwards_377()
+    q = Q377
+    if P is None:
+        return (0, 1)
+    x, y = P
+    u, v = te["s"] * (x + 1) % q, te["s"] * y % q
+    return (te["f"] * u * pow(v, -1, q) % q, (u - 1) * pow(u + 1, -1, q) % q)
+
+
+def te_to_weierstrass(E, te=None):
+    te = te or edwards_377()
+    q = Q377
+    xe, ye = E
+    if xe == 0 and ye == 1:
+        return None
+    u = (1 + ye) * pow(1 - ye, -1, q) % q
+    v = u * te["f"] * pow(xe, -1, q) % q
+    return ((u * te["si"] - 1) % q, v * te["si"] % q)
+
+
+def te_add(E1, E2, te=None):
+    """unified affine addition on -x^2 + y^2 = 1 + d x^2 y^2"""
+    te = te or edwards_377()
+    q, d = Q377, te["d"]
+    x1, y1 = E1
+    x2, y2 = E2
+    t = d * x1 * x2 * y1 * y2 % q
+    return ((x1 * y2 + y1 * x2) * pow(1 + t, -1, q) % q, (y1 * y2 + x1 * x2) * pow(1 - t, -1, q) % q)
+
+
+def _check_edwards_377():
+    import random
+    te = edwards_377()
+    q, d = Q377, te["d"]
+    rnd = random.Random(5)
+    pts = [ec_mul(rnd.randrange(1, R377), G1_377, q) for _ in range(6)]
+    for P in pts:
+        xe, ye = te_from_weierstrass(P, te)
+        assert (-xe * xe + ye * ye - 1 - d * xe * xe * ye * ye) % q == 0
+        assert te_to_weierstrass((xe, ye), te) == P
+    for P in pts[:3]:
+        for Q in pts[3:]:
+            for A, B in ((P, Q), (P, P), (P, None), (P, (P[0], (-P[1]) % q))):
+                want = ec_add(A, B, q)
+                got = te_add(te_from_weierstrass(A, te), te_from_weierstrass(B, te), te)
+                assert te_to_weierstrass(got, te) == want
+
+
+_check_edwards_377()
