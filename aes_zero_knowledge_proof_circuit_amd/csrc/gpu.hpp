@@ -20,6 +20,7 @@ void require_device();
 int current_device();
 void set_device(int ordinal);                    // throws GpuError("no HIP device ...") -- the product never falls back to the CPU
 void *dmalloc(size_t bytes);
+int knockin();                                   // ZKAES_KNOCKIN measurement mask (runtime.hip)
 size_t mem_free_bytes();                         // free device memory right now (hipMemGetInfo)
 void dfree(void *p);
 void h2d(void *dst, const void *src, size_t bytes, stream_t s);

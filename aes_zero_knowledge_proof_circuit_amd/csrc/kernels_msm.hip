@@ -3,13 +3,15 @@
 // Replaces ark-ec 0.3.0 VariableBaseMSM::multi_scalar_mul (one rayon task per window, Cargo.lock:118) behind
 // KZG10::commit / open (ark-poly-commit 0.3.0) -- SURVEY.md §8 a17.  GPU shape:
 //   1. k_digits      : scalars Montgomery -> canonical, split into c-bit window digits, emit (window|digit, index) pairs
-//   2. radix sort    : hipcub DeviceRadixSort over all windows at once (plumbing, not the hot op)
+//   2. grouping      : table mode: a two-level bucket partition written for this layout (k_part_*); per-window mode: rocPRIM radix sort over all windows at once
 //   3. k_bounds      : bucket [start, end) ranges in the sorted pair list
 //   4. k_accumulate  : ONE LANE PER BUCKET, XYZZ accumulator, mixed adds of affine bases gathered through the sorted
 //                      index list -- the dominant kernel (integer-ALU bound: ~10 Fq products of 12x12 v_mad_u64_u32 each per add)
 //   5. k_reduce_*    : running-sum reduction in 64-bucket segments, then an LDS tree per window
 //   6. host          : Horner over the <= 32 window sums (c doublings each)
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -29,10 +31,6 @@ template <class P> struct WeierLaw { using Params = P; using Base = Affine28<P>;
 template <class P> struct EdwardsLaw { using Params = P; using Base = Niels28<P>; using Acc = AccTE<P>; static constexpr bool edwards = true; };
 #endif
 
-// measurement knob (tools/gpu_runs/knockin.sh): ZKAES_KNOCKIN is a bit mask of pipeline parts to run TWICE (all idempotent, so proofs stay valid) --
-// 1 sort, 2 bucket reductions, 4 tail, 8 accumulate, 16 digits + bounds.  The drop in blocks/s of a saturated bench run is that part's real cost beside
-// the other contexts' kernels, which the one-context profile cannot show.
-static int knockin() { static const int v = [] { const char *e = getenv("ZKAES_KNOCKIN"); return e ? atoi(e) : 0; }(); return v; }
 static MsmStats g_stats;
 static std::mutex g_stats_mu;
 MsmStats msm_stats(bool reset) {
@@ -448,6 +446,7 @@ struct MsmWorkspace {
     uint32_t *sorted_keys = nullptr, *sorted_vals = nullptr;      // whichever half of the double buffers the radix sort finished in
     uint32_t *size_key = nullptr, *size_key2 = nullptr, *ids = nullptr, *order = nullptr, *extra = nullptr, *extra_off = nullptr;
     void *ovf_partial = nullptr; size_t cap_ovf = 0;
+    uint32_t *part_hist = nullptr, *part_offs = nullptr; size_t cap_part = 0;      // two-level partition: (coarse bin, workgroup) histogram and its scan
     size_t plan_n = 0, plan_pairs = 0; int plan_c = 0, plan_nwin = 0;     // state between msm_prepare and msm_finish
     bool plan_table = false; uint32_t plan_cap = BUCKET_CAP;
     uint32_t *deferred = nullptr, *deferred_count = nullptr;
@@ -503,10 +502,29 @@ MsmWorkspace *msm_workspace_create() {
 void msm_workspace_destroy(MsmWorkspace *w) {
     if (!w) return;
     for (void *p : {(void *)w->keys_a, (void *)w->keys_b, (void *)w->vals_a, (void *)w->vals_b, (void *)w->start, (void *)w->end, (void *)w->size_key, (void *)w->size_key2, (void *)w->ids,
-                    (void *)w->order, (void *)w->extra, (void *)w->extra_off, w->ovf_partial, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->wsum, w->tmp}) dfree(p);
+                    (void *)w->order, (void *)w->extra, (void *)w->extra_off, w->ovf_partial, (void *)w->part_hist, (void *)w->part_offs, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->wsum, w->tmp}) dfree(p);
     if (w->ev0) { (void)hipEventDestroy(w->ev0); (void)hipEventDestroy(w->ev1); }
     if (w->low) { (void)hipStreamDestroy(w->low); (void)hipEventDestroy(w->fence_a); (void)hipEventDestroy(w->fence_b); }
     delete w;
+}
+
+// size-balanced visiting order of the buckets (descending size: the 64 lanes of a wave run the same trip count) + overflow segments of oversized buckets
+static void order_buckets(MsmWorkspace &S, size_t nb, uint32_t cap, hipStream_t s) {
+    HIP_CHECK(hipMemsetAsync(S.extra + nb, 0, 4, s));
+    hipLaunchKernelGGL(k_bucket_sizes, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, S.start, S.end, (uint32_t)nb, cap, S.size_key, S.ids, S.extra);
+    HIP_LAUNCH_CHECK();
+    {
+        size_t tb = 0;
+        HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, S.extra, S.extra_off, 0u, nb + 1, rocprim::plus<uint32_t>(), s));
+        if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
+        HIP_CHECK(rocprim::exclusive_scan(S.tmp, tb, S.extra, S.extra_off, 0u, nb + 1, rocprim::plus<uint32_t>(), s));
+    }
+    {
+        size_t tb = 0;
+        HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, S.size_key, S.size_key2, S.ids, S.order, nb, 0u, 13u, s));
+        if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
+        HIP_CHECK(rocprim::radix_sort_pairs(S.tmp, tb, S.size_key, S.size_key2, S.ids, S.order, nb, 0u, 13u, s));
+    }
 }
 
 // shared middle: sort the (key, value) pairs, find bucket ranges, order buckets by descending size, cut oversized buckets
@@ -519,32 +537,17 @@ static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int
     if (sort_bits > 0 && sort_bits < key_bits) key_bits = sort_bits;       // stable sort on the bucket bits only (window-major input)
     size_t tmp_bytes = 0;
     // ping-pong sort: the result stays in whichever buffer the last radix pass wrote (no copy back)
-    hipcub::DoubleBuffer<uint32_t> dk(S.keys_a, S.keys_b), dv(S.vals_a, S.vals_b);
-    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, dk, dv, (int)pairs, 0, key_bits, s));
+    rocprim::double_buffer<uint32_t> dk(S.keys_a, S.keys_b), dv(S.vals_a, S.vals_b);
+    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, pairs, 0u, (unsigned)key_bits, s));
     if (tmp_bytes > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tmp_bytes); S.cap_tmp = tmp_bytes; }
-    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp, tmp_bytes, dk, dv, (int)pairs, 0, key_bits, s));
-    if (knockin() & 1) HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp, tmp_bytes, dk, dv, (int)pairs, 0, key_bits, s));
-    S.sorted_keys = dk.Current(); S.sorted_vals = dv.Current();
+    HIP_CHECK(rocprim::radix_sort_pairs(S.tmp, tmp_bytes, dk, dv, pairs, 0u, (unsigned)key_bits, s));
+    if (knockin() & 1) HIP_CHECK(rocprim::radix_sort_pairs(S.tmp, tmp_bytes, dk, dv, pairs, 0u, (unsigned)key_bits, s));
+    S.sorted_keys = dk.current(); S.sorted_vals = dv.current();
     HIP_CHECK(hipMemsetAsync(S.start, 0, nb * 4, s));
     HIP_CHECK(hipMemsetAsync(S.end, 0, nb * 4, s));
     hipLaunchKernelGGL(k_bounds, dim3((unsigned)(((pairs + 3) / 4 + 255) / 256)), dim3(256), 0, s, S.sorted_keys, pairs, (uint32_t)nb, S.start, S.end);
     HIP_LAUNCH_CHECK();
-    // size-balanced visiting order of the buckets
-    HIP_CHECK(hipMemsetAsync(S.extra + nb, 0, 4, s));
-    hipLaunchKernelGGL(k_bucket_sizes, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, S.start, S.end, (uint32_t)nb, cap, S.size_key, S.ids, S.extra);
-    HIP_LAUNCH_CHECK();
-    {
-        size_t tb = 0;
-        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, S.extra, S.extra_off, (int)(nb + 1), s));
-        if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
-        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(S.tmp, tb, S.extra, S.extra_off, (int)(nb + 1), s));
-    }
-    {
-        size_t tb = 0;
-        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, S.size_key, S.size_key2, S.ids, S.order, (int)nb, 0, 13, s));
-        if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
-        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp, tb, S.size_key, S.size_key2, S.ids, S.order, (int)nb, 0, 13, s));
-    }
+    order_buckets(S, nb, cap, s);
 }
 // shared tail over prepared buckets: accumulate from `bases`, fold overflow segments and deferred degenerate additions, reduce; returns the
 // nsets window sums.  May be called several times on one prepared state with different base arrays (same scalars, e.g. plain + shifted powers).
@@ -602,6 +605,7 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
     std::vector<XYZZ<Fq>> ws(nsets);
     uint32_t n_deferred = 0;
     if (dev_wsum_out) HIP_CHECK(hipMemcpyAsync(dev_wsum_out, S.wsum, sizeof(XYZZ<Fq>) * nsets, hipMemcpyDeviceToDevice, s));   // stays in HBM for a collective
+    sync((stream_t)s);        // drain first (sleeps in throughput mode): the pageable device-to-host copies below wait actively inside HIP
     HIP_CHECK(hipMemcpyAsync(ws.data(), S.wsum, sizeof(XYZZ<Fq>) * nsets, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(&n_deferred, S.deferred_count, 4, hipMemcpyDeviceToHost, s));
     sync((stream_t)s);
@@ -661,6 +665,7 @@ void convert_bases_te(Niels28<typename Curve::FqP> *dst, const Affine<typename C
     size_t lanes = (n + 7) / 8;
     hipLaunchKernelGGL(k_convert_bases_te, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, src, dst, n, d_bad);
     HIP_LAUNCH_CHECK();
+    sync((stream_t)s);        // drain first (sleeps in throughput mode): the pageable device-to-host copies below wait actively inside HIP
     HIP_CHECK(hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, s));
     sync((stream_t)s);
     dfree(d_bad);
@@ -807,6 +812,7 @@ XYZZ<typename Curve::Fq> msm_fold_window_sums_device(const XYZZ<typename Curve::
     hipLaunchKernelGGL((k_fold_ranks<Fq>), dim3(1), dim3(64), 0, s, dev_in, world, nwin, d_out);
     HIP_LAUNCH_CHECK();
     std::vector<XYZZ<Fq>> ws(nwin);
+    sync((stream_t)s);        // drain first (sleeps in throughput mode): the pageable device-to-host copies below wait actively inside HIP
     HIP_CHECK(hipMemcpyAsync(ws.data(), d_out, sizeof(XYZZ<Fq>) * nwin, hipMemcpyDeviceToHost, s));
     sync((stream_t)s);
     dfree(d_out);
@@ -844,6 +850,184 @@ void table_next(Affine<typename Curve::Fq> *next, const Affine<typename Curve::F
     HIP_LAUNCH_CHECK();
 }
 
+// ---- Two-level bucket partition: the table path's replacement for "digits -> radix sort -> bounds" (the generic three-pass 8-bit radix sort of 8-byte
+// (key, value) pairs cost 7.8 ms of a 79.5 ms chunk-proof in the saturated bench: profiles/r03_knockin_edwards.txt).  Specialised to this layout:
+//   * the keys are never materialised as 32-bit words: the 19 bucket bits split into a COARSE bin (the high bits, 2^(B-9) bins) and a 9-bit FINE key;
+//   * pass A (k_part_hist + one scan + k_part_scatter) reads the scalars (32 B each, twice), recodes them into window digits on the fly and scatters
+//     (fine key u16, value u32) into the coarse bins -- every workgroup ranks its tile in LDS and writes bin-contiguous runs; the per-(bin, workgroup)
+//     offsets come from a histogram pass over the same fixed tiling, so there are no global atomics and the output order is deterministic;
+//   * pass B (k_part_fine, one workgroup per coarse bin) counts the 512 fine keys of its bin in LDS, writes the bucket [start, end) ranges that k_bounds
+//     used to find, and scatters the values tile by tile through LDS into their final bucket-contiguous order;
+//   * zero digits are simply not emitted (no SKIP entries), the order inside a bucket is irrelevant to a sum.
+// Traffic per (point, window) pair: ~2.5 + 2.5 B of scalar reads, 6 B written + (2 + 6) B read + 4 B written = ~23 B against ~60 B for digits + radix sort.
+// Skewed scalars (few distinct digits) only make some workgroups of pass B long; nothing overflows.
+constexpr int PART_FINE_BITS = 9, PART_FINE = 1 << PART_FINE_BITS;
+constexpr int PART_THREADS = 256, PART_SPT = 4, PART_TILE = PART_THREADS * PART_SPT;      // scalars per tile of pass A
+constexpr int PART_MAXW = 16;                                                             // windows per scalar (c_hi >= 16)
+constexpr int PART_STAGE = PART_TILE * PART_MAXW;                                         // staged pairs per tile (LDS: 8 B each = 128 KB)
+constexpr uint32_t PART_NBIN_MAX = 1024;                                                  // coarse bins (bucket bits <= 19, i.e. c_hi <= 20)
+constexpr int PART_B_PER = 16, PART_B_TILE = PART_THREADS * PART_B_PER;                   // pass B tile: 4096 pairs
+constexpr uint32_t PART_GRID = 512;                                                       // workgroups of pass A (fixed tiling shared by histogram and scatter; 1 per CU fits by LDS)
+
+// block-wide exclusive scan of an LDS array of `len` counters into `out`; the total goes to *total_out (LDS).  Ends with a barrier.
+__device__ __forceinline__ void part_block_scan(const uint32_t *cnt, uint32_t *out, uint32_t len, uint32_t *wave_sums, uint32_t *total_out) {
+    const uint32_t per = (len + PART_THREADS - 1) / PART_THREADS, t = threadIdx.x, base = t * per;
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < per; i++) if (base + i < len) sum += cnt[base + i];
+    uint32_t incl = sum;                                     // inclusive scan across the 64 lanes of the wave
+    for (int d = 1; d < 64; d <<= 1) { uint32_t v = __shfl_up(incl, d, 64); if ((int)(t & 63) >= d) incl += v; }
+    if ((t & 63) == 63) wave_sums[t >> 6] = incl;
+    __syncthreads();
+    uint32_t off = 0;
+    for (uint32_t w = 0; w < (t >> 6); w++) off += wave_sums[w];
+    uint32_t run = off + incl - sum;
+    for (uint32_t i = 0; i < per; i++) if (base + i < len) { uint32_t c = cnt[base + i]; out[base + i] = run; run += c; }
+    if (t == PART_THREADS - 1) *total_out = run;
+    __syncthreads();
+}
+// window digits of scalar g of the (scal1 ++ scal2) list: fn(bucket = |digit| - 1, value word) for every non-zero digit
+template <class Fr, class Fn>
+__device__ __forceinline__ void part_digits(const Fr *__restrict__ s1, uint32_t n1, uint32_t off1, const Fr *__restrict__ s2, uint32_t off2, uint32_t g, const TableLayout &L, uint32_t stride, Fn &&fn) {
+    uint32_t raw[Fr::N + 1];
+    uint32_t base;
+    if (g < n1) { s1[g].to_raw(raw); base = off1 + g; } else { s2[g - n1].to_raw(raw); base = off2 + (g - n1); }
+    raw[Fr::N] = 0;
+    uint32_t carry = 0;
+    for (int w = 0; w < L.nwin; w++) {
+        const int c = L.width(w), bit = L.offset(w), limb = bit >> 5, sh = bit & 31;
+        const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
+        uint64_t two = limb <= Fr::N - 1 ? ((uint64_t)raw[limb] | ((uint64_t)raw[limb + 1] << 32)) : 0;
+        uint32_t v = ((uint32_t)(two >> sh) & mask) + carry;
+        uint32_t neg = 0;
+        carry = 0;
+        if (v > half) { v = (1u << c) - v; neg = 1u << 31; carry = 1; }
+        if (v) fn(v - 1, ((uint32_t)w * stride + base) | neg);
+    }
+}
+template <class Fr>
+__global__ void __launch_bounds__(PART_THREADS) k_part_hist(const Fr *__restrict__ s1, uint32_t n1, uint32_t off1, const Fr *__restrict__ s2, uint32_t n2, uint32_t off2, TableLayout L,
+                                                            uint32_t stride, uint32_t nbin, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t sh[PART_NBIN_MAX];
+    for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) sh[b] = 0;
+    __syncthreads();
+    const uint32_t n = n1 + n2, ntiles = (n + PART_TILE - 1) / PART_TILE;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+        for (int q = 0; q < PART_SPT; q++) {
+            uint32_t g = tile * PART_TILE + q * PART_THREADS + threadIdx.x;
+            if (g < n) part_digits<Fr>(s1, n1, off1, s2, off2, g, L, stride, [&](uint32_t bucket, uint32_t) { atomicAdd(&sh[bucket >> PART_FINE_BITS], 1u); });
+        }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) hist[(size_t)b * gridDim.x + blockIdx.x] = sh[b];      // bin-major: the scan gives every (bin, workgroup) its range
+}
+template <class Fr>
+__global__ void __launch_bounds__(PART_THREADS) k_part_scatter(const Fr *__restrict__ s1, uint32_t n1, uint32_t off1, const Fr *__restrict__ s2, uint32_t n2, uint32_t off2, TableLayout L,
+                                                               uint32_t stride, uint32_t nbin, const uint32_t *__restrict__ offs, uint32_t *__restrict__ out_val,
+                                                               uint16_t *__restrict__ out_fine) {
+    __shared__ uint32_t cursor[PART_NBIN_MAX], cnt[PART_NBIN_MAX], loc[PART_NBIN_MAX], fill[PART_NBIN_MAX], st_val[PART_STAGE], st_key[PART_STAGE];
+    __shared__ uint32_t wave_sums[PART_THREADS / 64], total;
+    for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) cursor[b] = offs[(size_t)b * gridDim.x + blockIdx.x];
+    const uint32_t n = n1 + n2, ntiles = (n + PART_TILE - 1) / PART_TILE;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) { cnt[b] = 0; fill[b] = 0; }
+        __syncthreads();
+        // 1. how many pairs of this tile fall into every coarse bin; 2. scan; 3. the digits again, every pair to its LDS slot (bin-contiguous);
+        //    recomputing the digits is a few hundred plain instructions per scalar and keeps the pairs out of registers
+        for (int q = 0; q < PART_SPT; q++) {
+            uint32_t g = tile * PART_TILE + q * PART_THREADS + threadIdx.x;
+            if (g < n) part_digits<Fr>(s1, n1, off1, s2, off2, g, L, stride, [&](uint32_t bucket, uint32_t) { atomicAdd(&cnt[bucket >> PART_FINE_BITS], 1u); });
+        }
+        __syncthreads();
+        part_block_scan(cnt, loc, nbin, wave_sums, &total);
+        for (int q = 0; q < PART_SPT; q++) {
+            uint32_t g = tile * PART_TILE + q * PART_THREADS + threadIdx.x;
+            if (g < n) part_digits<Fr>(s1, n1, off1, s2, off2, g, L, stride, [&](uint32_t bucket, uint32_t val) {
+                uint32_t bin = bucket >> PART_FINE_BITS, e = loc[bin] + atomicAdd(&fill[bin], 1u);
+                st_val[e] = val; st_key[e] = bucket;
+            });
+        }
+        __syncthreads();
+        const uint32_t tot = total;
+        for (uint32_t e = threadIdx.x; e < tot; e += PART_THREADS) {        // bin-contiguous runs: consecutive lanes write consecutive addresses
+            uint32_t bucket = st_key[e], bin = bucket >> PART_FINE_BITS, dst = cursor[bin] + (e - loc[bin]);
+            out_val[dst] = st_val[e];
+            out_fine[dst] = (uint16_t)(bucket & (PART_FINE - 1));
+        }
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) cursor[b] += cnt[b];
+    }
+}
+// pass B: one workgroup per coarse bin
+__global__ void __launch_bounds__(PART_THREADS) k_part_fine(const uint32_t *__restrict__ offs, uint32_t grid_a, const uint32_t *__restrict__ in_val, const uint16_t *__restrict__ in_fine,
+                                                            uint32_t *__restrict__ out_val, uint32_t *__restrict__ start, uint32_t *__restrict__ end) {
+    __shared__ uint32_t cnt[PART_FINE], cur[PART_FINE], tcnt[PART_FINE], tloc[PART_FINE], st_val[PART_B_TILE], wave_sums[PART_THREADS / 64], total;
+    __shared__ uint16_t st_f[PART_B_TILE];
+    const uint32_t bin = blockIdx.x, t = threadIdx.x;
+    const uint32_t lo = offs[(size_t)bin * grid_a], hi = offs[(size_t)(bin + 1) * grid_a];
+    for (uint32_t f = t; f < PART_FINE; f += PART_THREADS) cnt[f] = 0;
+    __syncthreads();
+    for (uint32_t e = lo + t; e < hi; e += PART_THREADS) atomicAdd(&cnt[in_fine[e]], 1u);
+    __syncthreads();
+    part_block_scan(cnt, cur, PART_FINE, wave_sums, &total);
+    for (uint32_t f = t; f < PART_FINE; f += PART_THREADS) {
+        const uint32_t k = bin * PART_FINE + f, st = lo + cur[f];
+        start[k] = st; end[k] = st + cnt[f];
+        cur[f] = st;                                     // running write position of fine key f
+    }
+    __syncthreads();
+    for (uint32_t t0 = lo; t0 < hi; t0 += PART_B_TILE) {
+        for (uint32_t f = t; f < PART_FINE; f += PART_THREADS) tcnt[f] = 0;
+        __syncthreads();
+        uint32_t v[PART_B_PER], fr[PART_B_PER];          // value, fine key | rank << 16  (rank < 4096)
+#pragma unroll
+        for (int i = 0; i < PART_B_PER; i++) {
+            uint32_t e = t0 + i * PART_THREADS + t;
+            fr[i] = 0xffffffffu;
+            if (e < hi) { uint32_t f = in_fine[e]; v[i] = in_val[e]; fr[i] = f | (atomicAdd(&tcnt[f], 1u) << 16); }
+        }
+        __syncthreads();
+        part_block_scan(tcnt, tloc, PART_FINE, wave_sums, &total);
+#pragma unroll
+        for (int i = 0; i < PART_B_PER; i++)
+            if (fr[i] != 0xffffffffu) { uint32_t f = fr[i] & 0xffffu, e = tloc[f] + (fr[i] >> 16); st_val[e] = v[i]; st_f[e] = (uint16_t)f; }
+        __syncthreads();
+        const uint32_t tot = total;
+        for (uint32_t e = t; e < tot; e += PART_THREADS) { uint32_t f = st_f[e]; out_val[cur[f] + (e - tloc[f])] = st_val[e]; }
+        __syncthreads();
+        for (uint32_t f = t; f < PART_FINE; f += PART_THREADS) cur[f] += tcnt[f];
+        __syncthreads();
+    }
+}
+// OFF by default (ZKAES_MSM_PARTITION=1 turns it on; read per call so that tests can flip it).  Measured on MI355X (profiles/r03_partition.md): the
+// grouping itself is ~0.2 ms faster per 2^22-point MSM, but k_accumulate runs 5.7 % SLOWER on its output (7.80 vs 7.38 ms): the stable radix sort leaves
+// every bucket ordered by (window, point index), so the lanes of a wave -- buckets of equal size, in lockstep -- gather from the same table copy at
+// nearby indices, a locality the (workgroup, tile)-ordered partition output does not have.  Bench: 75.2 vs 74.6 blocks/s, inside the box-to-box noise.
+static bool partition_enabled() { const char *e = getenv("ZKAES_MSM_PARTITION"); return e && atoi(e) != 0; }
+// digits + grouping of the table path through the two-level partition; leaves S.sorted_vals / S.start / S.end exactly as prepare_buckets would (up to
+// the order inside a bucket and the absent zero-digit entries)
+template <class Fr>
+static void partition_buckets(MsmWorkspace &S, const Fr *scal1, size_t n1, size_t off1, const Fr *scal2, size_t n2, size_t off2, const TableLayout &L, size_t stride, uint32_t cap, hipStream_t s) {
+    const int B = L.c_hi - 1;                                         // bucket bits
+    const uint32_t nbin = 1u << (B - PART_FINE_BITS), G = PART_GRID;
+    const size_t nb = (size_t)1 << B, nh = (size_t)nbin * G + 1;
+    if (nh > S.cap_part) { dfree(S.part_hist); dfree(S.part_offs); S.part_hist = (uint32_t *)dmalloc(nh * 4); S.part_offs = (uint32_t *)dmalloc(nh * 4); S.cap_part = nh; }
+    HIP_CHECK(hipMemsetAsync(S.part_hist + nh - 1, 0, 4, s));
+    for (int rep = (knockin() & 1) ? 0 : 1; rep < 2; rep++) {
+    hipLaunchKernelGGL((k_part_hist<Fr>), dim3(G), dim3(PART_THREADS), 0, s, scal1, (uint32_t)n1, (uint32_t)off1, scal2, (uint32_t)n2, (uint32_t)off2, L, (uint32_t)stride, nbin, S.part_hist);
+    HIP_LAUNCH_CHECK();
+    size_t tb = 0;
+    HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, S.part_hist, S.part_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
+    if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
+    HIP_CHECK(rocprim::exclusive_scan(S.tmp, tb, S.part_hist, S.part_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
+    hipLaunchKernelGGL((k_part_scatter<Fr>), dim3(G), dim3(PART_THREADS), 0, s, scal1, (uint32_t)n1, (uint32_t)off1, scal2, (uint32_t)n2, (uint32_t)off2, L, (uint32_t)stride, nbin,
+                       (const uint32_t *)S.part_offs, S.vals_a, (uint16_t *)S.keys_a);
+    HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_part_fine, dim3(nbin), dim3(PART_THREADS), 0, s, (const uint32_t *)S.part_offs, G, (const uint32_t *)S.vals_a, (const uint16_t *)S.keys_a, S.vals_b, S.start, S.end);
+    HIP_LAUNCH_CHECK();
+    }
+    S.sorted_vals = S.vals_b; S.sorted_keys = nullptr;
+    order_buckets(S, nb, cap, s);
+}
+
 // Table-mode Pippenger in the same two steps as the per-window variant.  msm_prepare_table: signed c-bit digits of up to two scalar vectors
 // (element i of vector v names table entry w * stride + off_v + i in window w), sort on the c - 1 bucket bits, bucket ranges;
 // msm_finish (above) with `tables` = copy 0 (optionally shifted by a constant index, e.g. to the shifted-powers part of every copy).
@@ -866,6 +1050,10 @@ void msm_prepare_table(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_
     const size_t nb = (size_t)1 << (L.c_hi - 1);
     S.plan_c = L.c_hi; S.plan_nwin = nwin; S.plan_pairs = pairs; S.plan_table = true; S.plan_cap = BUCKET_CAP_TABLE;
     ensure_scratch(S, pairs, nb, BUCKET_CAP_TABLE);
+    if (partition_enabled() && L.c_hi - 1 > PART_FINE_BITS && (1u << (L.c_hi - 1 - PART_FINE_BITS)) <= PART_NBIN_MAX && L.nwin <= PART_MAXW && pairs >= ((size_t)1 << 16)) {
+        partition_buckets<Fr>(S, scal1, n1, off1, scal2, n2, off2, L, stride, BUCKET_CAP_TABLE, s);
+        return;
+    }
     if (n1) { hipLaunchKernelGGL((k_digits_table<Fr>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, scal1, (uint32_t)n1, 0u, (uint32_t)n, (uint32_t)off1, L, (uint32_t)stride, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
     if (n2) { hipLaunchKernelGGL((k_digits_table<Fr>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, scal2, (uint32_t)n2, (uint32_t)n1, (uint32_t)n, (uint32_t)off2, L, (uint32_t)stride, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
     prepare_buckets<typename Curve::FqP>(S, pairs, L.c_hi - 1, 1, L.c_hi - 1, BUCKET_CAP_TABLE, s);
@@ -1058,6 +1246,7 @@ static bool class_sum_impl(MsmWorkspace *ws_, const typename Law::Base *bases, c
     hipLaunchKernelGGL((k_points_to_std<A>), dim3(1), dim3(64), 0, s, (const A *)fin, 2u, (XYZZ<Fq> *)S.wsum); HIP_LAUNCH_CHECK();
     XYZZ<Fq> r[2];
     uint32_t flags = 0;
+    sync((stream_t)s);        // drain first (sleeps in throughput mode): the pageable device-to-host copies below wait actively inside HIP
     HIP_CHECK(hipMemcpyAsync(r, S.wsum, sizeof r, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(&flags, S.deferred_count, 4, hipMemcpyDeviceToHost, s));
     sync((stream_t)s);

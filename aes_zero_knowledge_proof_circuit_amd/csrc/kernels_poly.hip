@@ -3,7 +3,8 @@
 // They replace the dense-polynomial plumbing of ark-poly 0.3.0 (DensePolynomial add/mul_by_vanishing/divide_by_vanishing_poly,
 // `p / (X - z)`, evaluate, batch_inversion of ark-ff) that ark-marlin's prover_{first,second,third}_round and
 // KZG10::open call.  All are HBM-streaming: one 32-byte element per lane per access.
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
 #include "hip_util.hpp"
 
 namespace zk {
@@ -73,7 +74,7 @@ void divide_by_vanishing(F *q, F *rem, const F *p, size_t len, size_t m, stream_
 }
 
 // ---- p / (X - z):  q_i = p_{i+1} + z q_{i+1}  =  z^-(i+1) * sum_{j > i} p_j z^j.
-// One single-pass device scan (rocPRIM look-back, through hipcub) over the REVERSED sequence t_j = p_j z^j, with the two scalings folded into
+// One single-pass device scan (rocPRIM's decoupled look-back scan) over the REVERSED sequence t_j = p_j z^j, with the two scalings folded into
 // the scan's input and output iterators: reads p once, writes q once, everything coalesced.  z^j = ZL[j mod 1024] * ZH[j div 1024] from two
 // small tables built per opening point (and the same for 1/z).  Field arithmetic is exact, so the result is bit-identical to the recurrence.
 constexpr int DL_LO_BITS = 10;
@@ -113,7 +114,7 @@ size_t divide_by_linear_scratch(size_t len) {       // in field elements
     size_t tables = 2 * ((1u << DL_LO_BITS) + (len >> DL_LO_BITS) + 1);
     size_t temp = 0;
     DivlinIn in{nullptr, nullptr, nullptr, 0, 0}; DivlinOut out{nullptr, nullptr, nullptr, 0, 0};
-    HIP_CHECK(hipcub::DeviceScan::InclusiveScan(nullptr, temp, in, out, FieldAdd(), (int)len, (hipStream_t)0));
+    HIP_CHECK(rocprim::inclusive_scan(nullptr, temp, in, out, len, FieldAdd(), (hipStream_t)0));
     return tables + (temp + sizeof(F) - 1) / sizeof(F) + 8;
 }
 void divide_by_linear(F *q, const F *p, size_t len, const F &z, F *scratch, size_t scratch_elems, stream_t s_) {
@@ -128,11 +129,11 @@ void divide_by_linear(F *q, const F *p, size_t len, const F &z, F *scratch, size
     size_t used = 2 * ((size_t)lo_count + hi_count), temp_bytes = 0;
     DivlinIn in{p, zl, zh, (ptrdiff_t)(len - 1), 0};
     DivlinOut out{q, il, ih, (ptrdiff_t)(len - 1), 0};
-    HIP_CHECK(hipcub::DeviceScan::InclusiveScan(nullptr, temp_bytes, in, out, FieldAdd(), (int)qlen, s));
+    HIP_CHECK(rocprim::inclusive_scan(nullptr, temp_bytes, in, out, qlen, FieldAdd(), s));
     if (used * sizeof(F) + temp_bytes > scratch_elems * sizeof(F)) throw GpuError("divide_by_linear: scratch too small");
     uint32_t tn = hi_count > lo_count ? hi_count : lo_count;
     hipLaunchKernelGGL(k_divlin_tables, GRID(tn), 0, s, z, z.inverse(), hi_count, zl, zh, il, ih); HIP_LAUNCH_CHECK();
-    HIP_CHECK(hipcub::DeviceScan::InclusiveScan(temp, temp_bytes, in, out, FieldAdd(), (int)qlen, s));
+    HIP_CHECK(rocprim::inclusive_scan(temp, temp_bytes, in, out, qlen, FieldAdd(), s));
 }
 
 // ---- evaluation: chunks of 64 coefficients by Horner, then sum_t partial_t * (x^64)^t
@@ -162,6 +163,7 @@ F poly_eval(const F *p, size_t len, const F &x, F *scratch, stream_t s_) {
     hipLaunchKernelGGL(k_eval_chunks, GRID(nch), 0, s, p, len, x, scratch); HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_eval_combine, dim3(1), dim3(256), 0, s, scratch, nch, x.pow_u64(64), scratch + nch); HIP_LAUNCH_CHECK();
     F out;
+    sync((stream_t)s);        // drain first (sleeps in throughput mode): the pageable device-to-host copies below wait actively inside HIP
     HIP_CHECK(hipMemcpyAsync(&out, scratch + nch, sizeof(F), hipMemcpyDeviceToHost, s));
     sync((stream_t)s);
     return out;
@@ -222,6 +224,7 @@ size_t count_nonzero(const F *p, size_t n, stream_t s_) {
     unsigned long long *d = (unsigned long long *)dmalloc(8), h = 0;
     HIP_CHECK(hipMemsetAsync(d, 0, 8, s));
     if (n) { hipLaunchKernelGGL(k_count_nonzero, GRID(n), 0, s, p, n, d); HIP_LAUNCH_CHECK(); }
+    sync((stream_t)s);        // drain first (sleeps in throughput mode): the pageable device-to-host copies below wait actively inside HIP
     HIP_CHECK(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, s));
     sync((stream_t)s);
     dfree(d);
@@ -354,12 +357,13 @@ uint64_t chacha_field_stream(F *out, size_t count, const uint32_t key[8], int ro
         hipLaunchKernelGGL(k_chacha_blocks, GRID(nblocks), 0, s, words, first_block, nblocks, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7], rounds); HIP_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_rand_flags, GRID(ncand), 0, s, (const uint32_t *)words, word_off, ncand, flags); HIP_LAUNCH_CHECK();
         size_t tb = 0;
-        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flags, pos, (int)ncand, s));
+        HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, flags, pos, 0u, (size_t)ncand, rocprim::plus<uint32_t>(), s));
         if (tb > tmp_bytes) throw GpuError("chacha_field_stream: scan scratch too small");
-        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, flags, pos, (int)ncand, s));
+        HIP_CHECK(rocprim::exclusive_scan(tmp, tb, flags, pos, 0u, (size_t)ncand, rocprim::plus<uint32_t>(), s));
         HIP_CHECK(hipMemsetAsync(last, 0xff, 4, s));
         hipLaunchKernelGGL(k_rand_compact, GRID(ncand), 0, s, (const uint32_t *)words, word_off, ncand, (const uint32_t *)flags, (const uint32_t *)pos, out + done, (uint32_t)want, last); HIP_LAUNCH_CHECK();
         uint32_t h_last = 0, h_tail[2] = {0, 0};
+        sync((stream_t)s);        // drain first (sleeps in throughput mode): the pageable device-to-host copies below wait actively inside HIP
         HIP_CHECK(hipMemcpyAsync(&h_last, last, 4, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipMemcpyAsync(&h_tail[0], pos + ncand - 1, 4, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipMemcpyAsync(&h_tail[1], flags + ncand - 1, 4, hipMemcpyDeviceToHost, s));

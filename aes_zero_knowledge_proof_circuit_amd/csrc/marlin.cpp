@@ -536,11 +536,12 @@ class ProvingKeyImpl {
         return d;
     }
 
-    // Window tables trade latency for throughput: 13 instead of 15 windows of mixed additions, but the short top window's buckets cost ~2 ms of
-    // serial segment chains per MSM (k_accumulate_tail).  With several proofs in flight that latency hides behind other contexts' kernels (+9 % blocks/s);
-    // a lone encrypt() call -- what the reference's criterion bench times -- would just get slower (16 B: 62.6 vs 54 ms), so it keeps the per-window buckets.
-    bool table_ok(const ProverContext &cx, size_t len) const { return use_tables && (cx.throughput || force_tables) && len >= table_min_n; }
-    bool force_tables = false;         // ZKAES_MSM_TABLES=2: tables for lone calls too (measurements)
+    // Window tables: 13 balanced windows over ONE bucket set instead of 15 windows with their own buckets.  Round 2 kept them away from a lone encrypt() call
+    // (the short top window of that layout cost ~2 ms of serial segment chains per MSM); with balanced windows they win there too
+    // (profiles/r03_latency.json: 16 B 36.4 -> 34.3 ms, 64 B 98.6 -> 91.4 ms), so every MSM of at least table_min_n points uses them.
+    // ZKAES_MSM_TABLES=0 builds no tables, =3 keeps lone calls on the per-window buckets (A/B measurements).
+    bool table_ok(const ProverContext &cx, size_t len) const { return use_tables && (cx.throughput || !lone_calls_without_tables) && len >= table_min_n; }
+    bool lone_calls_without_tables = false;
     using Lane = ProverContext::Lane;
     // MSM against powers_of_g starting at `off` (plain or shifted range); device scalars
     XYZZ<Fq377> msm_powers(ProverContext &cx, Lane &ln, bool shifted, size_t off, const F *scalars, size_t len) {
@@ -669,7 +670,7 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
     kzg_setup_points(srs_beta, g, gamma_g, srs_h);
     // window tables pay from the one-block key (|K| = 2^20: 35.5 -> 38.2 proofs/s in batch mode) upwards; tiny circuits keep per-window buckets only
     use_tables = lg_k >= 20 && !(flags & KEY_NO_TABLES);
-    if (const char *e = getenv("ZKAES_MSM_TABLES")) { use_tables = atoi(e) != 0 && !(flags & KEY_NO_TABLES); force_tables = atoi(e) == 2; }
+    if (const char *e = getenv("ZKAES_MSM_TABLES")) { use_tables = atoi(e) != 0 && !(flags & KEY_NO_TABLES); lone_calls_without_tables = atoi(e) == 3; }
     // c = 20: 13 signed windows instead of 15 and 2^19 buckets in ONE set (the 15 x 2^16 per-window buckets cost more to reduce).  c = 22 saves one more
     // window but its 2^21 buckets triple k_reduce_l1 (1.95 ms vs 0.67 ms per MSM): measured slower (profiles/r02_msm_tables.md)
     table_c = 20;

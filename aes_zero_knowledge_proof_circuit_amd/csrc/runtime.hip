@@ -19,6 +19,11 @@ struct HwQueueDefault {
 } g_hw_queue_default;
 }  // namespace
 
+// measurement knob (tools/gpu_runs/r03_knockin.sh): ZKAES_KNOCKIN is a bit mask of pipeline parts to run TWICE (all idempotent, so proofs stay valid) --
+// 1 MSM sort, 2 bucket reductions, 4 tail, 8 accumulate, 32 every NTT.  The drop in blocks/s of a saturated bench run is that part's real cost beside
+// the other contexts' kernels, which a one-context profile cannot show.
+int knockin() { static const int v = [] { const char *e = getenv("ZKAES_KNOCKIN"); return e ? atoi(e) : 0; }(); return v; }
+
 int device_count() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -60,7 +65,9 @@ void *dmalloc(size_t bytes) { void *p = nullptr; HIP_CHECK(hipMalloc(&p, bytes ?
 size_t mem_free_bytes() { size_t f = 0, t = 0; HIP_CHECK(hipMemGetInfo(&f, &t)); return f; }
 void dfree(void *p) { if (p) (void)hipFree(p); }
 void h2d(void *dst, const void *src, size_t bytes, stream_t s) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)s)); }
-void d2h(void *dst, const void *src, size_t bytes, stream_t s) { if (bytes) { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)s)); sync(s); } }
+// a device-to-host copy into pageable memory waits INSIDE hipMemcpyAsync (spinning) for everything queued before it: drain the stream with sync() first,
+// which sleeps in throughput mode, so that only the copy itself (microseconds) is waited for actively
+void d2h(void *dst, const void *src, size_t bytes, stream_t s) { if (bytes) { sync(s); HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)s)); HIP_CHECK(hipStreamSynchronize((hipStream_t)s)); } }
 void d2d(void *dst, const void *src, size_t bytes, stream_t s) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s)); }
 void dzero(void *dst, size_t bytes, stream_t s) { if (bytes) HIP_CHECK(hipMemsetAsync(dst, 0, bytes, (hipStream_t)s)); }
 // With ZKAES_STREAM_PRIORITY=1 prover streams are HIGH priority and the MSM workspace of the same context owns a LOW-priority side stream that

@@ -5,7 +5,7 @@
 //! ark-serialize bytes of `IndexVerifierKey` (`VerifyingKey::to_ark_bytes`), the proving key stays a device-resident handle.
 use anyhow::{anyhow, Result};
 use std::ffi::CStr;
-use std::os::raw::{c_char, c_int};
+use std::os::raw::{c_char, c_int, c_uint};
 use std::sync::Arc;
 
 #[repr(C)]
@@ -19,10 +19,14 @@ extern "C" {
     fn zkaes_pk_free(pk: *mut zkaes_pk);
     fn zkaes_vk_free(vk: *mut zkaes_vk);
     fn zkaes_synthesize_keys(plaintext_length: usize, pk: *mut *mut zkaes_pk, vk: *mut *mut zkaes_vk) -> c_int;
+    fn zkaes_synthesize_keys_ex2(circuit_kind: c_int, plaintext_length: usize, srs_num_constraints: usize, srs_num_variables: usize, srs_num_non_zero: usize, flags: c_uint,
+                                 pk: *mut *mut zkaes_pk, vk: *mut *mut zkaes_vk) -> c_int;
     fn zkaes_encrypt(message: *const u8, message_len: usize, secret_key: *const u8, pk: *const zkaes_pk, proof: *mut *mut u8, proof_len: *mut usize) -> c_int;
     fn zkaes_verify_encryption(vk: *const zkaes_vk, proof: *const u8, proof_len: usize, ciphertext: *const u8, ciphertext_len: usize, accepted: *mut c_int) -> c_int;
-    fn zkaes_encrypt_chunked_seeded(message: *const u8, message_len: usize, secret_key: *const u8, pk: *const zkaes_pk, zk_seed32: *const u8, proofs: *mut *mut u8,
-                                    proofs_len: *mut usize, proof_lens: *mut usize, n_chunks: usize) -> c_int;
+    fn zkaes_encrypt_chunked(message: *const u8, message_len: usize, secret_key: *const u8, pk: *const zkaes_pk, proofs: *mut *mut u8, proofs_len: *mut usize,
+                             proof_lens: *mut usize, n_chunks: usize) -> c_int;
+    fn zkaes_encrypt_chunked_seeded_at(message: *const u8, message_len: usize, secret_key: *const u8, pk: *const zkaes_pk, zk_seed32: *const u8, first_proof_index: u64,
+                                       proofs: *mut *mut u8, proofs_len: *mut usize, proof_lens: *mut usize, n_chunks: usize) -> c_int;
     fn zkaes_vk_serialize_ark(vk: *const zkaes_vk, out: *mut *mut u8, out_len: *mut usize) -> c_int;
     fn zkaes_vk_deserialize_ark(bytes: *const u8, len: usize, vk: *mut *mut zkaes_vk) -> c_int;
 }
@@ -75,6 +79,17 @@ pub fn synthesize_keys(plaintext_length: usize) -> Result<(ProvingKey, Verifying
     Ok((ProvingKey(Arc::new(PkHandle(pk))), VerifyingKey(Arc::new(VkHandle(vk)))))
 }
 
+/// Key synthesis options (include/zkaes.h ZKAES_KEY_*)
+pub const KEY_NO_TABLES: u32 = 1;   // no fixed-base window tables of the SRS: saves 6-37 GB of device memory per key, multi-proof calls run ~9 % slower
+
+/// `synthesize_keys` with options: `flags` = KEY_NO_TABLES to keep the key small (the tables are also skipped automatically when the device is short of memory)
+pub fn synthesize_keys_with(plaintext_length: usize, flags: u32) -> Result<(ProvingKey, VerifyingKey)> {
+    let (mut pk, mut vk) = (std::ptr::null_mut(), std::ptr::null_mut());
+    // circuit kind 0 = the AES circuit; the universal-SRS literals of src/lib.rs:141
+    if unsafe { zkaes_synthesize_keys_ex2(0, plaintext_length, 866_944, 513, 4_062_064, flags as c_uint, &mut pk, &mut vk) } != 0 { return Err(last_error()); }
+    Ok((ProvingKey(Arc::new(PkHandle(pk))), VerifyingKey(Arc::new(VkHandle(vk)))))
+}
+
 /// zk_aes::encrypt (src/lib.rs:60): returns the ark-serialize bytes of the MarlinProof (`deserialize_proof(bytes)` gives the arkworks type)
 pub fn encrypt(message: &[u8], secret_key: &[u8; 16], proving_key: &ProvingKey) -> Result<Vec<u8>> {
     let (mut p, mut n) = (std::ptr::null_mut(), 0usize);
@@ -89,16 +104,34 @@ pub fn verify_encryption(verifying_key: &VerifyingKey, proof: &[u8], ciphertext:
     Ok(accepted != 0)
 }
 
+/// Prover randomness of a multi-proof call
+pub enum ZkSeed<'a> {
+    /// a fresh 32-byte seed from the operating system per call (the default of the C entry point): zero-knowledge across proofs
+    Fresh,
+    /// caller's seed; proof i of the call draws from StdRng(Blake2s(seed || (first_proof_index + i))) -- a job split over several calls / ranks under one
+    /// seed passes the job-global index of each call's first proof
+    Seeded { seed: &'a [u8; 32], first_proof_index: u64 },
+    /// the reference's fixed `test_rng` stream in EVERY proof (src/lib.rs:65): byte-parity with the CPU path, NOT zero-knowledge across proofs -- tests only
+    ReferenceParity,
+}
+
 /// Long ECB messages (not in the reference API: its SRS literal caps one proof at 96 bytes): ceil(len / chunk) independent chunk-proofs on the key of
-/// `chunk` bytes, many in flight on the GPU (ECB blocks are independent, src/lib.rs:194).  `zk_seed`: 32 bytes of fresh randomness; proof i draws its
-/// blinding from StdRng(Blake2s(seed || i)).  `None` reproduces the reference's fixed `test_rng` seed in every proof -- byte-parity, not zero-knowledge.
-pub fn encrypt_chunked(message: &[u8], secret_key: &[u8; 16], proving_key: &ProvingKey, chunk_len: usize, zk_seed: Option<&[u8; 32]>) -> Result<Vec<Vec<u8>>> {
+/// `chunk` bytes, many in flight on the GPU (ECB blocks are independent, src/lib.rs:194).
+pub fn encrypt_chunked(message: &[u8], secret_key: &[u8; 16], proving_key: &ProvingKey, chunk_len: usize, zk_seed: ZkSeed) -> Result<Vec<Vec<u8>>> {
     if chunk_len == 0 || message.len() % chunk_len != 0 { return Err(anyhow!("message length must be a multiple of the key's plaintext length")); }
     let n = message.len() / chunk_len;
     let (mut p, mut total) = (std::ptr::null_mut(), 0usize);
     let mut lens = vec![0usize; n.max(1)];
-    let seed = zk_seed.map_or(std::ptr::null(), |s| s.as_ptr());
-    if unsafe { zkaes_encrypt_chunked_seeded(message.as_ptr(), message.len(), secret_key.as_ptr(), (proving_key.0).0, seed, &mut p, &mut total, lens.as_mut_ptr(), n) } != 0 { return Err(last_error()); }
+    let rc = match zk_seed {
+        ZkSeed::Fresh => unsafe { zkaes_encrypt_chunked(message.as_ptr(), message.len(), secret_key.as_ptr(), (proving_key.0).0, &mut p, &mut total, lens.as_mut_ptr(), n) },
+        ZkSeed::Seeded { seed, first_proof_index } => unsafe {
+            zkaes_encrypt_chunked_seeded_at(message.as_ptr(), message.len(), secret_key.as_ptr(), (proving_key.0).0, seed.as_ptr(), first_proof_index, &mut p, &mut total, lens.as_mut_ptr(), n)
+        },
+        ZkSeed::ReferenceParity => unsafe {
+            zkaes_encrypt_chunked_seeded_at(message.as_ptr(), message.len(), secret_key.as_ptr(), (proving_key.0).0, std::ptr::null(), 0, &mut p, &mut total, lens.as_mut_ptr(), n)
+        },
+    };
+    if rc != 0 { return Err(last_error()); }
     let blob = take_bytes(p, total);
     let mut out = Vec::with_capacity(n);
     let mut off = 0;

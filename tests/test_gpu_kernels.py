@@ -105,10 +105,10 @@ def test_msm_2_16_matches_oracle(zko, api):
 
 
 @pytest.mark.parametrize("cid", [377, 381])
-@pytest.mark.parametrize("n,c", [(1, 8), (33, 5), (1000, 11), (1 << 12, 13), ((1 << 13) + 3, 20)])
+@pytest.mark.parametrize("n,c", [(1, 8), (33, 5), (1000, 11), (1 << 12, 13), ((1 << 13) + 3, 20), ((1 << 14) + 77, 18), (5000, 16)])
 def test_msm_precomputed_window_tables_match_oracle(zko, api, cid, n, c):
     """the prover's SRS path: tables 2^(offset of window j) P_i over balanced windows (254 or 256 bits spread evenly: widths c and c - 1), one shared
-    bucket set (kernels_msm.hip msm_table, TableLayout)"""
+    bucket set (kernels_msm.hip msm_table, TableLayout); pairs grouped by digits + rocPRIM radix sort"""
     bases = oracle_points(zko, cid, n, 3 * n + c)
     scalars = bytearray(rand_fr_mont(n, zko.FR[cid], 5 * n + c))
     if n >= 33:
@@ -121,6 +121,28 @@ def test_msm_precomputed_window_tables_match_oracle(zko, api, cid, n, c):
     assert inf == bool(ref_inf)
     if not inf:
         assert got == ref.raw
+
+
+@pytest.mark.parametrize("n,c,distinct", [((1 << 13) + 3, 20, 0), ((1 << 14) + 77, 18, 0), (5000, 16, 0), (20_000, 16, 3)])
+def test_msm_table_two_level_partition_matches_oracle(zko, api, monkeypatch, n, c, distinct):
+    """the opt-in grouping of the table path (ZKAES_MSM_PARTITION=1: k_part_hist / k_part_scatter / k_part_fine instead of digits + radix sort + bounds;
+    measured no faster end to end, profiles/r03_partition.md) must give the same sums -- uniform scalars incl. 0, 1, r - 1, and three distinct scalars
+    (every pair in a handful of buckets: long workgroups in pass B, overflow segments in the accumulation)"""
+    monkeypatch.setenv("ZKAES_MSM_PARTITION", "1")
+    bases = oracle_points(zko, 377, n, 7 * n + c)
+    if distinct:
+        vals = [int.from_bytes(np.random.RandomState(300 + i).bytes(31), "little") for i in range(distinct)]
+        scalars = zko.fr_pack([vals[i % distinct] for i in range(n)])
+    else:
+        scalars = bytearray(rand_fr_mont(n, zko.FR[377], 11 * n + c))
+        scalars[0:32] = bytes(32)
+        scalars[32:64] = zko.fr_pack([1], 377)
+        scalars[64:96] = zko.fr_pack([zko.FR[377] - 1], 377)
+        scalars = bytes(scalars)
+    ref = C.create_string_buffer(96)
+    ref_inf = zko.lib().zko_api_msm(377, bases, scalars, C.c_size_t(n), ref)
+    got, inf = api.msm_table(377, bases, scalars, c)
+    assert not inf and not ref_inf and got == ref.raw
 
 
 @pytest.mark.parametrize("distinct", [1, 3])

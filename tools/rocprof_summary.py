@@ -9,10 +9,13 @@ import sys
 
 
 def short(name):
-    name = re.sub(r"<.*", "", name.replace("void ", ""))
+    law = " [Edwards]" if ("EdwardsLaw" in name or "AccTE" in name) else (" [XYZZ]" if ("WeierLaw" in name or "Acc28" in name) else "")
+    name = re.sub(r"<.*", "", name.replace("void ", "")) + law
     if "rocprim" in name:
         m = re.search(r"radix_sort_\w+", name)
         return "rocprim::" + (m.group(0) if m else "kernel")
+    if law:
+        return name.split("(")[0].replace(law, "") + law
     return name.split("(")[0]
 
 

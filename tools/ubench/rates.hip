@@ -71,6 +71,109 @@ __global__ void k_fsqr28(G *out, G a, int iters) {
     for (int i = 0; i < iters; i++) { x = x.sqr() + y; y = y.sqr() + x; }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x + y;
 }
+// ---- FP64-FMA probes ("measure an FP64-FMA field product", kill criterion < 1.25 x the ff28 product rate).
+// RATE probes: they issue the instruction mix and dependency structure of the two known FP64 big-integer schemes on 377-bit operands, in the default
+// rounding mode (the exact schemes need round-toward-zero, which changes no rate) -- they are not validated field implementations.
+__global__ void k_fma64(double *out, double a, int iters) {
+    double acc[8];
+    for (int k = 0; k < 8; k++) acc[k] = threadIdx.x + k;
+    double x = a + threadIdx.x * 1e-9;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] = fma(acc[k], x, 0.5);
+    }
+    double s = 0; for (int k = 0; k < 8; k++) s += acc[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// (a) 16 x 24-bit limbs held as doubles: a limb product is < 2^48, a double column absorbs the 32 products of a Montgomery product exactly (< 2^53), so
+//     v_fma_f64 plays the role v_mad_u64_u32 plays in ff28.cuh.  Per row: 16 product FMAs, the row's Montgomery factor m = -t_i mod 2^24 (p = 1 mod 2^24:
+//     floor via a magic-constant add, one FMA for the remainder), 15 reduction FMAs, one carry add.  Final: 16-limb carry normalisation.
+struct Fq24d { double l[16]; };
+__device__ __forceinline__ Fq24d mul24d(const Fq24d &a, const Fq24d &b, const double *pm) {
+    const double M52 = 6755399441055744.0, I24 = 1.0 / 16777216.0, T24 = 16777216.0;      // 1.5 * 2^52 (round-to-integer magic), 2^-24, 2^24
+    double t[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) t[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) t[i + j] = fma(a.l[j], b.l[i], t[i + j]);
+        double q = (t[i] * I24 + M52) - M52;              // t_i / 2^24 rounded
+        double lo = fma(-q, T24, t[i]);                   // remainder
+        double m = T24 - lo;                              // -t_i mod 2^24 (up to the boundary case the exact scheme patches)
+#pragma unroll
+        for (int j = 1; j < 16; j++) t[i + j] = fma(m, pm[j], t[i + j]);
+        t[i + 1] += q + 1.0;
+    }
+    Fq24d r;
+    double c = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        double v = t[16 + i] + c;
+        double q = (v * I24 + M52) - M52;
+        r.l[i] = fma(-q, T24, v);
+        c = q;
+    }
+    return r;
+}
+__global__ void k_fmul24d(double *out, double seed, int iters) {
+    double pm[16];
+    Fq24d x, y;
+    for (int i = 0; i < 16; i++) { pm[i] = 1234567.0 + 4099.0 * i; x.l[i] = seed + i + (threadIdx.x & 0xff); y.l[i] = seed * 3 + i; }
+    for (int i = 0; i < iters; i++) { x = mul24d(x, y, pm); y = mul24d(y, x, pm); }
+    double s = 0; for (int i = 0; i < 16; i++) s += x.l[i] + y.l[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// (b) Emmart-Zheng-Weems: 8 x 52-bit limbs, every 104-bit limb product split into halves with two FMAs against 2^104-scaled constants, halves accumulated
+//     as 64-bit INTEGERS: per limb product 2 x v_fma_f64 + 1 x v_add_f64 + 2 x 64-bit integer add; 64 products + 64 for the reduction, 8 row factors.
+struct Fq52d { double l[8]; };
+__device__ __forceinline__ Fq52d mul52d(const Fq52d &a, const Fq52d &b, const double *pm) {
+    const double C1 = 20282409603651670423947251286016.0, C2 = 20282409603651674927546878656512.0;   // 2^104, 2^104 + 2^52
+    long long lo[17], hi[17];
+#pragma unroll
+    for (int i = 0; i < 17; i++) { lo[i] = 0; hi[i] = 0; }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            double ph = fma(a.l[j], b.l[i], C1);
+            double pl = fma(a.l[j], b.l[i], C2 - ph);
+            hi[i + j + 1] += __double_as_longlong(ph);
+            lo[i + j] += __double_as_longlong(pl);
+        }
+        double m = (double)((lo[i] + hi[i]) & 0xfffffffffffffll);         // row factor (times -p^-1 mod 2^52 = -1 for this prime)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            double ph = fma(m, pm[j], C1);
+            double pl = fma(m, pm[j], C2 - ph);
+            hi[i + j + 1] += __double_as_longlong(ph);
+            lo[i + j] += __double_as_longlong(pl);
+        }
+    }
+    Fq52d r;
+    long long c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { long long v = lo[8 + i] + hi[8 + i] + c; r.l[i] = (double)(v & 0xfffffffffffffll); c = v >> 52; }
+    return r;
+}
+__global__ void k_fmul52d(double *out, double seed, int iters) {
+    double pm[8];
+    Fq52d x, y;
+    for (int i = 0; i < 8; i++) { pm[i] = 1234567890123.0 + 4099.0 * i; x.l[i] = seed + i + (threadIdx.x & 0xff); y.l[i] = seed * 3 + i; }
+    for (int i = 0; i < iters; i++) { x = mul52d(x, y, pm); y = mul52d(y, x, pm); }
+    double s = 0; for (int i = 0; i < 8; i++) s += x.l[i] + y.l[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// ---- global-atomic rate on 2^19 counters with uniformly random keys (would a counting scatter beat the radix sort of the MSM's (bucket, point) pairs?)
+__global__ void k_atomic_slots(uint32_t *cnt, uint32_t *slots, uint32_t nkeys_per_thread, uint32_t mask, uint32_t stride) {
+    uint32_t x = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u;
+    for (uint32_t i = 0; i < nkeys_per_thread; i++) {
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+        uint32_t k = x & mask;
+        uint32_t slot = atomicAdd(&cnt[k], 1u);
+        if (slots && slot < stride) slots[(size_t)k * stride + slot] = x;          // the scattered 4-byte write of a counting scatter
+    }
+}
 template <class Fn> float timeit(Fn fn) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     fn(); hipDeviceSynchronize();
@@ -100,5 +203,27 @@ int main() {
     printf("Fq377x28 mul  : %.2f Gmul/s (%.3f ms)\n", lanes * 400 / ms / 1e6, ms);
     ms = timeit([&] { hipLaunchKernelGGL((k_fsqr28<Fq377x28>), dim3(blocks), dim3(threads), 0, 0, (Fq377x28 *)buf, g, 200); });
     printf("Fq377x28 sqr  : %.2f Gsqr/s (%.3f ms)\n", lanes * 400 / ms / 1e6, ms);
+    {
+        const uint32_t nb = 1u << 19, stride = 256, per = 64;
+        uint32_t *cnt, *slots; CK(hipMalloc(&cnt, nb * 4)); CK(hipMalloc(&slots, (size_t)nb * stride * 4));
+        for (int with_write = 0; with_write < 2; with_write++) {
+            CK(hipMemset(cnt, 0, nb * 4));
+            hipLaunchKernelGGL(k_atomic_slots, dim3(blocks), dim3(threads), 0, 0, cnt, with_write ? slots : nullptr, 4u, nb - 1, stride); CK(hipDeviceSynchronize());
+            CK(hipMemset(cnt, 0, nb * 4));
+            hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+            hipEventRecord(a);
+            hipLaunchKernelGGL(k_atomic_slots, dim3(blocks), dim3(threads), 0, 0, cnt, with_write ? slots : nullptr, per, nb - 1, stride);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float t; hipEventElapsedTime(&t, a, b);
+            printf("global atomicAdd (returning) on 2^19 random counters%s: %.2f G/s (%.3f ms for %.0f M)\n", with_write ? " + scattered 4-byte slot write" : "", lanes * per / t / 1e6, t, lanes * per / 1e6);
+        }
+        hipFree(cnt); hipFree(slots);
+    }
+    ms = timeit([&] { hipLaunchKernelGGL(k_fma64, dim3(blocks), dim3(threads), 0, 0, (double *)buf, 1.0000001, iters); });
+    printf("v_fma_f64     : %.2f Tops/s (%.3f ms)\n", lanes * iters * 8 / ms / 1e9, ms);
+    ms = timeit([&] { hipLaunchKernelGGL(k_fmul24d, dim3(blocks), dim3(threads), 0, 0, (double *)buf, 1000.0, 200); });
+    printf("Fq377 FP64 16x24-bit limbs (rate probe): %.2f Gmul/s (%.3f ms)\n", lanes * 400 / ms / 1e6, ms);
+    ms = timeit([&] { hipLaunchKernelGGL(k_fmul52d, dim3(blocks), dim3(threads), 0, 0, (double *)buf, 1000.0, 200); });
+    printf("Fq377 FP64 8x52-bit limbs, split FMAs + int64 sums (rate probe): %.2f Gmul/s (%.3f ms)\n", lanes * 400 / ms / 1e6, ms);
     return 0;
 }
