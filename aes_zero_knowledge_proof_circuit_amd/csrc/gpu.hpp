@@ -63,7 +63,7 @@ template <class Curve>
 XYZZ<typename Curve::Fq> msm_finish(MsmWorkspace *ws, const Affine28<typename Curve::FqP> *bases, stream_t s);
 #if ZK_MSM_EDWARDS
 // BLS12-377 only -- the prover's path over its fixed SRS: bases precomputed on the curve's twisted Edwards model (te28.cuh: Niels28 = (y - x, y + x, 2 d x y),
-// 168 B), bucket additions of 7 field products instead of 10 and no special cases.  convert_bases_te maps Weierstrass affine points (which MUST lie in the
+// 168 B padded to a 64-byte aligned 192-byte record), bucket additions of 7 field products instead of 10 and no special cases.  convert_bases_te maps Weierstrass affine points (which MUST lie in the
 // prime-order subgroup; a point of order 2 or 4 is refused) to that form; msm / msm_finish / msm_table / class_sum are overloaded on the base type and
 // return the same Weierstrass XYZZ results as their Affine28 versions.
 template <class Curve> void convert_bases_te(Niels28<typename Curve::FqP> *dst, const Affine<typename Curve::Fq> *src, size_t n, stream_t s);

@@ -398,7 +398,7 @@ std::vector<Fr> ciphertext_to_public_input(const uint8_t *ct, size_t len) {
 
 // =====================================================================================================================
 // proving key
-// the SRS in the form k_accumulate gathers: BLS12-377's twisted Edwards model (te28.cuh, 168 B per point, 7 products per bucket addition) in the default
+// the SRS in the form k_accumulate gathers: BLS12-377's twisted Edwards model (te28.cuh, 192 B per point incl. padding, 7 products per bucket addition) in the default
 // build, the reduced-radix Weierstrass affine form (112 B, 10 products) with -DZK_MSM_RADIX=30
 #if ZK_MSM_EDWARDS
 using SrsPoint = Niels28<Fq377P>;

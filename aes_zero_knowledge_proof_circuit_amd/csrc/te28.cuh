@@ -25,10 +25,19 @@
 
 namespace zk {
 
-// precomputed affine point (y - x, y + x, 2 d x y) in the reduced-radix Montgomery form: 3 x 56 B.  The identity is (1, 1, 0): the SRS's "infinity"
+// precomputed affine point (y - x, y + x, 2 d x y) in the reduced-radix Montgomery form: 3 x 56 B (+ 24 B of padding to a 64-byte aligned 192-byte record).  The identity is (1, 1, 0): the SRS's "infinity"
 // entries (none in practice) need no test in the hot loop.
+#ifndef ZK_NIELS_PAD
+#define ZK_NIELS_PAD 1          // 1 (default): records padded to 192 B and 64-byte aligned -- exactly three 64-byte sectors per gather instead of 3.5 on average for packed 168-byte
+                                // records: k_accumulate 7.31 -> 7.13 ms at 2^22 points, bench +1.1 % (profiles/r03_niels_padding.txt), for 14 % more table memory.  0 = packed.
+#endif
+#if ZK_NIELS_PAD
+template <class P>
+struct alignas(64) Niels28 { FpMsm<P> ymx, ypx, td; uint32_t pad[6]; };
+#else
 template <class P>
 struct Niels28 { FpMsm<P> ymx, ypx, td; };
+#endif
 // extended projective point: same 224 B as the XYZZ accumulator, so the MSM scratch buffers serve both
 template <class P>
 struct AccTE { FpMsm<P> x, y, z, t; };

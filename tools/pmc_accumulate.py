@@ -78,7 +78,7 @@ for name, ctrs in PASSES.items():
 
 KIB = 1024.0
 nwin = 15 if wbits <= 0 else (253 + 1 + wbits - 1) // wbits
-base_bytes = 168 if edwards else 112                   # one gathered base: Niels28 (te28.cuh) or Affine28
+base_bytes = 192 if edwards else 112                   # one gathered base: Niels28 (te28.cuh: 168 B padded to a 64-byte aligned 192-byte record) or Affine28
 n_conv = n * (nwin if wbits > 0 else 1)                # the table path converts all window copies in one launch
 fetch = vals[("k_accumulate", "FETCH_SIZE")] * KIB
 write = vals[("k_accumulate", "WRITE_SIZE")] * KIB

@@ -1,12 +1,12 @@
 // tools/ubench/gather_probe.hip -- calibration kernel for rocprofv3's FETCH_SIZE on k_accumulate's access pattern (tools/pmc_accumulate.py):
-// every lane reads ONE 168-byte record (the size and 8-byte alignment of a Niels28 SRS point, csrc/te28.cuh) at a pseudo-random index of a 6 GB array
+// every lane reads ONE 192-byte, 64-byte aligned record (a Niels28 SRS point, csrc/te28.cuh) at a pseudo-random index of a 6 GB array
 // (far beyond the 256 MB Infinity Cache, every record read once: no reuse), with the same 16-byte loads the compiler emits for the bucket kernel.
 // The host prints how many bytes that touches at 64-byte and at 128-byte granularity; FETCH_SIZE of this kernel divided by those numbers tells how
 // the counter tallies such gathers on gfx950 (MI355X_MICROARCH.md: wide coalesced streams report exactly half; "other access widths: calibrate").
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
-struct Rec { uint32_t w[42]; };
+struct alignas(64) Rec { uint32_t w[48]; };       // 192 B, 64-byte aligned: the Niels28 record of csrc/te28.cuh (168 B of coordinates + padding)
 __global__ void __launch_bounds__(64) k_gather_probe(const Rec *__restrict__ recs, uint64_t nrec, uint32_t n, uint32_t *__restrict__ out) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
@@ -14,11 +14,11 @@ __global__ void __launch_bounds__(64) k_gather_probe(const Rec *__restrict__ rec
     Rec r = recs[idx];
     uint32_t s = 0;
 #pragma unroll
-    for (int i = 0; i < 42; i++) s ^= r.w[i];
+    for (int i = 0; i < 48; i++) s ^= r.w[i];
     out[t] = s;
 }
 int main() {
-    const uint64_t nrec = 36000000ull;            // 6.05 GB
+    const uint64_t nrec = 32000000ull;            // 6.1 GB
     const uint32_t n = 1u << 24;
     Rec *d; uint32_t *o;
     if (hipMalloc(&d, nrec * sizeof(Rec)) != hipSuccess || hipMalloc(&o, (size_t)n * 4) != hipSuccess) { printf("alloc failed\n"); return 1; }
