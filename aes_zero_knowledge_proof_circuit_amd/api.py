@@ -6,7 +6,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CIRCUIT_AES, CIRCUIT_OPS_XOR, CIRCUIT_OPS_ADD = 0, 1, 2
-KEY_NO_TABLES = 1                  # zkaes_synthesize_keys_ex2 flag: no fixed-base window tables (saves 6-24 GB per key)
+KEY_NO_TABLES = 1                  # zkaes_synthesize_keys_ex2 flag: no fixed-base window tables (saves 10-42 GB per key)
 PARITY = "parity"                  # zk_seed=PARITY: the reference's fixed ark_std::test_rng() stream for every proof (byte-parity tests only)
 
 

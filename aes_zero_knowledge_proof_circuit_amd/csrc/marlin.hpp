@@ -81,7 +81,7 @@ class ProvingKey {
     ProvingKeyImpl *impl;
 };
 
-// universal_setup(literals) + index; GPU required.  flags: KEY_NO_TABLES = do not build the fixed-base window tables of the SRS (13 copies, 6-24 GB per key):
+// universal_setup(literals) + index; GPU required.  flags: KEY_NO_TABLES = do not build the fixed-base window tables of the SRS (13 copies, 10-42 GB per key):
 // multi-proof calls then run 15 per-window-bucket windows instead of 13 table windows (~9 % fewer blocks/s), and the key fits a GPU that is short of memory.
 // Without the flag the tables are built when memory allows (hipMemGetInfo) and silently skipped otherwise.
 enum : unsigned { KEY_NO_TABLES = 1u };

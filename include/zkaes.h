@@ -11,10 +11,11 @@
  *   - proofs cross the boundary as bytes in the ark-serialize 0.3 compressed layout of ark_marlin::Proof
  *     (what simpleworks' (de)serialize_proof reads/writes, re-exported at src/lib.rs:52);
  *   - byte buffers returned through `uint8_t**` are owned by the library: release with zkaes_bytes_free.
- *   - a key for a plaintext of 16 bytes or more also holds fixed-base window tables of the SRS (13 copies, ~6 GB for the one-block key, ~24 GB for the
+ *   - a key for a plaintext of 16 bytes or more also holds fixed-base window tables of the SRS (13 copies of 192-byte records: ~10 GB for the one-block key, ~42 GB for the
  *     4- to 6-block keys; skipped when the device is short of memory or with ZKAES_KEY_NO_TABLES): multi-proof calls (zkaes_encrypt_chunked / _batch) run their
- *     large MSMs through them (13 balanced windows of 19-20 bits over ONE bucket set instead of 15 windows with their own buckets), a lone zkaes_encrypt call
- *     keeps the per-window buckets and runs the independent commitments of each round on four MSM lanes (streams + host threads) side by side;
+ *     large MSMs (>= 500 k points) through them (13 balanced windows of 19-20 bits over ONE bucket set instead of 15 windows with their own buckets), and so does a
+ *     lone zkaes_encrypt call, which additionally runs the independent commitments of each round on four MSM lanes (streams + host threads) side by side.  The
+ *     SRS points are stored on BLS12-377's twisted Edwards model (7-product bucket additions): the prover's MSMs assume prime-order-subgroup bases, as KZG's are;
  *   - host threads of a multi-proof call wait for the GPU by polling with short sleeps (a fraction of a core per prover context); a lone zkaes_encrypt call
  *     spins, for latency.  ZKAES_WAIT=spin|sleep forces one policy;
  *   - when the library is loaded it exports GPU_MAX_HW_QUEUES=16 unless the variable is already set (one hardware queue per prover context; the ROCm default of 4
@@ -68,7 +69,7 @@ int zkaes_proof_roundtrip(const uint8_t *proof, size_t proof_len, uint8_t **out,
 /* as zkaes_synthesize_keys with an explicit circuit kind and universal-SRS literals (generate_universal_srs arguments) */
 int zkaes_synthesize_keys_ex(int circuit_kind, size_t plaintext_length, size_t srs_num_constraints, size_t srs_num_variables, size_t srs_num_non_zero, zkaes_pk **pk,
                              zkaes_vk **vk);
-/* the same with option flags.  ZKAES_KEY_NO_TABLES: do not build the fixed-base window tables of the SRS (saves 6-24 GB of device memory per key; multi-proof
+/* the same with option flags.  ZKAES_KEY_NO_TABLES: do not build the fixed-base window tables of the SRS (saves 10-42 GB of device memory per key; multi-proof
  * calls then use 15 per-window-bucket windows instead of 13 table windows, ~9 % fewer proofs per second).  Unknown flag bits are an error. */
 #define ZKAES_KEY_NO_TABLES 1u
 int zkaes_synthesize_keys_ex2(int circuit_kind, size_t plaintext_length, size_t srs_num_constraints, size_t srs_num_variables, size_t srs_num_non_zero, unsigned flags,

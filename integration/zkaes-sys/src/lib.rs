@@ -80,7 +80,7 @@ pub fn synthesize_keys(plaintext_length: usize) -> Result<(ProvingKey, Verifying
 }
 
 /// Key synthesis options (include/zkaes.h ZKAES_KEY_*)
-pub const KEY_NO_TABLES: u32 = 1;   // no fixed-base window tables of the SRS: saves 6-37 GB of device memory per key, multi-proof calls run ~9 % slower
+pub const KEY_NO_TABLES: u32 = 1;   // no fixed-base window tables of the SRS: saves 10-42 GB of device memory per key, multi-proof calls run ~9 % slower
 
 /// `synthesize_keys` with options: `flags` = KEY_NO_TABLES to keep the key small (the tables are also skipped automatically when the device is short of memory)
 pub fn synthesize_keys_with(plaintext_length: usize, flags: u32) -> Result<(ProvingKey, VerifyingKey)> {
