@@ -133,7 +133,7 @@ ZK_HD bool on_curve(const Affine<Fq> &a, const Fq &b) {
     return a.y.sqr() == a.x.sqr() * a.x + b;
 }
 
-// affine point in the reduced-radix form the MSM accumulate kernel consumes (FpMsm): 2 x 13 x 30-bit limbs = 104 B (ff28: 2 x 14 = 112 B), (0,0) = infinity
+// affine point in the reduced-radix form the Weierstrass-law accumulate kernel consumes (FpMsm): 2 x 14 x 28-bit limbs = 112 B by default (ff28.cuh; 2 x 13 x 30-bit = 104 B with -DZK_MSM_RADIX=30), (0,0) = infinity
 template <class P>
 struct Affine28 {
     FpMsm<P> x, y;

@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(256) k_reduce_window(const A *__restrict__ par
 template <class A> __global__ void k_sum_tree(const A *__restrict__ in, uint32_t total, uint32_t per, A *__restrict__ out);
 
 constexpr uint32_t DEFERRED_CAP = 1u << 20;
-constexpr size_t ACC_BYTES = sizeof(Acc28<Fq377P>);          // one XYZZ bucket in the reduced-radix form (208 B with ff30, 224 B with ff28; same for both curves)
+constexpr size_t ACC_BYTES = sizeof(Acc28<Fq377P>);          // one XYZZ bucket in the reduced-radix form (224 B with the default ff28, 208 B with ff30; same for both curves)
 static_assert(sizeof(Acc28<Fq381P>) == ACC_BYTES, "bucket size differs between the curves");
 #if ZK_MSM_EDWARDS
 static_assert(sizeof(AccTE<Fq377P>) == ACC_BYTES, "the Edwards accumulator must fit the XYZZ bucket slots");
@@ -529,7 +529,7 @@ static void order_buckets(MsmWorkspace &S, size_t nb, uint32_t cap, hipStream_t 
 
 // shared middle: sort the (key, value) pairs, find bucket ranges, order buckets by descending size, cut oversized buckets
 template <class P>
-static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int sort_bits, uint32_t cap, hipStream_t s) {
+static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int sort_bits, uint32_t cap, hipStream_t s, int begin_bit = 0) {
     // c here = log2(buckets per set); keys run over [0, nb) plus the out-of-range key nb for zero digits
     size_t nb = (size_t)nsets << c;
     int key_bits = 1;
@@ -538,10 +538,10 @@ static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int
     size_t tmp_bytes = 0;
     // ping-pong sort: the result stays in whichever buffer the last radix pass wrote (no copy back)
     rocprim::double_buffer<uint32_t> dk(S.keys_a, S.keys_b), dv(S.vals_a, S.vals_b);
-    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, pairs, 0u, (unsigned)key_bits, s));
+    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, pairs, (unsigned)begin_bit, (unsigned)key_bits, s));
     if (tmp_bytes > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tmp_bytes); S.cap_tmp = tmp_bytes; }
-    HIP_CHECK(rocprim::radix_sort_pairs(S.tmp, tmp_bytes, dk, dv, pairs, 0u, (unsigned)key_bits, s));
-    if (knockin() & 1) HIP_CHECK(rocprim::radix_sort_pairs(S.tmp, tmp_bytes, dk, dv, pairs, 0u, (unsigned)key_bits, s));
+    HIP_CHECK(rocprim::radix_sort_pairs(S.tmp, tmp_bytes, dk, dv, pairs, (unsigned)begin_bit, (unsigned)key_bits, s));
+    if (knockin() & 1) HIP_CHECK(rocprim::radix_sort_pairs(S.tmp, tmp_bytes, dk, dv, pairs, (unsigned)begin_bit, (unsigned)key_bits, s));
     S.sorted_keys = dk.current(); S.sorted_vals = dv.current();
     HIP_CHECK(hipMemsetAsync(S.start, 0, nb * 4, s));
     HIP_CHECK(hipMemsetAsync(S.end, 0, nb * 4, s));
@@ -850,6 +850,104 @@ void table_next(Affine<typename Curve::Fq> *next, const Affine<typename Curve::F
     HIP_LAUNCH_CHECK();
 }
 
+// ---- Pre-split digits: one radix pass less for the table path, with the (window, point index) order inside buckets intact.
+// An LSD radix sort on bucket bits [0, B) is the same as a STABLE split on the low SB = B - 16 bits followed by a stable sort on bits [SB, B).  The digit
+// kernel can do that split itself while it writes the pairs: two launches over the scalars (32 B each) -- k_split_hist counts, per (class = low bits,
+// window, 256-scalar block), how many pairs there are; one scan turns the counts into positions; k_split_scatter recodes the digits again and writes every
+// pair to  position(class, window, block) + its rank inside the block (wave ballots + per-wave counts: stable) -- ~32-element runs per class and window.
+// The radix sort then only covers bits [SB, B): 16 bits = two 8-bit passes instead of three over the 8-byte pairs (7.4 GB less traffic per 6-block proof).
+constexpr int SPLIT_THREADS = 256, SPLIT_WAVES = SPLIT_THREADS / 64, SPLIT_MAXW = 16, SPLIT_MAXCLS = 8;
+// digit words of scalar g: d[w] = bucket | neg << 31 | skip << 30 for w < nwin
+template <class Fr>
+__device__ __forceinline__ uint32_t split_digits(const Fr *__restrict__ s1, uint32_t n1, uint32_t off1, const Fr *__restrict__ s2, uint32_t off2, uint32_t g, const TableLayout &L, uint32_t d[SPLIT_MAXW]) {
+    uint32_t raw[Fr::N + 1];
+    uint32_t base;
+    if (g < n1) { s1[g].to_raw(raw); base = off1 + g; } else { s2[g - n1].to_raw(raw); base = off2 + (g - n1); }
+    raw[Fr::N] = 0;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < SPLIT_MAXW; w++) {
+        d[w] = VAL_SKIP;
+        if (w < L.nwin) {
+            const int c = L.width(w), bit = L.offset(w), limb = bit >> 5, sh = bit & 31;
+            const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
+            uint64_t two = limb <= Fr::N - 1 ? ((uint64_t)raw[limb] | ((uint64_t)raw[limb + 1] << 32)) : 0;
+            uint32_t v = ((uint32_t)(two >> sh) & mask) + carry;
+            uint32_t neg = 0;
+            carry = 0;
+            if (v > half) { v = (1u << c) - v; neg = 1u << 31; carry = 1; }
+            if (v) d[w] = (v - 1) | neg;
+        }
+    }
+    return base;
+}
+template <class Fr>
+__global__ void __launch_bounds__(SPLIT_THREADS) k_split_hist(const Fr *__restrict__ s1, uint32_t n1, uint32_t off1, const Fr *__restrict__ s2, uint32_t n2, uint32_t off2, TableLayout L,
+                                                              int split_bits, uint32_t nblocks, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t cnt[SPLIT_MAXW * SPLIT_MAXCLS];
+    const uint32_t n = n1 + n2, g = blockIdx.x * SPLIT_THREADS + threadIdx.x, ncls = 1u << split_bits, cmask = ncls - 1;
+    for (uint32_t i = threadIdx.x; i < SPLIT_MAXW * SPLIT_MAXCLS; i += SPLIT_THREADS) cnt[i] = 0;
+    __syncthreads();
+    uint32_t d[SPLIT_MAXW];
+    const bool active = g < n;
+    if (active) split_digits<Fr>(s1, n1, off1, s2, off2, g, L, d);
+#pragma unroll
+    for (int w = 0; w < SPLIT_MAXW; w++) {
+        if (w < L.nwin) {
+            const uint32_t cls = active ? ((d[w] & VAL_SKIP) ? 0u : (d[w] & cmask)) : 0xffffffffu;
+            for (uint32_t k = 0; k < ncls; k++) {
+                uint64_t m = __ballot(cls == k);
+                if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt[w * SPLIT_MAXCLS + k], (uint32_t)__popcll(m));
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < (uint32_t)L.nwin * ncls; i += SPLIT_THREADS) {
+        const uint32_t w = i / ncls, k = i % ncls;
+        hist[((size_t)k * L.nwin + w) * nblocks + blockIdx.x] = cnt[w * SPLIT_MAXCLS + k];          // class-major, then window, then block: the order of the split
+    }
+}
+template <class Fr>
+__global__ void __launch_bounds__(SPLIT_THREADS) k_split_scatter(const Fr *__restrict__ s1, uint32_t n1, uint32_t off1, const Fr *__restrict__ s2, uint32_t n2, uint32_t off2, TableLayout L,
+                                                                 uint32_t stride, int split_bits, uint32_t nblocks, const uint32_t *__restrict__ offs, uint32_t *__restrict__ keys,
+                                                                 uint32_t *__restrict__ vals) {
+    __shared__ uint32_t wc[SPLIT_MAXW][SPLIT_WAVES][SPLIT_MAXCLS];
+    const uint32_t n = n1 + n2, g = blockIdx.x * SPLIT_THREADS + threadIdx.x, ncls = 1u << split_bits, cmask = ncls - 1;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t d[SPLIT_MAXW];
+    const bool active = g < n;
+    uint32_t base = 0;
+    if (active) base = split_digits<Fr>(s1, n1, off1, s2, off2, g, L, d);
+#pragma unroll
+    for (int w = 0; w < SPLIT_MAXW; w++) {
+        if (w < L.nwin) {
+            const uint32_t cls = active ? ((d[w] & VAL_SKIP) ? 0u : (d[w] & cmask)) : 0xffffffffu;
+            for (uint32_t k = 0; k < ncls; k++) {
+                uint64_t m = __ballot(cls == k);
+                if (lane == 0) wc[w][wave][k] = (uint32_t)__popcll(m);
+            }
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+    for (int w = 0; w < SPLIT_MAXW; w++) {
+        if (w < L.nwin) {
+            const bool skip = (d[w] & VAL_SKIP) != 0;
+            const uint32_t cls = skip ? 0u : (d[w] & cmask);
+            // same ballots as above (all lanes of the wave take this path together up to `active`, which only differs in the last block's tail)
+            uint64_t mine = 0;
+            for (uint32_t k = 0; k < ncls; k++) { uint64_t m = __ballot(cls == k); if (k == cls) mine = m; }
+            uint32_t pos = offs[((size_t)cls * L.nwin + w) * nblocks + blockIdx.x] + (uint32_t)__popcll(mine & lt);
+            for (uint32_t v = 0; v < wave; v++) pos += wc[w][v][cls];
+            keys[pos] = skip ? 0u : (d[w] & VAL_INDEX);
+            vals[pos] = skip ? VAL_SKIP : (((uint32_t)w * stride + base) | (d[w] & (1u << 31)));
+        }
+    }
+}
+static bool presplit_enabled() { const char *e = getenv("ZKAES_MSM_PRESPLIT"); return !e || atoi(e) != 0; }
+
 // ---- Two-level bucket partition: the table path's replacement for "digits -> radix sort -> bounds" (the generic three-pass 8-bit radix sort of 8-byte
 // (key, value) pairs cost 7.8 ms of a 79.5 ms chunk-proof in the saturated bench: profiles/r03_knockin_edwards.txt).  Specialised to this layout:
 //   * the keys are never materialised as 32-bit words: the 19 bucket bits split into a COARSE bin (the high bits, 2^(B-9) bins) and a 9-bit FINE key;
@@ -1052,6 +1150,24 @@ void msm_prepare_table(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_
     ensure_scratch(S, pairs, nb, BUCKET_CAP_TABLE);
     if (partition_enabled() && L.c_hi - 1 > PART_FINE_BITS && (1u << (L.c_hi - 1 - PART_FINE_BITS)) <= PART_NBIN_MAX && L.nwin <= PART_MAXW && pairs >= ((size_t)1 << 16)) {
         partition_buckets<Fr>(S, scal1, n1, off1, scal2, n2, off2, L, stride, BUCKET_CAP_TABLE, s);
+        return;
+    }
+    const int B = L.c_hi - 1, split_bits = B > 16 ? (B - 16 < 3 ? B - 16 : 3) : 0;
+    if (presplit_enabled() && split_bits > 0 && nwin <= SPLIT_MAXW && pairs >= ((size_t)1 << 16)) {
+        // the digit kernels already split the pairs (stably) on the low `split_bits` bucket bits: the radix sort starts above them
+        const uint32_t nblocks = (uint32_t)((n + SPLIT_THREADS - 1) / SPLIT_THREADS);
+        const size_t nh = ((size_t)nwin << split_bits) * nblocks;
+        if (nh > S.cap_part) { dfree(S.part_hist); dfree(S.part_offs); S.part_hist = (uint32_t *)dmalloc(nh * 4); S.part_offs = (uint32_t *)dmalloc(nh * 4); S.cap_part = nh; }
+        hipLaunchKernelGGL((k_split_hist<Fr>), dim3(nblocks), dim3(SPLIT_THREADS), 0, s, scal1, (uint32_t)n1, (uint32_t)off1, scal2, (uint32_t)n2, (uint32_t)off2, L, split_bits, nblocks, S.part_hist);
+        HIP_LAUNCH_CHECK();
+        size_t tb = 0;
+        HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, S.part_hist, S.part_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
+        if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
+        HIP_CHECK(rocprim::exclusive_scan(S.tmp, tb, S.part_hist, S.part_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
+        hipLaunchKernelGGL((k_split_scatter<Fr>), dim3(nblocks), dim3(SPLIT_THREADS), 0, s, scal1, (uint32_t)n1, (uint32_t)off1, scal2, (uint32_t)n2, (uint32_t)off2, L, (uint32_t)stride, split_bits,
+                           nblocks, (const uint32_t *)S.part_offs, S.keys_a, S.vals_a);
+        HIP_LAUNCH_CHECK();
+        prepare_buckets<typename Curve::FqP>(S, pairs, B, 1, B, BUCKET_CAP_TABLE, s, split_bits);
         return;
     }
     if (n1) { hipLaunchKernelGGL((k_digits_table<Fr>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, scal1, (uint32_t)n1, 0u, (uint32_t)n, (uint32_t)off1, L, (uint32_t)stride, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }

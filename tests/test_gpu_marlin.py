@@ -167,6 +167,21 @@ def test_chunked_message_equals_individual_proofs(api, aes16):
     assert proofs == [api.encrypt(msg[16 * i:16 * i + 16], key, pk) for i in range(5)]
 
 
+def test_key_flags_no_tables_same_proofs(api, aes16, vectors):
+    """zkaes_synthesize_keys_ex2: a key without the fixed-base window tables (KEY_NO_TABLES: per-window buckets for every MSM) gives the SAME proof bytes as the
+    default key (tables, 13 balanced windows, one bucket set) for a lone call and for a multi-proof call; unknown flag bits are an error"""
+    pk, vk = aes16
+    pk_nt, vk_nt = api.synthesize_keys(16, flags=api.KEY_NO_TABLES)
+    msg, key = bytes(vectors["plaintext"]), bytes(vectors["key"])
+    proof = api.encrypt(msg, key, pk)
+    assert api.encrypt(msg, key, pk_nt) == proof
+    assert pk_nt.encrypt_chunked(msg * 3, key, zk_seed=api.PARITY) == [proof] * 3 == pk.encrypt_chunked(msg * 3, key, zk_seed=api.PARITY)
+    assert api.verify_encryption(vk_nt, proof, bytes(vectors["ciphertext"])) is True
+    assert vk_nt.to_ark_bytes() == vk.to_ark_bytes()
+    with pytest.raises(api.ZkAesError, match="unknown flag"):
+        api.synthesize_keys(16, flags=0x80)
+
+
 def test_empty_message_and_size_limits(api):
     """edge cases: a 0-byte message proves only the key schedule (no public inputs); 96 bytes is the largest plaintext that fits the
     reference's universal-SRS literal (src/lib.rs:141), 112 bytes must be refused like arkworks' IndexTooLarge."""
