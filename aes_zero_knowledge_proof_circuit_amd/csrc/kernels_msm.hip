@@ -881,24 +881,32 @@ __device__ __forceinline__ uint32_t split_digits(const Fr *__restrict__ s1, uint
     }
     return base;
 }
+// lanes of the wave whose class equals this lane's (inactive lanes pass cls = ~0 and match nobody active): one ballot per class bit
+__device__ __forceinline__ uint64_t split_same_class(uint32_t cls, int split_bits, bool active) {
+    uint64_t same = __ballot(active);
+    for (int b = 0; b < split_bits; b++) {
+        uint64_t m = __ballot(active && ((cls >> b) & 1));
+        same &= ((cls >> b) & 1) ? m : ~m;
+    }
+    return same;
+}
 template <class Fr>
 __global__ void __launch_bounds__(SPLIT_THREADS) k_split_hist(const Fr *__restrict__ s1, uint32_t n1, uint32_t off1, const Fr *__restrict__ s2, uint32_t n2, uint32_t off2, TableLayout L,
                                                               int split_bits, uint32_t nblocks, uint32_t *__restrict__ hist) {
     __shared__ uint32_t cnt[SPLIT_MAXW * SPLIT_MAXCLS];
-    const uint32_t n = n1 + n2, g = blockIdx.x * SPLIT_THREADS + threadIdx.x, ncls = 1u << split_bits, cmask = ncls - 1;
+    const uint32_t n = n1 + n2, g = blockIdx.x * SPLIT_THREADS + threadIdx.x, ncls = 1u << split_bits, cmask = ncls - 1, lane = threadIdx.x & 63;
     for (uint32_t i = threadIdx.x; i < SPLIT_MAXW * SPLIT_MAXCLS; i += SPLIT_THREADS) cnt[i] = 0;
     __syncthreads();
     uint32_t d[SPLIT_MAXW];
     const bool active = g < n;
     if (active) split_digits<Fr>(s1, n1, off1, s2, off2, g, L, d);
+    const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
 #pragma unroll
     for (int w = 0; w < SPLIT_MAXW; w++) {
         if (w < L.nwin) {
-            const uint32_t cls = active ? ((d[w] & VAL_SKIP) ? 0u : (d[w] & cmask)) : 0xffffffffu;
-            for (uint32_t k = 0; k < ncls; k++) {
-                uint64_t m = __ballot(cls == k);
-                if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt[w * SPLIT_MAXCLS + k], (uint32_t)__popcll(m));
-            }
+            const uint32_t cls = active ? ((d[w] & VAL_SKIP) ? 0u : (d[w] & cmask)) : 0u;
+            const uint64_t same = split_same_class(cls, split_bits, active);
+            if (active && (same & lt) == 0) atomicAdd(&cnt[w * SPLIT_MAXCLS + cls], (uint32_t)__popcll(same));        // the first lane of every class present in the wave
         }
     }
     __syncthreads();
@@ -912,34 +920,33 @@ __global__ void __launch_bounds__(SPLIT_THREADS) k_split_scatter(const Fr *__res
                                                                  uint32_t stride, int split_bits, uint32_t nblocks, const uint32_t *__restrict__ offs, uint32_t *__restrict__ keys,
                                                                  uint32_t *__restrict__ vals) {
     __shared__ uint32_t wc[SPLIT_MAXW][SPLIT_WAVES][SPLIT_MAXCLS];
-    const uint32_t n = n1 + n2, g = blockIdx.x * SPLIT_THREADS + threadIdx.x, ncls = 1u << split_bits, cmask = ncls - 1;
+    const uint32_t n = n1 + n2, g = blockIdx.x * SPLIT_THREADS + threadIdx.x, cmask = (1u << split_bits) - 1;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t d[SPLIT_MAXW];
+    for (uint32_t i = threadIdx.x; i < SPLIT_MAXW * SPLIT_WAVES * SPLIT_MAXCLS; i += SPLIT_THREADS) (&wc[0][0][0])[i] = 0;
+    __syncthreads();
+    uint32_t d[SPLIT_MAXW], rank[SPLIT_MAXW];
     const bool active = g < n;
     uint32_t base = 0;
     if (active) base = split_digits<Fr>(s1, n1, off1, s2, off2, g, L, d);
+    const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
 #pragma unroll
     for (int w = 0; w < SPLIT_MAXW; w++) {
+        rank[w] = 0;
         if (w < L.nwin) {
-            const uint32_t cls = active ? ((d[w] & VAL_SKIP) ? 0u : (d[w] & cmask)) : 0xffffffffu;
-            for (uint32_t k = 0; k < ncls; k++) {
-                uint64_t m = __ballot(cls == k);
-                if (lane == 0) wc[w][wave][k] = (uint32_t)__popcll(m);
-            }
+            const uint32_t cls = active ? ((d[w] & VAL_SKIP) ? 0u : (d[w] & cmask)) : 0u;
+            const uint64_t same = split_same_class(cls, split_bits, active);
+            rank[w] = (uint32_t)__popcll(same & lt);                                   // stable: lanes of a class keep their order
+            if (active && rank[w] == 0) wc[w][wave][cls] = (uint32_t)__popcll(same);
         }
     }
     __syncthreads();
     if (!active) return;
-    const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
 #pragma unroll
     for (int w = 0; w < SPLIT_MAXW; w++) {
         if (w < L.nwin) {
             const bool skip = (d[w] & VAL_SKIP) != 0;
             const uint32_t cls = skip ? 0u : (d[w] & cmask);
-            // same ballots as above (all lanes of the wave take this path together up to `active`, which only differs in the last block's tail)
-            uint64_t mine = 0;
-            for (uint32_t k = 0; k < ncls; k++) { uint64_t m = __ballot(cls == k); if (k == cls) mine = m; }
-            uint32_t pos = offs[((size_t)cls * L.nwin + w) * nblocks + blockIdx.x] + (uint32_t)__popcll(mine & lt);
+            uint32_t pos = offs[((size_t)cls * L.nwin + w) * nblocks + blockIdx.x] + rank[w];
             for (uint32_t v = 0; v < wave; v++) pos += wc[w][v][cls];
             keys[pos] = skip ? 0u : (d[w] & VAL_INDEX);
             vals[pos] = skip ? VAL_SKIP : (((uint32_t)w * stride + base) | (d[w] & (1u << 31)));
