@@ -88,6 +88,11 @@ struct Fp28 {
         return r;
     }
     ZK_HD Fp28 dbl() const { return *this + *this; }
+    // ---- lazy limb arithmetic: NO carry propagation, limbs may exceed 28 bits.  Only valid as ONE operand of a product whose other operand is normalized:
+    // a column then holds at most 14 limb products of (2^30.4 x 2^28) plus the reduction's 14 x 2^56, below 2^63 (te28.cuh lists the operands that use it).
+    ZK_HD Fp28 add_lazy(const Fp28 &b) const { Fp28 r; for (int i = 0; i < N; i++) r.l[i] = l[i] + b.l[i]; return r; }
+    ZK_HD Fp28 dbl_lazy() const { Fp28 r; for (int i = 0; i < N; i++) r.l[i] = l[i] << 1; return r; }
+    template <int K> ZK_HD Fp28 sub_lazy(const Fp28 &b) const { Fp28 r; for (int i = 0; i < N; i++) r.l[i] = l[i] + kp_spread<K>(i) - b.l[i]; return r; }   // b normalized; limbs <= (K + 2) 2^28
     // limb i of K p (normalized; the top limb keeps the excess) and the same with the borrows pre-distributed:
     // sum c_i 2^(28 i) = K p with c_i >= 2^28 - 1 below the top, so a_i - b_i + c_i never goes negative for a normalized b
     template <int K> ZK_HD static constexpr uint32_t kp_limb(int i) {

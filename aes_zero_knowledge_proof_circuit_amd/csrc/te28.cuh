@@ -64,17 +64,37 @@ ZK_HD Niels28<P> niels_identity() { Niels28<P> r; r.ymx = FpMsm<P>::k_one(); r.y
 // -(x, y) = (-x, y): swap y - x and y + x, negate 2 d x y
 template <class P>
 ZK_HD Niels28<P> niels_neg(const Niels28<P> &n) { Niels28<P> r; r.ymx = n.ypx; r.ypx = n.ymx; r.td = FpMsm<P>::zero().template sub<2>(n.td); return r; }
+// the same for the hot loop: 2p - td without the carry chain (td only ever multiplies the normalized T1)
+template <class P>
+ZK_HD Niels28<P> niels_neg_lazy(const Niels28<P> &n) { Niels28<P> r; r.ymx = n.ypx; r.ypx = n.ymx; r.td = FpMsm<P>::zero().template sub_lazy<2>(n.td); return r; }
 
-// acc += n, seven products, everything inlined (hot loop of k_accumulate).  acc coordinates < 2.1 p in, < 1.2 p out; n's coordinates < 2.1 p.
+// acc += n, seven products, everything inlined (hot loop of k_accumulate).  acc coordinates are products (normalized limbs, < 1.2 p) in and out; n's
+// coordinates normalized (the negated 2dxy may be lazy).
+// ZK_TE_LAZY=1 propagates carries only where a product needs a normalized operand (every product then has exactly one lazy operand, limbs up to 2^30.4:
+// Y1 -+ X1, 2 Z1, H and F skip the carry chain): 3,846 instead of 4,013 VALU instructions per addition -- and measurably SLOWER on MI355X
+// (k_accumulate 7.17 vs 7.08 ms at 2^22 points, bench 78.3 vs 79.1 blocks/s, profiles/r03_te_lazy.txt: the saved instructions are cheap 32-bit ones, the
+// kernel needs 214 instead of 198 VGPRs).  Off; kept as a checked (tests/te28_host_check.cpp builds both) A/B knob.
+#ifndef ZK_TE_LAZY
+#define ZK_TE_LAZY 0
+#endif
 template <class P>
 ZK_HD void te_madd(AccTE<P> &a, const Niels28<P> &n) {
     using G = FpMsm<P>;
-    G A = a.y.template sub<3>(a.x) * n.ymx;          // (Y1 - X1)(y2 - x2)
-    G B = (a.y + a.x) * n.ypx;                       // (Y1 + X1)(y2 + x2)
-    G C = a.t * n.td;                                // T1 2 d x2 y2
-    G D = a.z.dbl();                                 // 2 Z1            (Z2 = 1)
+#if ZK_TE_LAZY
+    G A = a.y.template sub_lazy<3>(a.x) * n.ymx;     // (Y1 - X1)(y2 - x2)
+    G B = a.y.add_lazy(a.x) * n.ypx;                 // (Y1 + X1)(y2 + x2)
+    G C = a.t * n.td;                                // T1 2 d x2 y2          (T1 normalized, td possibly lazy)
+    G D = a.z.dbl_lazy();                            // 2 Z1                  (Z2 = 1)
+    G E = B.template sub<2>(A), H = B.add_lazy(A);   // E normalized, H lazy
+    G F = D.template sub_lazy<2>(C), Gg = D + C;     // F lazy (D lazy + 2p - C), G normalized
+#else
+    G A = a.y.template sub<3>(a.x) * n.ymx;
+    G B = (a.y + a.x) * n.ypx;
+    G C = a.t * n.td;
+    G D = a.z.dbl();
     G E = B.template sub<2>(A), H = B + A;           // < 3.2 p, < 2.4 p
     G F = D.template sub<2>(C), Gg = D + C;          // < 6.2 p, < 5.4 p
+#endif
     a.x = E * F; a.y = Gg * H; a.t = E * H; a.z = F * Gg;
 }
 // a += b, unified (add-2008-hwcd-3): nine products

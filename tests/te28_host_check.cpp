@@ -34,8 +34,8 @@ int main() {
         if (flag) { bad++; printf("subgroup point flagged\n"); }
         for (int variant = 0; variant < 4; variant++) {
             Niels28<P> a1 = q1, a2 = q2; Affine<Fq> s1 = p1, s2 = p2;
-            if (variant & 1) { a1 = niels_neg<P>(a1); s1 = s1.neg(); }
-            if (variant & 2) { a2 = niels_neg<P>(a2); s2 = s2.neg(); }
+            if (variant & 1) { a1 = (it & 1) ? niels_neg_lazy<P>(a1) : niels_neg<P>(a1); s1 = s1.neg(); }      // the hot loop negates without the carry chain
+            if (variant & 2) { a2 = niels_neg_lazy<P>(a2); s2 = s2.neg(); }
             // accumulate from the identity: a1, a2, a1, a2, ... and a1 twice in a row (P + P through the unified law)
             AccTE<P> acc = te_identity<P>();
             XYZZ<Fq> ref = XYZZ<Fq>::inf();

@@ -84,12 +84,13 @@ def test_twisted_edwards_group_law_matches_xyzz_reference():
     doubling of the bucket reduction, negation, both maps) against XYZZ<Fq> on random points of the prime-order subgroup: accumulation chains from the
     identity incl. P + P and P - P through the unified law, running sums, double-and-add, infinity <-> identity, a 2-torsion point is refused."""
     src_path = os.path.join(ROOT, "tests", "te28_host_check.cpp")
-    with tempfile.TemporaryDirectory() as d:
-        exe = os.path.join(d, "t")
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", CSRC, src_path, "-o", exe])
-        out = subprocess.run([exe], capture_output=True, text=True)
-        assert out.returncode == 0, out.stdout + out.stderr
-        assert out.stdout.split() == ["te377", "0"], out.stdout
+    for lazy in (0, 1):                          # 1 = the carry-free variant of te_madd (a measured-slower A/B knob, csrc/te28.cuh)
+        with tempfile.TemporaryDirectory() as d:
+            exe = os.path.join(d, "t")
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-DZK_TE_LAZY=%d" % lazy, "-I", CSRC, src_path, "-o", exe])
+            out = subprocess.run([exe], capture_output=True, text=True)
+            assert out.returncode == 0, out.stdout + out.stderr
+            assert out.stdout.split() == ["te377", "0"], (lazy, out.stdout)
 
 
 SRC29 = r'''
