@@ -353,8 +353,9 @@ def run(args, api, dist_env=None):
                                             "note": "the kernel's real roof: 2649 v_mad_u64_u32 per bucket addition (7 Fq products x 378 on the curve's twisted Edwards model; round 2's XYZZ mixed add needed 3416), one addition per "
                                                     "(point, window) pair; peak = rate of the same Fq product stream in isolation (tools/ubench/rates.hip: 74.4 G products/s x 378). frac uses the same chip time "
                                                     "per launch as roofline.frac; frac_of_wall = all multiplies of the timed region / whole timed region."},
-                         "note": "integer-ALU bound (7 Fq limb products with their Montgomery reductions = 2649 v_mad_u64_u32 per bucket addition); HBM fraction of O(1%) is the expected regime (BASELINE.md §3); traffic is ~17x the "
-                                 "algorithmic bytes by construction: every window gathers its own 192-byte (64-byte aligned) precomputed copy of the base (13 windows), ~1.5 TB/s of sector traffic, not the limiter"},
+                         "note": "integer-ALU bound (7 Fq limb products with their Montgomery reductions = 2649 v_mad_u64_u32 per bucket addition); HBM fraction of O(1%) is the expected regime (BASELINE.md §3); traffic is ~23x the "
+                                 "algorithmic bytes by construction: every one of the 13 windows gathers its own 192-byte (64-byte aligned) precomputed copy of the base + a 4-byte index (2,548 B per point against 128 B), "
+                                 "~1.7 TB/s, not the limiter"},
         }
         if kernel_ms_per_step > 1e3 * elapsed / args.steps * 1.02:
             out["roofline"]["inconsistent"] = "kernel chip time per step exceeds the step itself"
