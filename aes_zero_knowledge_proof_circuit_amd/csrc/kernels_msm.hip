@@ -191,7 +191,7 @@ __global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_
 #define ZK_ACC_WAVES 2          // waves per SIMD the compiler must fit k_accumulate into (A/B knob: 3 spills with ff28, tools/gpu_runs/gpu_round2_occupancy.sh)
 #endif
 #ifndef ZK_ACC_PREFETCH
-#define ZK_ACC_PREFETCH 1       // software prefetch of the next gathered point (28 registers)
+#define ZK_ACC_PREFETCH 1       // software prefetch of the next gathered point (28 registers on the XYZZ law, 42 on the Edwards law)
 #endif
 template <class Law>
 __global__ void __launch_bounds__(64, ZK_ACC_WAVES) k_accumulate(const typename Law::Base *__restrict__ bases, const uint32_t *__restrict__ vals,
@@ -210,12 +210,19 @@ __global__ void __launch_bounds__(64, ZK_ACC_WAVES) k_accumulate(const typename 
         // unified law: the accumulator starts at the identity, P = +-Q and identity bases need no branch, nothing is deferred
         AccTE<P> acc = te_identity<P>();
         if (s < e) {
+#if ZK_ACC_PREFETCH
             uint32_t idx = vals[s];
             Niels28<P> nxt = bases[idx & VAL_INDEX];
+#endif
             for (uint32_t i = s; i < e; i++) {
+#if ZK_ACC_PREFETCH
                 Niels28<P> p = nxt;
                 uint32_t cur = idx;
                 if (i + 1 < e) { idx = vals[i + 1]; nxt = bases[idx & VAL_INDEX]; }   // prefetch the next gather under this add's ALU work
+#else
+                uint32_t cur = vals[i];
+                Niels28<P> p = bases[cur & VAL_INDEX];
+#endif
                 if (cur & VAL_SKIP) continue;
                 if (cur >> 31) p = niels_neg<P>(p);                                    // negative digit: add -P
                 te_madd<P>(acc, p);
