@@ -123,6 +123,25 @@ def test_msm_precomputed_window_tables_match_oracle(zko, api, cid, n, c):
         assert got == ref.raw
 
 
+@pytest.mark.parametrize("n,c", [((1 << 14) + 5, 20), (9000, 18), (6000, 17)])
+def test_msm_table_presplit_and_three_pass_sort_agree_with_oracle(zko, api, monkeypatch, n, c):
+    """from 2^16 (point, window) pairs and more than 16 bucket bits the digit kernels split the pairs stably on the low bucket bits (k_split_hist /
+    k_split_scatter) and the radix sort covers 16 bits in two passes; ZKAES_MSM_PRESPLIT=0 keeps digits + the full-width sort.  Both must match the oracle,
+    incl. the scalars 0 (every digit zero: SKIP entries), 1 and r - 1."""
+    bases = oracle_points(zko, 377, n, 13 * n + c)
+    scalars = bytearray(rand_fr_mont(n, zko.FR[377], 17 * n + c))
+    scalars[0:32] = bytes(32)
+    scalars[32:64] = zko.fr_pack([1], 377)
+    scalars[64:96] = zko.fr_pack([zko.FR[377] - 1], 377)
+    scalars[96:128] = bytes(32)
+    ref = C.create_string_buffer(96)
+    ref_inf = zko.lib().zko_api_msm(377, bases, bytes(scalars), C.c_size_t(n), ref)
+    for presplit in ("1", "0"):
+        monkeypatch.setenv("ZKAES_MSM_PRESPLIT", presplit)
+        got, inf = api.msm_table(377, bases, bytes(scalars), c)
+        assert not inf and not ref_inf and got == ref.raw, presplit
+
+
 @pytest.mark.parametrize("n,c,distinct", [((1 << 13) + 3, 20, 0), ((1 << 14) + 77, 18, 0), (5000, 16, 0), (20_000, 16, 3)])
 def test_msm_table_two_level_partition_matches_oracle(zko, api, monkeypatch, n, c, distinct):
     """the opt-in grouping of the table path (ZKAES_MSM_PARTITION=1: k_part_hist / k_part_scatter / k_part_fine instead of digits + radix sort + bounds;
