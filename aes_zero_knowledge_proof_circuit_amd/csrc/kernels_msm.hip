@@ -160,17 +160,6 @@ __global__ void k_bounds(const uint32_t *__restrict__ keys, size_t total, uint32
     }
 }
 
-// 16-bit-key layout: the sorted keys hold bucket >> split_bits, the low split_bits bucket bits ride in bits 28.. of the value word
-__global__ void k_bounds16(const uint16_t *__restrict__ keys, const uint32_t *__restrict__ vals, size_t total, int split_bits, uint32_t *__restrict__ start, uint32_t *__restrict__ end) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const uint32_t cm = (1u << split_bits) - 1;
-    auto full = [&](size_t j) { return ((uint32_t)keys[j] << split_bits) | ((vals[j] >> 28) & cm); };
-    const uint32_t key = full(i);
-    if (i == 0 || full(i - 1) != key) start[key] = (uint32_t)i;
-    if (i + 1 == total || full(i + 1) != key) end[key] = (uint32_t)(i + 1);
-}
-
 // standard (12 x 32, R = 2^384) bases -> reduced-radix copies; done once per SRS at key synthesis, or per call for ad-hoc bases
 template <class P>
 __global__ void k_convert_bases(const Affine<Fp<P>> *__restrict__ src, Affine28<P> *__restrict__ dst, size_t n) {
@@ -208,10 +197,7 @@ template <class Law>
 __global__ void __launch_bounds__(64, ZK_ACC_WAVES) k_accumulate(const typename Law::Base *__restrict__ bases, const uint32_t *__restrict__ vals,
                                                        const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, const uint32_t *__restrict__ order,
                                                        uint32_t nbuckets_total, uint32_t cap, typename Law::Acc *__restrict__ buckets,
-                                                       uint32_t *__restrict__ deferred, uint32_t deferred_cap, uint32_t *__restrict__ deferred_count,
-                                                       uint32_t idx_mask, uint32_t skip_mask) {
-    // value word: bit 31 = negate; the base index is `cur & idx_mask`, `cur & skip_mask` marks a zero digit.  Classic layout: 30 index bits + skip bit 30;
-    // 16-bit-key layout (pre-split digits): 28 index bits, bits 28-30 carry the low bucket bits for k_bounds16, no skip entries (skip_mask = 0)
+                                                       uint32_t *__restrict__ deferred, uint32_t deferred_cap, uint32_t *__restrict__ deferred_count) {
     using P = typename Law::Params;
     using G = FpMsm<P>;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -226,18 +212,18 @@ __global__ void __launch_bounds__(64, ZK_ACC_WAVES) k_accumulate(const typename 
         if (s < e) {
 #if ZK_ACC_PREFETCH
             uint32_t idx = vals[s];
-            Niels28<P> nxt = bases[idx & idx_mask];
+            Niels28<P> nxt = bases[idx & VAL_INDEX];
 #endif
             for (uint32_t i = s; i < e; i++) {
 #if ZK_ACC_PREFETCH
                 Niels28<P> p = nxt;
                 uint32_t cur = idx;
-                if (i + 1 < e) { idx = vals[i + 1]; nxt = bases[idx & idx_mask]; }   // prefetch the next gather under this add's ALU work
+                if (i + 1 < e) { idx = vals[i + 1]; nxt = bases[idx & VAL_INDEX]; }   // prefetch the next gather under this add's ALU work
 #else
                 uint32_t cur = vals[i];
-                Niels28<P> p = bases[cur & idx_mask];
+                Niels28<P> p = bases[cur & VAL_INDEX];
 #endif
-                if (cur & skip_mask) continue;
+                if (cur & VAL_SKIP) continue;
                 if (cur >> 31) p = niels_neg<P>(p);                                    // negative digit: add -P
                 te_madd<P>(acc, p);
             }
@@ -253,18 +239,18 @@ __global__ void __launch_bounds__(64, ZK_ACC_WAVES) k_accumulate(const typename 
         if (s < e) {
 #if ZK_ACC_PREFETCH
             uint32_t idx = vals[s];
-            Affine28<P> nxt = bases[idx & idx_mask];
+            Affine28<P> nxt = bases[idx & VAL_INDEX];
 #endif
             for (uint32_t i = s; i < e; i++) {
 #if ZK_ACC_PREFETCH
                 Affine28<P> p = nxt;
                 uint32_t cur = idx;
-                if (i + 1 < e) { idx = vals[i + 1]; nxt = bases[idx & idx_mask]; }   // prefetch the next gather under this add's ALU work
+                if (i + 1 < e) { idx = vals[i + 1]; nxt = bases[idx & VAL_INDEX]; }   // prefetch the next gather under this add's ALU work
 #else
                 uint32_t cur = vals[i];
-                Affine28<P> p = bases[cur & idx_mask];
+                Affine28<P> p = bases[cur & VAL_INDEX];
 #endif
-                if ((cur & skip_mask) || p.is_inf()) continue;
+                if ((cur & VAL_SKIP) || p.is_inf()) continue;
                 if (cur >> 31) p.y = G::zero().template sub<2>(p.y);                 // negative digit: add -P  (y < 1.2 p as a product, so 2p - y > 0)
                 if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_one(); acc.zzz = acc.zz; acc_inf = false; continue; }
                 if (!madd28(acc, p)) {
@@ -281,13 +267,13 @@ __global__ void __launch_bounds__(64, ZK_ACC_WAVES) k_accumulate(const typename 
 // replay of the deferred (bucket, point) pairs with the complete formulas; one lane, sequential (the list is empty in practice)
 template <class P>
 __device__ void accumulate_fixup(const Affine28<P> *__restrict__ bases, Acc28<P> *__restrict__ buckets, const uint32_t *__restrict__ deferred, uint32_t deferred_cap,
-                                 const volatile uint32_t *deferred_count, uint32_t idx_mask) {
+                                 const volatile uint32_t *deferred_count) {
     uint32_t n = *deferred_count;
     if (n > deferred_cap) n = deferred_cap;
     for (uint32_t i = 0; i < n; i++) {
         XYZZ<Fp<P>> b = to_std_point<P>(buckets[deferred[2 * i]]);
         uint32_t v = deferred[2 * i + 1];
-        Affine<Fp<P>> q = bases[v & idx_mask].to_std();
+        Affine<Fp<P>> q = bases[v & VAL_INDEX].to_std();
         b.madd((v >> 31) ? q.neg() : q);
         buckets[deferred[2 * i]] = from_std_point<P>(b);
     }
@@ -302,7 +288,7 @@ template <class Law>
 __global__ void __launch_bounds__(64, 2) k_accumulate_tail(const typename Law::Base *__restrict__ bases, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ start,
                                                             const uint32_t *__restrict__ end, const uint32_t *__restrict__ extra_off, uint32_t nb, uint32_t max_segments, uint32_t cap,
                                                             typename Law::Acc *__restrict__ partial, typename Law::Acc *__restrict__ buckets, uint32_t *__restrict__ deferred, uint32_t deferred_cap,
-                                                            uint32_t *__restrict__ deferred_count, uint32_t idx_mask, uint32_t skip_mask) {
+                                                            uint32_t *__restrict__ deferred_count) {
     using P = typename Law::Params;
     using A = typename Law::Acc;
     using G = FpMsm<P>;
@@ -326,8 +312,8 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_tail(const typename Law::B
                 acc = te_identity<P>();
                 for (uint32_t i = s; i < e; i++) {
                     uint32_t cur = vals[i];
-                    if (cur & skip_mask) continue;
-                    Niels28<P> p = bases[cur & idx_mask];
+                    if (cur & VAL_SKIP) continue;
+                    Niels28<P> p = bases[cur & VAL_INDEX];
                     if (cur >> 31) p = niels_neg<P>(p);
                     te_madd<P>(acc, p);
                 }
@@ -337,8 +323,8 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_tail(const typename Law::B
                 bool acc_inf = true;
                 for (uint32_t i = s; i < e; i++) {
                     uint32_t cur = vals[i];
-                    Affine28<P> p = bases[cur & idx_mask];
-                    if ((cur & skip_mask) || p.is_inf()) continue;
+                    Affine28<P> p = bases[cur & VAL_INDEX];
+                    if ((cur & VAL_SKIP) || p.is_inf()) continue;
                     if (cur >> 31) p.y = G::zero().template sub<2>(p.y);
                     if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_one(); acc.zzz = acc.zz; acc_inf = false; continue; }
                     if (!madd28(acc, p)) {
@@ -367,7 +353,7 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_tail(const typename Law::B
         __syncthreads();
         if (ticket != gridDim.x - 1 || threadIdx.x != 0) return;
         __threadfence();
-        accumulate_fixup<P>(bases, buckets, deferred, deferred_cap, deferred_count, idx_mask);
+        accumulate_fixup<P>(bases, buckets, deferred, deferred_cap, deferred_count);
     }
 }
 // bucket k with its overflow partials folded in (k_reduce_l1's load)
@@ -453,50 +439,6 @@ __global__ void __launch_bounds__(256) k_reduce_window(const A *__restrict__ par
     if (t == 0) out[w] = PtOps<A>::to_std(sh[0]);     // always the Weierstrass XYZZ form in the library-wide Montgomery representation
 }
 
-// the same for the ONE bucket set of the 16-bit-key table path: zero digits were accumulated as digit +1 (no skip entries there) and listed in
-// zero_list[1 ..] (count in [0]); their bases are summed here and subtracted from the window sum
-constexpr uint32_t ZERO_CAP = 4096;
-template <class Law>
-__device__ __forceinline__ void law_add_base(typename Law::Acc &acc, const typename Law::Base &b) {
-    using P = typename Law::Params;
-#if ZK_MSM_EDWARDS
-    if constexpr (Law::edwards) { te_madd<P>(acc, b); } else
-#endif
-    {
-        if (b.is_inf()) return;
-        Acc28<P> p; p.x = b.x; p.y = b.y; p.zz = FpMsm<P>::k_one(); p.zzz = p.zz;
-        add28<P>(acc, p);
-    }
-}
-template <class Law>
-__global__ void __launch_bounds__(256) k_reduce_window_fix(const typename Law::Acc *__restrict__ partial, uint32_t per_window, XYZZ<Fp<typename Law::Params>> *__restrict__ out,
-                                                           const typename Law::Base *__restrict__ bases, const uint32_t *__restrict__ zero_list, uint32_t idx_mask) {
-    using A = typename Law::Acc;
-    __shared__ A sh[256];
-    uint32_t t = threadIdx.x;
-    A acc = PtOps<A>::identity();
-    for (uint32_t i = t; i < per_window; i += 256) PtOps<A>::add(acc, partial[i]);
-    sh[t] = acc;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)t < s) { A a = sh[t]; PtOps<A>::add(a, sh[t + s]); sh[t] = a; }
-        __syncthreads();
-    }
-    A total = sh[0];
-    __syncthreads();
-    uint32_t nz = zero_list[0];
-    if (nz > ZERO_CAP) nz = ZERO_CAP;                   // (the host sees the overflow and redoes the MSM on the classic layout)
-    acc = PtOps<A>::identity();
-    for (uint32_t i = t; i < nz; i += 256) law_add_base<Law>(acc, bases[zero_list[1 + i] & idx_mask]);
-    sh[t] = acc;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)t < s) { A a = sh[t]; PtOps<A>::add(a, sh[t + s]); sh[t] = a; }
-        __syncthreads();
-    }
-    if (t == 0) { PtOps<A>::add(total, PtOps<A>::neg(sh[0])); out[0] = PtOps<A>::to_std(total); }
-}
-
 template <class A> __global__ void k_sum_tree(const A *__restrict__ in, uint32_t total, uint32_t per, A *__restrict__ out);
 
 constexpr uint32_t DEFERRED_CAP = 1u << 20;
@@ -514,10 +456,6 @@ struct MsmWorkspace {
     uint32_t *part_hist = nullptr, *part_offs = nullptr; size_t cap_part = 0;      // two-level partition: (coarse bin, workgroup) histogram and its scan
     size_t plan_n = 0, plan_pairs = 0; int plan_c = 0, plan_nwin = 0;     // state between msm_prepare and msm_finish
     bool plan_table = false; uint32_t plan_cap = BUCKET_CAP;
-    uint32_t plan_idx_mask = VAL_INDEX, plan_skip_mask = VAL_SKIP;       // how k_accumulate reads a value word (classic / 16-bit-key layout)
-    bool plan_key16 = false;
-    uint32_t *zero_list = nullptr;                                        // 16-bit-key layout: [0] = number of zero digits, [1 .. ZERO_CAP] their value words
-    const void *plan_s1 = nullptr, *plan_s2 = nullptr; size_t plan_n1 = 0, plan_off1 = 0, plan_n2 = 0, plan_off2 = 0, plan_stride = 0; int plan_table_c = 0;   // for the fallback re-prepare
     uint32_t *deferred = nullptr, *deferred_count = nullptr;
     void *buckets = nullptr, *seg_s = nullptr, *seg_w = nullptr, *partial = nullptr, *wsum = nullptr, *tmp = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, fence_a = nullptr, fence_b = nullptr;
@@ -528,7 +466,6 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
     if (!S.ev0) {
         HIP_CHECK(hipEventCreate(&S.ev0)); HIP_CHECK(hipEventCreate(&S.ev1));
         S.deferred = (uint32_t *)dmalloc(2 * DEFERRED_CAP * 4); S.deferred_count = (uint32_t *)dmalloc(8);
-        S.zero_list = (uint32_t *)dmalloc((ZERO_CAP + 1) * 4);
     }
     if (pairs / cap + 64 > S.cap_ovf) { dfree(S.ovf_partial); S.cap_ovf = pairs / cap + 64; S.ovf_partial = dmalloc(S.cap_ovf * ACC_BYTES); }
     if (pairs > S.cap_pairs) {
@@ -572,7 +509,7 @@ MsmWorkspace *msm_workspace_create() {
 void msm_workspace_destroy(MsmWorkspace *w) {
     if (!w) return;
     for (void *p : {(void *)w->keys_a, (void *)w->keys_b, (void *)w->vals_a, (void *)w->vals_b, (void *)w->start, (void *)w->end, (void *)w->size_key, (void *)w->size_key2, (void *)w->ids,
-                    (void *)w->order, (void *)w->extra, (void *)w->extra_off, w->ovf_partial, (void *)w->part_hist, (void *)w->part_offs, (void *)w->zero_list, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->wsum, w->tmp}) dfree(p);
+                    (void *)w->order, (void *)w->extra, (void *)w->extra_off, w->ovf_partial, (void *)w->part_hist, (void *)w->part_offs, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->wsum, w->tmp}) dfree(p);
     if (w->ev0) { (void)hipEventDestroy(w->ev0); (void)hipEventDestroy(w->ev1); }
     if (w->low) { (void)hipStreamDestroy(w->low); (void)hipEventDestroy(w->fence_a); (void)hipEventDestroy(w->fence_b); }
     delete w;
@@ -599,30 +536,13 @@ static void order_buckets(MsmWorkspace &S, size_t nb, uint32_t cap, hipStream_t 
 
 // shared middle: sort the (key, value) pairs, find bucket ranges, order buckets by descending size, cut oversized buckets
 template <class P>
-static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int sort_bits, uint32_t cap, hipStream_t s, int begin_bit = 0, bool key16 = false) {
+static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int sort_bits, uint32_t cap, hipStream_t s, int begin_bit = 0) {
     // c here = log2(buckets per set); keys run over [0, nb) plus the out-of-range key nb for zero digits
     size_t nb = (size_t)nsets << c;
     int key_bits = 1;
     while (((size_t)1 << key_bits) <= nb) key_bits++;
     if (sort_bits > 0 && sort_bits < key_bits) key_bits = sort_bits;       // stable sort on the bucket bits only (window-major input)
     size_t tmp_bytes = 0;
-    HIP_CHECK(hipMemsetAsync(S.start, 0, nb * 4, s));
-    HIP_CHECK(hipMemsetAsync(S.end, 0, nb * 4, s));
-    if (key16) {
-        // pre-split digits with 16-bit keys: the keys ARE bucket >> begin_bit, so the sort covers their low (key_bits - begin_bit) <= 16 bits; 6-byte pairs
-        rocprim::double_buffer<uint16_t> dk((uint16_t *)S.keys_a, (uint16_t *)S.keys_b);
-        rocprim::double_buffer<uint32_t> dv(S.vals_a, S.vals_b);
-        const unsigned end_bit = (unsigned)(key_bits - begin_bit);
-        HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, pairs, 0u, end_bit, s));
-        if (tmp_bytes > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tmp_bytes); S.cap_tmp = tmp_bytes; }
-        HIP_CHECK(rocprim::radix_sort_pairs(S.tmp, tmp_bytes, dk, dv, pairs, 0u, end_bit, s));
-        if (knockin() & 1) HIP_CHECK(rocprim::radix_sort_pairs(S.tmp, tmp_bytes, dk, dv, pairs, 0u, end_bit, s));
-        S.sorted_keys = nullptr; S.sorted_vals = dv.current();
-        hipLaunchKernelGGL(k_bounds16, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, (const uint16_t *)dk.current(), (const uint32_t *)S.sorted_vals, pairs, begin_bit, S.start, S.end);
-        HIP_LAUNCH_CHECK();
-        order_buckets(S, nb, cap, s);
-        return;
-    }
     // ping-pong sort: the result stays in whichever buffer the last radix pass wrote (no copy back)
     rocprim::double_buffer<uint32_t> dk(S.keys_a, S.keys_b), dv(S.vals_a, S.vals_b);
     HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, pairs, (unsigned)begin_bit, (unsigned)key_bits, s));
@@ -630,6 +550,8 @@ static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int
     HIP_CHECK(rocprim::radix_sort_pairs(S.tmp, tmp_bytes, dk, dv, pairs, (unsigned)begin_bit, (unsigned)key_bits, s));
     if (knockin() & 1) HIP_CHECK(rocprim::radix_sort_pairs(S.tmp, tmp_bytes, dk, dv, pairs, (unsigned)begin_bit, (unsigned)key_bits, s));
     S.sorted_keys = dk.current(); S.sorted_vals = dv.current();
+    HIP_CHECK(hipMemsetAsync(S.start, 0, nb * 4, s));
+    HIP_CHECK(hipMemsetAsync(S.end, 0, nb * 4, s));
     hipLaunchKernelGGL(k_bounds, dim3((unsigned)(((pairs + 3) / 4 + 255) / 256)), dim3(256), 0, s, S.sorted_keys, pairs, (uint32_t)nb, S.start, S.end);
     HIP_LAUNCH_CHECK();
     order_buckets(S, nb, cap, s);
@@ -638,7 +560,7 @@ static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int
 // nsets window sums.  May be called several times on one prepared state with different base arrays (same scalars, e.g. plain + shifted powers).
 template <class Law>
 static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, const typename Law::Base *bases, size_t pairs, int c, int nsets, size_t n_points, uint32_t cap, hipStream_t s, float *acc_ms,
-                                            XYZZ<Fp<typename Law::Params>> *dev_wsum_out = nullptr, bool *zero_overflow = nullptr) {
+                                            XYZZ<Fp<typename Law::Params>> *dev_wsum_out = nullptr) {
     using P = typename Law::Params;
     using A = typename Law::Acc;
     using Fq = Fp<P>;
@@ -651,23 +573,23 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
     if (S.low) { HIP_CHECK(hipEventRecord(S.fence_a, s)); HIP_CHECK(hipStreamWaitEvent(S.low, S.fence_a, 0)); }
     if (knockin() & 8) {        // (measurement only) one extra, untimed launch
         hipLaunchKernelGGL((k_accumulate<Law>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, sa, bases, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb, cap,
-                           (A *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count, S.plan_idx_mask, S.plan_skip_mask);
+                           (A *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
         HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 8, sa));
     }
     HIP_CHECK(hipEventRecord(S.ev0, sa));
     hipLaunchKernelGGL((k_accumulate<Law>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, sa, bases, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb, cap,
-                       (A *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count, S.plan_idx_mask, S.plan_skip_mask);
+                       (A *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
     HIP_CHECK(hipEventRecord(S.ev1, sa));
     if (S.low) { HIP_CHECK(hipEventRecord(S.fence_b, S.low)); HIP_CHECK(hipStreamWaitEvent(s, S.fence_b, 0)); }
     uint32_t max_seg = (uint32_t)(pairs / cap + 1);
     // oversized buckets + deferred degenerate additions (none for uniformly distributed digits: every lane exits at once)
     hipLaunchKernelGGL((k_accumulate_tail<Law>), dim3((max_seg + 63) / 64), dim3(64), 0, s, bases, S.sorted_vals, S.start, S.end, S.extra_off, (uint32_t)nb, max_seg, cap,
-                       (A *)S.ovf_partial, (A *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count, S.plan_idx_mask, S.plan_skip_mask);
+                       (A *)S.ovf_partial, (A *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
     if (knockin() & 4) {        // (measurement only) the tail kernel once more: its ticket never reaches gridDim - 1 again, so the deferred replay runs once
         hipLaunchKernelGGL((k_accumulate_tail<Law>), dim3((max_seg + 63) / 64), dim3(64), 0, s, bases, S.sorted_vals, S.start, S.end, S.extra_off, (uint32_t)nb, max_seg, cap,
-                           (A *)S.ovf_partial, (A *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count, S.plan_idx_mask, S.plan_skip_mask);
+                           (A *)S.ovf_partial, (A *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     }
     uint32_t segs = (1u << c) / RED_L1, groups = (segs + RED_L2 - 1) / RED_L2;
     for (int rep = (knockin() & 2) ? 0 : 1; rep < 2; rep++) {
@@ -681,11 +603,9 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
         uint32_t mid = (groups + 255) / 256;
         hipLaunchKernelGGL((k_sum_tree<A>), dim3(mid), dim3(256), 0, s, (const A *)S.partial, groups, 256u, (A *)S.seg_s);
         HIP_LAUNCH_CHECK();
-        if (S.plan_key16) hipLaunchKernelGGL((k_reduce_window_fix<Law>), dim3(1), dim3(256), 0, s, (const A *)S.seg_s, mid, (XYZZ<Fq> *)S.wsum, bases, (const uint32_t *)S.zero_list, S.plan_idx_mask);
-        else hipLaunchKernelGGL((k_reduce_window<A>), dim3(1), dim3(256), 0, s, (const A *)S.seg_s, mid, (XYZZ<Fq> *)S.wsum);
+        hipLaunchKernelGGL((k_reduce_window<A>), dim3(1), dim3(256), 0, s, (const A *)S.seg_s, mid, (XYZZ<Fq> *)S.wsum);
     } else {
-        if (S.plan_key16) hipLaunchKernelGGL((k_reduce_window_fix<Law>), dim3(1), dim3(256), 0, s, (const A *)S.partial, groups, (XYZZ<Fq> *)S.wsum, bases, (const uint32_t *)S.zero_list, S.plan_idx_mask);
-        else hipLaunchKernelGGL((k_reduce_window<A>), dim3((unsigned)nsets), dim3(256), 0, s, (const A *)S.partial, groups, (XYZZ<Fq> *)S.wsum);
+        hipLaunchKernelGGL((k_reduce_window<A>), dim3((unsigned)nsets), dim3(256), 0, s, (const A *)S.partial, groups, (XYZZ<Fq> *)S.wsum);
     }
     HIP_LAUNCH_CHECK();
     }
@@ -695,10 +615,7 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
     sync((stream_t)s);        // drain first (sleeps in throughput mode): the pageable device-to-host copies below wait actively inside HIP
     HIP_CHECK(hipMemcpyAsync(ws.data(), S.wsum, sizeof(XYZZ<Fq>) * nsets, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(&n_deferred, S.deferred_count, 4, hipMemcpyDeviceToHost, s));
-    uint32_t n_zero = 0;
-    if (S.plan_key16) HIP_CHECK(hipMemcpyAsync(&n_zero, S.zero_list, 4, hipMemcpyDeviceToHost, s));
     sync((stream_t)s);
-    if (zero_overflow) *zero_overflow = S.plan_key16 && n_zero > ZERO_CAP;      // more zero digits than the correction list holds: the caller redoes the MSM on the classic layout
     if (n_deferred > DEFERRED_CAP) throw GpuError("msm: more than 2^20 degenerate additions (repeated base points); refusing to return a wrong sum");
     HIP_CHECK(hipEventElapsedTime(acc_ms, S.ev0, S.ev1));
     (void)n_points;
@@ -796,15 +713,11 @@ void msm_prepare(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_t n1, 
     if (pairs >= ((size_t)1 << 31)) throw GpuError("msm: n x windows exceeds the 2^31 pairs the sort indexes with int");
     const size_t nb = (size_t)nwin << (c - 1);
     S.plan_c = c; S.plan_nwin = nwin; S.plan_pairs = pairs; S.plan_table = false; S.plan_cap = BUCKET_CAP;
-    S.plan_idx_mask = VAL_INDEX; S.plan_skip_mask = VAL_SKIP; S.plan_key16 = false;
     ensure_scratch(S, pairs, nb, BUCKET_CAP);
     if (n1) { hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, scal1, (uint32_t)n1, 0u, (uint32_t)n, 0u, c, nwin, (uint32_t)nb, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
     if (n2) { hipLaunchKernelGGL((k_digits<Fr>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, scal2, (uint32_t)n2, (uint32_t)n1, (uint32_t)n, (uint32_t)val_off2, c, nwin, (uint32_t)nb, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
     prepare_buckets<typename Curve::FqP>(S, pairs, c - 1, nwin, c - 1, BUCKET_CAP, s);
 }
-template <class Curve>
-static void prepare_table_impl(MsmWorkspace &S, const typename Curve::Fr *scal1, size_t n1, size_t off1, const typename Curve::Fr *scal2, size_t n2, size_t off2, int c, size_t stride, hipStream_t s,
-                               bool allow_key16);
 template <class Curve, class Law>
 static XYZZ<typename Curve::Fq> msm_finish_impl(MsmWorkspace *ws_, const typename Law::Base *bases, stream_t s_) {
     using Fq = typename Curve::Fq;
@@ -817,12 +730,7 @@ static XYZZ<typename Curve::Fq> msm_finish_impl(MsmWorkspace *ws_, const typenam
     const int c = S.plan_c, nwin = S.plan_nwin;
     float ms = 0;
     if (S.plan_table) {      // `bases` = table copy 0 (+ a constant index shift): the window weights live in the copies, ONE bucket set, no Horner
-        bool zero_overflow = false;
-        std::vector<XYZZ<Fq>> one = run_buckets<Law>(S, bases, S.plan_pairs, c - 1, 1, S.plan_n, S.plan_cap, s, &ms, nullptr, &zero_overflow);
-        if (zero_overflow) {      // thousands of zero digits (sparse scalars): group again on the classic layout, which carries skip entries
-            prepare_table_impl<Curve>(S, (const typename Curve::Fr *)S.plan_s1, S.plan_n1, S.plan_off1, (const typename Curve::Fr *)S.plan_s2, S.plan_n2, S.plan_off2, S.plan_table_c, S.plan_stride, s, false);
-            one = run_buckets<Law>(S, bases, S.plan_pairs, S.plan_c - 1, 1, S.plan_n, S.plan_cap, s, &ms);
-        }
+        std::vector<XYZZ<Fq>> one = run_buckets<Law>(S, bases, S.plan_pairs, c - 1, 1, S.plan_n, S.plan_cap, s, &ms);
         add_stats(ms, S.plan_n, S.plan_pairs, t_begin);
         return one[0];
     }
@@ -1017,7 +925,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) k_split_hist(const Fr *__restri
 template <class Fr>
 __global__ void __launch_bounds__(SPLIT_THREADS) k_split_scatter(const Fr *__restrict__ s1, uint32_t n1, uint32_t off1, const Fr *__restrict__ s2, uint32_t n2, uint32_t off2, TableLayout L,
                                                                  uint32_t stride, int split_bits, uint32_t nblocks, const uint32_t *__restrict__ offs, uint32_t *__restrict__ keys,
-                                                                 uint32_t *__restrict__ vals, int key16, uint32_t *__restrict__ zero_list) {
+                                                                 uint32_t *__restrict__ vals) {
     __shared__ uint32_t wc[SPLIT_MAXW][SPLIT_WAVES][SPLIT_MAXCLS];
     const uint32_t n = n1 + n2, g = blockIdx.x * SPLIT_THREADS + threadIdx.x, cmask = (1u << split_bits) - 1;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1047,17 +955,8 @@ __global__ void __launch_bounds__(SPLIT_THREADS) k_split_scatter(const Fr *__res
             const uint32_t cls = skip ? 0u : (d[w] & cmask);
             uint32_t pos = offs[((size_t)cls * L.nwin + w) * nblocks + blockIdx.x] + rank[w];
             for (uint32_t v = 0; v < wave; v++) pos += wc[w][v][cls];
-            if (key16) {
-                // 16-bit keys (bucket >> split_bits), class bits in the value word; a zero digit is written as digit +1 (bucket 0, class 0) and listed for the
-                // correction in k_reduce_window_fix -- there is no room left for a skip bit
-                const uint32_t idx = (uint32_t)w * stride + base;
-                ((uint16_t *)keys)[pos] = skip ? (uint16_t)0 : (uint16_t)((d[w] & VAL_INDEX) >> split_bits);
-                vals[pos] = skip ? idx : (idx | (cls << 28) | (d[w] & (1u << 31)));
-                if (skip) { uint32_t slot = atomicAdd(zero_list, 1u); if (slot < ZERO_CAP) zero_list[1 + slot] = idx; }
-            } else {
-                keys[pos] = skip ? 0u : (d[w] & VAL_INDEX);
-                vals[pos] = skip ? VAL_SKIP : (((uint32_t)w * stride + base) | (d[w] & (1u << 31)));
-            }
+            keys[pos] = skip ? 0u : (d[w] & VAL_INDEX);
+            vals[pos] = skip ? VAL_SKIP : (((uint32_t)w * stride + base) | (d[w] & (1u << 31)));
         }
     }
 }
@@ -1244,11 +1143,13 @@ static void partition_buckets(MsmWorkspace &S, const Fr *scal1, size_t n1, size_
 // Table-mode Pippenger in the same two steps as the per-window variant.  msm_prepare_table: signed c-bit digits of up to two scalar vectors
 // (element i of vector v names table entry w * stride + off_v + i in window w), sort on the c - 1 bucket bits, bucket ranges;
 // msm_finish (above) with `tables` = copy 0 (optionally shifted by a constant index, e.g. to the shifted-powers part of every copy).
-static bool key16_enabled() { const char *e = getenv("ZKAES_MSM_KEY16"); return !e || atoi(e) != 0; }
 template <class Curve>
-static void prepare_table_impl(MsmWorkspace &S, const typename Curve::Fr *scal1, size_t n1, size_t off1, const typename Curve::Fr *scal2, size_t n2, size_t off2, int c, size_t stride, hipStream_t s,
-                               bool allow_key16) {
+void msm_prepare_table(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_t n1, size_t off1, const typename Curve::Fr *scal2, size_t n2, size_t off2, int c, size_t stride,
+                       stream_t s_) {
     using Fr = typename Curve::Fr;
+    hipStream_t s = (hipStream_t)s_;
+    if (!ws_) throw GpuError("msm: null workspace");
+    MsmWorkspace &S = *ws_;
     size_t n = n1 + n2;
     S.plan_n = n;
     if (n == 0) return;
@@ -1260,8 +1161,6 @@ static void prepare_table_impl(MsmWorkspace &S, const typename Curve::Fr *scal1,
     size_t pairs = n * (size_t)nwin;
     const size_t nb = (size_t)1 << (L.c_hi - 1);
     S.plan_c = L.c_hi; S.plan_nwin = nwin; S.plan_pairs = pairs; S.plan_table = true; S.plan_cap = BUCKET_CAP_TABLE;
-    S.plan_idx_mask = VAL_INDEX; S.plan_skip_mask = VAL_SKIP; S.plan_key16 = false;
-    S.plan_s1 = scal1; S.plan_n1 = n1; S.plan_off1 = off1; S.plan_s2 = scal2; S.plan_n2 = n2; S.plan_off2 = off2; S.plan_stride = stride; S.plan_table_c = c;
     ensure_scratch(S, pairs, nb, BUCKET_CAP_TABLE);
     if (partition_enabled() && L.c_hi - 1 > PART_FINE_BITS && (1u << (L.c_hi - 1 - PART_FINE_BITS)) <= PART_NBIN_MAX && L.nwin <= PART_MAXW && pairs >= ((size_t)1 << 16)) {
         partition_buckets<Fr>(S, scal1, n1, off1, scal2, n2, off2, L, stride, BUCKET_CAP_TABLE, s);
@@ -1269,9 +1168,7 @@ static void prepare_table_impl(MsmWorkspace &S, const typename Curve::Fr *scal1,
     }
     const int B = L.c_hi - 1, split_bits = B > 16 ? (B - 16 < 3 ? B - 16 : 3) : 0;
     if (presplit_enabled() && split_bits > 0 && nwin <= SPLIT_MAXW && pairs >= ((size_t)1 << 16)) {
-        // the digit kernels already split the pairs (stably) on the low `split_bits` bucket bits: the radix sort starts above them.  When the other bucket bits fit
-        // 16 and the table indices 28 bits, the keys are written as 16-bit words (6-byte pairs through the sort) and the split bits ride in the value word.
-        const bool key16 = allow_key16 && key16_enabled() && B - split_bits <= 16 && (uint64_t)nwin * stride < (1ull << 28);
+        // the digit kernels already split the pairs (stably) on the low `split_bits` bucket bits: the radix sort starts above them
         const uint32_t nblocks = (uint32_t)((n + SPLIT_THREADS - 1) / SPLIT_THREADS);
         const size_t nh = ((size_t)nwin << split_bits) * nblocks;
         if (nh > S.cap_part) { dfree(S.part_hist); dfree(S.part_offs); S.part_hist = (uint32_t *)dmalloc(nh * 4); S.part_offs = (uint32_t *)dmalloc(nh * 4); S.cap_part = nh; }
@@ -1281,25 +1178,15 @@ static void prepare_table_impl(MsmWorkspace &S, const typename Curve::Fr *scal1,
         HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, S.part_hist, S.part_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
         if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
         HIP_CHECK(rocprim::exclusive_scan(S.tmp, tb, S.part_hist, S.part_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
-        if (key16) {
-            HIP_CHECK(hipMemsetAsync(S.zero_list, 0, 4, s));
-            S.plan_key16 = true; S.plan_idx_mask = (1u << 28) - 1; S.plan_skip_mask = 0;
-        }
         hipLaunchKernelGGL((k_split_scatter<Fr>), dim3(nblocks), dim3(SPLIT_THREADS), 0, s, scal1, (uint32_t)n1, (uint32_t)off1, scal2, (uint32_t)n2, (uint32_t)off2, L, (uint32_t)stride, split_bits,
-                           nblocks, (const uint32_t *)S.part_offs, S.keys_a, S.vals_a, key16 ? 1 : 0, S.zero_list);
+                           nblocks, (const uint32_t *)S.part_offs, S.keys_a, S.vals_a);
         HIP_LAUNCH_CHECK();
-        prepare_buckets<typename Curve::FqP>(S, pairs, B, 1, B, BUCKET_CAP_TABLE, s, split_bits, key16);
+        prepare_buckets<typename Curve::FqP>(S, pairs, B, 1, B, BUCKET_CAP_TABLE, s, split_bits);
         return;
     }
     if (n1) { hipLaunchKernelGGL((k_digits_table<Fr>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, scal1, (uint32_t)n1, 0u, (uint32_t)n, (uint32_t)off1, L, (uint32_t)stride, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
     if (n2) { hipLaunchKernelGGL((k_digits_table<Fr>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, scal2, (uint32_t)n2, (uint32_t)n1, (uint32_t)n, (uint32_t)off2, L, (uint32_t)stride, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
     prepare_buckets<typename Curve::FqP>(S, pairs, L.c_hi - 1, 1, L.c_hi - 1, BUCKET_CAP_TABLE, s);
-}
-template <class Curve>
-void msm_prepare_table(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_t n1, size_t off1, const typename Curve::Fr *scal2, size_t n2, size_t off2, int c, size_t stride,
-                       stream_t s_) {
-    if (!ws_) throw GpuError("msm: null workspace");
-    prepare_table_impl<Curve>(*ws_, scal1, n1, off1, scal2, n2, off2, c, stride, (hipStream_t)s_, true);
 }
 template <class Curve>
 XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *tables, size_t stride, size_t off, int c, const typename Curve::Fr *scalars, size_t n, stream_t s_) {
