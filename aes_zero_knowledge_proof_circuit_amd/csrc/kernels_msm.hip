@@ -392,36 +392,47 @@ __global__ void __launch_bounds__(64) k_reduce_l1(const A *__restrict__ buckets,
     seg_s[t] = run;
     seg_w[t] = tot;
 }
+// Two roles per group (whole 64-lane workgroups take one role, so nobody diverges): a lane's time is its NUMBER of point operations, and one lane doing both the
+// running sums (29 operations) and the scalar product (8 + up to 28) was the longest chain of the whole reduction (630 us of the 1.36 ms a bucket reduction costs
+// a lone encrypt() call).  Role 0 writes sw + L1 (tot2 - run) to partial[.. 2h], role 1 sums its S_g again and writes (L1 g0) run to partial[.. 2h + 1]; the trees behind
+// add everything up anyway.
 template <class A>
 __global__ void __launch_bounds__(64) k_reduce_l2(const A *__restrict__ seg_s, const A *__restrict__ seg_w, int c, int nwin, A *__restrict__ partial) {
     uint32_t segs = (1u << c) / RED_L1, groups = (segs + RED_L2 - 1) / RED_L2;
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t role = blockIdx.x & 1;
+    uint32_t t = (blockIdx.x >> 1) * blockDim.x + threadIdx.x;
     if (t >= groups * (uint32_t)nwin) return;
     uint32_t w = t / groups, h = t % groups;
     uint32_t g0 = h * RED_L2, g1 = g0 + RED_L2 < segs ? g0 + RED_L2 : segs;
     const A *S = seg_s + (size_t)w * segs, *W = seg_w + (size_t)w * segs;
-    A run = PtOps<A>::identity(), tot2 = PtOps<A>::identity(), sw = PtOps<A>::identity();
-    for (int g = (int)g1 - 1; g >= (int)g0; g--) {
-        PtOps<A>::add(run, S[g]);
-        PtOps<A>::add(tot2, run);           // tot2 = sum (g - g0 + 1) S_g
-        PtOps<A>::add(sw, W[g]);
-    }
-    // bucket j carries weight j + 1:  sum_g [W_g + L1 g S_g] = sw + L1 (tot2 - run) + (L1 g0) run     (run = sum S_g, L1 = 8)
-    A a = tot2;
-    PtOps<A>::add(a, PtOps<A>::neg(run));
-    for (int i = 0; i < 3; i++) PtOps<A>::dbl(a);      // * RED_L1
-    PtOps<A>::add(sw, a);
-    if (g0 != 0) {
-        uint32_t m = RED_L1 * g0;
-        A acc = PtOps<A>::identity();
-        int top = 31 - __clz(m);
-        for (int bit = top; bit >= 0; bit--) {
-            PtOps<A>::dbl(acc);
-            if ((m >> bit) & 1) PtOps<A>::add(acc, run);
+    A *out = partial + (size_t)w * 2 * groups + 2 * h + role;
+    if (role == 0) {
+        A run = PtOps<A>::identity(), tot2 = PtOps<A>::identity(), sw = PtOps<A>::identity();
+        for (int g = (int)g1 - 1; g >= (int)g0; g--) {
+            PtOps<A>::add(run, S[g]);
+            PtOps<A>::add(tot2, run);           // tot2 = sum (g - g0 + 1) S_g
+            PtOps<A>::add(sw, W[g]);
         }
-        PtOps<A>::add(sw, acc);
+        // bucket j carries weight j + 1:  sum_g [W_g + L1 g S_g] = sw + L1 (tot2 - run) + (L1 g0) run     (run = sum S_g, L1 = 8); the last term is role 1's
+        A a = tot2;
+        PtOps<A>::add(a, PtOps<A>::neg(run));
+        for (int i = 0; i < 3; i++) PtOps<A>::dbl(a);      // * RED_L1
+        PtOps<A>::add(sw, a);
+        *out = sw;
+    } else {
+        A acc = PtOps<A>::identity();
+        if (g0 != 0) {
+            A run = PtOps<A>::identity();
+            for (int g = (int)g1 - 1; g >= (int)g0; g--) PtOps<A>::add(run, S[g]);
+            uint32_t m = RED_L1 * g0;
+            int top = 31 - __clz(m);
+            for (int bit = top; bit >= 0; bit--) {
+                PtOps<A>::dbl(acc);
+                if ((m >> bit) & 1) PtOps<A>::add(acc, run);
+            }
+        }
+        *out = acc;
     }
-    partial[t] = sw;
 }
 
 template <class A>
@@ -432,7 +443,9 @@ __global__ void __launch_bounds__(256) k_reduce_window(const A *__restrict__ par
     for (uint32_t i = t; i < per_window; i += 256) PtOps<A>::add(acc, partial[(size_t)w * per_window + i]);
     sh[t] = acc;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    int s0 = 128;
+    while (s0 >= 1 && (uint32_t)s0 >= per_window) s0 >>= 1;        // slots beyond per_window hold the identity: skip the tree levels that would only add those
+    for (int s = s0; s > 0; s >>= 1) {
         if ((int)t < s) { A a = sh[t]; PtOps<A>::add(a, sh[t + s]); sh[t] = a; }
         __syncthreads();
     }
@@ -483,7 +496,7 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
         S.size_key = (uint32_t *)dmalloc(buckets * 4); S.size_key2 = (uint32_t *)dmalloc(buckets * 4); S.ids = (uint32_t *)dmalloc(buckets * 4); S.order = (uint32_t *)dmalloc(buckets * 4);
         S.buckets = dmalloc(buckets * ACC_BYTES);
         S.seg_s = dmalloc((buckets / RED_L1 + 64) * ACC_BYTES); S.seg_w = dmalloc((buckets / RED_L1 + 64) * ACC_BYTES);
-        S.partial = dmalloc((buckets / (RED_L1 * RED_L2) + 64 * 64) * ACC_BYTES); S.wsum = dmalloc(192 * 64);
+        S.partial = dmalloc((2 * (buckets / (RED_L1 * RED_L2)) + 2 * 64 * 64) * ACC_BYTES); S.wsum = dmalloc(192 * 64);
         // (window sums: at most 64 sets)
     }
 }
@@ -596,16 +609,17 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
     hipLaunchKernelGGL((k_reduce_l1<A>), dim3((unsigned)((segs * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.buckets, c, nsets, (A *)S.seg_s, (A *)S.seg_w,
                        S.extra_off, max_seg, (const A *)S.ovf_partial);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_reduce_l2<A>), dim3((unsigned)((groups * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.seg_s, (const A *)S.seg_w, c, nsets, (A *)S.partial);
+    hipLaunchKernelGGL((k_reduce_l2<A>), dim3(2u * (unsigned)((groups * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.seg_s, (const A *)S.seg_w, c, nsets, (A *)S.partial);
     HIP_LAUNCH_CHECK();
-    if (nsets == 1 && groups > 2048) {
+    const uint32_t parts = 2 * groups;                 // two partials per group (k_reduce_l2's two roles)
+    if (nsets == 1 && parts > 2048) {
         // one big bucket set (table mode): 256-partial blocks first, so the final LDS tree does not walk tens of thousands of partials serially
-        uint32_t mid = (groups + 255) / 256;
-        hipLaunchKernelGGL((k_sum_tree<A>), dim3(mid), dim3(256), 0, s, (const A *)S.partial, groups, 256u, (A *)S.seg_s);
+        uint32_t mid = (parts + 255) / 256;
+        hipLaunchKernelGGL((k_sum_tree<A>), dim3(mid), dim3(256), 0, s, (const A *)S.partial, parts, 256u, (A *)S.seg_s);
         HIP_LAUNCH_CHECK();
         hipLaunchKernelGGL((k_reduce_window<A>), dim3(1), dim3(256), 0, s, (const A *)S.seg_s, mid, (XYZZ<Fq> *)S.wsum);
     } else {
-        hipLaunchKernelGGL((k_reduce_window<A>), dim3((unsigned)nsets), dim3(256), 0, s, (const A *)S.partial, groups, (XYZZ<Fq> *)S.wsum);
+        hipLaunchKernelGGL((k_reduce_window<A>), dim3((unsigned)nsets), dim3(256), 0, s, (const A *)S.partial, parts, (XYZZ<Fq> *)S.wsum);
     }
     HIP_LAUNCH_CHECK();
     }
