@@ -131,56 +131,8 @@ struct Fp28 {
         }
     }
 
-    // almost-Montgomery product, column by column (product scanning): the carry out of column k is the ADDEND that starts column k + 1's chain of
-    // multiply-accumulates, so carries cost a shift (and a mask for the limb) and no 64-bit additions.  Same integers as the row-wise form below:
-    // m_k = -column_k mod 2^28 (p = 1 mod 2^28), column k < 14 carries (column_k + m_k) >> 28 = (column_k + 2^28 - 1) >> 28.
-    // a b + c as ONE v_mad_u64_u32 with c as the addend: written as an instruction because the compiler re-associates `c + a b + ...` so that the value computed
-    // last (the carry) is added last, with a separate 64-bit add
-    static __device__ __forceinline__ uint64_t mad_vv(uint32_t a, uint32_t b, uint64_t c) {
-        uint64_t d;
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
-        return d;
-    }
-    static __device__ __forceinline__ uint64_t mad_vs(uint32_t a, uint32_t b, uint64_t c) {     // b: a constant, kept in a scalar register
-        uint64_t d;
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c) : "vcc");
-        return d;
-    }
-    ZK_HD Fp28 mul_columns(const Fp28 &b) const {
-        static_assert(mod28(0) == 1u && PINV == MASK, "column form is written for p = 1 (mod 2^28)");
-        uint32_t m[N];
-        Fp28 r;
-        uint64_t acc = 0;
-#pragma unroll
-        for (int k = 0; k < 2 * N - 1; k++) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-            for (int i = 0; i < N; i++) { int j = k - i; if (j >= 0 && j < N) acc = mad_vv(l[i], b.l[j], acc); }
-#pragma unroll
-            for (int i = 0; i < N; i++) { int j = k - i; if (i < k && j >= 1 && j < N) acc = mad_vs(m[i], mod28(j), acc); }
-#else
-#pragma unroll
-            for (int i = 0; i < N; i++) { int j = k - i; if (j >= 0 && j < N) acc += (uint64_t)l[i] * b.l[j]; }
-#pragma unroll
-            for (int i = 0; i < N; i++) { int j = k - i; if (i < k && j >= 1 && j < N) acc += (uint64_t)m[i] * mod28(j); }
-#endif
-            if (k < N) {
-                m[k] = (0u - (uint32_t)acc) & MASK;
-                acc = (acc + MASK) >> 28;
-            } else {
-                r.l[k - N] = (uint32_t)acc & MASK;
-                acc >>= 28;
-            }
-        }
-        r.l[N - 1] = (uint32_t)acc;
-        return r;
-    }
-#ifndef ZK_FF28_COLUMNS
-#define ZK_FF28_COLUMNS 0
-#endif
     // almost-Montgomery product: row-wise operand scanning, 64-bit column accumulators, no carry chain
     ZK_HD Fp28 operator*(const Fp28 &b) const {
-        if constexpr (ZK_FF28_COLUMNS && mod28(0) == 1u && PINV == MASK) return mul_columns(b);
         uint64_t t[2 * N];
 #pragma unroll
         for (int i = 0; i < 2 * N; i++) t[i] = 0;
