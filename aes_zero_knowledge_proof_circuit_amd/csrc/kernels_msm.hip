@@ -191,7 +191,8 @@ __global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_
 #define ZK_ACC_WAVES 2          // waves per SIMD the compiler must fit k_accumulate into (A/B knob: 3 spills with ff28, tools/gpu_runs/gpu_round2_occupancy.sh)
 #endif
 #ifndef ZK_ACC_PREFETCH
-#define ZK_ACC_PREFETCH 1       // software prefetch of the next gathered point (28 registers on the XYZZ law, 42 on the Edwards law)
+#define ZK_ACC_PREFETCH 2       // software prefetch of the next gathered point: 1 = into a second register set at the top of the addition (28 registers on the XYZZ law,
+                                // 42 on the Edwards law), 2 (Edwards law only; XYZZ treats it as 1) = into the current point's registers once its three products are done
 #endif
 template <class Law>
 __global__ void __launch_bounds__(64, ZK_ACC_WAVES) k_accumulate(const typename Law::Base *__restrict__ bases, const uint32_t *__restrict__ vals,
@@ -210,6 +211,19 @@ __global__ void __launch_bounds__(64, ZK_ACC_WAVES) k_accumulate(const typename 
         // unified law: the accumulator starts at the identity, P = +-Q and identity bases need no branch, nothing is deferred
         AccTE<P> acc = te_identity<P>();
         if (s < e) {
+#if ZK_ACC_PREFETCH == 2
+            // the next point's gather is issued in the middle of the current addition, into the registers the current point no longer needs (te_madd_signed)
+            uint32_t idx = vals[s];
+            Niels28<P> p = bases[idx & VAL_INDEX];
+            for (uint32_t i = s; i < e; i++) {
+                const uint32_t cur = idx;
+                const bool more = i + 1 < e;
+                if (more) idx = vals[i + 1];
+                const Niels28<P> *next = bases + (idx & VAL_INDEX);                    // the last iteration re-reads its own point: no branch around the load
+                if (cur & VAL_SKIP) { p = *next; continue; }
+                te_madd_signed<P>(acc, p, cur >> 31, next);
+            }
+#else
 #if ZK_ACC_PREFETCH
             uint32_t idx = vals[s];
             Niels28<P> nxt = bases[idx & VAL_INDEX];
@@ -224,9 +238,14 @@ __global__ void __launch_bounds__(64, ZK_ACC_WAVES) k_accumulate(const typename 
                 Niels28<P> p = bases[cur & VAL_INDEX];
 #endif
                 if (cur & VAL_SKIP) continue;
-                if (cur >> 31) p = niels_neg<P>(p);                                    // negative digit: add -P
+#if ZK_TE_SIGN_SELECT
+                te_madd_signed<P>(acc, p, cur >> 31);                                  // negative digit: add -P
+#else
+                if (cur >> 31) p = niels_neg<P>(p);
                 te_madd<P>(acc, p);
+#endif
             }
+#endif
         }
         buckets[k] = acc;
         return;

@@ -12,10 +12,11 @@ namespace gpu {
 // streams share a queue and a 10 ms k_accumulate of one context blocks the sort / reduction / NTT kernels of the contexts behind it.
 // One hardware queue per prover context keeps them independent (measured +1.5 % without window tables, +4.7 % with: profiles/r02_msm_tables.md).
 // The variable is read when the HIP runtime initialises, i.e. at the first HIP call of the process: libzkaes sets it (without overriding a value
-// the caller exported) when the library is loaded; a process that initialised HIP earlier must export it itself.
+// the caller exported) when the library is loaded; a process that initialised HIP earlier must export it itself.  An embedder whose other threads may read the
+// environment while the library loads opts out with ZKAES_KEEP_ENV=1 (and exports GPU_MAX_HW_QUEUES itself if it wants the 16 queues).
 namespace {
 struct HwQueueDefault {
-    HwQueueDefault() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+    HwQueueDefault() { if (!getenv("ZKAES_KEEP_ENV")) setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 } g_hw_queue_default;
 }  // namespace
 

@@ -97,6 +97,36 @@ ZK_HD void te_madd(AccTE<P> &a, const Niels28<P> &n) {
 #endif
     a.x = E * F; a.y = Gg * H; a.t = E * H; a.z = F * Gg;
 }
+// acc += (neg ? -n : n) without touching n: -(x, y) = (-x, y) swaps n's first two coordinates and negates the third, i.e. A = (Y1 - X1)(y2 + x2), B = (Y1 + X1)(y2 - x2) and
+// C changes sign, which swaps F = D - C and G = D + C.  56 per-limb selects instead of a divergent branch with a 14-limb negation and 42 register moves (ZK_TE_SIGN_SELECT).
+#ifndef ZK_TE_SIGN_SELECT
+#define ZK_TE_SIGN_SELECT 1
+#endif
+// `next` (may be null): the record of the lane's NEXT addition, loaded into n as soon as the three products that read n are done -- the gather flies under the remaining
+// four products and lands in the registers the current point just vacated (no second register set, no copies at the loop's back edge).
+template <class P>
+ZK_HD void te_madd_signed(AccTE<P> &a, Niels28<P> &n, bool neg, const Niels28<P> *next = nullptr) {
+    using G = FpMsm<P>;
+    G m1, m2;
+#pragma unroll
+    for (int i = 0; i < G::N; i++) { m1.l[i] = neg ? n.ypx.l[i] : n.ymx.l[i]; m2.l[i] = neg ? n.ymx.l[i] : n.ypx.l[i]; }
+    G A = a.y.template sub<3>(a.x) * m1;
+    G B = (a.y + a.x) * m2;
+    G C = a.t * n.td;
+    if (next) {                                      // callers in hot loops pass a non-null pointer on every iteration (straight-line code)
+#if defined(__HIP_DEVICE_COMPILE__)
+        // pin the gather behind the three products: without the fence the compiler hoists the loads to the top of the iteration, into a second register set
+        asm volatile("" : "+v"(A.l[G::N - 1]), "+v"(B.l[G::N - 1]), "+v"(C.l[G::N - 1]) : : "memory");
+#endif
+        n = *next;
+    }
+    G D = a.z.dbl();
+    G E = B.template sub<2>(A), H = B + A;
+    G U = D.template sub<2>(C), V = D + C, F, Gg;
+#pragma unroll
+    for (int i = 0; i < G::N; i++) { F.l[i] = neg ? V.l[i] : U.l[i]; Gg.l[i] = neg ? U.l[i] : V.l[i]; }
+    a.x = E * F; a.y = Gg * H; a.t = E * H; a.z = F * Gg;
+}
 // a += b, unified (add-2008-hwcd-3): nine products
 template <class P>
 ZK_EC_FN void te_add(AccTE<P> &a, const AccTE<P> &b) {

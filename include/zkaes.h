@@ -19,7 +19,8 @@
  *   - host threads of a multi-proof call wait for the GPU by polling with short sleeps (a fraction of a core per prover context); a lone zkaes_encrypt call
  *     spins, for latency.  ZKAES_WAIT=spin|sleep forces one policy;
  *   - when the library is loaded it exports GPU_MAX_HW_QUEUES=16 unless the variable is already set (one hardware queue per prover context; the ROCm default of 4
- *     lets the contexts' kernels queue behind each other).  It is read at the first HIP call of the process: export it yourself if HIP is initialised earlier;
+ *     lets the contexts' kernels queue behind each other).  It is read at the first HIP call of the process: export it yourself if HIP is initialised earlier.
+ *     ZKAES_KEEP_ENV=1 makes the library leave the environment alone (for hosts whose other threads read it while libraries load);
  *   - the library needs a HIP device (gfx950) for key synthesis and proving and FAILS (non-zero + message) when
  *     none is present -- there is no CPU fallback; zkaes_verify_* runs on the host, as in the reference.
  */

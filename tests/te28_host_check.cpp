@@ -44,6 +44,22 @@ int main() {
                 te_madd<P>(acc, first ? a1 : a2); ref.madd(first ? s1 : s2);
                 if (!same(acc, ref)) { bad++; if (bad < 5) printf("madd mismatch it=%d variant=%d r=%d\n", it, variant, r); }
             }
+            // the hot loop's form: the sign as a flag (selects instead of a negated copy) and the next point loaded into the current point's storage mid-addition
+            {
+                AccTE<P> sg = te_identity<P>(); XYZZ<Fq> rs = XYZZ<Fq>::inf();
+                Niels28<P> cur = q1;
+                for (int r = 0; r < 6; r++) {
+                    const bool neg = (r * 5 + it + variant) % 3 == 0, use1 = (r & 1) == 0, next1 = ((r + 1) & 1) == 0;
+                    te_madd_signed<P>(sg, cur, neg, next1 ? &q1 : &q2);
+                    Affine<Fq> sp = use1 ? p1 : p2; if (neg) sp = sp.neg();
+                    rs.madd(sp);
+                    if (!same(sg, rs)) { bad++; if (bad < 5) printf("signed madd mismatch it=%d variant=%d r=%d\n", it, variant, r); }
+                    const Niels28<P> &want = next1 ? q1 : q2;
+                    for (int i = 0; i < 14; i++) if (cur.ymx.l[i] != want.ymx.l[i] || cur.ypx.l[i] != want.ypx.l[i] || cur.td.l[i] != want.td.l[i]) { bad++; break; }
+                }
+                AccTE<P> z = te_identity<P>(); Niels28<P> c2 = q1; te_madd_signed<P>(z, c2, false); te_madd_signed<P>(z, c2, true);
+                if (!te_to_std_point<P>(z).is_inf()) { bad++; if (bad < 5) printf("P-P (signed madd) not identity\n"); }
+            }
             // P + (-P) = identity through madd
             { AccTE<P> z = te_identity<P>(); te_madd<P>(z, a1); te_madd<P>(z, niels_neg<P>(a1)); if (!te_to_std_point<P>(z).is_inf()) { bad++; if (bad < 5) printf("P-P (madd) not identity\n"); } }
             // reduction pattern: run = B, tot += run repeatedly (doubling on the first repeat), neg, dbl, scalar double-and-add

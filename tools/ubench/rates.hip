@@ -187,6 +187,11 @@ int main() {
     float ms;
     ms = timeit([&] { hipLaunchKernelGGL(k_mad, dim3(blocks), dim3(threads), 0, 0, (uint64_t *)buf, 12345u, 67891u, iters); });
     printf("v_mad_u64_u32 : %.2f Tops/s (%.3f ms)\n", lanes * iters * 8 / ms / 1e9, ms);
+    // is the multiplier's speed operand-dependent?  (the limbs of ff28 are 28 bits wide, the probe above multiplies 14- and 17-bit numbers)
+    for (uint32_t mag : {0x00003039u, 0x00f12345u, 0x0f123457u, 0xf1234567u}) {
+        ms = timeit([&] { hipLaunchKernelGGL(k_mad, dim3(blocks), dim3(threads), 0, 0, (uint64_t *)buf, mag, mag ^ 0x5a5a5u, iters); });
+        printf("v_mad_u64_u32 with operands ~ 0x%08x: %.2f Tops/s (%.3f ms)\n", mag, lanes * iters * 8 / ms / 1e9, ms);
+    }
     ms = timeit([&] { hipLaunchKernelGGL(k_add64, dim3(blocks), dim3(threads), 0, 0, (uint64_t *)buf, 12345ull, iters); });
     printf("add64 (x2 per step + shift): %.2f Tsteps/s (%.3f ms)\n", lanes * iters * 8 / ms / 1e9, ms);
     ms = timeit([&] { hipLaunchKernelGGL(k_add32, dim3(blocks), dim3(threads), 0, 0, (uint32_t *)buf, 12345u, iters); });
