@@ -88,8 +88,9 @@ struct Fp28 {
         return r;
     }
     ZK_HD Fp28 dbl() const { return *this + *this; }
-    // ---- lazy limb arithmetic: NO carry propagation, limbs may exceed 28 bits.  Only valid as ONE operand of a product whose other operand is normalized:
-    // a column then holds at most 14 limb products of (2^30.4 x 2^28) plus the reduction's 14 x 2^56, below 2^63 (te28.cuh lists the operands that use it).
+    // ---- lazy limb arithmetic: NO carry propagation, limbs may exceed 28 bits.  Valid as ONE operand of a product whose other operand is normalized:
+    // a column then holds at most 14 limb products of (2^30.4 x 2^28) plus the reduction's 14 x 2^56, below 2^63; two lazy operands only where the caller bounds
+    // 14 x (limb bound a) x (limb bound b) + 14 x 2^56 below 2^64 (te28.cuh lists the operands that use it, with their bounds).
     ZK_HD Fp28 add_lazy(const Fp28 &b) const { Fp28 r; for (int i = 0; i < N; i++) r.l[i] = l[i] + b.l[i]; return r; }
     ZK_HD Fp28 dbl_lazy() const { Fp28 r; for (int i = 0; i < N; i++) r.l[i] = l[i] << 1; return r; }
     template <int K> ZK_HD Fp28 sub_lazy(const Fp28 &b) const { Fp28 r; for (int i = 0; i < N; i++) r.l[i] = l[i] + kp_spread<K>(i) - b.l[i]; return r; }   // b normalized; limbs <= (K + 2) 2^28
@@ -119,10 +120,13 @@ struct Fp28 {
     // 64-bit add of m: t_i + m clears the low 28 bits and carries exactly one unit when they were non-zero, i.e. (t_i + 2^28 - 1) >> 28.
     ZK_HD static void reduce_row(uint64_t *t, int i) {
         if constexpr (mod28(0) == 1u && PINV == MASK) {
-            uint32_t m = (0u - (uint32_t)t[i]) & MASK;
+            // u = t_i + 2^28 - 1: its high part is the carry (t_i + m) >> 28 (one unit exactly when the low 28 bits of t_i are non-zero) and its low 28 bits are
+            // those of t_i - 1, so m = -t_i mod 2^28 = ~u mod 2^28
+            const uint64_t u = t[i] + MASK;
+            const uint32_t m = ~(uint32_t)u & MASK;
 #pragma unroll
             for (int j = 1; j < N; j++) t[i + j] += (uint64_t)m * mod28(j);
-            t[i + 1] += (t[i] + MASK) >> 28;           // = (t_i + m) >> 28: the low 28 bits carry one unit exactly when they are non-zero
+            t[i + 1] += u >> 28;
         } else {
             uint32_t m = (((uint32_t)t[i] & MASK) * PINV) & MASK;
 #pragma unroll

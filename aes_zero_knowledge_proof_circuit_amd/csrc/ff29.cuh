@@ -90,10 +90,11 @@ struct Fp29 {
 #pragma unroll
             for (int j = 0; j < N; j++) t[i + j] += (uint64_t)l[j] * b.l[i];
             if constexpr (mod29(0) == 1u && PINV == MASK) {       // p = 1 (mod 2^29) (both BLS scalar fields): m = -t_i, no multiply for limb 0
-                uint32_t m = (0u - (uint32_t)t[i]) & MASK;
+                const uint64_t u = t[i] + MASK;                   // high part: the carry (t_i + m) >> 29; low 29 bits: those of t_i - 1, so m = -t_i = ~u (mod 2^29), one v_bitop3_b32
+                const uint32_t m = ~(uint32_t)u & MASK;
 #pragma unroll
                 for (int j = 1; j < N; j++) t[i + j] += (uint64_t)m * mod29(j);
-                t[i + 1] += (t[i] + MASK) >> B;                   // = (t_i + m) >> 29
+                t[i + 1] += u >> B;
             } else {
                 uint32_t m = (((uint32_t)t[i] & MASK) * PINV) & MASK;
 #pragma unroll

@@ -70,12 +70,12 @@ ZK_HD Niels28<P> niels_neg_lazy(const Niels28<P> &n) { Niels28<P> r; r.ymx = n.y
 
 // acc += n, seven products, everything inlined (hot loop of k_accumulate).  acc coordinates are products (normalized limbs, < 1.2 p) in and out; n's
 // coordinates normalized (the negated 2dxy may be lazy).
-// ZK_TE_LAZY=1 propagates carries only where a product needs a normalized operand (every product then has exactly one lazy operand, limbs up to 2^30.4:
-// Y1 -+ X1, 2 Z1, H and F skip the carry chain): 3,846 instead of 4,013 VALU instructions per addition -- and measurably SLOWER on MI355X
-// (k_accumulate 7.17 vs 7.08 ms at 2^22 points, bench 78.3 vs 79.1 blocks/s, profiles/r03_te_lazy.txt: the saved instructions are cheap 32-bit ones, the
-// kernel needs 214 instead of 198 VGPRs).  Off; kept as a checked (tests/te28_host_check.cpp builds both) A/B knob.
+// ZK_TE_LAZY=1 propagates carries only where a product needs them.  In te_madd (negated copy of the point, the next gather in a second register set) it was
+// measurably SLOWER (3,846 vs 4,013 VALU instructions but 214 vs 198 VGPRs: k_accumulate 7.17 vs 7.08 ms at 2^22 points, profiles/r03_te_lazy.txt); in the hot
+// loop's te_madd_signed below (sign as selects, gather mid-addition: 175 VGPRs either way) it pays: 3,691 vs 3,820 instructions, 6.62 vs 6.75 ms
+// (profiles/r03_accumulate_instruction_diet.txt).  On; tests/te28_host_check.cpp builds both.
 #ifndef ZK_TE_LAZY
-#define ZK_TE_LAZY 0
+#define ZK_TE_LAZY 1
 #endif
 template <class P>
 ZK_HD void te_madd(AccTE<P> &a, const Niels28<P> &n) {
@@ -110,8 +110,14 @@ ZK_HD void te_madd_signed(AccTE<P> &a, Niels28<P> &n, bool neg, const Niels28<P>
     G m1, m2;
 #pragma unroll
     for (int i = 0; i < G::N; i++) { m1.l[i] = neg ? n.ypx.l[i] : n.ymx.l[i]; m2.l[i] = neg ? n.ymx.l[i] : n.ypx.l[i]; }
+#if ZK_TE_LAZY
+    // carries only where a product needs a normalized operand: Y1 -+ X1 skip the chain (limbs < 2^30.4, their partners are table entries)
+    G A = a.y.template sub_lazy<3>(a.x) * m1;
+    G B = a.y.add_lazy(a.x) * m2;
+#else
     G A = a.y.template sub<3>(a.x) * m1;
     G B = (a.y + a.x) * m2;
+#endif
     G C = a.t * n.td;
     if (next) {                                      // callers in hot loops pass a non-null pointer on every iteration (straight-line code)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -120,9 +126,16 @@ ZK_HD void te_madd_signed(AccTE<P> &a, Niels28<P> &n, bool neg, const Niels28<P>
 #endif
         n = *next;
     }
-    G D = a.z.dbl();
-    G E = B.template sub<2>(A), H = B + A;
+#if ZK_TE_LAZY
+    // E, H lazy (limbs < 3 2^28 and < 2 2^28: even E H keeps a column below 97 2^56), D lazy into the normalizing D -+ C: F and G are normalized whichever way the sign swaps them
+    G E = B.template sub_lazy<2>(A), H = B.add_lazy(A);
+    G D = a.z.dbl_lazy();
     G U = D.template sub<2>(C), V = D + C, F, Gg;
+#else
+    G E = B.template sub<2>(A), H = B + A;
+    G D = a.z.dbl();
+    G U = D.template sub<2>(C), V = D + C, F, Gg;
+#endif
 #pragma unroll
     for (int i = 0; i < G::N; i++) { F.l[i] = neg ? V.l[i] : U.l[i]; Gg.l[i] = neg ? U.l[i] : V.l[i]; }
     a.x = E * F; a.y = Gg * H; a.t = E * H; a.z = F * Gg;
