@@ -153,6 +153,38 @@ struct Fp28 {
         r.l[N - 1] = (uint32_t)(t[2 * N - 1] + c);
         return r;
     }
+    // The same product with the rows' "+ 2^28 - 1" riding on the multiply-accumulate chains: columns 0..13 START at `bias`, which must hold 2^28 - 1 in a register pair
+    // the compiler cannot see through and that was defined before the operands (hot_loop_bias() at kernel entry).  A known constant is re-associated to the end
+    // of every column's sum and costs a 64-bit add per row -- 14 per product; an unknown early value stays the chain's first addend.
+    ZK_HD static Fp28 mul_biased(const Fp28 &a, const Fp28 &b, uint64_t bias) {
+        static_assert(mod28(0) == 1u && PINV == MASK, "written for p = 1 (mod 2^28)");
+        uint64_t t[2 * N];
+#pragma unroll
+        for (int i = 0; i < 2 * N; i++) t[i] = i < N ? bias : 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+#pragma unroll
+            for (int j = 0; j < N; j++) t[i + j] += (uint64_t)a.l[j] * b.l[i];
+            const uint64_t u = t[i];                            // = column + 2^28 - 1 (see reduce_row)
+            const uint32_t m = ~(uint32_t)u & MASK;
+#pragma unroll
+            for (int j = 1; j < N; j++) t[i + j] += (uint64_t)m * mod28(j);
+            t[i + 1] += u >> 28;
+        }
+        Fp28 r;
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < N - 1; i++) { uint64_t v = t[N + i] + c; r.l[i] = (uint32_t)v & MASK; c = v >> 28; }
+        r.l[N - 1] = (uint32_t)(t[2 * N - 1] + c);
+        return r;
+    }
+    ZK_HD static uint64_t hot_loop_bias() {
+        uint64_t v = MASK;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+s"(v));
+#endif
+        return v;
+    }
     // (a b + c d) / R' with ONE Montgomery reduction: both limb products accumulate into the same 64-bit columns (28 products of < 2^56
     // plus the 14 reduction products per column stay below 2^62), which saves the 196 multiplies of a second reduction.
     // Inputs normalized; the result is < ((a b + c d) / R') + p, e.g. < 1.01 p for a b + c d < 64 p^2.

@@ -201,6 +201,8 @@ __global__ void __launch_bounds__(64, ZK_ACC_WAVES) k_accumulate(const typename 
                                                        uint32_t *__restrict__ deferred, uint32_t deferred_cap, uint32_t *__restrict__ deferred_count) {
     using P = typename Law::Params;
     using G = FpMsm<P>;
+    [[maybe_unused]] uint64_t bias = 0;
+    if constexpr (Law::edwards) bias = FpMsm<P>::hot_loop_bias();           // before anything else: see ff28.cuh mul_biased
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nbuckets_total) return;
     uint32_t k = order[t];
@@ -221,7 +223,7 @@ __global__ void __launch_bounds__(64, ZK_ACC_WAVES) k_accumulate(const typename 
                 if (more) idx = vals[i + 1];
                 const Niels28<P> *next = bases + (idx & VAL_INDEX);                    // the last iteration re-reads its own point: no branch around the load
                 if (cur & VAL_SKIP) { p = *next; continue; }
-                te_madd_signed<P>(acc, p, cur >> 31, next);
+                te_madd_signed<P, ZK_TE_BIASED != 0>(acc, p, cur >> 31, next, bias);
             }
 #else
 #if ZK_ACC_PREFETCH

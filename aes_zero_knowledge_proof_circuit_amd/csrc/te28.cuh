@@ -99,26 +99,40 @@ ZK_HD void te_madd(AccTE<P> &a, const Niels28<P> &n) {
 }
 // acc += (neg ? -n : n) without touching n: -(x, y) = (-x, y) swaps n's first two coordinates and negates the third, i.e. A = (Y1 - X1)(y2 + x2), B = (Y1 + X1)(y2 - x2) and
 // C changes sign, which swaps F = D - C and G = D + C.  56 per-limb selects instead of a divergent branch with a 14-limb negation and 42 register moves (ZK_TE_SIGN_SELECT).
+#ifndef ZK_TE_BIASED
+#define ZK_TE_BIASED 1
+#endif
 #ifndef ZK_TE_SIGN_SELECT
 #define ZK_TE_SIGN_SELECT 1
 #endif
 // `next` (may be null): the record of the lane's NEXT addition, loaded into n as soon as the three products that read n are done -- the gather flies under the remaining
 // four products and lands in the registers the current point just vacated (no second register set, no copies at the loop's back edge).
-template <class P>
-ZK_HD void te_madd_signed(AccTE<P> &a, Niels28<P> &n, bool neg, const Niels28<P> *next = nullptr) {
+template <bool BIASED, class G>
+ZK_HD G mul_maybe_biased(const G &x, const G &y, uint64_t bias) {
+    if constexpr (BIASED) return G::mul_biased(x, y, bias);
+    else return x * y;
+}
+template <class P, bool BIASED = false>
+ZK_HD void te_madd_signed(AccTE<P> &a, Niels28<P> &n, bool neg, const Niels28<P> *next = nullptr, uint64_t bias = 0) {
     using G = FpMsm<P>;
+#if ZK_TE_BIASED
+    // BIASED: bias = FpMsm<P>::hot_loop_bias() taken at kernel entry (ff28.cuh mul_biased: 14 fewer 64-bit adds per product)
+#define ZK_TE_MUL(x, y) mul_maybe_biased<BIASED>(x, y, bias)
+#else
+#define ZK_TE_MUL(x, y) ((x) * (y))
+#endif
     G m1, m2;
 #pragma unroll
     for (int i = 0; i < G::N; i++) { m1.l[i] = neg ? n.ypx.l[i] : n.ymx.l[i]; m2.l[i] = neg ? n.ymx.l[i] : n.ypx.l[i]; }
 #if ZK_TE_LAZY
     // carries only where a product needs a normalized operand: Y1 -+ X1 skip the chain (limbs < 2^30.4, their partners are table entries)
-    G A = a.y.template sub_lazy<3>(a.x) * m1;
-    G B = a.y.add_lazy(a.x) * m2;
+    G A = ZK_TE_MUL(a.y.template sub_lazy<3>(a.x), m1);
+    G B = ZK_TE_MUL(a.y.add_lazy(a.x), m2);
 #else
-    G A = a.y.template sub<3>(a.x) * m1;
-    G B = (a.y + a.x) * m2;
+    G A = ZK_TE_MUL(a.y.template sub<3>(a.x), m1);
+    G B = ZK_TE_MUL(a.y + a.x, m2);
 #endif
-    G C = a.t * n.td;
+    G C = ZK_TE_MUL(a.t, n.td);
     if (next) {                                      // callers in hot loops pass a non-null pointer on every iteration (straight-line code)
 #if defined(__HIP_DEVICE_COMPILE__)
         // pin the gather behind the three products: without the fence the compiler hoists the loads to the top of the iteration, into a second register set
@@ -138,7 +152,8 @@ ZK_HD void te_madd_signed(AccTE<P> &a, Niels28<P> &n, bool neg, const Niels28<P>
 #endif
 #pragma unroll
     for (int i = 0; i < G::N; i++) { F.l[i] = neg ? V.l[i] : U.l[i]; Gg.l[i] = neg ? U.l[i] : V.l[i]; }
-    a.x = E * F; a.y = Gg * H; a.t = E * H; a.z = F * Gg;
+    a.x = ZK_TE_MUL(E, F); a.y = ZK_TE_MUL(Gg, H); a.t = ZK_TE_MUL(E, H); a.z = ZK_TE_MUL(F, Gg);
+#undef ZK_TE_MUL
 }
 // a += b, unified (add-2008-hwcd-3): nine products
 template <class P>

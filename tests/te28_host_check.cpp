@@ -46,11 +46,13 @@ int main() {
             }
             // the hot loop's form: the sign as a flag (selects instead of a negated copy) and the next point loaded into the current point's storage mid-addition
             {
-                AccTE<P> sg = te_identity<P>(); XYZZ<Fq> rs = XYZZ<Fq>::inf();
-                Niels28<P> cur = q1;
+                AccTE<P> sg = te_identity<P>(), sb = sg; XYZZ<Fq> rs = XYZZ<Fq>::inf();
+                Niels28<P> cur = q1, curb = q1;
                 for (int r = 0; r < 6; r++) {
                     const bool neg = (r * 5 + it + variant) % 3 == 0, use1 = (r & 1) == 0, next1 = ((r + 1) & 1) == 0;
                     te_madd_signed<P>(sg, cur, neg, next1 ? &q1 : &q2);
+                    te_madd_signed<P, true>(sb, curb, neg, next1 ? &q1 : &q2, FpMsm<P>::hot_loop_bias());        // products with the rows' bias as the columns' start value
+                    for (int i = 0; i < 14; i++) if (sb.x.l[i] != sg.x.l[i] || sb.y.l[i] != sg.y.l[i] || sb.z.l[i] != sg.z.l[i] || sb.t.l[i] != sg.t.l[i]) { bad++; if (bad < 5) printf("biased product differs it=%d r=%d\n", it, r); break; }
                     Affine<Fq> sp = use1 ? p1 : p2; if (neg) sp = sp.neg();
                     rs.madd(sp);
                     if (!same(sg, rs)) { bad++; if (bad < 5) printf("signed madd mismatch it=%d variant=%d r=%d\n", it, variant, r); }
