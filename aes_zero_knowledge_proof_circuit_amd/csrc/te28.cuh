@@ -70,12 +70,12 @@ ZK_HD Niels28<P> niels_neg_lazy(const Niels28<P> &n) { Niels28<P> r; r.ymx = n.y
 
 // acc += n, seven products, everything inlined (hot loop of k_accumulate).  acc coordinates are products (normalized limbs, < 1.2 p) in and out; n's
 // coordinates normalized (the negated 2dxy may be lazy).
-// ZK_TE_LAZY=1 propagates carries only where a product needs them.  In te_madd (negated copy of the point, the next gather in a second register set) it was
+// ZK_TE_LAZY >= 1 propagates carries only where a product needs them (2: D -+ C lazy too).  In te_madd (negated copy of the point, the next gather in a second register set) it was
 // measurably SLOWER (3,846 vs 4,013 VALU instructions but 214 vs 198 VGPRs: k_accumulate 7.17 vs 7.08 ms at 2^22 points, profiles/r03_te_lazy.txt); in the hot
-// loop's te_madd_signed below (sign as selects, gather mid-addition: 175 VGPRs either way) it pays: 3,691 vs 3,820 instructions, 6.62 vs 6.75 ms
-// (profiles/r03_accumulate_instruction_diet.txt).  On; tests/te28_host_check.cpp builds both.
+// loop's te_madd_signed below (sign as selects, gather mid-addition: 175 VGPRs either way) it pays: 3,550 vs 3,820 instructions
+// (profiles/r03_accumulate_instruction_diet.txt).  On; tests/te28_host_check.cpp builds all three.
 #ifndef ZK_TE_LAZY
-#define ZK_TE_LAZY 1
+#define ZK_TE_LAZY 2
 #endif
 template <class P>
 ZK_HD void te_madd(AccTE<P> &a, const Niels28<P> &n) {
@@ -141,10 +141,15 @@ ZK_HD void te_madd_signed(AccTE<P> &a, Niels28<P> &n, bool neg, const Niels28<P>
         n = *next;
     }
 #if ZK_TE_LAZY
-    // E, H lazy (limbs < 3 2^28 and < 2 2^28: even E H keeps a column below 97 2^56), D lazy into the normalizing D -+ C: F and G are normalized whichever way the sign swaps them
+    // all four factors of the second level lazy.  Limb bounds in units of 2^28: E = B + 2p' - A < 3, H = B + A < 2, D = 2 Z1 < 2, U = D + 2p' - C < 4, V = D + C < 3
+    // (2p' = kp_spread<2> < 2 per limb).  The widest products, E U and U V, put 14 x 12 x 2^56 into a column, the reduction 13 x 2^56 more: 181 x 2^56 < 2^64.
     G E = B.template sub_lazy<2>(A), H = B.add_lazy(A);
     G D = a.z.dbl_lazy();
-    G U = D.template sub<2>(C), V = D + C, F, Gg;
+#if ZK_TE_LAZY >= 2
+    G U = D.template sub_lazy<2>(C), V = D.add_lazy(C), F, Gg;
+#else
+    G U = D.template sub<2>(C), V = D + C, F, Gg;          // A/B: D -+ C with the carry chain (3,603 instead of 3,550 instructions)
+#endif
 #else
     G E = B.template sub<2>(A), H = B + A;
     G D = a.z.dbl();

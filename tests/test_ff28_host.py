@@ -49,8 +49,33 @@ template <class P, class G> int run(const char *name) {
     printf("%s %d\n", name, bad);
     return bad;
 }
+// products of two LAZY operands at the limb bounds the hot loop allows (te28.cuh te_madd_signed: 4 x 2^28 and 3 x 2^28 per limb), plain and with the
+// reduction rows' bias as the column start: the 64-bit columns must not wrap
+int lazy_bounds() {
+    using G = Fp28<Fq377P>;
+    int bad = 0;
+    srand(11);
+    for (int it = 0; it < 2000; it++) {
+        G x, y;
+        int64_t tx[14], ty[14];
+        for (int i = 0; i < 14; i++) {
+            const bool top = i == 13;
+            uint32_t bx = top ? (1u << 18) : (4u << 28) - 1, by = top ? (1u << 17) : (3u << 28) - 1;
+            x.l[i] = it == 0 ? bx : bx - ((uint32_t)rand() & (it & 1 ? 0xffu : 0x7ffffffu) % bx);
+            y.l[i] = it == 0 ? by : by - ((uint32_t)rand() & (it & 2 ? 0xfu : 0x3ffffffu) % by);
+            tx[i] = x.l[i]; ty[i] = y.l[i];
+        }
+        Fp<Fq377P> want = G::normalize(tx).to_std() * G::normalize(ty).to_std();
+        bad += !((x * y).to_std() == want);
+        bad += !(G::mul_biased(x, y, G::hot_loop_bias()).to_std() == want);
+        G pl = x * y, pb = G::mul_biased(x, y, G::hot_loop_bias());
+        for (int i = 0; i < 14; i++) bad += pl.l[i] != pb.l[i];
+    }
+    printf("lazy_bounds %d\n", bad);
+    return bad;
+}
 int main() {
-    return run<Fq377P, Fp28<Fq377P>>("fq377x28") + run<Fq381P, Fp28<Fq381P>>("fq381x28") + run<Fq377P, Fp30<Fq377P>>("fq377x30") + run<Fq381P, Fp30<Fq381P>>("fq381x30");
+    return lazy_bounds() + run<Fq377P, Fp28<Fq377P>>("fq377x28") + run<Fq381P, Fp28<Fq381P>>("fq381x28") + run<Fq377P, Fp30<Fq377P>>("fq377x30") + run<Fq381P, Fp30<Fq381P>>("fq381x30");
 }
 '''
 
@@ -62,7 +87,7 @@ def test_reduced_radix_field_matches_montgomery_reference():
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", CSRC, src, "-o", exe])
         out = subprocess.run([exe], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout + out.stderr
-        assert out.stdout.split() == ["fq377x28", "0", "fq381x28", "0", "fq377x30", "0", "fq381x30", "0"]
+        assert out.stdout.split() == ["lazy_bounds", "0", "fq377x28", "0", "fq381x28", "0", "fq377x30", "0", "fq381x30", "0"]
 
 
 
@@ -84,7 +109,7 @@ def test_twisted_edwards_group_law_matches_xyzz_reference():
     doubling of the bucket reduction, negation, both maps) against XYZZ<Fq> on random points of the prime-order subgroup: accumulation chains from the
     identity incl. P + P and P - P through the unified law, running sums, double-and-add, infinity <-> identity, a 2-torsion point is refused."""
     src_path = os.path.join(ROOT, "tests", "te28_host_check.cpp")
-    for lazy in (0, 1):                          # 1 = the carry-free variant of te_madd (a measured-slower A/B knob, csrc/te28.cuh)
+    for lazy in (0, 1, 2):                       # carry-free operands where the products allow them: off, first level + E, H, all of te_madd_signed (default), csrc/te28.cuh
         with tempfile.TemporaryDirectory() as d:
             exe = os.path.join(d, "t")
             subprocess.check_call(["g++", "-std=c++17", "-O2", "-DZK_TE_LAZY=%d" % lazy, "-I", CSRC, src_path, "-o", exe])

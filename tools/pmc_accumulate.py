@@ -42,7 +42,7 @@ def collect(name, counters):
     rows = {}
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"]
-        short = "k_accumulate" if "k_accumulate<" in k else ("k_convert_bases" if "k_convert_bases" in k else ("k_digits" if "k_digits" in k else None))
+        short = "k_accumulate" if "k_accumulate<" in k else ("k_convert_bases" if "k_convert_bases" in k else ("k_digits" if ("k_digits" in k or "k_split_hist" in k) else None))   # k_split_hist: the pre-split path's pass over the scalars (reads 32 B each, writes counts only)
         if short:
             rows.setdefault((short, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in rows.items()}, {k: len(v) for k, v in rows.items()}
