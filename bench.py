@@ -42,7 +42,7 @@ MADS_PER_ADD = 2649.0   # v_mad_u64_u32 per bucket addition of k_accumulate<Edwa
 CIRCUIT_MODEL_NOTE = ("R1CS of the restated ark-r1cs-std 0.3.1 gadget semantics: 629,856 constraints / 3,002,900 non-zeros at 64 bytes; the reference's own SRS literal "
                       "(src/lib.rs:141) records 866,944 / 4,062,064 for that size and no variant of the source-less simpleworks shift/rotate calls reproduces it "
                       "(tools/circuit_variants.py, DESIGN.md section 2a) -- at the literal's density a 2^20 domain holds 4 blocks per chunk-proof, not 6: `--chunk 4` measures that configuration "
-                      "(52.0 blocks/s on this code, profiles/r03_bench_chunk4.json); integration/check_on_cargo_box.sh is the run that settles which one is right")
+                      "(53.7 blocks/s on this code, profiles/r03_bench_chunk4.json); integration/check_on_cargo_box.sh is the run that settles which one is right")
 
 from aes_zero_knowledge_proof_circuit_amd import sharding  # noqa: E402
 

@@ -10,10 +10,14 @@ import sys
 
 def short(name):
     law = " [Edwards]" if ("EdwardsLaw" in name or "AccTE" in name) else (" [XYZZ]" if ("WeierLaw" in name or "Acc28" in name) else "")
+    full = name
     name = re.sub(r"<.*", "", name.replace("void ", "")) + law
     if "rocprim" in name:
-        m = re.search(r"radix_sort_\w+", name)
-        return "rocprim::" + (m.group(0) if m else "kernel")
+        # rocPRIM launches everything through a few kernel templates: keep the template's own name (onesweep_iteration_kernel, lookback_scan_kernel, ...) and,
+        # for the generic ones, the algorithm named in their configuration
+        base = name.split("::")[-1] or "kernel"
+        m = re.search(r"(radix_sort_\w+|onesweep\w*|lookback_scan\w*|scan\w*|partition\w*|transform\w*|histogram\w*)", full)
+        return "rocprim::" + (base if base not in ("kernel", "") else (m.group(1) if m else "kernel"))
     if law:
         return name.split("(")[0].replace(law, "") + law
     return name.split("(")[0]
