@@ -29,6 +29,7 @@ void d2d(void *dst, const void *src, size_t bytes, stream_t s);
 void dzero(void *dst, size_t bytes, stream_t s);
 void sync(stream_t s);                    // wait for the stream: spins (lone calls) or polls with sleeps while a ThroughputWaits scope is alive
 // RAII marker of a multi-proof call: host threads of its prover contexts wait by polling + nanosleep instead of spinning (runtime.hip)
+bool throughput_mode();                   // true while a ThroughputWaits scope is alive (a multi-proof call is in flight): kernels may pick the throughput variant of a step
 struct ThroughputWaits { explicit ThroughputWaits(bool on); ~ThroughputWaits(); ThroughputWaits(const ThroughputWaits &) = delete; ThroughputWaits &operator=(const ThroughputWaits &) = delete; private: bool on_; };
 stream_t stream_create();                 // high priority unless ZKAES_STREAM_PRIORITY=0
 bool stream_priorities_enabled();

@@ -183,6 +183,71 @@ __global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_
     ids[k] = k;
 }
 
+// The same ordering as a counting sort written for it: the key is the bucket's size (13 bits), nothing needs the order among buckets of equal size, so one histogram,
+// one scan over 8,192 bins and one scatter replace the ~16 launches of a generic sort of 2^19 (key, id) pairs (rocPRIM picks a merge sort at that size: 150 tiny launches
+// per 6-block proof).  k_order_hist also writes the overflow-segment counts k_bucket_sizes writes.  Used for lone calls (see order_by_counting).
+constexpr int ORD_BINS = 8192, ORD_THREADS = 256, ORD_PER_THREAD = 8, ORD_PER_BLOCK = ORD_THREADS * ORD_PER_THREAD;
+__device__ __forceinline__ uint32_t order_key(uint32_t sz) { return 8191u - (sz > 8191u ? 8191u : sz); }
+__global__ void __launch_bounds__(ORD_THREADS) k_order_hist(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, uint32_t nb, uint32_t cap, uint32_t *__restrict__ extra,
+                                                             uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[ORD_BINS];
+    for (int b = threadIdx.x; b < ORD_BINS; b += ORD_THREADS) h[b] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * ORD_PER_BLOCK;
+#pragma unroll
+    for (int r = 0; r < ORD_PER_THREAD; r++) {
+        uint32_t k = base + r * ORD_THREADS + threadIdx.x;
+        if (k < nb) {
+            uint32_t sz = end[k] - start[k];
+            extra[k] = sz > cap ? (sz - 1) / cap : 0;
+            atomicAdd(&h[order_key(sz)], 1u);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) extra[nb] = 0;
+    __syncthreads();
+    for (int b = threadIdx.x; b < ORD_BINS; b += ORD_THREADS) if (h[b]) atomicAdd(&hist[b], h[b]);
+}
+// exclusive scan of the 8,192 bin counts by one workgroup; leaves `hist` zeroed for the next MSM of this workspace
+__global__ void __launch_bounds__(1024) k_order_scan(uint32_t *__restrict__ hist, uint32_t *__restrict__ offs) {
+    __shared__ uint32_t part[1024];
+    constexpr int PER = ORD_BINS / 1024;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; i++) { v[i] = hist[threadIdx.x * PER + i]; hist[threadIdx.x * PER + i] = 0; sum += v[i]; }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        uint32_t add = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+#pragma unroll
+    for (int i = 0; i < PER; i++) { offs[threadIdx.x * PER + i] = run; run += v[i]; }
+}
+__global__ void __launch_bounds__(ORD_THREADS) k_order_scatter(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, uint32_t nb, uint32_t *__restrict__ offs,
+                                                                uint32_t *__restrict__ order) {
+    __shared__ uint32_t h[ORD_BINS];
+    for (int b = threadIdx.x; b < ORD_BINS; b += ORD_THREADS) h[b] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * ORD_PER_BLOCK;
+    uint32_t key[ORD_PER_THREAD], rank[ORD_PER_THREAD];
+#pragma unroll
+    for (int r = 0; r < ORD_PER_THREAD; r++) {
+        uint32_t k = base + r * ORD_THREADS + threadIdx.x;
+        if (k < nb) { key[r] = order_key(end[k] - start[k]); rank[r] = atomicAdd(&h[key[r]], 1u); }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < ORD_BINS; b += ORD_THREADS) if (h[b]) h[b] = atomicAdd(&offs[b], h[b]);     // this workgroup's run of slots inside bin b
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ORD_PER_THREAD; r++) {
+        uint32_t k = base + r * ORD_THREADS + threadIdx.x;
+        if (k < nb) order[h[key[r]] + rank[r]] = k;
+    }
+}
+
 // ONE LANE PER BUCKET, buckets visited in descending-size order so the 64 lanes of a wave run the same trip count.
 // The loop body has no function call: the (cryptographically negligible, but reachable with repeated bases) P == +-Q case is
 // appended to a deferred list and replayed by the last workgroup of k_accumulate_tail with the complete addition law.  Buckets stay in the
@@ -488,6 +553,7 @@ struct MsmWorkspace {
     uint32_t *size_key = nullptr, *size_key2 = nullptr, *ids = nullptr, *order = nullptr, *extra = nullptr, *extra_off = nullptr;
     void *ovf_partial = nullptr; size_t cap_ovf = 0;
     uint32_t *part_hist = nullptr, *part_offs = nullptr; size_t cap_part = 0;      // two-level partition: (coarse bin, workgroup) histogram and its scan
+    uint32_t *ord_hist = nullptr;                                                  // 2 x ORD_BINS: bin counts (kept zero between MSMs) and their scan
     size_t plan_n = 0, plan_pairs = 0; int plan_c = 0, plan_nwin = 0;     // state between msm_prepare and msm_finish
     bool plan_table = false; uint32_t plan_cap = BUCKET_CAP;
     uint32_t *deferred = nullptr, *deferred_count = nullptr;
@@ -500,6 +566,8 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
     if (!S.ev0) {
         HIP_CHECK(hipEventCreate(&S.ev0)); HIP_CHECK(hipEventCreate(&S.ev1));
         S.deferred = (uint32_t *)dmalloc(2 * DEFERRED_CAP * 4); S.deferred_count = (uint32_t *)dmalloc(8);
+        S.ord_hist = (uint32_t *)dmalloc(2 * ORD_BINS * 4);
+        HIP_CHECK(hipMemset(S.ord_hist, 0, 2 * ORD_BINS * 4));
     }
     if (pairs / cap + 64 > S.cap_ovf) { dfree(S.ovf_partial); S.cap_ovf = pairs / cap + 64; S.ovf_partial = dmalloc(S.cap_ovf * ACC_BYTES); }
     if (pairs > S.cap_pairs) {
@@ -543,24 +611,43 @@ MsmWorkspace *msm_workspace_create() {
 void msm_workspace_destroy(MsmWorkspace *w) {
     if (!w) return;
     for (void *p : {(void *)w->keys_a, (void *)w->keys_b, (void *)w->vals_a, (void *)w->vals_b, (void *)w->start, (void *)w->end, (void *)w->size_key, (void *)w->size_key2, (void *)w->ids,
-                    (void *)w->order, (void *)w->extra, (void *)w->extra_off, w->ovf_partial, (void *)w->part_hist, (void *)w->part_offs, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->wsum, w->tmp}) dfree(p);
+                    (void *)w->order, (void *)w->extra, (void *)w->extra_off, w->ovf_partial, (void *)w->part_hist, (void *)w->part_offs, (void *)w->ord_hist, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->wsum, w->tmp}) dfree(p);
     if (w->ev0) { (void)hipEventDestroy(w->ev0); (void)hipEventDestroy(w->ev1); }
     if (w->low) { (void)hipStreamDestroy(w->low); (void)hipEventDestroy(w->fence_a); (void)hipEventDestroy(w->fence_b); }
     delete w;
 }
 
 // size-balanced visiting order of the buckets (descending size: the 64 lanes of a wave run the same trip count) + overflow segments of oversized buckets
+// Measured (profiles/r03_order_counting.txt): 0.10-0.14 ms less per MSM for a lone call (16-byte encrypt() 31.2 -> 30.4 ms), but 0.7 % FEWER blocks/s with 16 contexts in
+// flight -- the generic sort's tiny launches hide behind the other contexts' kernels and its stable output keeps equal-size buckets in index order.  So: counting for
+// lone calls, the sort while a multi-proof call is in flight; ZKAES_MSM_ORDER=count|sort forces one.
+static bool order_by_counting() {
+    static const int forced = [] { const char *e = getenv("ZKAES_MSM_ORDER"); return !e ? 0 : !strcmp(e, "sort") ? 1 : !strcmp(e, "count") ? 2 : 0; }();
+    return forced == 2 || (forced == 0 && !throughput_mode());
+}
 static void order_buckets(MsmWorkspace &S, size_t nb, uint32_t cap, hipStream_t s) {
-    HIP_CHECK(hipMemsetAsync(S.extra + nb, 0, 4, s));
-    hipLaunchKernelGGL(k_bucket_sizes, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, S.start, S.end, (uint32_t)nb, cap, S.size_key, S.ids, S.extra);
-    HIP_LAUNCH_CHECK();
+    const bool counting = order_by_counting();
+    const unsigned oblocks = (unsigned)((nb + ORD_PER_BLOCK - 1) / ORD_PER_BLOCK);
+    if (counting) {
+        hipLaunchKernelGGL(k_order_hist, dim3(oblocks), dim3(ORD_THREADS), 0, s, S.start, S.end, (uint32_t)nb, cap, S.extra, S.ord_hist);
+        HIP_LAUNCH_CHECK();
+    } else {
+        HIP_CHECK(hipMemsetAsync(S.extra + nb, 0, 4, s));
+        hipLaunchKernelGGL(k_bucket_sizes, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, S.start, S.end, (uint32_t)nb, cap, S.size_key, S.ids, S.extra);
+        HIP_LAUNCH_CHECK();
+    }
     {
         size_t tb = 0;
         HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, S.extra, S.extra_off, 0u, nb + 1, rocprim::plus<uint32_t>(), s));
         if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
         HIP_CHECK(rocprim::exclusive_scan(S.tmp, tb, S.extra, S.extra_off, 0u, nb + 1, rocprim::plus<uint32_t>(), s));
     }
-    {
+    if (counting) {
+        hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(1024), 0, s, S.ord_hist, S.ord_hist + ORD_BINS);
+        HIP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_order_scatter, dim3(oblocks), dim3(ORD_THREADS), 0, s, S.start, S.end, (uint32_t)nb, S.ord_hist + ORD_BINS, S.order);
+        HIP_LAUNCH_CHECK();
+    } else {
         size_t tb = 0;
         HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, S.size_key, S.size_key2, S.ids, S.order, nb, 0u, 13u, s));
         if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }

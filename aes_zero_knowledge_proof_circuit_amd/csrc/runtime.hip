@@ -46,6 +46,7 @@ int wait_override() { static const int v = [] { const char *e = getenv("ZKAES_WA
 }  // namespace
 ThroughputWaits::ThroughputWaits(bool on) : on_(on) { if (on_) g_throughput_waits.fetch_add(1); }
 ThroughputWaits::~ThroughputWaits() { if (on_) g_throughput_waits.fetch_sub(1); }
+bool throughput_mode() { return g_throughput_waits.load(std::memory_order_relaxed) > 0; }
 void sync(stream_t s_) {
     hipStream_t s = (hipStream_t)s_;
     const int ov = wait_override();

@@ -16,8 +16,8 @@ def short(name):
         # rocPRIM launches everything through a few kernel templates: keep the template's own name (onesweep_iteration_kernel, lookback_scan_kernel, ...) and,
         # for the generic ones, the algorithm named in their configuration
         base = name.split("::")[-1] or "kernel"
-        m = re.search(r"(radix_sort_\w+|onesweep\w*|lookback_scan\w*|scan\w*|partition\w*|transform\w*|histogram\w*)", full)
-        return "rocprim::" + (base if base not in ("kernel", "") else (m.group(1) if m else "kernel"))
+        m = re.search(r"(radix_sort_\w+|onesweep\w*|lookback_scan\w*|\w*scan\w*|partition\w*|transform\w*|histogram\w*)", full.split("trampoline_kernel", 1)[-1])
+        return "rocprim::" + (base if base not in ("kernel", "trampoline_kernel", "") else (m.group(1) if m else base))
     if law:
         return name.split("(")[0].replace(law, "") + law
     return name.split("(")[0]
@@ -29,6 +29,11 @@ def main():
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
     agg = {}
+    if len(sys.argv) > 4:           # optional: dump the full rocPRIM kernel names (they only differ in their template arguments)
+        with open(sys.argv[4], "w") as f:
+            for name, calls, total, avg, pct in rows:
+                if "rocprim" in name:
+                    f.write("%d calls %.1f ms: %s\n" % (calls, total / 1e3, name[:400]))
     for name, calls, total, avg, pct in rows:
         k = short(name)
         a = agg.setdefault(k, [0, 0.0, 0.0])
