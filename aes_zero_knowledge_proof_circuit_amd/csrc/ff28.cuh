@@ -12,6 +12,9 @@
 // Conversion from the library-wide 12x32 form (R = 2^384): split limbs, multiply by 2^8 R' mod p; back: multiply by R mod p... (to_std).
 #pragma once
 #include "ff.cuh"
+#ifndef ZK_FF28_SAD
+#define ZK_FF28_SAD 1           // lazy subtraction as v_sad_u32 (A/B: -DZK_FF28_SAD=0)
+#endif
 #ifndef ZK_CHEAP_PRETEST
 #define ZK_CHEAP_PRETEST 1      // one-limb pre-tests before the full zero / infinity tests of the MSM hot loop (A/B: -DZK_CHEAP_PRETEST=0)
 #endif
@@ -93,7 +96,19 @@ struct Fp28 {
     // 14 x (limb bound a) x (limb bound b) + 14 x 2^56 below 2^64 (te28.cuh lists the operands that use it, with their bounds).
     ZK_HD Fp28 add_lazy(const Fp28 &b) const { Fp28 r; for (int i = 0; i < N; i++) r.l[i] = l[i] + b.l[i]; return r; }
     ZK_HD Fp28 dbl_lazy() const { Fp28 r; for (int i = 0; i < N; i++) r.l[i] = l[i] << 1; return r; }
-    template <int K> ZK_HD Fp28 sub_lazy(const Fp28 &b) const { Fp28 r; for (int i = 0; i < N; i++) r.l[i] = l[i] + kp_spread<K>(i) - b.l[i]; return r; }   // b normalized; limbs <= (K + 2) 2^28
+    // b normalized; limbs <= (K + 2) 2^28.  On the device limbs 0..12 are ONE instruction each: kp_spread >= 2^28 - 1 >= b_i there, so l + (kp - b) = |kp - b| + l = v_sad_u32
+    // (the top limb keeps the two-instruction form: b's excess sits there)
+    template <int K> ZK_HD Fp28 sub_lazy(const Fp28 &b) const {
+        Fp28 r;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+#if defined(__HIP_DEVICE_COMPILE__) && ZK_FF28_SAD
+            if (i < N - 1) { asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r.l[i]) : "s"(kp_spread<K>(i)), "v"(b.l[i]), "v"(l[i])); continue; }
+#endif
+            r.l[i] = l[i] + kp_spread<K>(i) - b.l[i];
+        }
+        return r;
+    }
     // limb i of K p (normalized; the top limb keeps the excess) and the same with the borrows pre-distributed:
     // sum c_i 2^(28 i) = K p with c_i >= 2^28 - 1 below the top, so a_i - b_i + c_i never goes negative for a normalized b
     template <int K> ZK_HD static constexpr uint32_t kp_limb(int i) {

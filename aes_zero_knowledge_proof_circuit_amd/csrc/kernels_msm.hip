@@ -281,12 +281,21 @@ __global__ void __launch_bounds__(64, ZK_ACC_WAVES) k_accumulate(const typename 
 #if ZK_ACC_PREFETCH == 2
             // the next point's gather is issued in the middle of the current addition, into the registers the current point no longer needs (te_madd_signed)
             uint32_t idx = vals[s];
+#if ZK_TE_PRESWAP
+            Niels28<P> p = niels_load_signed<P>(bases + (idx & VAL_INDEX), idx >> 31);  // a negative digit's record arrives with (y - x, y + x) swapped
+#else
             Niels28<P> p = bases[idx & VAL_INDEX];
+#endif
             for (uint32_t i = s; i < e; i++) {
                 const uint32_t cur = idx;
                 const bool more = i + 1 < e;
                 if (more) idx = vals[i + 1];
                 const Niels28<P> *next = bases + (idx & VAL_INDEX);                    // the last iteration re-reads its own point: no branch around the load
+#if ZK_TE_PRESWAP
+                if (cur & VAL_SKIP) { p = niels_load_signed<P>(next, idx >> 31); continue; }
+                te_madd_signed<P, ZK_TE_BIASED != 0, true>(acc, p, cur >> 31, next, bias, idx >> 31);
+                continue;
+#endif
                 if (cur & VAL_SKIP) { p = *next; continue; }
                 te_madd_signed<P, ZK_TE_BIASED != 0>(acc, p, cur >> 31, next, bias);
             }

@@ -99,6 +99,9 @@ ZK_HD void te_madd(AccTE<P> &a, const Niels28<P> &n) {
 }
 // acc += (neg ? -n : n) without touching n: -(x, y) = (-x, y) swaps n's first two coordinates and negates the third, i.e. A = (Y1 - X1)(y2 + x2), B = (Y1 + X1)(y2 - x2) and
 // C changes sign, which swaps F = D - C and G = D + C.  56 per-limb selects instead of a divergent branch with a 14-limb negation and 42 register moves (ZK_TE_SIGN_SELECT).
+#ifndef ZK_TE_PRESWAP
+#define ZK_TE_PRESWAP 1
+#endif
 #ifndef ZK_TE_BIASED
 #define ZK_TE_BIASED 1
 #endif
@@ -112,8 +115,17 @@ ZK_HD G mul_maybe_biased(const G &x, const G &y, uint64_t bias) {
     if constexpr (BIASED) return G::mul_biased(x, y, bias);
     else return x * y;
 }
-template <class P, bool BIASED = false>
-ZK_HD void te_madd_signed(AccTE<P> &a, Niels28<P> &n, bool neg, const Niels28<P> *next = nullptr, uint64_t bias = 0) {
+// a table record with its first two coordinates swapped when the digit that uses it is negative: the swap costs nothing at the gather (two field addresses), 28 selects after it
+template <class P>
+ZK_HD Niels28<P> niels_load_signed(const Niels28<P> *rec, bool neg) {
+    const FpMsm<P> *f = &rec->ymx;                   // ymx and ypx are adjacent
+    Niels28<P> r;
+    r.ymx = f[neg ? 1 : 0]; r.ypx = f[neg ? 0 : 1]; r.td = rec->td;
+    return r;
+}
+// PRESWAPPED: n was loaded with niels_load_signed(.., neg) and `next` is loaded with the sign of ITS digit, next_neg
+template <class P, bool BIASED = false, bool PRESWAPPED = false>
+ZK_HD void te_madd_signed(AccTE<P> &a, Niels28<P> &n, bool neg, const Niels28<P> *next = nullptr, uint64_t bias = 0, bool next_neg = false) {
     using G = FpMsm<P>;
 #if ZK_TE_BIASED
     // BIASED: bias = FpMsm<P>::hot_loop_bias() taken at kernel entry (ff28.cuh mul_biased: 14 fewer 64-bit adds per product)
@@ -122,8 +134,11 @@ ZK_HD void te_madd_signed(AccTE<P> &a, Niels28<P> &n, bool neg, const Niels28<P>
 #define ZK_TE_MUL(x, y) ((x) * (y))
 #endif
     G m1, m2;
+    if constexpr (PRESWAPPED) { m1 = n.ymx; m2 = n.ypx; }
+    else {
 #pragma unroll
-    for (int i = 0; i < G::N; i++) { m1.l[i] = neg ? n.ypx.l[i] : n.ymx.l[i]; m2.l[i] = neg ? n.ymx.l[i] : n.ypx.l[i]; }
+        for (int i = 0; i < G::N; i++) { m1.l[i] = neg ? n.ypx.l[i] : n.ymx.l[i]; m2.l[i] = neg ? n.ymx.l[i] : n.ypx.l[i]; }
+    }
 #if ZK_TE_LAZY
     // carries only where a product needs a normalized operand: Y1 -+ X1 skip the chain (limbs < 2^30.4, their partners are table entries)
     G A = ZK_TE_MUL(a.y.template sub_lazy<3>(a.x), m1);
@@ -138,16 +153,18 @@ ZK_HD void te_madd_signed(AccTE<P> &a, Niels28<P> &n, bool neg, const Niels28<P>
         // pin the gather behind the three products: without the fence the compiler hoists the loads to the top of the iteration, into a second register set
         asm volatile("" : "+v"(A.l[G::N - 1]), "+v"(B.l[G::N - 1]), "+v"(C.l[G::N - 1]) : : "memory");
 #endif
-        n = *next;
+        if constexpr (PRESWAPPED) n = niels_load_signed<P>(next, next_neg);
+        else n = *next;
     }
 #if ZK_TE_LAZY
     // all four factors of the second level lazy.  Limb bounds in units of 2^28: E = B + 2p' - A < 3, H = B + A < 2, D = 2 Z1 < 2, U = D + 2p' - C < 4, V = D + C < 3
     // (2p' = kp_spread<2> < 2 per limb).  The widest products, E U and U V, put 14 x 12 x 2^56 into a column, the reduction 13 x 2^56 more: 181 x 2^56 < 2^64.
     G E = B.template sub_lazy<2>(A), H = B.add_lazy(A);
-    G D = a.z.dbl_lazy();
 #if ZK_TE_LAZY >= 2
+    G D = a.z.dbl_lazy();
     G U = D.template sub_lazy<2>(C), V = D.add_lazy(C), F, Gg;
 #else
+    G D = a.z.dbl_lazy();
     G U = D.template sub<2>(C), V = D + C, F, Gg;          // A/B: D -+ C with the carry chain (3,603 instead of 3,550 instructions)
 #endif
 #else
