@@ -16,8 +16,12 @@ def short(name):
         # rocPRIM launches everything through a few kernel templates: keep the template's own name (onesweep_iteration_kernel, lookback_scan_kernel, ...) and,
         # for the generic ones, the algorithm named in their configuration
         base = name.split("::")[-1] or "kernel"
-        m = re.search(r"(radix_sort_\w+|onesweep\w*|lookback_scan\w*|\w*scan\w*|partition\w*|transform\w*|histogram\w*)", full.split("trampoline_kernel", 1)[-1])
-        return "rocprim::" + (base if base not in ("kernel", "trampoline_kernel", "") else (m.group(1) if m else base))
+        if base not in ("kernel", "trampoline_kernel", ""):
+            return "rocprim::" + base
+        # trampoline_kernel<config, target_arch, algorithm<...>, ...>: the algorithm is the first detail:: name after the architecture argument
+        tail = full.split("target_arch)", 1)[-1]
+        m = re.search(r"detail::(\w+)", tail) or re.search(r"(radix_sort_\w+|merge_sort_\w+|\w*scan\w*|partition\w*|transform\w*|histogram\w*)", full)
+        return "rocprim::" + (m.group(1) if m else base)
     if law:
         return name.split("(")[0].replace(law, "") + law
     return name.split("(")[0]
