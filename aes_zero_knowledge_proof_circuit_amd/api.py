@@ -301,11 +301,17 @@ def msm_fold_window_sums_dev(curve_id, dev_ptr, world, n_total):
     return out.raw, bool(inf.value)
 
 
-def msm_table(curve_id, bases_bytes, scalars_bytes, window_bits):
+def msm_table(curve_id, bases_bytes, scalars_bytes, window_bits, srs=False):
+    """precomputed-window MSM.  srs=True (377 only): the prover's SRS path on the twisted Edwards model -- bases MUST lie in the prime-order subgroup"""
     n = len(scalars_bytes) // 32
     out = C.create_string_buffer(96)
     inf = C.c_int()
-    _check(lib().zkaes_msm_table(int(curve_id), bytes(bases_bytes), bytes(scalars_bytes), C.c_size_t(n), int(window_bits), out, C.byref(inf)))
+    if srs:
+        if int(curve_id) != 377:
+            raise ValueError("the SRS (twisted Edwards) table path exists for BLS12-377 only")
+        _check(lib().zkaes_msm_table_srs(bytes(bases_bytes), bytes(scalars_bytes), C.c_size_t(n), int(window_bits), out, C.byref(inf)))
+    else:
+        _check(lib().zkaes_msm_table(int(curve_id), bytes(bases_bytes), bytes(scalars_bytes), C.c_size_t(n), int(window_bits), out, C.byref(inf)))
     return out.raw, bool(inf.value)
 
 

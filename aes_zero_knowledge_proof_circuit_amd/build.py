@@ -16,12 +16,10 @@ OBJ = os.path.join(CSRC, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_SOURCES = ["runtime.hip", "kernels_ntt.hip", "kernels_msm.hip", "kernels_poly.hip", "kernels_witness.hip", "capi_kernels.hip"]
 CXX_SOURCES = ["circuit.cpp", "marlin.cpp", "capi.cpp"]
-HEADERS = ["ff.cuh", "ff28.cuh", "ff29.cuh", "ff30.cuh", "ec.cuh", "ec28.cuh", "te28.cuh", "gpu.hpp", "hip_util.hpp", "consts32.h", "trace_layout.h", "circuit.hpp", "marlin.hpp", "pairing.hpp", "transcript.hpp",
+HEADERS = ["ff.cuh", "ff28.cuh", "ff29.cuh", "ec.cuh", "ec28.cuh", "te28.cuh", "gpu.hpp", "hip_util.hpp", "consts32.h", "trace_layout.h", "circuit.hpp", "marlin.hpp", "pairing.hpp", "transcript.hpp",
            os.path.join("..", "..", "include", "zkaes.h")]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-I", CSRC, "-Wno-unused-result"]
-if os.environ.get("ZK_MSM_RADIX"):          # 30 = the 13 x 30-bit signed-limb field for the MSM (csrc/ff30.cuh; A/B measurements); default 28 (csrc/ec.cuh)
-    COMMON.append("-DZK_MSM_RADIX=" + os.environ["ZK_MSM_RADIX"])
-if os.environ.get("ZK_EXTRA_DEFINES"):      # e.g. "-DZK_CHEAP_PRETEST=0" for A/B builds on the GPU box
+if os.environ.get("ZK_EXTRA_DEFINES"):      # e.g. "-DZKAES_MEASURE" (knock-in hooks of the measurement builds) for A/B builds on the GPU box
     COMMON += os.environ["ZK_EXTRA_DEFINES"].split()
 
 

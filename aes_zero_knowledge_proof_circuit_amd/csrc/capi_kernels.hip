@@ -75,7 +75,9 @@ template <class Curve> void run_msm(const uint8_t *bases, const uint8_t *scalars
     zk::gpu::dfree(db28);
     zk::gpu::dfree(db); zk::gpu::dfree(ds); zk::gpu::stream_destroy(s);
 }
-template <class Curve> void run_msm_table(const uint8_t *bases, const uint8_t *scalars, size_t n, int c, uint8_t *out_xy, int *out_inf) {
+// EDWARDS (377 only): the prover's SRS path -- tables on the curve's twisted Edwards model; the bases must lie in the prime-order subgroup.  Otherwise the
+// Weierstrass law (any curve point).
+template <class Curve, bool EDWARDS> void run_msm_table(const uint8_t *bases, const uint8_t *scalars, size_t n, int c, uint8_t *out_xy, int *out_inf) {
     using Fq = typename Curve::Fq; using Fr = typename Curve::Fr;
     zk::gpu::require_device();
     if (c < 2 || c > 22) throw std::invalid_argument("window bits must be in [2, 22]");
@@ -87,15 +89,12 @@ template <class Curve> void run_msm_table(const uint8_t *bases, const uint8_t *s
     zk::gpu::build_window_tables<Curve>(tab, n, c, s);
     zk::gpu::MsmWorkspace *ws = zk::gpu::msm_workspace_create();
     zk::Affine<Fq> a;
-#if ZK_MSM_EDWARDS
-    if constexpr (Curve::ID == 377) {        // the prover's SRS path: tables on the twisted Edwards model (bases must lie in the prime-order subgroup)
+    if constexpr (EDWARDS) {
         zk::Niels28<typename Curve::FqP> *tabte = (zk::Niels28<typename Curve::FqP> *)zk::gpu::dmalloc(nt * n * sizeof(zk::Niels28<typename Curve::FqP>));
         zk::gpu::convert_bases_te<Curve>(tabte, tab, nt * n, s);
         a = zk::gpu::msm_table<Curve>(ws, tabte, n, 0, c, ds, n, s).to_affine();
         zk::gpu::dfree(tabte);
-    } else
-#endif
-    {
+    } else {
         zk::Affine28<typename Curve::FqP> *tab28 = (zk::Affine28<typename Curve::FqP> *)zk::gpu::dmalloc(nt * n * sizeof(zk::Affine28<typename Curve::FqP>));
         zk::gpu::convert_bases<Curve>(tab28, tab, nt * n, s);
         a = zk::gpu::msm_table<Curve>(ws, tab28, n, 0, c, ds, n, s).to_affine();
@@ -170,7 +169,10 @@ int zkaes_g1_sum(int curve_id, const uint8_t *points_xy, const int *inf, size_t 
     return guardk([&] { if (curve_id == 381) run_g1_sum<zk::Bls381>(points_xy, inf, n, out_xy, out_inf); else if (curve_id == 377) run_g1_sum<zk::Bls377>(points_xy, inf, n, out_xy, out_inf); else throw std::invalid_argument("curve_id must be 377 or 381"); });
 }
 int zkaes_msm_table(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, int window_bits, uint8_t *out_xy, int *out_inf) {
-    return guardk([&] { if (curve_id == 381) run_msm_table<zk::Bls381>(bases, scalars, n, window_bits, out_xy, out_inf); else if (curve_id == 377) run_msm_table<zk::Bls377>(bases, scalars, n, window_bits, out_xy, out_inf); else throw std::invalid_argument("curve_id must be 377 or 381"); });
+    return guardk([&] { if (curve_id == 381) run_msm_table<zk::Bls381, false>(bases, scalars, n, window_bits, out_xy, out_inf); else if (curve_id == 377) run_msm_table<zk::Bls377, false>(bases, scalars, n, window_bits, out_xy, out_inf); else throw std::invalid_argument("curve_id must be 377 or 381"); });
+}
+int zkaes_msm_table_srs(const uint8_t *bases, const uint8_t *scalars, size_t n, int window_bits, uint8_t *out_xy, int *out_inf) {
+    return guardk([&] { run_msm_table<zk::Bls377, true>(bases, scalars, n, window_bits, out_xy, out_inf); });
 }
 int zkaes_set_device(int ordinal) { return guardk([&] { HIP_CHECK(hipSetDevice(ordinal)); }); }
 int zkaes_ntt(int field_id, uint8_t *data, size_t n, int inverse) {
@@ -197,12 +199,10 @@ int zkaes_msm_bench_synth(size_t n, int window_bits, int reps, double *ms_total,
         zk::gpu::fixed_base_powers<zk::Bls377>(tab, g, beta, 1, n, s);
         if (window_bits > 0) zk::gpu::build_window_tables<zk::Bls377>(tab, n, window_bits, s);
         // window_bits == 0: the generic path (Weierstrass model, XYZZ buckets, 112-byte bases); < 0 or > 0: the prover's SRS path on the twisted Edwards model
-        const bool edwards = ZK_MSM_EDWARDS && window_bits != 0;
+        const bool edwards = window_bits != 0;
         zk::Affine28<zk::Fq377P> *tab28 = nullptr;
-#if ZK_MSM_EDWARDS
         zk::Niels28<zk::Fq377P> *tabte = nullptr;
         if (edwards) { tabte = (zk::Niels28<zk::Fq377P> *)zk::gpu::dmalloc(nt * n * sizeof(zk::Niels28<zk::Fq377P>)); zk::gpu::convert_bases_te<zk::Bls377>(tabte, tab, nt * n, s); }
-#endif
         if (!edwards) { tab28 = (zk::Affine28<zk::Fq377P> *)zk::gpu::dmalloc(nt * n * sizeof(zk::Affine28<zk::Fq377P>)); zk::gpu::convert_bases<zk::Bls377>(tab28, tab, nt * n, s); }
         std::vector<Fr> sc(n);
         uint64_t x = 88172645463325252ull;
@@ -212,9 +212,7 @@ int zkaes_msm_bench_synth(size_t n, int window_bits, int reps, double *ms_total,
         zk::gpu::sync(s);
         zk::gpu::MsmWorkspace *ws = zk::gpu::msm_workspace_create();
         auto run = [&]() -> zk::XYZZ<Fq> {
-#if ZK_MSM_EDWARDS
             if (edwards) return window_bits > 0 ? zk::gpu::msm_table<zk::Bls377>(ws, tabte, n, 0, window_bits, ds, n, s) : zk::gpu::msm<zk::Bls377>(ws, tabte, ds, n, s);
-#endif
             return window_bits > 0 ? zk::gpu::msm_table<zk::Bls377>(ws, tab28, n, 0, window_bits, ds, n, s) : zk::gpu::msm<zk::Bls377>(ws, tab28, ds, n, s);
         };
         {
@@ -232,9 +230,7 @@ int zkaes_msm_bench_synth(size_t n, int window_bits, int reps, double *ms_total,
         zk::gpu::event_destroy(e0); zk::gpu::event_destroy(e1);
         zk::gpu::msm_workspace_destroy(ws);
         zk::gpu::dfree(tab28);
-#if ZK_MSM_EDWARDS
         zk::gpu::dfree(tabte);
-#endif
         zk::gpu::dfree(tab); zk::gpu::dfree(ds); zk::gpu::stream_destroy(s);
     });
 }

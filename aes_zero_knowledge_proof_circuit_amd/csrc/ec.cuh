@@ -8,21 +8,11 @@
 #pragma once
 #include "ff.cuh"
 #include "ff28.cuh"
-#include "ff30.cuh"
 
-// the reduced-radix base field the MSM kernels compute in: 14 unsigned 28-bit limbs (ff28.cuh, 378 multiply-accumulates per product; the default) or,
-// with -DZK_MSM_RADIX=30, 13 signed 30-bit limbs (ff30.cuh, 325).  Measured equal on MI355X (profiles/r02_msm_radix30.md): k_accumulate is bound by its
-// TOTAL VALU instruction count (5,096 vs 5,086 per mixed add: ff30 saves 595 multiplies and spends 585 more plain instructions on signed carries),
-// not by the multiplies alone.  The "28" in Affine28 / Acc28 / madd28 names the default.
-#ifndef ZK_MSM_RADIX
-#define ZK_MSM_RADIX 28
-#endif
+// the reduced-radix base field the MSM kernels compute in: 14 unsigned 28-bit limbs (ff28.cuh, 378 multiply-accumulates per product).  A 13 x 30-bit signed-limb
+// variant measured equal on MI355X (profiles/r02_msm_radix30.md: k_accumulate is bound by its TOTAL VALU instruction count) and was removed in round 4.
 namespace zk {
-#if ZK_MSM_RADIX == 28
 template <class P> using FpMsm = Fp28<P>;
-#else
-template <class P> using FpMsm = Fp30<P>;
-#endif
 }
 
 // The group operations are deliberately NOT inlined on the device: each is 9-14 Fq products (~300 VALU instructions
@@ -133,15 +123,11 @@ ZK_HD bool on_curve(const Affine<Fq> &a, const Fq &b) {
     return a.y.sqr() == a.x.sqr() * a.x + b;
 }
 
-// affine point in the reduced-radix form the Weierstrass-law accumulate kernel consumes (FpMsm): 2 x 14 x 28-bit limbs = 112 B by default (ff28.cuh; 2 x 13 x 30-bit = 104 B with -DZK_MSM_RADIX=30), (0,0) = infinity
+// affine point in the reduced-radix form the Weierstrass-law accumulate kernel consumes (FpMsm): 2 x 14 x 28-bit limbs = 112 B (ff28.cuh), (0,0) = infinity
 template <class P>
 struct Affine28 {
     FpMsm<P> x, y;
-#if ZK_CHEAP_PRETEST
     ZK_HD bool is_inf() const { return (x.l[0] | y.l[0]) == 0 && x.limbs_zero() && y.limbs_zero(); }      // one-word pre-test: the full OR only when both low limbs are zero
-#else
-    ZK_HD bool is_inf() const { return x.limbs_zero() && y.limbs_zero(); }
-#endif
     ZK_HD static Affine28 from_std(const Affine<Fp<P>> &a) { Affine28 r; r.x = FpMsm<P>::from_std(a.x); r.y = FpMsm<P>::from_std(a.y); return r; }
     ZK_HD Affine<Fp<P>> to_std() const { Affine<Fp<P>> r; r.x = x.to_std(); r.y = y.to_std(); return r; }
 };

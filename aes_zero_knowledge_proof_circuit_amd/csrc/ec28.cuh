@@ -5,10 +5,8 @@
 
 namespace zk {
 
-// Bucket accumulator in the reduced-radix form (FpMsm: ff28.cuh by default, ff30.cuh with -DZK_MSM_RADIX=30).  Values are NOT kept below p: the bounds are
-// tracked statically.  The bound comments below are ff28's (unsigned limbs: every subtraction adds the multiple of p named in sub<K> that keeps it
-// non-negative: x < 6.2 p, y < 3.2 p, zz, zzz < 1.2 p); with ff30 the limbs are signed, sub<K> is a plain subtraction, products lie in (-0.51 p, 0.51 p)
-// and every intermediate stays below 3 p in magnitude (|x3| <= |r^2| + |ppp| + 2 |qq| < 2.1 p, |pd|, |t| < 2.6 p) -- far inside the 8 p the product accepts.
+// Bucket accumulator in the reduced-radix form (FpMsm = ff28.cuh).  Values are NOT kept below p: the bounds are tracked statically (unsigned limbs: every
+// subtraction adds the multiple of p named in sub<K> that keeps it non-negative: x < 6.2 p, y < 3.2 p, zz, zzz < 1.2 p).
 template <class P>
 struct Acc28 { FpMsm<P> x, y, zz, zzz; };
 

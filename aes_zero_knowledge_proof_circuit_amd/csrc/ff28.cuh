@@ -12,12 +12,6 @@
 // Conversion from the library-wide 12x32 form (R = 2^384): split limbs, multiply by 2^8 R' mod p; back: multiply by R mod p... (to_std).
 #pragma once
 #include "ff.cuh"
-#ifndef ZK_FF28_SAD
-#define ZK_FF28_SAD 1           // lazy subtraction as v_sad_u32 (A/B: -DZK_FF28_SAD=0)
-#endif
-#ifndef ZK_CHEAP_PRETEST
-#define ZK_CHEAP_PRETEST 1      // one-limb pre-tests before the full zero / infinity tests of the MSM hot loop (A/B: -DZK_CHEAP_PRETEST=0)
-#endif
 
 namespace zk {
 
@@ -40,9 +34,7 @@ struct Fp28 {
     // v is a product (< 1.2 p): v == 0 (mod p)  <=>  v in {0, p}
     ZK_HD static bool product_is_zero(const Fp28 &v) {
         // one-limb pre-test first (hot path of k_accumulate: every VALU instruction counts): v in {0, p} needs limb 0 in {0, p_0}
-#if ZK_CHEAP_PRETEST
         if (v.l[0] != 0u && v.l[0] != mod28(0)) return false;
-#endif
         uint32_t z0 = 0, zp = 0;
 #pragma unroll
         for (int i = 0; i < N; i++) { z0 |= v.l[i]; zp |= v.l[i] ^ mod28(i); }
@@ -102,7 +94,7 @@ struct Fp28 {
         Fp28 r;
 #pragma unroll
         for (int i = 0; i < N; i++) {
-#if defined(__HIP_DEVICE_COMPILE__) && ZK_FF28_SAD
+#if defined(__HIP_DEVICE_COMPILE__)
             if (i < N - 1) { asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r.l[i]) : "s"(kp_spread<K>(i)), "v"(b.l[i]), "v"(l[i])); continue; }
 #endif
             r.l[i] = l[i] + kp_spread<K>(i) - b.l[i];

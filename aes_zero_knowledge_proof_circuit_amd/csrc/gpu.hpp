@@ -20,7 +20,9 @@ void require_device();
 int current_device();
 void set_device(int ordinal);                    // throws GpuError("no HIP device ...") -- the product never falls back to the CPU
 void *dmalloc(size_t bytes);
-int knockin();                                   // ZKAES_KNOCKIN measurement mask (runtime.hip)
+#ifdef ZKAES_MEASURE
+int knockin();                                   // ZKAES_KNOCKIN measurement mask (runtime.hip; measurement builds only)
+#endif
 size_t mem_free_bytes();                         // free device memory right now (hipMemGetInfo)
 void dfree(void *p);
 void h2d(void *dst, const void *src, size_t bytes, stream_t s);
@@ -31,8 +33,7 @@ void sync(stream_t s);                    // wait for the stream: spins (lone ca
 // RAII marker of a multi-proof call: host threads of its prover contexts wait by polling + nanosleep instead of spinning (runtime.hip)
 bool throughput_mode();                   // true while a ThroughputWaits scope is alive (a multi-proof call is in flight): kernels may pick the throughput variant of a step
 struct ThroughputWaits { explicit ThroughputWaits(bool on); ~ThroughputWaits(); ThroughputWaits(const ThroughputWaits &) = delete; ThroughputWaits &operator=(const ThroughputWaits &) = delete; private: bool on_; };
-stream_t stream_create();                 // high priority unless ZKAES_STREAM_PRIORITY=0
-bool stream_priorities_enabled();
+stream_t stream_create();
 void stream_destroy(stream_t s);
 // event timing on a stream (ms)
 void *event_create();
@@ -62,7 +63,6 @@ template <class Curve>
 void msm_prepare(MsmWorkspace *ws, const typename Curve::Fr *scal1, size_t n1, const typename Curve::Fr *scal2, size_t n2, size_t val_off2, stream_t s, int force_c = 0);
 template <class Curve>
 XYZZ<typename Curve::Fq> msm_finish(MsmWorkspace *ws, const Affine28<typename Curve::FqP> *bases, stream_t s);
-#if ZK_MSM_EDWARDS
 // BLS12-377 only -- the prover's path over its fixed SRS: bases precomputed on the curve's twisted Edwards model (te28.cuh: Niels28 = (y - x, y + x, 2 d x y),
 // 168 B padded to a 64-byte aligned 192-byte record), bucket additions of 7 field products instead of 10 and no special cases.  convert_bases_te maps Weierstrass affine points (which MUST lie in the
 // prime-order subgroup; a point of order 2 or 4 is refused) to that form; msm / msm_finish / msm_table / class_sum are overloaded on the base type and
@@ -76,7 +76,6 @@ template <class Curve>
 XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws, const Niels28<typename Curve::FqP> *tables, size_t stride, size_t off, int c, const typename Curve::Fr *scalars, size_t n, stream_t s);
 template <class Curve>
 bool class_sum(MsmWorkspace *ws, const Niels28<typename Curve::FqP> *bases, const int8_t *vals, size_t n, XYZZ<typename Curve::Fq> *out, stream_t s);
-#endif
 // ONE MSM sharded by point range over ranks: msm_sharded_plan gives the window plan of the whole MSM (all ranks agree on it);
 // msm_window_sums_device runs this rank's slice and leaves n_windows XYZZ window sums (192 B each, standard Montgomery form) at dev_out in HBM
 // -- the payload of the one all-gather; msm_fold_window_sums_device adds `world` such blocks (rank-major) per window on the device and finishes

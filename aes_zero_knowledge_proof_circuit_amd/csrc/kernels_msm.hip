@@ -3,8 +3,10 @@
 // Replaces ark-ec 0.3.0 VariableBaseMSM::multi_scalar_mul (one rayon task per window, Cargo.lock:118) behind
 // KZG10::commit / open (ark-poly-commit 0.3.0) -- SURVEY.md §8 a17.  GPU shape:
 //   1. k_digits      : scalars Montgomery -> canonical, split into c-bit window digits, emit (window|digit, index) pairs
-//   2. grouping      : table mode: a two-level bucket partition written for this layout (k_part_*); per-window mode: rocPRIM radix sort over all windows at once
-//   3. k_bounds      : bucket [start, end) ranges in the sorted pair list
+//   2. grouping      : table mode: the digit kernels split the pairs stably on the low 3 bucket bits (k_split_*), rocPRIM's radix sort does the other 16 in two passes;
+//                      per-window mode: one stable radix sort on the bucket bits over all windows at once
+//   3. k_bounds      : bucket [start, end) ranges in the sorted pair list (empty buckets filled in on the way: nothing is memset)
+//      k_order_*     : visiting order of the buckets by descending size (counting sort, deterministic) + the list of oversized buckets
 //   4. k_accumulate  : ONE LANE PER BUCKET, XYZZ accumulator, mixed adds of affine bases gathered through the sorted
 //                      index list -- the dominant kernel (integer-ALU bound: ~10 Fq products of 12x12 v_mad_u64_u32 each per add)
 //   5. k_reduce_*    : running-sum reduction in 64-bucket segments, then an LDS tree per window
@@ -27,9 +29,7 @@ namespace gpu {
 // BLS12-377's twisted Edwards model with extended accumulators and 168-byte precomputed (y - x, y + x, 2 d x y) bases (te28.cuh: 7 products per
 // bucket addition instead of 10, no special cases) -- what the prover runs over its fixed SRS.
 template <class P> struct WeierLaw { using Params = P; using Base = Affine28<P>; using Acc = Acc28<P>; static constexpr bool edwards = false; };
-#if ZK_MSM_EDWARDS
 template <class P> struct EdwardsLaw { using Params = P; using Base = Niels28<P>; using Acc = AccTE<P>; static constexpr bool edwards = true; };
-#endif
 
 static MsmStats g_stats;
 static std::mutex g_stats_mu;
@@ -140,23 +140,37 @@ __global__ void __launch_bounds__(64) k_table_next(const Affine<Fq> *__restrict_
     }
 }
 
-// four consecutive sorted keys per lane (one 16-byte load + the two neighbours): a group starts where the key changes
-__global__ void k_bounds(const uint32_t *__restrict__ keys, size_t total, uint32_t nb, uint32_t *__restrict__ start, uint32_t *__restrict__ end) {
+// four consecutive sorted keys per lane (one 16-byte load + the two neighbours): a group starts where the key changes.  Nothing is memset beforehand: the lane that sees
+// the key change also writes the (empty) ranges of the buckets the sorted list skips, the first / last lane those before the first / after the last key.
+// The list is ordered by `rank`: table mode (nwin = 1) by the key itself; per-window mode -- keys (window << cbits) | bucket, sorted stably on the bucket bits of a
+// window-major list -- by (bucket, window).
+__device__ __forceinline__ uint32_t bounds_rank(uint32_t key, int cbits, uint32_t nwin) { return nwin == 1 ? key : (key & ((1u << cbits) - 1)) * nwin + (key >> cbits); }
+__device__ __forceinline__ uint32_t bounds_key(uint32_t rank, int cbits, uint32_t nwin) { return nwin == 1 ? rank : ((rank % nwin) << cbits) | (rank / nwin); }
+__global__ void k_bounds(const uint32_t *__restrict__ keys, size_t total, int cbits, uint32_t nwin, uint32_t *__restrict__ start, uint32_t *__restrict__ end) {
     size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i0 >= total) return;
+    const uint32_t nb = nwin << cbits;
     uint32_t k[6];                                        // k[0] = key before the quad, k[5] = key after it
     if (i0 + 4 <= total) { uint4 v = *reinterpret_cast<const uint4 *>(keys + i0); k[1] = v.x; k[2] = v.y; k[3] = v.z; k[4] = v.w; }
-    else { for (int j = 0; j < 4; j++) k[1 + j] = i0 + j < total ? keys[i0 + j] : 0xffffffffu; }
-    k[0] = i0 ? keys[i0 - 1] : 0xffffffffu;
-    k[5] = i0 + 4 < total ? keys[i0 + 4] : 0xffffffffu;
+    else { for (int j = 0; j < 4; j++) k[1 + j] = i0 + j < total ? keys[i0 + j] : 0u; }
+    k[0] = i0 ? keys[i0 - 1] : 0u;
+    k[5] = i0 + 4 < total ? keys[i0 + 4] : 0u;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         size_t i = i0 + j;
         if (i >= total) break;
-        uint32_t key = k[1 + j];
-        if (key >= nb) continue;                          // table-mode marker for zero digits
-        if (i == 0 || k[j] != key) start[key] = (uint32_t)i;
-        if (i + 1 == total || k[2 + j] != key) end[key] = (uint32_t)(i + 1);
+        const uint32_t key = k[1 + j];
+        if (i == 0 || k[j] != key) {
+            const uint32_t r1 = bounds_rank(key, cbits, nwin);
+            uint32_t r0 = 0;
+            if (i != 0) { end[k[j]] = (uint32_t)i; r0 = bounds_rank(k[j], cbits, nwin) + 1; }
+            for (uint32_t r = r0; r < r1; r++) { const uint32_t g = bounds_key(r, cbits, nwin); start[g] = (uint32_t)i; end[g] = (uint32_t)i; }
+            start[key] = (uint32_t)i;
+        }
+        if (i + 1 == total) {
+            end[key] = (uint32_t)total;
+            for (uint32_t r = bounds_rank(key, cbits, nwin) + 1; r < nb; r++) { const uint32_t g = bounds_key(r, cbits, nwin); start[g] = (uint32_t)total; end[g] = (uint32_t)total; }
+        }
     }
 }
 
@@ -172,79 +186,79 @@ __global__ void k_convert_bases(const Affine<Fp<P>> *__restrict__ src, Affine28<
 // cap = 2048 for the per-window buckets (average bucket ~50 points), 512 in table mode (balanced windows: the 2^18 buckets every window reaches hold
 // ~20 n / 2^19 points, ~330 for the largest MSM of a 6-block proof; uniform digits therefore never overflow).
 constexpr uint32_t BUCKET_CAP = 2048, BUCKET_CAP_TABLE = 512;
-__global__ void k_bucket_sizes(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, uint32_t nb, uint32_t cap, uint32_t *__restrict__ size_key,
-                               uint32_t *__restrict__ ids, uint32_t *__restrict__ extra) {
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nb) return;
-    uint32_t sz = end[k] - start[k];
-    extra[k] = sz > cap ? (sz - 1) / cap : 0;
-    if (sz > 8191u) sz = 8191u;
-    size_key[k] = 8191u - sz;             // ascending sort on this 13-bit key = descending bucket size (sizes above 8191 tie)
-    ids[k] = k;
-}
+constexpr uint32_t NO_SLOT = 0xffffffffu;
 
-// The same ordering as a counting sort written for it: the key is the bucket's size (13 bits), nothing needs the order among buckets of equal size, so one histogram,
-// one scan over 8,192 bins and one scatter replace the ~16 launches of a generic sort of 2^19 (key, id) pairs (rocPRIM picks a merge sort at that size: 150 tiny launches
-// per 6-block proof).  k_order_hist also writes the overflow-segment counts k_bucket_sizes writes.  Used for lone calls (see order_by_counting).
-constexpr int ORD_BINS = 8192, ORD_THREADS = 256, ORD_PER_THREAD = 8, ORD_PER_BLOCK = ORD_THREADS * ORD_PER_THREAD;
-__device__ __forceinline__ uint32_t order_key(uint32_t sz) { return 8191u - (sz > 8191u ? 8191u : sz); }
-__global__ void __launch_bounds__(ORD_THREADS) k_order_hist(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, uint32_t nb, uint32_t cap, uint32_t *__restrict__ extra,
-                                                             uint32_t *__restrict__ hist) {
+// Visiting order of the buckets: descending size, so that the 64 lanes of a wave run the same trip count.  A counting sort written for it (the key is the bucket's
+// size clamped to 10 bits; a generic sort of 2^19 (key, id) pairs is ~16 tiny launches): per-workgroup LDS histograms over contiguous bucket ranges, ONE scan by one
+// workgroup (bin-major, so buckets of one size keep the order of their ranges: deterministic positions, no global atomics), one scatter.
+// The histogram pass also lists the oversized buckets (size > cap) -- slot, bucket and number of overflow segments -- through one atomic counter; the scan workgroup turns
+// the segment counts into offsets and re-arms the counter.  For uniformly distributed digits the list is empty.
+// ctrl words: [0] list counter (armed at zero between MSMs), [1] list length, [2] overflow segments in total, [3] class-sum flags
+constexpr int ORD_BINS = 1024, ORD_THREADS = 256, ORD_MAX_BLOCKS = 128;
+__device__ __forceinline__ uint32_t order_key(uint32_t sz) { return (ORD_BINS - 1) - (sz > ORD_BINS - 1 ? ORD_BINS - 1 : sz); }
+__global__ void __launch_bounds__(ORD_THREADS) k_order_hist(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, uint32_t nb, uint32_t per_block, uint32_t cap,
+                                                             uint32_t *__restrict__ ovf_slot, uint32_t *__restrict__ ovf_bucket, uint32_t *__restrict__ ovf_nseg, uint32_t ovf_cap,
+                                                             uint32_t *__restrict__ ctrl, uint32_t *__restrict__ hist) {
     __shared__ uint32_t h[ORD_BINS];
     for (int b = threadIdx.x; b < ORD_BINS; b += ORD_THREADS) h[b] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * ORD_PER_BLOCK;
-#pragma unroll
-    for (int r = 0; r < ORD_PER_THREAD; r++) {
-        uint32_t k = base + r * ORD_THREADS + threadIdx.x;
-        if (k < nb) {
-            uint32_t sz = end[k] - start[k];
-            extra[k] = sz > cap ? (sz - 1) / cap : 0;
-            atomicAdd(&h[order_key(sz)], 1u);
+    const uint32_t lo = blockIdx.x * per_block, hi = lo + per_block < nb ? lo + per_block : nb;
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += ORD_THREADS) {
+        const uint32_t sz = end[k] - start[k];
+        uint32_t slot = NO_SLOT;
+        if (sz > cap) {
+            slot = atomicAdd(&ctrl[0], 1u);
+            if (slot < ovf_cap) { ovf_bucket[slot] = k; ovf_nseg[slot] = (sz - 1) / cap; } else slot = NO_SLOT;      // (cannot happen: at most pairs / cap buckets exceed cap)
         }
+        ovf_slot[k] = slot;
+        atomicAdd(&h[order_key(sz)], 1u);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) extra[nb] = 0;
     __syncthreads();
-    for (int b = threadIdx.x; b < ORD_BINS; b += ORD_THREADS) if (h[b]) atomicAdd(&hist[b], h[b]);
+    for (int b = threadIdx.x; b < ORD_BINS; b += ORD_THREADS) hist[(size_t)b * gridDim.x + blockIdx.x] = h[b];
 }
-// exclusive scan of the 8,192 bin counts by one workgroup; leaves `hist` zeroed for the next MSM of this workspace
-__global__ void __launch_bounds__(1024) k_order_scan(uint32_t *__restrict__ hist, uint32_t *__restrict__ offs) {
-    __shared__ uint32_t part[1024];
-    constexpr int PER = ORD_BINS / 1024;
-    uint32_t v[PER], sum = 0;
-#pragma unroll
-    for (int i = 0; i < PER; i++) { v[i] = hist[threadIdx.x * PER + i]; hist[threadIdx.x * PER + i] = 0; sum += v[i]; }
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        uint32_t add = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0;
+// one workgroup, one bin per lane: exclusive scan of the (bin, workgroup) counts in bin-major order; then the overflow list's segment offsets
+__global__ void __launch_bounds__(ORD_BINS) k_order_scan(const uint32_t *__restrict__ hist, uint32_t *__restrict__ offs, uint32_t nblk, uint32_t *__restrict__ ctrl,
+                                                          const uint32_t *__restrict__ ovf_nseg, uint32_t *__restrict__ ovf_off, uint32_t ovf_cap) {
+    __shared__ uint32_t part[ORD_BINS];
+    const uint32_t t = threadIdx.x;
+    auto block_exclusive = [&](uint32_t v) {            // exclusive prefix of v over the workgroup; part[ORD_BINS - 1] holds the total afterwards
+        part[t] = v;
         __syncthreads();
-        part[threadIdx.x] += add;
+        for (int d = 1; d < ORD_BINS; d <<= 1) {
+            uint32_t add = t >= (unsigned)d ? part[t - d] : 0;
+            __syncthreads();
+            part[t] += add;
+            __syncthreads();
+        }
+        return part[t] - v;
+    };
+    const uint32_t *row = hist + (size_t)t * nblk;
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < nblk; i++) sum += row[i];
+    uint32_t run = block_exclusive(sum);
+    for (uint32_t i = 0; i < nblk; i++) { const uint32_t c = row[i]; offs[(size_t)t * nblk + i] = run; run += c; }
+    uint32_t n = ctrl[0];
+    if (n > ovf_cap) n = ovf_cap;
+    uint32_t base = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += ORD_BINS) {     // (empty for uniformly distributed digits)
         __syncthreads();
+        const uint32_t v = c0 + t < n ? ovf_nseg[c0 + t] : 0;
+        const uint32_t ex = block_exclusive(v);
+        if (c0 + t < n) ovf_off[c0 + t] = base + ex;
+        base += part[ORD_BINS - 1];
     }
-    uint32_t run = part[threadIdx.x] - sum;
-#pragma unroll
-    for (int i = 0; i < PER; i++) { offs[threadIdx.x * PER + i] = run; run += v[i]; }
+    __syncthreads();
+    if (t == 0) { ovf_off[n] = base; ctrl[1] = n; ctrl[2] = base; ctrl[0] = 0; }
 }
-__global__ void __launch_bounds__(ORD_THREADS) k_order_scatter(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, uint32_t nb, uint32_t *__restrict__ offs,
-                                                                uint32_t *__restrict__ order) {
+__global__ void __launch_bounds__(ORD_THREADS) k_order_scatter(const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, uint32_t nb, uint32_t per_block,
+                                                                const uint32_t *__restrict__ offs, uint32_t *__restrict__ order) {
     __shared__ uint32_t h[ORD_BINS];
     for (int b = threadIdx.x; b < ORD_BINS; b += ORD_THREADS) h[b] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * ORD_PER_BLOCK;
-    uint32_t key[ORD_PER_THREAD], rank[ORD_PER_THREAD];
-#pragma unroll
-    for (int r = 0; r < ORD_PER_THREAD; r++) {
-        uint32_t k = base + r * ORD_THREADS + threadIdx.x;
-        if (k < nb) { key[r] = order_key(end[k] - start[k]); rank[r] = atomicAdd(&h[key[r]], 1u); }
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < ORD_BINS; b += ORD_THREADS) if (h[b]) h[b] = atomicAdd(&offs[b], h[b]);     // this workgroup's run of slots inside bin b
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < ORD_PER_THREAD; r++) {
-        uint32_t k = base + r * ORD_THREADS + threadIdx.x;
-        if (k < nb) order[h[key[r]] + rank[r]] = k;
+    const uint32_t lo = blockIdx.x * per_block, hi = lo + per_block < nb ? lo + per_block : nb;
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += ORD_THREADS) {
+        const uint32_t key = order_key(end[k] - start[k]);
+        order[offs[(size_t)key * gridDim.x + blockIdx.x] + atomicAdd(&h[key], 1u)] = k;
     }
 }
 
@@ -252,15 +266,10 @@ __global__ void __launch_bounds__(ORD_THREADS) k_order_scatter(const uint32_t *_
 // The loop body has no function call: the (cryptographically negligible, but reachable with repeated bases) P == +-Q case is
 // appended to a deferred list and replayed by the last workgroup of k_accumulate_tail with the complete addition law.  Buckets stay in the
 // reduced-radix form through the reduction kernels; only the per-window sums are converted back for the host.
-#ifndef ZK_ACC_WAVES
-#define ZK_ACC_WAVES 2          // waves per SIMD the compiler must fit k_accumulate into (A/B knob: 3 spills with ff28, tools/gpu_runs/gpu_round2_occupancy.sh)
-#endif
-#ifndef ZK_ACC_PREFETCH
-#define ZK_ACC_PREFETCH 2       // software prefetch of the next gathered point: 1 = into a second register set at the top of the addition (28 registers on the XYZZ law,
-                                // 42 on the Edwards law), 2 (Edwards law only; XYZZ treats it as 1) = into the current point's registers once its three products are done
-#endif
+// At least two waves per SIMD: the kernel issues at its limit there (three or four waves with spills are slower: profiles/r03_accumulate_occupancy.txt; round 4's build
+// fits three without spills -- 162 registers -- and measures exactly like the same code capped at two, profiles/r04_accumulate_waves.txt).
 template <class Law>
-__global__ void __launch_bounds__(64, ZK_ACC_WAVES) k_accumulate(const typename Law::Base *__restrict__ bases, const uint32_t *__restrict__ vals,
+__global__ void __launch_bounds__(64, 2) k_accumulate(const typename Law::Base *__restrict__ bases, const uint32_t *__restrict__ vals,
                                                        const uint32_t *__restrict__ start, const uint32_t *__restrict__ end, const uint32_t *__restrict__ order,
                                                        uint32_t nbuckets_total, uint32_t cap, typename Law::Acc *__restrict__ buckets,
                                                        uint32_t *__restrict__ deferred, uint32_t deferred_cap, uint32_t *__restrict__ deferred_count) {
@@ -273,78 +282,32 @@ __global__ void __launch_bounds__(64, ZK_ACC_WAVES) k_accumulate(const typename 
     uint32_t k = order[t];
     uint32_t s = start[k], e = end[k];
     if (e - s > cap) e = s + cap;                                          // the remainder goes through the overflow segments of k_accumulate_tail
-#if ZK_MSM_EDWARDS
     if constexpr (Law::edwards) {
-        // unified law: the accumulator starts at the identity, P = +-Q and identity bases need no branch, nothing is deferred
+        // unified law: the accumulator starts at the identity, P = +-Q and identity bases need no branch, nothing is deferred.  The next point's gather is issued in the
+        // middle of the current addition, into the registers the current point no longer needs; a negative digit's record arrives with (y - x, y + x) swapped (te_madd_hot).
         AccTE<P> acc = te_identity<P>();
         if (s < e) {
-#if ZK_ACC_PREFETCH == 2
-            // the next point's gather is issued in the middle of the current addition, into the registers the current point no longer needs (te_madd_signed)
             uint32_t idx = vals[s];
-#if ZK_TE_PRESWAP
-            Niels28<P> p = niels_load_signed<P>(bases + (idx & VAL_INDEX), idx >> 31);  // a negative digit's record arrives with (y - x, y + x) swapped
-#else
-            Niels28<P> p = bases[idx & VAL_INDEX];
-#endif
+            Niels28<P> p = niels_load_signed<P>(bases + (idx & VAL_INDEX), idx >> 31);
             for (uint32_t i = s; i < e; i++) {
                 const uint32_t cur = idx;
-                const bool more = i + 1 < e;
-                if (more) idx = vals[i + 1];
-                const Niels28<P> *next = bases + (idx & VAL_INDEX);                    // the last iteration re-reads its own point: no branch around the load
-#if ZK_TE_PRESWAP
+                if (i + 1 < e) idx = vals[i + 1];
+                const Niels28<P> *next = bases + (idx & VAL_INDEX);        // the last iteration re-reads its own point: no branch around the load
                 if (cur & VAL_SKIP) { p = niels_load_signed<P>(next, idx >> 31); continue; }
-                te_madd_signed<P, ZK_TE_BIASED != 0, true>(acc, p, cur >> 31, next, bias, idx >> 31);
-                continue;
-#endif
-                if (cur & VAL_SKIP) { p = *next; continue; }
-                te_madd_signed<P, ZK_TE_BIASED != 0>(acc, p, cur >> 31, next, bias);
+                te_madd_hot<P>(acc, p, cur >> 31, next, idx >> 31, bias);
             }
-#else
-#if ZK_ACC_PREFETCH
-            uint32_t idx = vals[s];
-            Niels28<P> nxt = bases[idx & VAL_INDEX];
-#endif
-            for (uint32_t i = s; i < e; i++) {
-#if ZK_ACC_PREFETCH
-                Niels28<P> p = nxt;
-                uint32_t cur = idx;
-                if (i + 1 < e) { idx = vals[i + 1]; nxt = bases[idx & VAL_INDEX]; }   // prefetch the next gather under this add's ALU work
-#else
-                uint32_t cur = vals[i];
-                Niels28<P> p = bases[cur & VAL_INDEX];
-#endif
-                if (cur & VAL_SKIP) continue;
-#if ZK_TE_SIGN_SELECT
-                te_madd_signed<P>(acc, p, cur >> 31);                                  // negative digit: add -P
-#else
-                if (cur >> 31) p = niels_neg<P>(p);
-                te_madd<P>(acc, p);
-#endif
-            }
-#endif
         }
         buckets[k] = acc;
-        return;
-    } else
-#endif
-    {
-    Acc28<P> acc;
-    bool acc_inf = true;
-    {
+    } else {
+        Acc28<P> acc;
+        bool acc_inf = true;
         if (s < e) {
-#if ZK_ACC_PREFETCH
             uint32_t idx = vals[s];
             Affine28<P> nxt = bases[idx & VAL_INDEX];
-#endif
             for (uint32_t i = s; i < e; i++) {
-#if ZK_ACC_PREFETCH
                 Affine28<P> p = nxt;
                 uint32_t cur = idx;
                 if (i + 1 < e) { idx = vals[i + 1]; nxt = bases[idx & VAL_INDEX]; }   // prefetch the next gather under this add's ALU work
-#else
-                uint32_t cur = vals[i];
-                Affine28<P> p = bases[cur & VAL_INDEX];
-#endif
                 if ((cur & VAL_SKIP) || p.is_inf()) continue;
                 if (cur >> 31) p.y = G::zero().template sub<2>(p.y);                 // negative digit: add -P  (y < 1.2 p as a product, so 2p - y > 0)
                 if (acc_inf) { acc.x = p.x; acc.y = p.y; acc.zz = G::k_one(); acc.zzz = acc.zz; acc_inf = false; continue; }
@@ -354,9 +317,8 @@ __global__ void __launch_bounds__(64, ZK_ACC_WAVES) k_accumulate(const typename 
                 }
             }
         }
-    }
-    if (acc_inf) acc = inf28<P>();
-    buckets[k] = acc;
+        if (acc_inf) acc = inf28<P>();
+        buckets[k] = acc;
     }
 }
 // replay of the deferred (bucket, point) pairs with the complete formulas; one lane, sequential (the list is empty in practice)
@@ -374,35 +336,35 @@ __device__ void accumulate_fixup(const Affine28<P> *__restrict__ bases, Acc28<P>
     }
 }
 
-// overflow segment t of bucket k covers sorted positions [start[k] + (j+1) CAP, min(start[k] + (j+2) CAP, end[k])), j = t - extra_off[k]
-// ONE tail launch per MSM (it used to be three): the overflow segments, then -- in whichever workgroup finishes last (ticket counter
-// deferred_count[1]) -- the replay of the deferred degenerate additions of this kernel and of k_accumulate.  The overflow partials are folded
-// into their buckets by k_reduce_l1 when it loads them.  For uniformly distributed digits there are no segments and no deferred pairs: every
-// lane exits after two loads.
+// overflow segment t of list entry q (bucket k = ovf_bucket[q]) covers sorted positions [start[k] + (j+1) CAP, min(start[k] + (j+2) CAP, end[k])), j = t - ovf_off[q]
+// ONE tail launch per MSM: the overflow segments, then -- Weierstrass law only, in whichever workgroup finishes last (ticket counter deferred_count[1]) -- the replay of
+// the deferred degenerate additions of this kernel and of k_accumulate.  The overflow partials are folded into their buckets by the reduction when it loads them.
+// For uniformly distributed digits there are no segments and no deferred pairs: every lane exits after one load.
 template <class Law>
 __global__ void __launch_bounds__(64, 2) k_accumulate_tail(const typename Law::Base *__restrict__ bases, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ start,
-                                                            const uint32_t *__restrict__ end, const uint32_t *__restrict__ extra_off, uint32_t nb, uint32_t max_segments, uint32_t cap,
+                                                            const uint32_t *__restrict__ end, const uint32_t *__restrict__ ctrl, const uint32_t *__restrict__ ovf_bucket,
+                                                            const uint32_t *__restrict__ ovf_off, uint32_t max_segments, uint32_t cap,
                                                             typename Law::Acc *__restrict__ partial, typename Law::Acc *__restrict__ buckets, uint32_t *__restrict__ deferred, uint32_t deferred_cap,
                                                             uint32_t *__restrict__ deferred_count) {
     using P = typename Law::Params;
     using A = typename Law::Acc;
     using G = FpMsm<P>;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t total = extra_off[nb];                   // exclusive scan has nb + 1 entries
+    const uint32_t nlist = ctrl[1];
+    uint32_t total = ctrl[2];
     if (total > max_segments) total = max_segments;
     // workgroups whose 64 segment slots are all beyond `total` (every workgroup, for uniform digits) skip the segment work and its LDS fold
     if (blockIdx.x * blockDim.x < total) {
         __shared__ A sh[64];
         __shared__ uint32_t key[64];
-        uint32_t k = 0xffffffffu;
+        uint32_t q = NO_SLOT;
         A acc;
         if (t < total) {
-            uint32_t lo = 0, hi = nb;                         // largest k with extra_off[k] <= t
-            while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (extra_off[mid] <= t) lo = mid; else hi = mid; }
-            k = lo;
-            uint32_t j = t - extra_off[k];
+            uint32_t lo = 0, hi = nlist;                      // largest q with ovf_off[q] <= t
+            while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (ovf_off[mid] <= t) lo = mid; else hi = mid; }
+            q = lo;
+            const uint32_t k = ovf_bucket[q], j = t - ovf_off[q];
             uint32_t s = start[k] + (j + 1) * cap, e = s + cap < end[k] ? s + cap : end[k];
-#if ZK_MSM_EDWARDS
             if constexpr (Law::edwards) {
                 acc = te_identity<P>();
                 for (uint32_t i = s; i < e; i++) {
@@ -412,9 +374,7 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_tail(const typename Law::B
                     if (cur >> 31) p = niels_neg<P>(p);
                     te_madd<P>(acc, p);
                 }
-            } else
-#endif
-            {
+            } else {
                 bool acc_inf = true;
                 for (uint32_t i = s; i < e; i++) {
                     uint32_t cur = vals[i];
@@ -431,12 +391,12 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_tail(const typename Law::B
             }
             sh[threadIdx.x] = acc;
         }
-        key[threadIdx.x] = k;
+        key[threadIdx.x] = q;
         __syncthreads();
         // the segments of one bucket are consecutive t: the first lane of every (workgroup, bucket) run folds its run (<= 63 additions) and stores ONE
-        // partial at its own slot; k_reduce_l1's load_bucket then visits one slot per workgroup the bucket's segments span, not one per segment
-        if (t < total && (threadIdx.x == 0 || key[threadIdx.x - 1] != k)) {
-            for (uint32_t q = threadIdx.x + 1; q < 64 && key[q] == k; q++) PtOps<A>::add(acc, sh[q]);
+        // partial at its own slot; load_bucket then visits one slot per workgroup the bucket's segments span, not one per segment
+        if (t < total && (threadIdx.x == 0 || key[threadIdx.x - 1] != q)) {
+            for (uint32_t r = threadIdx.x + 1; r < 64 && key[r] == q; r++) PtOps<A>::add(acc, sh[r]);
             partial[t] = acc;
         }
     }
@@ -451,12 +411,14 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_tail(const typename Law::B
         accumulate_fixup<P>(bases, buckets, deferred, deferred_cap, deferred_count);
     }
 }
-// bucket k with its overflow partials folded in (k_reduce_l1's load)
+// bucket k with its overflow partials folded in (the reduction's load)
 template <class A>
-__device__ __forceinline__ A load_bucket(const A *__restrict__ buckets, size_t k, const uint32_t *__restrict__ extra_off, uint32_t max_segments, const A *__restrict__ partial) {
+__device__ __forceinline__ A load_bucket(const A *__restrict__ buckets, size_t k, const uint32_t *__restrict__ ovf_slot, const uint32_t *__restrict__ ovf_off, uint32_t max_segments,
+                                         const A *__restrict__ partial) {
     A acc = buckets[k];
-    uint32_t a = extra_off[k], b = extra_off[k + 1];
-    if (a != b) {
+    const uint32_t q = ovf_slot[k];
+    if (q != NO_SLOT) {
+        uint32_t a = ovf_off[q], b = ovf_off[q + 1];
         if (b > max_segments) b = max_segments;
         // one folded partial per 64-segment workgroup of k_accumulate_tail that the bucket's segments [a, b) span, stored at the run's first slot
         for (uint32_t w = a / 64; w * 64 < b; w++) { uint32_t i = w * 64 > a ? w * 64 : a; if (i < b) PtOps<A>::add(acc, partial[i]); }
@@ -472,7 +434,7 @@ __device__ __forceinline__ A load_bucket(const A *__restrict__ buckets, size_t k
 constexpr int RED_L1 = 8, RED_L2 = 8;
 template <class A>
 __global__ void __launch_bounds__(64) k_reduce_l1(const A *__restrict__ buckets, int c, int nwin, A *__restrict__ seg_s, A *__restrict__ seg_w,
-                                                   const uint32_t *__restrict__ extra_off, uint32_t max_segments, const A *__restrict__ ovf_partial) {
+                                                   const uint32_t *__restrict__ ovf_slot, const uint32_t *__restrict__ ovf_off, uint32_t max_segments, const A *__restrict__ ovf_partial) {
     uint32_t segs = (1u << c) / RED_L1;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= segs * (uint32_t)nwin) return;
@@ -480,7 +442,7 @@ __global__ void __launch_bounds__(64) k_reduce_l1(const A *__restrict__ buckets,
     const size_t k0 = ((size_t)w << c) + (size_t)g * RED_L1;
     A run = PtOps<A>::identity(), tot = PtOps<A>::identity();
     for (int d = RED_L1 - 1; d >= 0; d--) {
-        A b = load_bucket<A>(buckets, k0 + d, extra_off, max_segments, ovf_partial);
+        A b = load_bucket<A>(buckets, k0 + d, ovf_slot, ovf_off, max_segments, ovf_partial);
         PtOps<A>::add(run, b);
         PtOps<A>::add(tot, run);
     }
@@ -531,7 +493,8 @@ __global__ void __launch_bounds__(64) k_reduce_l2(const A *__restrict__ seg_s, c
 }
 
 template <class A>
-__global__ void __launch_bounds__(256) k_reduce_window(const A *__restrict__ partial, uint32_t per_window, XYZZ<Fp<typename PtOps<A>::Params>> *__restrict__ out) {
+__global__ void __launch_bounds__(256) k_reduce_window(const A *__restrict__ partial, uint32_t per_window, XYZZ<Fp<typename PtOps<A>::Params>> *__restrict__ out,
+                                                        XYZZ<Fp<typename PtOps<A>::Params>> *__restrict__ out2) {
     __shared__ A sh[256];
     uint32_t w = blockIdx.x, t = threadIdx.x;
     A acc = PtOps<A>::identity();
@@ -544,41 +507,55 @@ __global__ void __launch_bounds__(256) k_reduce_window(const A *__restrict__ par
         if ((int)t < s) { A a = sh[t]; PtOps<A>::add(a, sh[t + s]); sh[t] = a; }
         __syncthreads();
     }
-    if (t == 0) out[w] = PtOps<A>::to_std(sh[0]);     // always the Weierstrass XYZZ form in the library-wide Montgomery representation
+    if (t == 0) {                                     // always the Weierstrass XYZZ form in the library-wide Montgomery representation
+        const auto r = PtOps<A>::to_std(sh[0]);
+        out[w] = r;                                   // (host-mapped pinned memory in the prover: no copy launch)
+        if (out2) out2[w] = r;
+    }
 }
 
 template <class A> __global__ void k_sum_tree(const A *__restrict__ in, uint32_t total, uint32_t per, A *__restrict__ out);
 
 constexpr uint32_t DEFERRED_CAP = 1u << 20;
-constexpr size_t ACC_BYTES = sizeof(Acc28<Fq377P>);          // one XYZZ bucket in the reduced-radix form (224 B with the default ff28, 208 B with ff30; same for both curves)
+constexpr size_t ACC_BYTES = sizeof(Acc28<Fq377P>);          // one bucket in the reduced-radix form: 224 B, XYZZ and extended Edwards alike, same for both curves
 static_assert(sizeof(Acc28<Fq381P>) == ACC_BYTES, "bucket size differs between the curves");
-#if ZK_MSM_EDWARDS
 static_assert(sizeof(AccTE<Fq377P>) == ACC_BYTES, "the Edwards accumulator must fit the XYZZ bucket slots");
-#endif
+constexpr int MAX_WSUMS = 64;                                // window sums per MSM (per-window mode: <= 37 windows)
 struct MsmWorkspace {
     size_t cap_pairs = 0, cap_buckets = 0, cap_tmp = 0;
     uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr, *start = nullptr, *end = nullptr;
     uint32_t *sorted_keys = nullptr, *sorted_vals = nullptr;      // whichever half of the double buffers the radix sort finished in
-    uint32_t *size_key = nullptr, *size_key2 = nullptr, *ids = nullptr, *order = nullptr, *extra = nullptr, *extra_off = nullptr;
-    void *ovf_partial = nullptr; size_t cap_ovf = 0;
-    uint32_t *part_hist = nullptr, *part_offs = nullptr; size_t cap_part = 0;      // two-level partition: (coarse bin, workgroup) histogram and its scan
-    uint32_t *ord_hist = nullptr;                                                  // 2 x ORD_BINS: bin counts (kept zero between MSMs) and their scan
+    uint32_t *order = nullptr, *ovf_slot = nullptr;               // per bucket: visiting order, slot in the overflow list (NO_SLOT for all but oversized buckets)
+    uint32_t *ovf_bucket = nullptr, *ovf_nseg = nullptr, *ovf_off = nullptr; void *ovf_partial = nullptr; size_t cap_ovf = 0;    // overflow list + the segments' partial sums
+    uint32_t *split_hist = nullptr, *split_offs = nullptr; size_t cap_split = 0;   // pre-split digits: (class, window, block) counts and their scan
+    uint32_t *ord_hist = nullptr, *ord_offs = nullptr;            // ORD_BINS x ORD_MAX_BLOCKS counts and their scan
+    uint32_t *ctrl = nullptr;                                     // 8 control words (see k_order_hist); armed at zero between MSMs
+    bool ctrl_dirty = false;                                      // an exception left the order pass half done: re-arm ctrl before the next one
     size_t plan_n = 0, plan_pairs = 0; int plan_c = 0, plan_nwin = 0;     // state between msm_prepare and msm_finish
     bool plan_table = false; uint32_t plan_cap = BUCKET_CAP;
     uint32_t *deferred = nullptr, *deferred_count = nullptr;
-    void *buckets = nullptr, *seg_s = nullptr, *seg_w = nullptr, *partial = nullptr, *wsum = nullptr, *tmp = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, fence_a = nullptr, fence_b = nullptr;
-    hipStream_t low = nullptr;                                     // low-priority side stream for k_accumulate (ZKAES_STREAM_PRIORITY=1; default off)
+    void *buckets = nullptr, *seg_s = nullptr, *seg_w = nullptr, *partial = nullptr, *tmp = nullptr;
+    void *h_res = nullptr, *d_res = nullptr;                      // pinned host memory the last reduction kernel writes the window sums (+ flags) into, and its device address
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
+constexpr size_t RES_BYTES = 192 * MAX_WSUMS + 64;
 static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t cap) {
     if (cap == 0) cap = BUCKET_CAP;
     if (!S.ev0) {
         HIP_CHECK(hipEventCreate(&S.ev0)); HIP_CHECK(hipEventCreate(&S.ev1));
         S.deferred = (uint32_t *)dmalloc(2 * DEFERRED_CAP * 4); S.deferred_count = (uint32_t *)dmalloc(8);
-        S.ord_hist = (uint32_t *)dmalloc(2 * ORD_BINS * 4);
-        HIP_CHECK(hipMemset(S.ord_hist, 0, 2 * ORD_BINS * 4));
+        S.ord_hist = (uint32_t *)dmalloc((size_t)ORD_BINS * ORD_MAX_BLOCKS * 4); S.ord_offs = (uint32_t *)dmalloc((size_t)ORD_BINS * ORD_MAX_BLOCKS * 4);
+        S.ctrl = (uint32_t *)dmalloc(32);
+        HIP_CHECK(hipMemset(S.ctrl, 0, 32));
+        HIP_CHECK(hipHostMalloc(&S.h_res, RES_BYTES, hipHostMallocMapped));
+        HIP_CHECK(hipHostGetDevicePointer(&S.d_res, S.h_res, 0));
     }
-    if (pairs / cap + 64 > S.cap_ovf) { dfree(S.ovf_partial); S.cap_ovf = pairs / cap + 64; S.ovf_partial = dmalloc(S.cap_ovf * ACC_BYTES); }
+    if (pairs / cap + 64 > S.cap_ovf) {
+        dfree(S.ovf_partial); dfree(S.ovf_bucket); dfree(S.ovf_nseg); dfree(S.ovf_off);
+        S.cap_ovf = pairs / cap + 64;
+        S.ovf_partial = dmalloc(S.cap_ovf * ACC_BYTES);
+        S.ovf_bucket = (uint32_t *)dmalloc(S.cap_ovf * 4); S.ovf_nseg = (uint32_t *)dmalloc(S.cap_ovf * 4); S.ovf_off = (uint32_t *)dmalloc((S.cap_ovf + 1) * 4);
+    }
     if (pairs > S.cap_pairs) {
         dfree(S.keys_a); dfree(S.keys_b); dfree(S.vals_a); dfree(S.vals_b);
         S.cap_pairs = pairs;
@@ -586,91 +563,51 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
         S.vals_a = (uint32_t *)dmalloc(pairs * 4); S.vals_b = (uint32_t *)dmalloc(pairs * 4);
     }
     if (buckets > S.cap_buckets) {
-        dfree(S.start); dfree(S.end); dfree(S.buckets); dfree(S.partial); dfree(S.wsum); dfree(S.seg_s); dfree(S.seg_w);
-        dfree(S.size_key); dfree(S.size_key2); dfree(S.ids); dfree(S.order); dfree(S.extra); dfree(S.extra_off);
-        S.extra = (uint32_t *)dmalloc((buckets + 1) * 4); S.extra_off = (uint32_t *)dmalloc((buckets + 1) * 4);
+        dfree(S.start); dfree(S.end); dfree(S.buckets); dfree(S.partial); dfree(S.seg_s); dfree(S.seg_w); dfree(S.order); dfree(S.ovf_slot);
         S.cap_buckets = buckets;
         S.start = (uint32_t *)dmalloc(buckets * 4); S.end = (uint32_t *)dmalloc(buckets * 4);
-        S.size_key = (uint32_t *)dmalloc(buckets * 4); S.size_key2 = (uint32_t *)dmalloc(buckets * 4); S.ids = (uint32_t *)dmalloc(buckets * 4); S.order = (uint32_t *)dmalloc(buckets * 4);
+        S.order = (uint32_t *)dmalloc(buckets * 4); S.ovf_slot = (uint32_t *)dmalloc(buckets * 4);
         S.buckets = dmalloc(buckets * ACC_BYTES);
         S.seg_s = dmalloc((buckets / RED_L1 + 64) * ACC_BYTES); S.seg_w = dmalloc((buckets / RED_L1 + 64) * ACC_BYTES);
-        S.partial = dmalloc((2 * (buckets / (RED_L1 * RED_L2)) + 2 * 64 * 64) * ACC_BYTES); S.wsum = dmalloc(192 * 64);
-        // (window sums: at most 64 sets)
+        S.partial = dmalloc((2 * (buckets / (RED_L1 * RED_L2)) + 2 * 64 * 64) * ACC_BYTES);
     }
 }
-bool stream_priorities_enabled() {
-    // measured (profiles/r02_bench_stream_priority.md): 59.7 blocks/s with the side stream, 61.1 without -- the hardware queues already interleave the
-    // contexts' kernels and the two extra event waits per MSM cost more than the priority buys.  Off unless ZKAES_STREAM_PRIORITY=1.
-    static const bool on = [] { const char *e = getenv("ZKAES_STREAM_PRIORITY"); return e && atoi(e) != 0; }();
-    return on;
-}
-MsmWorkspace *msm_workspace_create() {
-    MsmWorkspace *w = new MsmWorkspace();
-    if (stream_priorities_enabled()) {
-        int lo = 0, hi = 0;
-        HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));          // numerically: lo = least urgent, hi = most urgent
-        if (lo != hi) {
-            HIP_CHECK(hipStreamCreateWithPriority(&w->low, hipStreamNonBlocking, lo));
-            HIP_CHECK(hipEventCreateWithFlags(&w->fence_a, hipEventDisableTiming));
-            HIP_CHECK(hipEventCreateWithFlags(&w->fence_b, hipEventDisableTiming));
-        }
-    }
-    return w;
-}
+MsmWorkspace *msm_workspace_create() { return new MsmWorkspace(); }
 void msm_workspace_destroy(MsmWorkspace *w) {
     if (!w) return;
-    for (void *p : {(void *)w->keys_a, (void *)w->keys_b, (void *)w->vals_a, (void *)w->vals_b, (void *)w->start, (void *)w->end, (void *)w->size_key, (void *)w->size_key2, (void *)w->ids,
-                    (void *)w->order, (void *)w->extra, (void *)w->extra_off, w->ovf_partial, (void *)w->part_hist, (void *)w->part_offs, (void *)w->ord_hist, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->wsum, w->tmp}) dfree(p);
+    for (void *p : {(void *)w->keys_a, (void *)w->keys_b, (void *)w->vals_a, (void *)w->vals_b, (void *)w->start, (void *)w->end, (void *)w->order, (void *)w->ovf_slot,
+                    (void *)w->ovf_bucket, (void *)w->ovf_nseg, (void *)w->ovf_off, w->ovf_partial, (void *)w->split_hist, (void *)w->split_offs, (void *)w->ord_hist, (void *)w->ord_offs,
+                    (void *)w->ctrl, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->tmp}) dfree(p);
+    if (w->h_res) (void)hipHostFree(w->h_res);
     if (w->ev0) { (void)hipEventDestroy(w->ev0); (void)hipEventDestroy(w->ev1); }
-    if (w->low) { (void)hipStreamDestroy(w->low); (void)hipEventDestroy(w->fence_a); (void)hipEventDestroy(w->fence_b); }
     delete w;
 }
 
-// size-balanced visiting order of the buckets (descending size: the 64 lanes of a wave run the same trip count) + overflow segments of oversized buckets
-// Measured (profiles/r03_order_counting.txt): 0.10-0.14 ms less per MSM for a lone call (16-byte encrypt() 31.2 -> 30.4 ms), but 0.7 % FEWER blocks/s with 16 contexts in
-// flight -- the generic sort's tiny launches hide behind the other contexts' kernels and its stable output keeps equal-size buckets in index order.  So: counting for
-// lone calls, the sort while a multi-proof call is in flight; ZKAES_MSM_ORDER=count|sort forces one.
-static bool order_by_counting() {
-    static const int forced = [] { const char *e = getenv("ZKAES_MSM_ORDER"); return !e ? 0 : !strcmp(e, "sort") ? 1 : !strcmp(e, "count") ? 2 : 0; }();
-    return forced == 2 || (forced == 0 && !throughput_mode());
-}
+// size-balanced visiting order of the buckets + the overflow list: three small launches, no memset, no generic sort (k_order_* above).  The same path serves lone calls
+// and multi-proof calls: positions are deterministic (buckets of one size keep the order of their index ranges), which the generic stable sort used to provide at ~16 launches.
 static void order_buckets(MsmWorkspace &S, size_t nb, uint32_t cap, hipStream_t s) {
-    const bool counting = order_by_counting();
-    const unsigned oblocks = (unsigned)((nb + ORD_PER_BLOCK - 1) / ORD_PER_BLOCK);
-    if (counting) {
-        hipLaunchKernelGGL(k_order_hist, dim3(oblocks), dim3(ORD_THREADS), 0, s, S.start, S.end, (uint32_t)nb, cap, S.extra, S.ord_hist);
-        HIP_LAUNCH_CHECK();
-    } else {
-        HIP_CHECK(hipMemsetAsync(S.extra + nb, 0, 4, s));
-        hipLaunchKernelGGL(k_bucket_sizes, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, S.start, S.end, (uint32_t)nb, cap, S.size_key, S.ids, S.extra);
-        HIP_LAUNCH_CHECK();
-    }
-    {
-        size_t tb = 0;
-        HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, S.extra, S.extra_off, 0u, nb + 1, rocprim::plus<uint32_t>(), s));
-        if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
-        HIP_CHECK(rocprim::exclusive_scan(S.tmp, tb, S.extra, S.extra_off, 0u, nb + 1, rocprim::plus<uint32_t>(), s));
-    }
-    if (counting) {
-        hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(1024), 0, s, S.ord_hist, S.ord_hist + ORD_BINS);
-        HIP_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_order_scatter, dim3(oblocks), dim3(ORD_THREADS), 0, s, S.start, S.end, (uint32_t)nb, S.ord_hist + ORD_BINS, S.order);
-        HIP_LAUNCH_CHECK();
-    } else {
-        size_t tb = 0;
-        HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, S.size_key, S.size_key2, S.ids, S.order, nb, 0u, 13u, s));
-        if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
-        HIP_CHECK(rocprim::radix_sort_pairs(S.tmp, tb, S.size_key, S.size_key2, S.ids, S.order, nb, 0u, 13u, s));
-    }
+    if (S.ctrl_dirty) HIP_CHECK(hipMemsetAsync(S.ctrl, 0, 8, s));
+    S.ctrl_dirty = true;
+    unsigned nblk = (unsigned)((nb + 4095) / 4096);
+    if (nblk > (unsigned)ORD_MAX_BLOCKS) nblk = ORD_MAX_BLOCKS;
+    if (nblk < 1) nblk = 1;
+    const uint32_t per_block = (uint32_t)((nb + nblk - 1) / nblk);
+    hipLaunchKernelGGL(k_order_hist, dim3(nblk), dim3(ORD_THREADS), 0, s, S.start, S.end, (uint32_t)nb, per_block, cap, S.ovf_slot, S.ovf_bucket, S.ovf_nseg, (uint32_t)S.cap_ovf - 1, S.ctrl, S.ord_hist);
+    HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(ORD_BINS), 0, s, S.ord_hist, S.ord_offs, nblk, S.ctrl, S.ovf_nseg, S.ovf_off, (uint32_t)S.cap_ovf - 1);
+    HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_order_scatter, dim3(nblk), dim3(ORD_THREADS), 0, s, S.start, S.end, (uint32_t)nb, per_block, S.ord_offs, S.order);
+    HIP_LAUNCH_CHECK();
+    S.ctrl_dirty = false;
 }
 
-// shared middle: sort the (key, value) pairs, find bucket ranges, order buckets by descending size, cut oversized buckets
+// shared middle: sort the (key, value) pairs, find bucket ranges, order buckets by descending size, list oversized buckets
 template <class P>
 static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int sort_bits, uint32_t cap, hipStream_t s, int begin_bit = 0) {
-    // c here = log2(buckets per set); keys run over [0, nb) plus the out-of-range key nb for zero digits
+    // c here = log2(buckets per set); every key is a valid bucket index in [0, nsets << c)
     size_t nb = (size_t)nsets << c;
     int key_bits = 1;
-    while (((size_t)1 << key_bits) <= nb) key_bits++;
+    while (((size_t)1 << key_bits) < nb) key_bits++;
     if (sort_bits > 0 && sort_bits < key_bits) key_bits = sort_bits;       // stable sort on the bucket bits only (window-major input)
     size_t tmp_bytes = 0;
     // ping-pong sort: the result stays in whichever buffer the last radix pass wrote (no copy back)
@@ -678,11 +615,11 @@ static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int
     HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, pairs, (unsigned)begin_bit, (unsigned)key_bits, s));
     if (tmp_bytes > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tmp_bytes); S.cap_tmp = tmp_bytes; }
     HIP_CHECK(rocprim::radix_sort_pairs(S.tmp, tmp_bytes, dk, dv, pairs, (unsigned)begin_bit, (unsigned)key_bits, s));
+#ifdef ZKAES_MEASURE
     if (knockin() & 1) HIP_CHECK(rocprim::radix_sort_pairs(S.tmp, tmp_bytes, dk, dv, pairs, (unsigned)begin_bit, (unsigned)key_bits, s));
+#endif
     S.sorted_keys = dk.current(); S.sorted_vals = dv.current();
-    HIP_CHECK(hipMemsetAsync(S.start, 0, nb * 4, s));
-    HIP_CHECK(hipMemsetAsync(S.end, 0, nb * 4, s));
-    hipLaunchKernelGGL(k_bounds, dim3((unsigned)(((pairs + 3) / 4 + 255) / 256)), dim3(256), 0, s, S.sorted_keys, pairs, (uint32_t)nb, S.start, S.end);
+    hipLaunchKernelGGL(k_bounds, dim3((unsigned)(((pairs + 3) / 4 + 255) / 256)), dim3(256), 0, s, S.sorted_keys, pairs, c, (uint32_t)nsets, S.start, S.end);
     HIP_LAUNCH_CHECK();
     order_buckets(S, nb, cap, s);
 }
@@ -694,37 +631,34 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
     using P = typename Law::Params;
     using A = typename Law::Acc;
     using Fq = Fp<P>;
+    if (nsets > MAX_WSUMS) throw GpuError("msm: too many windows");
     size_t nb = (size_t)nsets << c;
-    HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 8, s));        // [0] deferred pairs, [1] the tail kernel's workgroup ticket
-    // k_accumulate goes to the context's LOW-priority side stream (when there is one): its grid fills the chip for milliseconds, and the short
-    // latency-bound kernels of the other prover contexts (sort passes, reductions, NTT passes, scans -- on their HIGH-priority main streams) must not
-    // queue behind its waves
-    hipStream_t sa = S.low ? S.low : s;
-    if (S.low) { HIP_CHECK(hipEventRecord(S.fence_a, s)); HIP_CHECK(hipStreamWaitEvent(S.low, S.fence_a, 0)); }
-    if (knockin() & 8) {        // (measurement only) one extra, untimed launch
-        hipLaunchKernelGGL((k_accumulate<Law>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, sa, bases, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb, cap,
+    if constexpr (!Law::edwards) HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 8, s));        // [0] deferred pairs, [1] the tail kernel's workgroup ticket (the Edwards law defers nothing)
+#ifdef ZKAES_MEASURE
+    if (knockin() & 8) {        // (measurement builds only) one extra, untimed launch
+        hipLaunchKernelGGL((k_accumulate<Law>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, bases, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb, cap,
                            (A *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
-        HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 8, sa));
+        if constexpr (!Law::edwards) HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 8, s));
     }
-    HIP_CHECK(hipEventRecord(S.ev0, sa));
-    hipLaunchKernelGGL((k_accumulate<Law>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, sa, bases, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb, cap,
+#endif
+    HIP_CHECK(hipEventRecord(S.ev0, s));
+    hipLaunchKernelGGL((k_accumulate<Law>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, bases, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb, cap,
                        (A *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
-    HIP_CHECK(hipEventRecord(S.ev1, sa));
-    if (S.low) { HIP_CHECK(hipEventRecord(S.fence_b, S.low)); HIP_CHECK(hipStreamWaitEvent(s, S.fence_b, 0)); }
+    HIP_CHECK(hipEventRecord(S.ev1, s));
     uint32_t max_seg = (uint32_t)(pairs / cap + 1);
     // oversized buckets + deferred degenerate additions (none for uniformly distributed digits: every lane exits at once)
-    hipLaunchKernelGGL((k_accumulate_tail<Law>), dim3((max_seg + 63) / 64), dim3(64), 0, s, bases, S.sorted_vals, S.start, S.end, S.extra_off, (uint32_t)nb, max_seg, cap,
+    hipLaunchKernelGGL((k_accumulate_tail<Law>), dim3((max_seg + 63) / 64), dim3(64), 0, s, bases, S.sorted_vals, S.start, S.end, S.ctrl, S.ovf_bucket, S.ovf_off, max_seg, cap,
                        (A *)S.ovf_partial, (A *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
     HIP_LAUNCH_CHECK();
-    if (knockin() & 4) {        // (measurement only) the tail kernel once more: its ticket never reaches gridDim - 1 again, so the deferred replay runs once
-        hipLaunchKernelGGL((k_accumulate_tail<Law>), dim3((max_seg + 63) / 64), dim3(64), 0, s, bases, S.sorted_vals, S.start, S.end, S.extra_off, (uint32_t)nb, max_seg, cap,
-                           (A *)S.ovf_partial, (A *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
-    }
+    XYZZ<Fq> *res = (XYZZ<Fq> *)S.d_res;
     uint32_t segs = (1u << c) / RED_L1, groups = (segs + RED_L2 - 1) / RED_L2;
-    for (int rep = (knockin() & 2) ? 0 : 1; rep < 2; rep++) {
+#ifdef ZKAES_MEASURE
+    for (int rep = (knockin() & 2) ? 0 : 1; rep < 2; rep++)
+#endif
+    {
     hipLaunchKernelGGL((k_reduce_l1<A>), dim3((unsigned)((segs * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.buckets, c, nsets, (A *)S.seg_s, (A *)S.seg_w,
-                       S.extra_off, max_seg, (const A *)S.ovf_partial);
+                       S.ovf_slot, S.ovf_off, max_seg, (const A *)S.ovf_partial);
     HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_reduce_l2<A>), dim3(2u * (unsigned)((groups * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.seg_s, (const A *)S.seg_w, c, nsets, (A *)S.partial);
     HIP_LAUNCH_CHECK();
@@ -734,20 +668,21 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
         uint32_t mid = (parts + 255) / 256;
         hipLaunchKernelGGL((k_sum_tree<A>), dim3(mid), dim3(256), 0, s, (const A *)S.partial, parts, 256u, (A *)S.seg_s);
         HIP_LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_reduce_window<A>), dim3(1), dim3(256), 0, s, (const A *)S.seg_s, mid, (XYZZ<Fq> *)S.wsum);
+        hipLaunchKernelGGL((k_reduce_window<A>), dim3(1), dim3(256), 0, s, (const A *)S.seg_s, mid, res, dev_wsum_out);
     } else {
-        hipLaunchKernelGGL((k_reduce_window<A>), dim3((unsigned)nsets), dim3(256), 0, s, (const A *)S.partial, parts, (XYZZ<Fq> *)S.wsum);
+        hipLaunchKernelGGL((k_reduce_window<A>), dim3((unsigned)nsets), dim3(256), 0, s, (const A *)S.partial, parts, res, dev_wsum_out);
     }
     HIP_LAUNCH_CHECK();
     }
     std::vector<XYZZ<Fq>> ws(nsets);
     uint32_t n_deferred = 0;
-    if (dev_wsum_out) HIP_CHECK(hipMemcpyAsync(dev_wsum_out, S.wsum, sizeof(XYZZ<Fq>) * nsets, hipMemcpyDeviceToDevice, s));   // stays in HBM for a collective
-    sync((stream_t)s);        // drain first (sleeps in throughput mode): the pageable device-to-host copies below wait actively inside HIP
-    HIP_CHECK(hipMemcpyAsync(ws.data(), S.wsum, sizeof(XYZZ<Fq>) * nsets, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipMemcpyAsync(&n_deferred, S.deferred_count, 4, hipMemcpyDeviceToHost, s));
-    sync((stream_t)s);
-    if (n_deferred > DEFERRED_CAP) throw GpuError("msm: more than 2^20 degenerate additions (repeated base points); refusing to return a wrong sum");
+    sync((stream_t)s);        // (sleeps in throughput mode) the window sums are in pinned host memory once the stream has drained: no copy launch
+    memcpy(ws.data(), S.h_res, sizeof(XYZZ<Fq>) * nsets);
+    if constexpr (!Law::edwards) {
+        HIP_CHECK(hipMemcpyAsync(&n_deferred, S.deferred_count, 4, hipMemcpyDeviceToHost, s));
+        sync((stream_t)s);
+        if (n_deferred > DEFERRED_CAP) throw GpuError("msm: more than 2^20 degenerate additions (repeated base points); refusing to return a wrong sum");
+    }
     HIP_CHECK(hipEventElapsedTime(acc_ms, S.ev0, S.ev1));
     (void)n_points;
     return ws;
@@ -761,7 +696,6 @@ static void add_stats(float acc_ms, size_t n, size_t pairs, std::chrono::steady_
     g_stats.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 }
 
-#if ZK_MSM_EDWARDS
 // Weierstrass affine (library-wide form) -> precomputed Edwards form (y - x, y + x, 2 d x y), 8 points per lane sharing ONE field inversion
 // (Montgomery's trick) for the two divisions of the map.  A point of order 2 or 4 (den = 0; never in the prime-order subgroup) raises *bad.
 __global__ void __launch_bounds__(64) k_convert_bases_te(const Affine<Fq377> *__restrict__ src, Niels28<Fq377P> *__restrict__ dst, size_t n, uint32_t *__restrict__ bad) {
@@ -810,7 +744,6 @@ void convert_bases_te(Niels28<typename Curve::FqP> *dst, const Affine<typename C
     if (h_bad) throw GpuError("convert_bases_te: a base point has order 2 or 4 -- the Edwards path needs points of the prime-order subgroup");
 }
 template void convert_bases_te<Bls377>(Niels28<Fq377P> *, const Affine<Fq377> *, size_t, stream_t);
-#endif
 
 template <class Curve>
 void convert_bases(Affine28<typename Curve::FqP> *dst, const Affine<typename Curve::Fq> *src, size_t n, stream_t s_) {
@@ -889,7 +822,6 @@ XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws_, const Affine28<typename Curve::F
     msm_prepare<Curve>(ws_, scalars, n, nullptr, 0, 0, s_);
     return msm_finish<Curve>(ws_, bases, s_);
 }
-#if ZK_MSM_EDWARDS
 template <class Curve>
 XYZZ<typename Curve::Fq> msm_finish(MsmWorkspace *ws_, const Niels28<typename Curve::FqP> *bases, stream_t s_) { return msm_finish_impl<Curve, EdwardsLaw<typename Curve::FqP>>(ws_, bases, s_); }
 template <class Curve>
@@ -898,7 +830,6 @@ XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws_, const Niels28<typename Curve::Fq
     msm_prepare<Curve>(ws_, scalars, n, nullptr, 0, 0, s_);
     return msm_finish<Curve>(ws_, bases, s_);
 }
-#endif
 
 // ---- ONE MSM sharded by point range over ranks (SURVEY.md 8e second row): every rank runs the buckets of its slice with the window plan of the WHOLE
 // MSM and leaves its window sums in device memory; after the all-gather (RCCL, HBM to HBM) k_fold_ranks adds the ranks' sums per window.
@@ -1091,185 +1022,6 @@ __global__ void __launch_bounds__(SPLIT_THREADS) k_split_scatter(const Fr *__res
         }
     }
 }
-static bool presplit_enabled() { const char *e = getenv("ZKAES_MSM_PRESPLIT"); return !e || atoi(e) != 0; }
-
-// ---- Two-level bucket partition: the table path's replacement for "digits -> radix sort -> bounds" (the generic three-pass 8-bit radix sort of 8-byte
-// (key, value) pairs cost 7.8 ms of a 79.5 ms chunk-proof in the saturated bench: profiles/r03_knockin_edwards.txt).  Specialised to this layout:
-//   * the keys are never materialised as 32-bit words: the 19 bucket bits split into a COARSE bin (the high bits, 2^(B-9) bins) and a 9-bit FINE key;
-//   * pass A (k_part_hist + one scan + k_part_scatter) reads the scalars (32 B each, twice), recodes them into window digits on the fly and scatters
-//     (fine key u16, value u32) into the coarse bins -- every workgroup ranks its tile in LDS and writes bin-contiguous runs; the per-(bin, workgroup)
-//     offsets come from a histogram pass over the same fixed tiling, so there are no global atomics and the output order is deterministic;
-//   * pass B (k_part_fine, one workgroup per coarse bin) counts the 512 fine keys of its bin in LDS, writes the bucket [start, end) ranges that k_bounds
-//     used to find, and scatters the values tile by tile through LDS into their final bucket-contiguous order;
-//   * zero digits are simply not emitted (no SKIP entries), the order inside a bucket is irrelevant to a sum.
-// Traffic per (point, window) pair: ~2.5 + 2.5 B of scalar reads, 6 B written + (2 + 6) B read + 4 B written = ~23 B against ~60 B for digits + radix sort.
-// Skewed scalars (few distinct digits) only make some workgroups of pass B long; nothing overflows.
-constexpr int PART_FINE_BITS = 9, PART_FINE = 1 << PART_FINE_BITS;
-constexpr int PART_THREADS = 256, PART_SPT = 4, PART_TILE = PART_THREADS * PART_SPT;      // scalars per tile of pass A
-constexpr int PART_MAXW = 16;                                                             // windows per scalar (c_hi >= 16)
-constexpr int PART_STAGE = PART_TILE * PART_MAXW;                                         // staged pairs per tile (LDS: 8 B each = 128 KB)
-constexpr uint32_t PART_NBIN_MAX = 1024;                                                  // coarse bins (bucket bits <= 19, i.e. c_hi <= 20)
-constexpr int PART_B_PER = 16, PART_B_TILE = PART_THREADS * PART_B_PER;                   // pass B tile: 4096 pairs
-constexpr uint32_t PART_GRID = 512;                                                       // workgroups of pass A (fixed tiling shared by histogram and scatter; 1 per CU fits by LDS)
-
-// block-wide exclusive scan of an LDS array of `len` counters into `out`; the total goes to *total_out (LDS).  Ends with a barrier.
-__device__ __forceinline__ void part_block_scan(const uint32_t *cnt, uint32_t *out, uint32_t len, uint32_t *wave_sums, uint32_t *total_out) {
-    const uint32_t per = (len + PART_THREADS - 1) / PART_THREADS, t = threadIdx.x, base = t * per;
-    uint32_t sum = 0;
-    for (uint32_t i = 0; i < per; i++) if (base + i < len) sum += cnt[base + i];
-    uint32_t incl = sum;                                     // inclusive scan across the 64 lanes of the wave
-    for (int d = 1; d < 64; d <<= 1) { uint32_t v = __shfl_up(incl, d, 64); if ((int)(t & 63) >= d) incl += v; }
-    if ((t & 63) == 63) wave_sums[t >> 6] = incl;
-    __syncthreads();
-    uint32_t off = 0;
-    for (uint32_t w = 0; w < (t >> 6); w++) off += wave_sums[w];
-    uint32_t run = off + incl - sum;
-    for (uint32_t i = 0; i < per; i++) if (base + i < len) { uint32_t c = cnt[base + i]; out[base + i] = run; run += c; }
-    if (t == PART_THREADS - 1) *total_out = run;
-    __syncthreads();
-}
-// window digits of scalar g of the (scal1 ++ scal2) list: fn(bucket = |digit| - 1, value word) for every non-zero digit
-template <class Fr, class Fn>
-__device__ __forceinline__ void part_digits(const Fr *__restrict__ s1, uint32_t n1, uint32_t off1, const Fr *__restrict__ s2, uint32_t off2, uint32_t g, const TableLayout &L, uint32_t stride, Fn &&fn) {
-    uint32_t raw[Fr::N + 1];
-    uint32_t base;
-    if (g < n1) { s1[g].to_raw(raw); base = off1 + g; } else { s2[g - n1].to_raw(raw); base = off2 + (g - n1); }
-    raw[Fr::N] = 0;
-    uint32_t carry = 0;
-    for (int w = 0; w < L.nwin; w++) {
-        const int c = L.width(w), bit = L.offset(w), limb = bit >> 5, sh = bit & 31;
-        const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
-        uint64_t two = limb <= Fr::N - 1 ? ((uint64_t)raw[limb] | ((uint64_t)raw[limb + 1] << 32)) : 0;
-        uint32_t v = ((uint32_t)(two >> sh) & mask) + carry;
-        uint32_t neg = 0;
-        carry = 0;
-        if (v > half) { v = (1u << c) - v; neg = 1u << 31; carry = 1; }
-        if (v) fn(v - 1, ((uint32_t)w * stride + base) | neg);
-    }
-}
-template <class Fr>
-__global__ void __launch_bounds__(PART_THREADS) k_part_hist(const Fr *__restrict__ s1, uint32_t n1, uint32_t off1, const Fr *__restrict__ s2, uint32_t n2, uint32_t off2, TableLayout L,
-                                                            uint32_t stride, uint32_t nbin, uint32_t *__restrict__ hist) {
-    __shared__ uint32_t sh[PART_NBIN_MAX];
-    for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) sh[b] = 0;
-    __syncthreads();
-    const uint32_t n = n1 + n2, ntiles = (n + PART_TILE - 1) / PART_TILE;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
-        for (int q = 0; q < PART_SPT; q++) {
-            uint32_t g = tile * PART_TILE + q * PART_THREADS + threadIdx.x;
-            if (g < n) part_digits<Fr>(s1, n1, off1, s2, off2, g, L, stride, [&](uint32_t bucket, uint32_t) { atomicAdd(&sh[bucket >> PART_FINE_BITS], 1u); });
-        }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) hist[(size_t)b * gridDim.x + blockIdx.x] = sh[b];      // bin-major: the scan gives every (bin, workgroup) its range
-}
-template <class Fr>
-__global__ void __launch_bounds__(PART_THREADS) k_part_scatter(const Fr *__restrict__ s1, uint32_t n1, uint32_t off1, const Fr *__restrict__ s2, uint32_t n2, uint32_t off2, TableLayout L,
-                                                               uint32_t stride, uint32_t nbin, const uint32_t *__restrict__ offs, uint32_t *__restrict__ out_val,
-                                                               uint16_t *__restrict__ out_fine) {
-    __shared__ uint32_t cursor[PART_NBIN_MAX], cnt[PART_NBIN_MAX], loc[PART_NBIN_MAX], fill[PART_NBIN_MAX], st_val[PART_STAGE], st_key[PART_STAGE];
-    __shared__ uint32_t wave_sums[PART_THREADS / 64], total;
-    for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) cursor[b] = offs[(size_t)b * gridDim.x + blockIdx.x];
-    const uint32_t n = n1 + n2, ntiles = (n + PART_TILE - 1) / PART_TILE;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) { cnt[b] = 0; fill[b] = 0; }
-        __syncthreads();
-        // 1. how many pairs of this tile fall into every coarse bin; 2. scan; 3. the digits again, every pair to its LDS slot (bin-contiguous);
-        //    recomputing the digits is a few hundred plain instructions per scalar and keeps the pairs out of registers
-        for (int q = 0; q < PART_SPT; q++) {
-            uint32_t g = tile * PART_TILE + q * PART_THREADS + threadIdx.x;
-            if (g < n) part_digits<Fr>(s1, n1, off1, s2, off2, g, L, stride, [&](uint32_t bucket, uint32_t) { atomicAdd(&cnt[bucket >> PART_FINE_BITS], 1u); });
-        }
-        __syncthreads();
-        part_block_scan(cnt, loc, nbin, wave_sums, &total);
-        for (int q = 0; q < PART_SPT; q++) {
-            uint32_t g = tile * PART_TILE + q * PART_THREADS + threadIdx.x;
-            if (g < n) part_digits<Fr>(s1, n1, off1, s2, off2, g, L, stride, [&](uint32_t bucket, uint32_t val) {
-                uint32_t bin = bucket >> PART_FINE_BITS, e = loc[bin] + atomicAdd(&fill[bin], 1u);
-                st_val[e] = val; st_key[e] = bucket;
-            });
-        }
-        __syncthreads();
-        const uint32_t tot = total;
-        for (uint32_t e = threadIdx.x; e < tot; e += PART_THREADS) {        // bin-contiguous runs: consecutive lanes write consecutive addresses
-            uint32_t bucket = st_key[e], bin = bucket >> PART_FINE_BITS, dst = cursor[bin] + (e - loc[bin]);
-            out_val[dst] = st_val[e];
-            out_fine[dst] = (uint16_t)(bucket & (PART_FINE - 1));
-        }
-        __syncthreads();
-        for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) cursor[b] += cnt[b];
-    }
-}
-// pass B: one workgroup per coarse bin
-__global__ void __launch_bounds__(PART_THREADS) k_part_fine(const uint32_t *__restrict__ offs, uint32_t grid_a, const uint32_t *__restrict__ in_val, const uint16_t *__restrict__ in_fine,
-                                                            uint32_t *__restrict__ out_val, uint32_t *__restrict__ start, uint32_t *__restrict__ end) {
-    __shared__ uint32_t cnt[PART_FINE], cur[PART_FINE], tcnt[PART_FINE], tloc[PART_FINE], st_val[PART_B_TILE], wave_sums[PART_THREADS / 64], total;
-    __shared__ uint16_t st_f[PART_B_TILE];
-    const uint32_t bin = blockIdx.x, t = threadIdx.x;
-    const uint32_t lo = offs[(size_t)bin * grid_a], hi = offs[(size_t)(bin + 1) * grid_a];
-    for (uint32_t f = t; f < PART_FINE; f += PART_THREADS) cnt[f] = 0;
-    __syncthreads();
-    for (uint32_t e = lo + t; e < hi; e += PART_THREADS) atomicAdd(&cnt[in_fine[e]], 1u);
-    __syncthreads();
-    part_block_scan(cnt, cur, PART_FINE, wave_sums, &total);
-    for (uint32_t f = t; f < PART_FINE; f += PART_THREADS) {
-        const uint32_t k = bin * PART_FINE + f, st = lo + cur[f];
-        start[k] = st; end[k] = st + cnt[f];
-        cur[f] = st;                                     // running write position of fine key f
-    }
-    __syncthreads();
-    for (uint32_t t0 = lo; t0 < hi; t0 += PART_B_TILE) {
-        for (uint32_t f = t; f < PART_FINE; f += PART_THREADS) tcnt[f] = 0;
-        __syncthreads();
-        uint32_t v[PART_B_PER], fr[PART_B_PER];          // value, fine key | rank << 16  (rank < 4096)
-#pragma unroll
-        for (int i = 0; i < PART_B_PER; i++) {
-            uint32_t e = t0 + i * PART_THREADS + t;
-            fr[i] = 0xffffffffu;
-            if (e < hi) { uint32_t f = in_fine[e]; v[i] = in_val[e]; fr[i] = f | (atomicAdd(&tcnt[f], 1u) << 16); }
-        }
-        __syncthreads();
-        part_block_scan(tcnt, tloc, PART_FINE, wave_sums, &total);
-#pragma unroll
-        for (int i = 0; i < PART_B_PER; i++)
-            if (fr[i] != 0xffffffffu) { uint32_t f = fr[i] & 0xffffu, e = tloc[f] + (fr[i] >> 16); st_val[e] = v[i]; st_f[e] = (uint16_t)f; }
-        __syncthreads();
-        const uint32_t tot = total;
-        for (uint32_t e = t; e < tot; e += PART_THREADS) { uint32_t f = st_f[e]; out_val[cur[f] + (e - tloc[f])] = st_val[e]; }
-        __syncthreads();
-        for (uint32_t f = t; f < PART_FINE; f += PART_THREADS) cur[f] += tcnt[f];
-        __syncthreads();
-    }
-}
-// OFF by default (ZKAES_MSM_PARTITION=1 turns it on; read per call so that tests can flip it).  Measured on MI355X (profiles/r03_partition.md): the
-// grouping itself is ~0.2 ms faster per 2^22-point MSM, but k_accumulate runs 5.7 % SLOWER on its output (7.80 vs 7.38 ms): the stable radix sort leaves
-// every bucket ordered by (window, point index), so the lanes of a wave -- buckets of equal size, in lockstep -- gather from the same table copy at
-// nearby indices, a locality the (workgroup, tile)-ordered partition output does not have.  Bench: 75.2 vs 74.6 blocks/s, inside the box-to-box noise.
-static bool partition_enabled() { const char *e = getenv("ZKAES_MSM_PARTITION"); return e && atoi(e) != 0; }
-// digits + grouping of the table path through the two-level partition; leaves S.sorted_vals / S.start / S.end exactly as prepare_buckets would (up to
-// the order inside a bucket and the absent zero-digit entries)
-template <class Fr>
-static void partition_buckets(MsmWorkspace &S, const Fr *scal1, size_t n1, size_t off1, const Fr *scal2, size_t n2, size_t off2, const TableLayout &L, size_t stride, uint32_t cap, hipStream_t s) {
-    const int B = L.c_hi - 1;                                         // bucket bits
-    const uint32_t nbin = 1u << (B - PART_FINE_BITS), G = PART_GRID;
-    const size_t nb = (size_t)1 << B, nh = (size_t)nbin * G + 1;
-    if (nh > S.cap_part) { dfree(S.part_hist); dfree(S.part_offs); S.part_hist = (uint32_t *)dmalloc(nh * 4); S.part_offs = (uint32_t *)dmalloc(nh * 4); S.cap_part = nh; }
-    HIP_CHECK(hipMemsetAsync(S.part_hist + nh - 1, 0, 4, s));
-    for (int rep = (knockin() & 1) ? 0 : 1; rep < 2; rep++) {
-    hipLaunchKernelGGL((k_part_hist<Fr>), dim3(G), dim3(PART_THREADS), 0, s, scal1, (uint32_t)n1, (uint32_t)off1, scal2, (uint32_t)n2, (uint32_t)off2, L, (uint32_t)stride, nbin, S.part_hist);
-    HIP_LAUNCH_CHECK();
-    size_t tb = 0;
-    HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, S.part_hist, S.part_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
-    if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
-    HIP_CHECK(rocprim::exclusive_scan(S.tmp, tb, S.part_hist, S.part_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
-    hipLaunchKernelGGL((k_part_scatter<Fr>), dim3(G), dim3(PART_THREADS), 0, s, scal1, (uint32_t)n1, (uint32_t)off1, scal2, (uint32_t)n2, (uint32_t)off2, L, (uint32_t)stride, nbin,
-                       (const uint32_t *)S.part_offs, S.vals_a, (uint16_t *)S.keys_a);
-    HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_part_fine, dim3(nbin), dim3(PART_THREADS), 0, s, (const uint32_t *)S.part_offs, G, (const uint32_t *)S.vals_a, (const uint16_t *)S.keys_a, S.vals_b, S.start, S.end);
-    HIP_LAUNCH_CHECK();
-    }
-    S.sorted_vals = S.vals_b; S.sorted_keys = nullptr;
-    order_buckets(S, nb, cap, s);
-}
 
 // Table-mode Pippenger in the same two steps as the per-window variant.  msm_prepare_table: signed c-bit digits of up to two scalar vectors
 // (element i of vector v names table entry w * stride + off_v + i in window w), sort on the c - 1 bucket bits, bucket ranges;
@@ -1293,24 +1045,20 @@ void msm_prepare_table(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_
     const size_t nb = (size_t)1 << (L.c_hi - 1);
     S.plan_c = L.c_hi; S.plan_nwin = nwin; S.plan_pairs = pairs; S.plan_table = true; S.plan_cap = BUCKET_CAP_TABLE;
     ensure_scratch(S, pairs, nb, BUCKET_CAP_TABLE);
-    if (partition_enabled() && L.c_hi - 1 > PART_FINE_BITS && (1u << (L.c_hi - 1 - PART_FINE_BITS)) <= PART_NBIN_MAX && L.nwin <= PART_MAXW && pairs >= ((size_t)1 << 16)) {
-        partition_buckets<Fr>(S, scal1, n1, off1, scal2, n2, off2, L, stride, BUCKET_CAP_TABLE, s);
-        return;
-    }
     const int B = L.c_hi - 1, split_bits = B > 16 ? (B - 16 < 3 ? B - 16 : 3) : 0;
-    if (presplit_enabled() && split_bits > 0 && nwin <= SPLIT_MAXW && pairs >= ((size_t)1 << 16)) {
+    if (split_bits > 0 && nwin <= SPLIT_MAXW && pairs >= ((size_t)1 << 16)) {
         // the digit kernels already split the pairs (stably) on the low `split_bits` bucket bits: the radix sort starts above them
         const uint32_t nblocks = (uint32_t)((n + SPLIT_THREADS - 1) / SPLIT_THREADS);
         const size_t nh = ((size_t)nwin << split_bits) * nblocks;
-        if (nh > S.cap_part) { dfree(S.part_hist); dfree(S.part_offs); S.part_hist = (uint32_t *)dmalloc(nh * 4); S.part_offs = (uint32_t *)dmalloc(nh * 4); S.cap_part = nh; }
-        hipLaunchKernelGGL((k_split_hist<Fr>), dim3(nblocks), dim3(SPLIT_THREADS), 0, s, scal1, (uint32_t)n1, (uint32_t)off1, scal2, (uint32_t)n2, (uint32_t)off2, L, split_bits, nblocks, S.part_hist);
+        if (nh > S.cap_split) { dfree(S.split_hist); dfree(S.split_offs); S.split_hist = (uint32_t *)dmalloc(nh * 4); S.split_offs = (uint32_t *)dmalloc(nh * 4); S.cap_split = nh; }
+        hipLaunchKernelGGL((k_split_hist<Fr>), dim3(nblocks), dim3(SPLIT_THREADS), 0, s, scal1, (uint32_t)n1, (uint32_t)off1, scal2, (uint32_t)n2, (uint32_t)off2, L, split_bits, nblocks, S.split_hist);
         HIP_LAUNCH_CHECK();
         size_t tb = 0;
-        HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, S.part_hist, S.part_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
+        HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, S.split_hist, S.split_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
         if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
-        HIP_CHECK(rocprim::exclusive_scan(S.tmp, tb, S.part_hist, S.part_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
+        HIP_CHECK(rocprim::exclusive_scan(S.tmp, tb, S.split_hist, S.split_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
         hipLaunchKernelGGL((k_split_scatter<Fr>), dim3(nblocks), dim3(SPLIT_THREADS), 0, s, scal1, (uint32_t)n1, (uint32_t)off1, scal2, (uint32_t)n2, (uint32_t)off2, L, (uint32_t)stride, split_bits,
-                           nblocks, (const uint32_t *)S.part_offs, S.keys_a, S.vals_a);
+                           nblocks, (const uint32_t *)S.split_offs, S.keys_a, S.vals_a);
         HIP_LAUNCH_CHECK();
         prepare_buckets<typename Curve::FqP>(S, pairs, B, 1, B, BUCKET_CAP_TABLE, s, split_bits);
         return;
@@ -1325,14 +1073,12 @@ XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws_, const Affine28<typename Cu
     msm_prepare_table<Curve>(ws_, scalars, n, off, nullptr, 0, 0, c, stride, s_);
     return msm_finish<Curve>(ws_, tables, s_);
 }
-#if ZK_MSM_EDWARDS
 template <class Curve>
 XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws_, const Niels28<typename Curve::FqP> *tables, size_t stride, size_t off, int c, const typename Curve::Fr *scalars, size_t n, stream_t s_) {
     if (n == 0) return XYZZ<typename Curve::Fq>::inf();
     msm_prepare_table<Curve>(ws_, scalars, n, off, nullptr, 0, 0, c, stride, s_);
     return msm_finish<Curve>(ws_, tables, s_);
 }
-#endif
 
 // ---- fixed-base powers: out[i] = beta^(from + i) * base
 template <class Fr>
@@ -1423,7 +1169,6 @@ __global__ void __launch_bounds__(64, 2) k_class_partials(const typename Law::Ba
     uint32_t s0 = t * CLS_CHUNK;
     if (s0 >= n) return;
     uint32_t e = s0 + CLS_CHUNK < n ? s0 + CLS_CHUNK : n;
-#if ZK_MSM_EDWARDS
     if constexpr (Law::edwards) {
         AccTE<P> a1 = te_identity<P>(), a2 = a1;
         for (uint32_t i = s0; i < e; i++) {
@@ -1439,7 +1184,6 @@ __global__ void __launch_bounds__(64, 2) k_class_partials(const typename Law::Ba
         part2[t] = a2;
         return;
     } else
-#endif
     {
     Acc28<P> a1, a2;
     bool inf1 = true, inf2 = true;
@@ -1477,10 +1221,12 @@ __global__ void __launch_bounds__(256) k_sum_tree(const A *__restrict__ in, uint
     }
     if (t == 0) out[b] = sh[0];
 }
+// the two class sums in the library-wide form + the flag word, straight into the workspace's pinned host result; re-arms the flag word
 template <class A>
-__global__ void k_points_to_std(const A *__restrict__ in, uint32_t n, XYZZ<Fp<typename PtOps<A>::Params>> *__restrict__ out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = PtOps<A>::to_std(in[i]);
+__global__ void k_class_result(const A *__restrict__ in, uint32_t *__restrict__ flags, XYZZ<Fp<typename PtOps<A>::Params>> *__restrict__ out) {
+    uint32_t i = threadIdx.x;
+    if (i < 2) out[i] = PtOps<A>::to_std(in[i]);
+    if (i == 2) { *reinterpret_cast<uint32_t *>(out + 2) = *flags; *flags = 0; }
 }
 
 template <class Curve, class Law>
@@ -1497,20 +1243,18 @@ static bool class_sum_impl(MsmWorkspace *ws_, const typename Law::Base *bases, c
     size_t need_buckets = 2 * (size_t)chunks + 2 * mid + 8;
     ensure_scratch(S, 1, need_buckets, 0);
     A *p1 = (A *)S.buckets, *p2 = p1 + chunks, *m1 = p2 + chunks, *m2 = m1 + mid, *fin = m2 + mid;
-    HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 4, s));
-    hipLaunchKernelGGL((k_class_partials<Law>), dim3((chunks + 63) / 64), dim3(64), 0, s, bases, vals, (uint32_t)n, p1, p2, S.deferred_count);
+    hipLaunchKernelGGL((k_class_partials<Law>), dim3((chunks + 63) / 64), dim3(64), 0, s, bases, vals, (uint32_t)n, p1, p2, S.ctrl + 3);
     HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_sum_tree<A>), dim3(mid), dim3(256), 0, s, (const A *)p1, chunks, 256u, m1); HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_sum_tree<A>), dim3(mid), dim3(256), 0, s, (const A *)p2, chunks, 256u, m2); HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_sum_tree<A>), dim3(1), dim3(256), 0, s, (const A *)m1, mid, mid, fin); HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_sum_tree<A>), dim3(1), dim3(256), 0, s, (const A *)m2, mid, mid, fin + 1); HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_points_to_std<A>), dim3(1), dim3(64), 0, s, (const A *)fin, 2u, (XYZZ<Fq> *)S.wsum); HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_class_result<A>), dim3(1), dim3(64), 0, s, (const A *)fin, S.ctrl + 3, (XYZZ<Fq> *)S.d_res); HIP_LAUNCH_CHECK();
     XYZZ<Fq> r[2];
     uint32_t flags = 0;
-    sync((stream_t)s);        // drain first (sleeps in throughput mode): the pageable device-to-host copies below wait actively inside HIP
-    HIP_CHECK(hipMemcpyAsync(r, S.wsum, sizeof r, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipMemcpyAsync(&flags, S.deferred_count, 4, hipMemcpyDeviceToHost, s));
-    sync((stream_t)s);
+    sync((stream_t)s);        // (sleeps in throughput mode) results are in pinned host memory once the stream has drained
+    memcpy(r, S.h_res, sizeof r);
+    memcpy(&flags, (const char *)S.h_res + sizeof r, 4);
     if (flags) return false;          // a value outside [-2, 2] or a degenerate addition: the caller falls back to the generic MSM
     XYZZ<Fq> t = r[1].dbl();
     t.add(r[0]);
@@ -1521,7 +1265,6 @@ template <class Curve>
 bool class_sum(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *bases, const int8_t *vals, size_t n, XYZZ<typename Curve::Fq> *out, stream_t s_) {
     return class_sum_impl<Curve, WeierLaw<typename Curve::FqP>>(ws_, bases, vals, n, out, s_);
 }
-#if ZK_MSM_EDWARDS
 template <class Curve>
 bool class_sum(MsmWorkspace *ws_, const Niels28<typename Curve::FqP> *bases, const int8_t *vals, size_t n, XYZZ<typename Curve::Fq> *out, stream_t s_) {
     return class_sum_impl<Curve, EdwardsLaw<typename Curve::FqP>>(ws_, bases, vals, n, out, s_);
@@ -1530,7 +1273,6 @@ template XYZZ<Fq377> msm_finish<Bls377>(MsmWorkspace *, const Niels28<Fq377P> *,
 template XYZZ<Fq377> msm<Bls377>(MsmWorkspace *, const Niels28<Fq377P> *, const Fr377 *, size_t, stream_t);
 template XYZZ<Fq377> msm_table<Bls377>(MsmWorkspace *, const Niels28<Fq377P> *, size_t, size_t, int, const Fr377 *, size_t, stream_t);
 template bool class_sum<Bls377>(MsmWorkspace *, const Niels28<Fq377P> *, const int8_t *, size_t, XYZZ<Fq377> *, stream_t);
-#endif
 
 template void msm_sharded_plan<Bls377>(size_t, int *, int *);
 template void msm_sharded_plan<Bls381>(size_t, int *, int *);

@@ -398,15 +398,9 @@ std::vector<Fr> ciphertext_to_public_input(const uint8_t *ct, size_t len) {
 
 // =====================================================================================================================
 // proving key
-// the SRS in the form k_accumulate gathers: BLS12-377's twisted Edwards model (te28.cuh, 192 B per point incl. padding, 7 products per bucket addition) in the default
-// build, the reduced-radix Weierstrass affine form (112 B, 10 products) with -DZK_MSM_RADIX=30
-#if ZK_MSM_EDWARDS
+// the SRS in the form k_accumulate gathers: BLS12-377's twisted Edwards model (te28.cuh, 192 B per point incl. padding, 7 products per bucket addition)
 using SrsPoint = Niels28<Fq377P>;
 static void srs_convert(SrsPoint *dst, const G1A *src, size_t n, gpu::stream_t s) { gpu::convert_bases_te<Bls377>(dst, src, n, s); }
-#else
-using SrsPoint = Affine28<Fq377P>;
-static void srs_convert(SrsPoint *dst, const G1A *src, size_t n, gpu::stream_t s) { gpu::convert_bases<Bls377>(dst, src, n, s); }
-#endif
 
 struct DevBuf {
     F *p = nullptr; size_t n = 0;

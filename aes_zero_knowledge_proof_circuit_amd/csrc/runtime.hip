@@ -20,10 +20,12 @@ struct HwQueueDefault {
 } g_hw_queue_default;
 }  // namespace
 
-// measurement knob (tools/gpu_runs/r03_knockin.sh): ZKAES_KNOCKIN is a bit mask of pipeline parts to run TWICE (all idempotent, so proofs stay valid) --
-// 1 MSM sort, 2 bucket reductions, 4 tail, 8 accumulate, 32 every NTT.  The drop in blocks/s of a saturated bench run is that part's real cost beside
-// the other contexts' kernels, which a one-context profile cannot show.
+#ifdef ZKAES_MEASURE
+// measurement builds only (ZK_EXTRA_DEFINES=-DZKAES_MEASURE python -m ...build --force): ZKAES_KNOCKIN is a bit mask of pipeline parts to run TWICE (all idempotent,
+// so proofs stay valid) -- 1 MSM sort, 2 bucket reductions, 8 accumulate, 32 every NTT.  The drop in blocks/s of a saturated bench run is that part's real cost beside
+// the other contexts' kernels, which a one-context profile cannot show.  Release builds carry none of it.
 int knockin() { static const int v = [] { const char *e = getenv("ZKAES_KNOCKIN"); return e ? atoi(e) : 0; }(); return v; }
+#endif
 
 int device_count() {
     int n = 0;
@@ -72,13 +74,11 @@ void h2d(void *dst, const void *src, size_t bytes, stream_t s) { if (bytes) HIP_
 void d2h(void *dst, const void *src, size_t bytes, stream_t s) { if (bytes) { sync(s); HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)s)); HIP_CHECK(hipStreamSynchronize((hipStream_t)s)); } }
 void d2d(void *dst, const void *src, size_t bytes, stream_t s) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s)); }
 void dzero(void *dst, size_t bytes, stream_t s) { if (bytes) HIP_CHECK(hipMemsetAsync(dst, 0, bytes, (hipStream_t)s)); }
-// With ZKAES_STREAM_PRIORITY=1 prover streams are HIGH priority and the MSM workspace of the same context owns a LOW-priority side stream that
-// carries only k_accumulate (kernels_msm.hip run_buckets); measured neutral-to-worse on MI355X, so the default is plain streams.
+// (stream priorities -- prover streams high, k_accumulate on a low-priority side stream -- measured neutral-to-worse on MI355X in round 2,
+// profiles/r02_bench_stream_priority.md, and were removed in round 4)
 stream_t stream_create() {
     hipStream_t s;
-    int lo = 0, hi = 0;
-    if (stream_priorities_enabled() && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamDefault, hi));
-    else HIP_CHECK(hipStreamCreate(&s));
+    HIP_CHECK(hipStreamCreate(&s));
     return (stream_t)s;
 }
 void stream_destroy(stream_t s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }

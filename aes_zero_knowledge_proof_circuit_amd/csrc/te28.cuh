@@ -17,32 +17,18 @@
 #pragma once
 #include "ec28.cuh"
 
-#if ZK_MSM_RADIX == 28
-#define ZK_MSM_EDWARDS 1
-#else
-#define ZK_MSM_EDWARDS 0
-#endif
-
 namespace zk {
 
 // precomputed affine point (y - x, y + x, 2 d x y) in the reduced-radix Montgomery form: 3 x 56 B (+ 24 B of padding to a 64-byte aligned 192-byte record).  The identity is (1, 1, 0): the SRS's "infinity"
 // entries (none in practice) need no test in the hot loop.
-#ifndef ZK_NIELS_PAD
-#define ZK_NIELS_PAD 1          // 1 (default): records padded to 192 B and 64-byte aligned -- exactly three 64-byte sectors per gather instead of 3.5 on average for packed 168-byte
-                                // records: k_accumulate 7.31 -> 7.13 ms at 2^22 points, bench +1.1 % (profiles/r03_niels_padding.txt), for 14 % more table memory.  0 = packed.
-#endif
-#if ZK_NIELS_PAD
+// (padded to 192 B and 64-byte aligned: exactly three 64-byte sectors per gather instead of 3.5 on average for packed 168-byte records -- k_accumulate 7.31 -> 7.13 ms
+// at 2^22 points, bench +1.1 %, profiles/r03_niels_padding.txt -- for 14 % more table memory)
 template <class P>
 struct alignas(64) Niels28 { FpMsm<P> ymx, ypx, td; uint32_t pad[6]; };
-#else
-template <class P>
-struct Niels28 { FpMsm<P> ymx, ypx, td; };
-#endif
 // extended projective point: same 224 B as the XYZZ accumulator, so the MSM scratch buffers serve both
 template <class P>
 struct AccTE { FpMsm<P> x, y, z, t; };
 
-#if ZK_MSM_EDWARDS
 struct Te377 {
     using P = Fq377P;
     using G = Fp28<P>;
@@ -64,58 +50,23 @@ ZK_HD Niels28<P> niels_identity() { Niels28<P> r; r.ymx = FpMsm<P>::k_one(); r.y
 // -(x, y) = (-x, y): swap y - x and y + x, negate 2 d x y
 template <class P>
 ZK_HD Niels28<P> niels_neg(const Niels28<P> &n) { Niels28<P> r; r.ymx = n.ypx; r.ypx = n.ymx; r.td = FpMsm<P>::zero().template sub<2>(n.td); return r; }
-// the same for the hot loop: 2p - td without the carry chain (td only ever multiplies the normalized T1)
-template <class P>
-ZK_HD Niels28<P> niels_neg_lazy(const Niels28<P> &n) { Niels28<P> r; r.ymx = n.ypx; r.ypx = n.ymx; r.td = FpMsm<P>::zero().template sub_lazy<2>(n.td); return r; }
 
-// acc += n, seven products, everything inlined (hot loop of k_accumulate).  acc coordinates are products (normalized limbs, < 1.2 p) in and out; n's
-// coordinates normalized (the negated 2dxy may be lazy).
-// ZK_TE_LAZY >= 1 propagates carries only where a product needs them (2: D -+ C lazy too).  In te_madd (negated copy of the point, the next gather in a second register set) it was
-// measurably SLOWER (3,846 vs 4,013 VALU instructions but 214 vs 198 VGPRs: k_accumulate 7.17 vs 7.08 ms at 2^22 points, profiles/r03_te_lazy.txt); in the hot
-// loop's te_madd_signed below (sign as selects, gather mid-addition: 175 VGPRs either way) it pays: 3,550 vs 3,820 instructions
-// (profiles/r03_accumulate_instruction_diet.txt).  On; tests/te28_host_check.cpp builds all three.
-#ifndef ZK_TE_LAZY
-#define ZK_TE_LAZY 2
-#endif
+// acc += n, seven products, everything inlined.  acc coordinates are products (normalized limbs, < 1.2 p) in and out; n's coordinates normalized.
+// Carries are propagated only where a product needs them (profiles/r03_te_lazy.txt, r03_accumulate_instruction_diet.txt).  The cold callers (overflow segments,
+// class sums) use this one; the hot loop of k_accumulate uses te_madd_hot below.
 template <class P>
 ZK_HD void te_madd(AccTE<P> &a, const Niels28<P> &n) {
     using G = FpMsm<P>;
-#if ZK_TE_LAZY
     G A = a.y.template sub_lazy<3>(a.x) * n.ymx;     // (Y1 - X1)(y2 - x2)
     G B = a.y.add_lazy(a.x) * n.ypx;                 // (Y1 + X1)(y2 + x2)
-    G C = a.t * n.td;                                // T1 2 d x2 y2          (T1 normalized, td possibly lazy)
+    G C = a.t * n.td;                                // T1 2 d x2 y2          (T1 normalized)
     G D = a.z.dbl_lazy();                            // 2 Z1                  (Z2 = 1)
     G E = B.template sub<2>(A), H = B.add_lazy(A);   // E normalized, H lazy
     G F = D.template sub_lazy<2>(C), Gg = D + C;     // F lazy (D lazy + 2p - C), G normalized
-#else
-    G A = a.y.template sub<3>(a.x) * n.ymx;
-    G B = (a.y + a.x) * n.ypx;
-    G C = a.t * n.td;
-    G D = a.z.dbl();
-    G E = B.template sub<2>(A), H = B + A;           // < 3.2 p, < 2.4 p
-    G F = D.template sub<2>(C), Gg = D + C;          // < 6.2 p, < 5.4 p
-#endif
     a.x = E * F; a.y = Gg * H; a.t = E * H; a.z = F * Gg;
 }
-// acc += (neg ? -n : n) without touching n: -(x, y) = (-x, y) swaps n's first two coordinates and negates the third, i.e. A = (Y1 - X1)(y2 + x2), B = (Y1 + X1)(y2 - x2) and
-// C changes sign, which swaps F = D - C and G = D + C.  56 per-limb selects instead of a divergent branch with a 14-limb negation and 42 register moves (ZK_TE_SIGN_SELECT).
-#ifndef ZK_TE_PRESWAP
-#define ZK_TE_PRESWAP 1
-#endif
-#ifndef ZK_TE_BIASED
-#define ZK_TE_BIASED 1
-#endif
-#ifndef ZK_TE_SIGN_SELECT
-#define ZK_TE_SIGN_SELECT 1
-#endif
-// `next` (may be null): the record of the lane's NEXT addition, loaded into n as soon as the three products that read n are done -- the gather flies under the remaining
-// four products and lands in the registers the current point just vacated (no second register set, no copies at the loop's back edge).
-template <bool BIASED, class G>
-ZK_HD G mul_maybe_biased(const G &x, const G &y, uint64_t bias) {
-    if constexpr (BIASED) return G::mul_biased(x, y, bias);
-    else return x * y;
-}
-// a table record with its first two coordinates swapped when the digit that uses it is negative: the swap costs nothing at the gather (two field addresses), 28 selects after it
+// a table record with its first two coordinates swapped when the digit that uses it is negative: -(x, y) = (-x, y) swaps y - x and y + x (and negates 2dxy, which te_madd_hot
+// folds into F <-> G).  The swap costs nothing at the gather (two field addresses).
 template <class P>
 ZK_HD Niels28<P> niels_load_signed(const Niels28<P> *rec, bool neg) {
     const FpMsm<P> *f = &rec->ymx;                   // ymx and ypx are adjacent
@@ -123,59 +74,34 @@ ZK_HD Niels28<P> niels_load_signed(const Niels28<P> *rec, bool neg) {
     r.ymx = f[neg ? 1 : 0]; r.ypx = f[neg ? 0 : 1]; r.td = rec->td;
     return r;
 }
-// PRESWAPPED: n was loaded with niels_load_signed(.., neg) and `next` is loaded with the sign of ITS digit, next_neg
-template <class P, bool BIASED = false, bool PRESWAPPED = false>
-ZK_HD void te_madd_signed(AccTE<P> &a, Niels28<P> &n, bool neg, const Niels28<P> *next = nullptr, uint64_t bias = 0, bool next_neg = false) {
+// The hot loop's addition: acc += (neg ? -n : n), where n was loaded with niels_load_signed(.., neg).  A negative digit changes the sign of C, which swaps F = D - C and G = D + C
+// (28 per-limb selects, no negated copy of the point).  `next` is the record of the lane's NEXT addition, loaded (with the sign of ITS digit, next_neg) into n as soon as the three
+// products that read n are done: the gather flies under the remaining four products and lands in the registers the current point just vacated -- no second register set, no copies
+// at the loop's back edge.  `bias` = FpMsm<P>::hot_loop_bias() taken at kernel entry (ff28.cuh mul_biased: 14 fewer 64-bit adds per product).
+// All four factors of the second level are lazy.  Limb bounds in units of 2^28: E = B + 2p' - A < 3, H = B + A < 2, D = 2 Z1 < 2, U = D + 2p' - C < 4, V = D + C < 3
+// (2p' = kp_spread<2> < 2 per limb).  The widest products, E U and U V, put 14 x 12 x 2^56 into a column, the reduction 13 x 2^56 more: 181 x 2^56 < 2^64
+// (tests/test_ff28_host.py multiplies at exactly those bounds).
+template <class P>
+ZK_HD void te_madd_hot(AccTE<P> &a, Niels28<P> &n, bool neg, const Niels28<P> *next, bool next_neg, uint64_t bias) {
     using G = FpMsm<P>;
-#if ZK_TE_BIASED
-    // BIASED: bias = FpMsm<P>::hot_loop_bias() taken at kernel entry (ff28.cuh mul_biased: 14 fewer 64-bit adds per product)
-#define ZK_TE_MUL(x, y) mul_maybe_biased<BIASED>(x, y, bias)
-#else
-#define ZK_TE_MUL(x, y) ((x) * (y))
-#endif
-    G m1, m2;
-    if constexpr (PRESWAPPED) { m1 = n.ymx; m2 = n.ypx; }
-    else {
-#pragma unroll
-        for (int i = 0; i < G::N; i++) { m1.l[i] = neg ? n.ypx.l[i] : n.ymx.l[i]; m2.l[i] = neg ? n.ymx.l[i] : n.ypx.l[i]; }
-    }
-#if ZK_TE_LAZY
-    // carries only where a product needs a normalized operand: Y1 -+ X1 skip the chain (limbs < 2^30.4, their partners are table entries)
-    G A = ZK_TE_MUL(a.y.template sub_lazy<3>(a.x), m1);
-    G B = ZK_TE_MUL(a.y.add_lazy(a.x), m2);
-#else
-    G A = ZK_TE_MUL(a.y.template sub<3>(a.x), m1);
-    G B = ZK_TE_MUL(a.y + a.x, m2);
-#endif
-    G C = ZK_TE_MUL(a.t, n.td);
-    if (next) {                                      // callers in hot loops pass a non-null pointer on every iteration (straight-line code)
+    G A = G::mul_biased(a.y.template sub_lazy<3>(a.x), n.ymx, bias);
+    G B = G::mul_biased(a.y.add_lazy(a.x), n.ypx, bias);
+    G C = G::mul_biased(a.t, n.td, bias);
 #if defined(__HIP_DEVICE_COMPILE__)
-        // pin the gather behind the three products: without the fence the compiler hoists the loads to the top of the iteration, into a second register set
-        asm volatile("" : "+v"(A.l[G::N - 1]), "+v"(B.l[G::N - 1]), "+v"(C.l[G::N - 1]) : : "memory");
+    // pin the gather between the three products and the other four: without the first fence the compiler hoists the loads to the top of the iteration (a second register
+    // set), without the second one the scheduler sinks them to its end (the gather's latency is then exposed at the top of the next addition)
+    asm volatile("" : "+v"(A.l[G::N - 1]), "+v"(B.l[G::N - 1]), "+v"(C.l[G::N - 1]) : : "memory");
 #endif
-        if constexpr (PRESWAPPED) n = niels_load_signed<P>(next, next_neg);
-        else n = *next;
-    }
-#if ZK_TE_LAZY
-    // all four factors of the second level lazy.  Limb bounds in units of 2^28: E = B + 2p' - A < 3, H = B + A < 2, D = 2 Z1 < 2, U = D + 2p' - C < 4, V = D + C < 3
-    // (2p' = kp_spread<2> < 2 per limb).  The widest products, E U and U V, put 14 x 12 x 2^56 into a column, the reduction 13 x 2^56 more: 181 x 2^56 < 2^64.
+    n = niels_load_signed<P>(next, next_neg);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(A.l[0]), "+v"(C.l[0]) : : "memory");
+#endif
     G E = B.template sub_lazy<2>(A), H = B.add_lazy(A);
-#if ZK_TE_LAZY >= 2
     G D = a.z.dbl_lazy();
     G U = D.template sub_lazy<2>(C), V = D.add_lazy(C), F, Gg;
-#else
-    G D = a.z.dbl_lazy();
-    G U = D.template sub<2>(C), V = D + C, F, Gg;          // A/B: D -+ C with the carry chain (3,603 instead of 3,550 instructions)
-#endif
-#else
-    G E = B.template sub<2>(A), H = B + A;
-    G D = a.z.dbl();
-    G U = D.template sub<2>(C), V = D + C, F, Gg;
-#endif
 #pragma unroll
     for (int i = 0; i < G::N; i++) { F.l[i] = neg ? V.l[i] : U.l[i]; Gg.l[i] = neg ? U.l[i] : V.l[i]; }
-    a.x = ZK_TE_MUL(E, F); a.y = ZK_TE_MUL(Gg, H); a.t = ZK_TE_MUL(E, H); a.z = ZK_TE_MUL(F, Gg);
-#undef ZK_TE_MUL
+    a.x = G::mul_biased(E, F, bias); a.y = G::mul_biased(Gg, H, bias); a.t = G::mul_biased(E, H, bias); a.z = G::mul_biased(F, Gg, bias);
 }
 // a += b, unified (add-2008-hwcd-3): nine products
 template <class P>
@@ -254,7 +180,6 @@ ZK_HD Niels28<Fq377P> niels_from_weierstrass(const Affine<Fp<Fq377P>> &p, bool *
     if (m.den.is_zero()) { if (bad) *bad = true; return niels_identity<Fq377P>(); }
     return te_niels_finish(m, m.den.inverse());
 }
-#endif  // ZK_MSM_EDWARDS
 
 // ---- one vocabulary for the bucket-reduction kernels over either accumulator type
 template <class A> struct PtOps;
@@ -266,7 +191,6 @@ template <class P> struct PtOps<Acc28<P>> {
     ZK_HD static Acc28<P> neg(const Acc28<P> &a) { return neg28<P>(a); }
     ZK_HD static XYZZ<Fp<P>> to_std(const Acc28<P> &a) { return to_std_point<P>(a); }
 };
-#if ZK_MSM_EDWARDS
 template <class P> struct PtOps<AccTE<P>> {
     using Params = P;
     ZK_HD static AccTE<P> identity() { return te_identity<P>(); }
@@ -275,6 +199,5 @@ template <class P> struct PtOps<AccTE<P>> {
     ZK_HD static AccTE<P> neg(const AccTE<P> &a) { return te_neg<P>(a); }
     ZK_HD static XYZZ<Fp<P>> to_std(const AccTE<P> &a) { return te_to_std_point<P>(a); }
 };
-#endif
 
 }  // namespace zk

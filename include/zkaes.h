@@ -165,10 +165,13 @@ int zkaes_g1_sum(int curve_id, const uint8_t *points_xy, const int *inf, size_t 
 int zkaes_msm_sharded_plan(int curve_id, size_t n_total, int *window_bits, int *n_windows, size_t *bytes_per_rank);
 int zkaes_msm_window_sums_dev(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n_local, size_t n_total, void *dev_out, size_t dev_out_bytes);
 int zkaes_msm_fold_window_sums_dev(int curve_id, const void *dev_in, int world, size_t n_total, uint8_t *out_xy, int *out_inf);
-/* same sum through the precomputed-window path the prover uses for the SRS (tables 2^(window offset j) P_i built on the fly here; one bucket set).  For curve 377
- * this runs on the curve's twisted Edwards model (7-product bucket additions), which requires bases in the prime-order subgroup (as every KZG SRS point is):
- * a base of order 2 or 4 is refused, other points outside the subgroup are the caller's responsibility.  Curve 381 has no such model and stays on XYZZ. */
+/* same sum through the precomputed-window layout the prover uses for the SRS (tables 2^(window offset j) P_i built on the fly here; one bucket set), on the
+ * Weierstrass model with XYZZ buckets: correct for ANY curve points, both curves. */
 int zkaes_msm_table(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, int window_bits, uint8_t *out_xy, int *out_inf);
+/* BLS12-377 only -- exactly the prover's SRS path: the tables on the curve's twisted Edwards model (7-product bucket additions; the law is unified but not complete).
+ * PRECONDITION: every base lies in the prime-order subgroup (as every KZG SRS point does).  A base of order 2 or 4 is refused; any other point outside the subgroup
+ * may silently give a wrong sum -- use zkaes_msm / zkaes_msm_table for untrusted points. */
+int zkaes_msm_table_srs(const uint8_t *bases, const uint8_t *scalars, size_t n, int window_bits, uint8_t *out_xy, int *out_inf);
 /* device-resident variant for benchmarking: repeats the MSM `reps` times over device copies, returns ms per MSM of the whole pipeline and of
  * the bucket-accumulation kernel alone */
 int zkaes_msm_bench(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, int reps, double *ms_total, double *ms_accumulate);

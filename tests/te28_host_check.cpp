@@ -34,8 +34,8 @@ int main() {
         if (flag) { bad++; printf("subgroup point flagged\n"); }
         for (int variant = 0; variant < 4; variant++) {
             Niels28<P> a1 = q1, a2 = q2; Affine<Fq> s1 = p1, s2 = p2;
-            if (variant & 1) { a1 = (it & 1) ? niels_neg_lazy<P>(a1) : niels_neg<P>(a1); s1 = s1.neg(); }      // the hot loop negates without the carry chain
-            if (variant & 2) { a2 = niels_neg_lazy<P>(a2); s2 = s2.neg(); }
+            if (variant & 1) { a1 = niels_neg<P>(a1); s1 = s1.neg(); }
+            if (variant & 2) { a2 = niels_neg<P>(a2); s2 = s2.neg(); }
             // accumulate from the identity: a1, a2, a1, a2, ... and a1 twice in a row (P + P through the unified law)
             AccTE<P> acc = te_identity<P>();
             XYZZ<Fq> ref = XYZZ<Fq>::inf();
@@ -44,23 +44,26 @@ int main() {
                 te_madd<P>(acc, first ? a1 : a2); ref.madd(first ? s1 : s2);
                 if (!same(acc, ref)) { bad++; if (bad < 5) printf("madd mismatch it=%d variant=%d r=%d\n", it, variant, r); }
             }
-            // the hot loop's form: the sign as a flag (selects instead of a negated copy) and the next point loaded into the current point's storage mid-addition
+            // the hot loop's form (te_madd_hot): the record arrives with its first two coordinates swapped for a negative digit, the sign swaps F and G, the products start their
+            // columns at the rows' bias, and the next record is loaded into the current one's storage mid-addition
             {
-                AccTE<P> sg = te_identity<P>(), sb = sg; XYZZ<Fq> rs = XYZZ<Fq>::inf();
-                Niels28<P> cur = q1, curb = q1;
+                const uint64_t bias = FpMsm<P>::hot_loop_bias();
+                AccTE<P> sg = te_identity<P>(); XYZZ<Fq> rs = XYZZ<Fq>::inf();
+                bool negs[7];
+                for (int r = 0; r < 7; r++) negs[r] = (r * 5 + it + variant) % 3 == 0;
+                Niels28<P> cur = niels_load_signed<P>(&q1, negs[0]);
                 for (int r = 0; r < 6; r++) {
-                    const bool neg = (r * 5 + it + variant) % 3 == 0, use1 = (r & 1) == 0, next1 = ((r + 1) & 1) == 0;
-                    te_madd_signed<P>(sg, cur, neg, next1 ? &q1 : &q2);
-                    te_madd_signed<P, true>(sb, curb, neg, next1 ? &q1 : &q2, FpMsm<P>::hot_loop_bias());        // products with the rows' bias as the columns' start value
-                    for (int i = 0; i < 14; i++) if (sb.x.l[i] != sg.x.l[i] || sb.y.l[i] != sg.y.l[i] || sb.z.l[i] != sg.z.l[i] || sb.t.l[i] != sg.t.l[i]) { bad++; if (bad < 5) printf("biased product differs it=%d r=%d\n", it, r); break; }
+                    const bool neg = negs[r], use1 = (r & 1) == 0, next1 = ((r + 1) & 1) == 0;
+                    te_madd_hot<P>(sg, cur, neg, next1 ? &q1 : &q2, negs[r + 1], bias);
                     Affine<Fq> sp = use1 ? p1 : p2; if (neg) sp = sp.neg();
                     rs.madd(sp);
-                    if (!same(sg, rs)) { bad++; if (bad < 5) printf("signed madd mismatch it=%d variant=%d r=%d\n", it, variant, r); }
-                    const Niels28<P> &want = next1 ? q1 : q2;
+                    if (!same(sg, rs)) { bad++; if (bad < 5) printf("hot madd mismatch it=%d variant=%d r=%d\n", it, variant, r); }
+                    const Niels28<P> want = niels_load_signed<P>(next1 ? &q1 : &q2, negs[r + 1]);
                     for (int i = 0; i < 14; i++) if (cur.ymx.l[i] != want.ymx.l[i] || cur.ypx.l[i] != want.ypx.l[i] || cur.td.l[i] != want.td.l[i]) { bad++; break; }
                 }
-                AccTE<P> z = te_identity<P>(); Niels28<P> c2 = q1; te_madd_signed<P>(z, c2, false); te_madd_signed<P>(z, c2, true);
-                if (!te_to_std_point<P>(z).is_inf()) { bad++; if (bad < 5) printf("P-P (signed madd) not identity\n"); }
+                AccTE<P> z = te_identity<P>(); Niels28<P> c2 = niels_load_signed<P>(&q1, false);
+                te_madd_hot<P>(z, c2, false, &q1, true, bias); te_madd_hot<P>(z, c2, true, &q1, false, bias);
+                if (!te_to_std_point<P>(z).is_inf()) { bad++; if (bad < 5) printf("P-P (hot madd) not identity\n"); }
             }
             // P + (-P) = identity through madd
             { AccTE<P> z = te_identity<P>(); te_madd<P>(z, a1); te_madd<P>(z, niels_neg<P>(a1)); if (!te_to_std_point<P>(z).is_inf()) { bad++; if (bad < 5) printf("P-P (madd) not identity\n"); } }

@@ -104,11 +104,12 @@ def test_msm_2_16_matches_oracle(zko, api):
     assert not inf and got == ref.raw
 
 
-@pytest.mark.parametrize("cid", [377, 381])
+@pytest.mark.parametrize("cid,srs", [(377, True), (377, False), (381, False)])
 @pytest.mark.parametrize("n,c", [(1, 8), (33, 5), (1000, 11), (1 << 12, 13), ((1 << 13) + 3, 20), ((1 << 14) + 77, 18), (5000, 16)])
-def test_msm_precomputed_window_tables_match_oracle(zko, api, cid, n, c):
+def test_msm_precomputed_window_tables_match_oracle(zko, api, cid, srs, n, c):
     """the prover's SRS path: tables 2^(offset of window j) P_i over balanced windows (254 or 256 bits spread evenly: widths c and c - 1), one shared
-    bucket set (kernels_msm.hip msm_table, TableLayout); pairs grouped by digits + rocPRIM radix sort"""
+    bucket set (kernels_msm.hip msm_table, TableLayout); pairs grouped by digits + rocPRIM radix sort.  srs = zkaes_msm_table_srs, the twisted Edwards
+    law the prover runs over its SRS (oracle points are multiples of the generator: in the prime-order subgroup); otherwise the generic XYZZ entry."""
     bases = oracle_points(zko, cid, n, 3 * n + c)
     scalars = bytearray(rand_fr_mont(n, zko.FR[cid], 5 * n + c))
     if n >= 33:
@@ -117,17 +118,18 @@ def test_msm_precomputed_window_tables_match_oracle(zko, api, cid, n, c):
         scalars[64:96] = zko.fr_pack([zko.FR[cid] - 1], cid)
     ref = C.create_string_buffer(96)
     ref_inf = zko.lib().zko_api_msm(cid, bases, bytes(scalars), C.c_size_t(n), ref)
-    got, inf = api.msm_table(cid, bases, bytes(scalars), c)
+    got, inf = api.msm_table(cid, bases, bytes(scalars), c, srs=srs)
     assert inf == bool(ref_inf)
     if not inf:
         assert got == ref.raw
 
 
-@pytest.mark.parametrize("n,c", [((1 << 14) + 5, 20), (9000, 18), (6000, 17)])
-def test_msm_table_presplit_and_three_pass_sort_agree_with_oracle(zko, api, monkeypatch, n, c):
+@pytest.mark.parametrize("srs", [True, False])
+@pytest.mark.parametrize("n,c", [((1 << 14) + 5, 20), (9000, 18), (6000, 17), (9000, 15)])
+def test_msm_table_presplit_digits_agree_with_oracle(zko, api, srs, n, c):
     """from 2^16 (point, window) pairs and more than 16 bucket bits the digit kernels split the pairs stably on the low bucket bits (k_split_hist /
-    k_split_scatter) and the radix sort covers 16 bits in two passes; ZKAES_MSM_PRESPLIT=0 keeps digits + the full-width sort.  Both must match the oracle,
-    incl. the scalars 0 (every digit zero: SKIP entries), 1 and r - 1."""
+    k_split_scatter) and the radix sort covers 16 bits in two passes; c = 15 (14 bucket bits) takes digits + one full-width sort.  Both must match the oracle,
+    incl. the scalars 0 (every digit zero: SKIP entries), 1 and r - 1, and empty buckets (k_bounds fills their ranges in: nothing is memset)."""
     bases = oracle_points(zko, 377, n, 13 * n + c)
     scalars = bytearray(rand_fr_mont(n, zko.FR[377], 17 * n + c))
     scalars[0:32] = bytes(32)
@@ -138,31 +140,7 @@ def test_msm_table_presplit_and_three_pass_sort_agree_with_oracle(zko, api, monk
         scalars[32 * i:32 * i + 32] = bytes(32)
     ref = C.create_string_buffer(96)
     ref_inf = zko.lib().zko_api_msm(377, bases, bytes(scalars), C.c_size_t(n), ref)
-    for presplit in ("1", "0"):
-        monkeypatch.setenv("ZKAES_MSM_PRESPLIT", presplit)
-        got, inf = api.msm_table(377, bases, bytes(scalars), c)
-        assert not inf and not ref_inf and got == ref.raw, presplit
-
-
-@pytest.mark.parametrize("n,c,distinct", [((1 << 13) + 3, 20, 0), ((1 << 14) + 77, 18, 0), (5000, 16, 0), (20_000, 16, 3)])
-def test_msm_table_two_level_partition_matches_oracle(zko, api, monkeypatch, n, c, distinct):
-    """the opt-in grouping of the table path (ZKAES_MSM_PARTITION=1: k_part_hist / k_part_scatter / k_part_fine instead of digits + radix sort + bounds;
-    measured no faster end to end, profiles/r03_partition.md) must give the same sums -- uniform scalars incl. 0, 1, r - 1, and three distinct scalars
-    (every pair in a handful of buckets: long workgroups in pass B, overflow segments in the accumulation)"""
-    monkeypatch.setenv("ZKAES_MSM_PARTITION", "1")
-    bases = oracle_points(zko, 377, n, 7 * n + c)
-    if distinct:
-        vals = [int.from_bytes(np.random.RandomState(300 + i).bytes(31), "little") for i in range(distinct)]
-        scalars = zko.fr_pack([vals[i % distinct] for i in range(n)])
-    else:
-        scalars = bytearray(rand_fr_mont(n, zko.FR[377], 11 * n + c))
-        scalars[0:32] = bytes(32)
-        scalars[32:64] = zko.fr_pack([1], 377)
-        scalars[64:96] = zko.fr_pack([zko.FR[377] - 1], 377)
-        scalars = bytes(scalars)
-    ref = C.create_string_buffer(96)
-    ref_inf = zko.lib().zko_api_msm(377, bases, scalars, C.c_size_t(n), ref)
-    got, inf = api.msm_table(377, bases, scalars, c)
+    got, inf = api.msm_table(377, bases, bytes(scalars), c, srs=srs)
     assert not inf and not ref_inf and got == ref.raw
 
 
@@ -179,16 +157,18 @@ def test_msm_skewed_scalars_use_the_overflow_path(zko, api, distinct):
     assert not inf and not ref_inf and got == ref.raw
 
 
+@pytest.mark.parametrize("srs", [True, False])
 @pytest.mark.parametrize("distinct,n,c", [(1, 40_000, 12), (3, 20_000, 16), (2, 140_000, 9)])
-def test_msm_table_skewed_scalars_fold_overflow_runs_across_workgroups(zko, api, distinct, n, c):
+def test_msm_table_skewed_scalars_fold_overflow_runs_across_workgroups(zko, api, srs, distinct, n, c):
     """table mode cuts buckets above 512 points into overflow segments; with one to three distinct scalars a bucket has 13 ... 136 segments, so its
-    runs span up to three 64-segment workgroups of k_accumulate_tail (LDS fold per workgroup) and k_reduce_l1 picks up one partial per workgroup"""
+    runs span up to three 64-segment workgroups of k_accumulate_tail (LDS fold per workgroup) and the reduction picks up one partial per workgroup; the oversized
+    buckets come from the overflow list the order pass builds (k_order_hist / k_order_scan)"""
     bases = oracle_points(zko, 377, n, 515 + n)
     vals = [int.from_bytes(np.random.RandomState(900 + i).bytes(31), "little") for i in range(distinct)]
     scalars = zko.fr_pack([vals[i % distinct] for i in range(n)])
     ref = C.create_string_buffer(96)
     ref_inf = zko.lib().zko_api_msm(377, bases, scalars, C.c_size_t(n), ref)
-    got, inf = api.msm_table(377, bases, scalars, c)
+    got, inf = api.msm_table(377, bases, scalars, c, srs=srs)
     assert not inf and not ref_inf and got == ref.raw
 
 
