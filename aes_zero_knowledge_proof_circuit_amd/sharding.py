@@ -30,6 +30,27 @@ def split_chunks(n_chunks, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def rank_cpu_share(cpus, local_rank, local_world):
+    """the `local_rank`-th of `local_world` contiguous shares of the sorted CPU list (sizes differ by at most one).  Linux numbers the cores of a socket contiguously
+    and GPUs 0..3 / 4..7 of an 8-GPU MI355X node hang off sockets 0 / 1, so a contiguous share is also the NUMA-local one."""
+    cpus = sorted(cpus)
+    lo, hi = split_chunks(len(cpus), local_rank, local_world)
+    return cpus[lo:hi]
+
+
+def bind_rank_cpus(local_rank, local_world):
+    """Pin this rank's process (prover threads, verifier pool, OpenMP) to its share of the CPUs it may run on; returns a description for the bench line, None where
+    the platform has no sched_setaffinity or the share would be empty (fewer CPUs than ranks)."""
+    import os
+    if not hasattr(os, "sched_setaffinity") or local_world <= 1:
+        return None
+    share = rank_cpu_share(os.sched_getaffinity(0), local_rank, local_world)
+    if not share:
+        return None
+    os.sched_setaffinity(0, share)
+    return {"local_rank": local_rank, "cpus": len(share), "first": share[0], "last": share[-1]}
+
+
 def reduce_report(elapsed, accepted, total, negatives_ok, device=None):
     """max-over-ranks time and summed acceptance counters (no-op without an initialized process group)"""
     import torch

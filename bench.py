@@ -41,15 +41,17 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MADS_PER_ADD = 2649.0   # v_mad_u64_u32 per bucket addition of k_accumulate<EdwardsLaw> (7 Fq products x 378 + 3; disassembly of the gfx950 code object)
 CIRCUIT_MODEL_NOTE = ("R1CS of the restated ark-r1cs-std 0.3.1 gadget semantics: 629,856 constraints / 3,002,900 non-zeros at 64 bytes; the reference's own SRS literal "
                       "(src/lib.rs:141) records 866,944 / 4,062,064 for that size and no variant of the source-less simpleworks shift/rotate calls reproduces it "
-                      "(tools/circuit_variants.py, DESIGN.md section 2a) -- at the literal's density a 2^20 domain holds 4 blocks per chunk-proof, not 6: `--chunk 4` measures that configuration "
-                      "(53.7 blocks/s on this code, profiles/r03_bench_chunk4.json); integration/check_on_cargo_box.sh is the run that settles which one is right")
+                      "(tools/circuit_variants.py, DESIGN.md section 2a) -- at the literal's density a 2^20 domain holds 4 blocks per chunk-proof, not 6: the `alt` object of this line is "
+                      "that configuration MEASURED in this run (after the timed region); integration/check_on_cargo_box.sh is the run that settles which one is right")
+ALT_CHUNK = 4            # blocks per chunk-proof that fit |H| = 2^20 at the density of the reference's SRS literal
+LATENCY_BYTES = (16, 32, 64)   # the reference's own criterion shape: ONE encrypt() per message size (benches/benchmark.rs:8-10, benches/benchmark_encrypt.rs:39-49)
 
 from aes_zero_knowledge_proof_circuit_amd import sharding  # noqa: E402
 
 synthetic = sharding.synthetic_bytes
 
 
-def cpu_baseline(samples_small=3, samples_chunk=1, chunk_blocks=6, budget_s=150.0):
+def cpu_baseline(samples_small=1, samples_chunk=1, chunk_blocks=6, budget_s=150.0):
     """The CPU oracle (oracle/, a C restatement of the same algorithm; NOT arkworks) timed on this box's host cores, SRS + index prebuilt
     outside the timed part like the GPU side: `samples_small` one-block chunk-proofs and `samples_chunk` proofs at the bench's own chunk size."""
     from oracle import zko
@@ -79,7 +81,8 @@ def cpu_baseline(samples_small=3, samples_chunk=1, chunk_blocks=6, budget_s=150.
     best_chunk = max(out["by_chunk"], key=lambda b: out["by_chunk"][b]["blocks_per_s"])
     out["value"] = out["by_chunk"][best_chunk]["blocks_per_s"]
     out["sample"] = "best of %s: %s" % (", ".join("%sx %s-block chunk-proof" % (len(v["samples_s"]), b) for b, v in out["by_chunk"].items()),
-                                        "%s-block chunk, %.1f s per proof (%d sample%s at that size; --cpu-chunk-samples N takes more, ~60 s each)" % (
+                                        "%s-block chunk, %.1f s per proof (%d sample%s at that size; --cpu-chunk-samples N takes more, about a minute each; a 3-sample run of an "
+                                        "earlier round is kept in profiles/r03_bench_cpu_baseline_3_samples.json)" % (
                                             best_chunk, out["by_chunk"][best_chunk]["best_s"], len(out["by_chunk"][best_chunk]["samples_s"]),
                                             "" if len(out["by_chunk"][best_chunk]["samples_s"]) == 1 else "s"))
     out["threads_effective"] = "MSM: windows x point-slices tasks (all %d threads); NTT / polynomial loops: OpenMP static; synthesis + transcript: 1 thread" % nthreads
@@ -100,11 +103,14 @@ def build_parser():
     ap.add_argument("--blocks", type=int, default=None, help="ECB blocks of the message (headline: per rank, default 4096; strong: whole job, default 8192 per rank = 65536 at 8 ranks)")
     ap.add_argument("--proofs", type=int, default=1024, help="batch mode: independent single-block proofs (whole job)")
     ap.add_argument("--chunk", type=int, default=6, help="blocks per chunk-proof (6 = the most that fits |H|=2^20, |K|=2^22 and the reference's SRS literal)")
-    ap.add_argument("--contexts", type=int, default=16, help="chunk-proofs in flight per GPU (separate HIP streams)")
+    ap.add_argument("--contexts", type=int, default=12, help="chunk-proofs in flight per GPU (separate HIP streams; 8, 12 and 16 measure the same, profiles/r03_knobs.txt -- 12 holds ~56 GB of workspaces)")
     ap.add_argument("--pipeline", type=int, default=2, help="timed slices in flight (1 = strictly one after the other: the chip drains at every step boundary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chunk-samples", type=int, default=1, help="CPU-oracle samples at the bench's chunk size, ~60 s each (0 = one-block samples only; profiles/ holds a 3-sample run)")
     ap.add_argument("--serial-probe", type=int, default=2, help="chunk-proofs proven one at a time after the timed region for un-overlapped kernel durations (0 = off)")
+    ap.add_argument("--alt-proofs", type=int, default=64, help="one rank, headline mode: chunk-proofs of the %d-block alt leg measured after the timed region (0 = off)" % ALT_CHUNK)
+    ap.add_argument("--latency-samples", type=int, default=5, help="one rank, headline mode: lone encrypt() calls timed per message size of the latency leg (0 = off)")
+    ap.add_argument("--cpu-small-samples", type=int, default=1, help="CPU-oracle samples of a one-block chunk-proof (~17 s each + 20 s of setup)")
     return ap
 
 
@@ -131,6 +137,8 @@ def run(args, api, dist_env=None):
     if api.device_count() <= 0:
         raise SystemExit("bench.py needs a HIP device: libzkaes has no CPU fallback")
     api.set_device(local_rank)
+
+    affinity = sharding.bind_rank_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if world > 1 else None
 
     mode = args.mode or ("headline" if world == 1 else "strong")
     chunk = 1 if mode == "batch" else args.chunk
@@ -246,9 +254,56 @@ def run(args, api, dist_env=None):
                       "achieved_GBs": round(128.0 * s1["points"] / 1e9 / (s1["accumulate_ms"] / 1e3), 2),
                       "int_multiplier_frac": round(MADS_PER_ADD * s1["pairs"] / 1e12 / (s1["accumulate_ms"] / 1e3) / 28.1, 4)}
 
-    # ---- acceptance: every timed proof must verify (host), the wrong-ciphertext negative must be rejected
     from oracle import zko   # checker only: byte-level AES for the expected ciphertext
     pool = ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 4))        # ctypes releases the GIL inside zkaes_verify_encryption
+
+    # ---- two more MEASURED legs of the one-GPU headline run, after the timed region (they are reported beside `value`, never inside it):
+    #   alt        the same prover at ALT_CHUNK blocks per chunk-proof -- what fits |H| = 2^20 if the reference's SRS literal, not our R1CS model, has the true density
+    #   latency_ms ONE encrypt() per message size, keys resident: the reference's own criterion shape (benches/benchmark_encrypt.rs:45-47)
+    alt = latency = None
+    if world == 1 and mode == "headline" and rank == 0 and (args.alt_proofs > 0 or args.latency_samples > 0):
+        small_keys = {}
+
+        def key_for(nbytes):
+            if nbytes == chunk_bytes and pk is not None:
+                return pk, vk
+            if rem and nbytes == 16 * rem and pk_rem is not None:
+                return pk_rem, vk_rem
+            if nbytes not in small_keys:
+                small_keys[nbytes] = api.synthesize_keys(nbytes)
+            return small_keys[nbytes]
+
+        if args.alt_proofs > 0 and chunk != ALT_CHUNK:
+            apk, avk = key_for(16 * ALT_CHUNK)
+            amsg = synthetic(16 * ALT_CHUNK * args.alt_proofs, 0x5EED + 4242)
+            apk.encrypt_chunked(amsg[:16 * ALT_CHUNK * min(contexts, args.alt_proofs)], key)          # warm-up: this key's prover contexts
+            ta = time.perf_counter()
+            aproofs = apk.encrypt_chunked(amsg, key)
+            ta = time.perf_counter() - ta
+            act = zko.aes_encrypt(amsg, key)
+            aok = sum(pool.map(lambda j: bool(api.verify_encryption(avk, aproofs[j], act[16 * ALT_CHUNK * j:16 * ALT_CHUNK * (j + 1)])), range(len(aproofs))))
+            ainfo = apk.info()
+            alt = {"chunk_blocks": ALT_CHUNK, "value": round(ALT_CHUNK * len(aproofs) / ta, 4), "unit": "blocks/s", "proofs": len(aproofs), "proofs_verified": "%d/%d" % (aok, len(aproofs)),
+                   "elapsed_s": round(ta, 3), "h": int(ainfo["h"]), "k": int(ainfo["k"]),
+                   "note": "measured in this run after the timed region, same contexts; the headline value is what this prover does at %d blocks per chunk-proof" % chunk}
+        if args.latency_samples > 0:
+            latency, lat_ok = {}, True
+            for nbytes in LATENCY_BYTES:
+                lpk, lvk = key_for(nbytes)
+                lmsg = synthetic(nbytes, 0x5EED + 9000 + nbytes)
+                api.encrypt(lmsg, key, lpk)                                                         # warm-up: lanes + workspaces of a lone call
+                ts = []
+                for _ in range(args.latency_samples):
+                    tl = time.perf_counter()
+                    lp = api.encrypt(lmsg, key, lpk)
+                    ts.append(time.perf_counter() - tl)
+                lat_ok = lat_ok and bool(api.verify_encryption(lvk, lp, zko.aes_encrypt(lmsg, key)))
+                latency[str(nbytes)] = round(1e3 * sorted(ts)[len(ts) // 2], 2)
+            latency["samples"] = args.latency_samples
+            latency["verified"] = lat_ok
+        small_keys.clear()
+
+    # ---- acceptance: every timed proof must verify (host), the wrong-ciphertext negative must be rejected
 
     def chunk_ct(i, ct_all):
         return ct_all[chunk_bytes * i:chunk_bytes * (i + 1)] if i < n_full else ct_all[chunk_bytes * n_full:]
@@ -343,7 +398,8 @@ def run(args, api, dist_env=None):
                        "parallelism": "independent chunk-proofs per rank, no data-path collective" if mode == "headline" else "chunk range per rank + one all-gather of proof bytes",
                        "circuit_model": CIRCUIT_MODEL_NOTE},
             "proofs_verified": "%d/%d" % (acc_sum, tot_sum), "wrong_ciphertext_rejected": bool(neg_sum == world),
-            "setup_s": round(setup_s, 2),
+            "alt": alt, "latency_ms": latency,
+            "setup_s": round(setup_s, 2), "cpu_affinity": affinity,
             "phase_ms_last_proof_avg": {k: round(v / args.steps, 2) for k, v in phase.items()},
             "roofline": {"bound": "hbm", "kernel": "k_accumulate (Pippenger bucket accumulation)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
@@ -365,8 +421,10 @@ def run(args, api, dist_env=None):
             out["roofline"]["inconsistent"] = "kernel chip time per step exceeds the step itself"
         if acc_sum != tot_sum or neg_sum != world or tot_sum != out["config"]["proofs_total"]:
             out["error"] = "verification failure"
+        if (alt and alt["proofs_verified"] != "%d/%d" % (alt["proofs"], alt["proofs"])) or (latency and not latency["verified"]):
+            out["error"] = "verification failure (alt / latency leg)"
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(samples_chunk=args.cpu_chunk_samples, chunk_blocks=chunk if chunk > 1 else 6, budget_s=150.0 + 75.0 * max(0, args.cpu_chunk_samples - 1))
+            cb = cpu_baseline(samples_small=args.cpu_small_samples, samples_chunk=args.cpu_chunk_samples, chunk_blocks=chunk if chunk > 1 else 6, budget_s=150.0 + 75.0 * max(0, args.cpu_chunk_samples - 1))
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = round(value / cb["value"], 2)
         print(json.dumps(out), flush=True)
@@ -389,7 +447,7 @@ def launch_ranks(argv, n):
            os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver only supports dmabuf IPC (RCCL across processes)
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))      # (rank r also binds itself to the r-th share of the CPU set: sharding.bind_rank_cpus)
     return subprocess.call(cmd, env=env)
 
 

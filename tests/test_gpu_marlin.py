@@ -49,6 +49,18 @@ def test_aes_witness_bit_exact(zko, api, aes16, vectors):
     assert (info["h"], info["k"], info["joint_nnz"]) == (1 << 18, 1 << 20, 728_810)
 
 
+def test_committed_cargo_box_artefacts_are_what_this_build_emits(api, aes16, vectors):
+    """staleness guard: tests/golden/gpu_aes16_{proof,vk_ark,vk}.bin are what integration/check_on_cargo_box.sh feeds to the unmodified arkworks verifier --
+    the CURRENT build must still emit exactly those bytes for the FIPS-197 block under the reference's fixed prover seed (regenerate with
+    tests/golden/make_gpu_fixtures.py if a deliberate change moves them, and say so in the commit)"""
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    pk, vk = aes16
+    proof = api.encrypt(bytes(vectors["plaintext"]), bytes(vectors["key"]), pk)
+    assert proof == open(os.path.join(gold, "gpu_aes16_proof.bin"), "rb").read()
+    assert vk.to_ark_bytes() == open(os.path.join(gold, "gpu_aes16_vk_ark.bin"), "rb").read()
+    assert vk.to_bytes() == open(os.path.join(gold, "gpu_aes16_vk.bin"), "rb").read()
+
+
 def test_encrypt_16_bytes_and_verify(api, aes16, vectors):
     # tests/integration_tests.rs:313-337
     pk, vk = aes16
