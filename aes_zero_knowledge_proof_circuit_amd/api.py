@@ -131,6 +131,18 @@ class ProvingKey:
         _check(lib().zkaes_pk_debug_fetch(self._p, name.encode(), C.byref(out), C.byref(n)))
         return _take(out, n)
 
+    def tables_built(self):
+        """(built, bytes): does the key hold the fixed-base window tables of its SRS?"""
+        b, n = C.c_int(), C.c_uint64()
+        _check(lib().zkaes_pk_tables_built(self._p, C.byref(b), C.byref(n)))
+        return bool(b.value), int(n.value)
+
+    def msm_partial_dev(self, scalars_bytes, offset, dev_ptr, dev_bytes=192):
+        """this rank's share of ONE MSM over the key's SRS powers [offset, offset + n) on the prover's own path (Edwards tables); the partial sum (one XYZZ point,
+        192 B) stays in device memory at dev_ptr"""
+        n = len(scalars_bytes) // 32
+        _check(lib().zkaes_pk_msm_partial_dev(self._p, bytes(scalars_bytes), C.c_size_t(n), C.c_size_t(offset), C.c_void_p(dev_ptr), C.c_size_t(dev_bytes)))
+
     def witness(self, message, secret_key):
         n = C.c_size_t()
         _check(lib().zkaes_aes_witness(self._p, bytes(message), C.c_size_t(len(message)), bytes(secret_key), None, C.c_size_t(0), C.byref(n)))
@@ -298,6 +310,13 @@ def msm_fold_window_sums_dev(curve_id, dev_ptr, world, n_total):
     out = C.create_string_buffer(96)
     inf = C.c_int()
     _check(lib().zkaes_msm_fold_window_sums_dev(int(curve_id), C.c_void_p(dev_ptr), int(world), C.c_size_t(n_total), out, C.byref(inf)))
+    return out.raw, bool(inf.value)
+
+
+def msm_fold_partials_dev(curve_id, dev_ptr, world):
+    out = C.create_string_buffer(96)
+    inf = C.c_int()
+    _check(lib().zkaes_msm_fold_partials_dev(int(curve_id), C.c_void_p(dev_ptr), int(world), out, C.byref(inf)))
     return out.raw, bool(inf.value)
 
 

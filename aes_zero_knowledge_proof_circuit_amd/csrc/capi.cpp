@@ -86,9 +86,8 @@ static void pack_proofs(const std::vector<zk::Proof> &ps, uint8_t **proofs, size
     }
     *proofs = give(all); *proofs_len = all.size();
 }
-// the unseeded multi-proof entry points draw a fresh seed from the OS per call; ZKAES_PARITY_RNG=1 (tests, byte-parity with the oracle) keeps the
-// reference's fixed ark_std::test_rng() stream for every proof instead
-static bool parity_rng() { const char *e = getenv("ZKAES_PARITY_RNG"); return e && atoi(e) != 0; }
+// the unseeded multi-proof entry points draw a fresh seed from the OS per call.  The reference's fixed ark_std::test_rng() stream for every proof (byte parity with the
+// oracle; NOT zero-knowledge across proofs) is reachable only explicitly, through the *_seeded entry points with a NULL seed -- no environment variable downgrades a caller.
 int zkaes_encrypt_chunked_seeded_at(const uint8_t *msg, size_t len, const uint8_t key[16], const zkaes_pk *pk, const uint8_t *zk_seed32, uint64_t first_proof_index, uint8_t **proofs,
                                     size_t *proofs_len, size_t *proof_lens, size_t n_chunks) {
     return guard([&] {
@@ -104,9 +103,8 @@ int zkaes_encrypt_chunked_seeded(const uint8_t *msg, size_t len, const uint8_t k
 }
 int zkaes_encrypt_chunked(const uint8_t *msg, size_t len, const uint8_t key[16], const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens, size_t n_chunks) {
     uint8_t seed[32];
-    const bool parity = parity_rng();
-    if (!parity) { int rc = guard([&] { zk::os_random_seed(seed); }); if (rc) return rc; }
-    return zkaes_encrypt_chunked_seeded_at(msg, len, key, pk, parity ? nullptr : seed, 0, proofs, proofs_len, proof_lens, n_chunks);
+    { int rc = guard([&] { zk::os_random_seed(seed); }); if (rc) return rc; }
+    return zkaes_encrypt_chunked_seeded_at(msg, len, key, pk, seed, 0, proofs, proofs_len, proof_lens, n_chunks);
 }
 int zkaes_encrypt_batch_seeded_at(size_t n, const uint8_t *messages, size_t messages_len, const uint8_t *secret_keys, size_t secret_keys_len, const zkaes_pk *pk,
                                   const uint8_t *zk_seed32, uint64_t first_proof_index, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens) {
@@ -125,9 +123,8 @@ int zkaes_encrypt_batch_seeded(size_t n, const uint8_t *messages, size_t message
 int zkaes_encrypt_batch(size_t n, const uint8_t *messages, const uint8_t *secret_keys, const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens) {
     size_t chunk = pk ? pk->pk->circuit().n_blocks * 16 : 0;
     uint8_t seed[32];
-    const bool parity = parity_rng();
-    if (!parity) { int rc = guard([&] { zk::os_random_seed(seed); }); if (rc) return rc; }
-    return zkaes_encrypt_batch_seeded_at(n, messages, n * chunk, secret_keys, n * 16, pk, parity ? nullptr : seed, 0, proofs, proofs_len, proof_lens);
+    { int rc = guard([&] { zk::os_random_seed(seed); }); if (rc) return rc; }
+    return zkaes_encrypt_batch_seeded_at(n, messages, n * chunk, secret_keys, n * 16, pk, seed, 0, proofs, proofs_len, proof_lens);
 }
 int zkaes_prove_ops(const zkaes_pk *pk, uint32_t x, uint32_t y, const uint8_t *seed, uint8_t **proof, size_t *proof_len) {
     return guard([&] {
@@ -217,6 +214,19 @@ int zkaes_pk_info(const zkaes_pk *pk, uint64_t out[12]) {
     return guard([&] {
         fill_info(pk->pk->circuit(), out);
         out[9] = pk->pk->vk().num_non_zero; out[10] = next_pow2(pk->pk->vk().num_constraints); out[11] = next_pow2(pk->pk->vk().num_non_zero);
+    });
+}
+int zkaes_pk_tables_built(const zkaes_pk *pk, int *built, uint64_t *table_bytes) {
+    return guard([&] {
+        if (!pk || !built) throw std::invalid_argument("null argument");
+        *built = pk->pk->tables_built(table_bytes) ? 1 : 0;
+    });
+}
+int zkaes_pk_msm_partial_dev(const zkaes_pk *pk, const uint8_t *scalars, size_t n_local, size_t offset, void *dev_out, size_t dev_out_bytes) {
+    return guard([&] {
+        if (!pk || (!scalars && n_local)) throw std::invalid_argument("null argument");
+        if (!dev_out || dev_out_bytes < 192) throw std::invalid_argument("zkaes_pk_msm_partial_dev: device buffer too small for the partial sum (192 bytes)");
+        pk->pk->msm_powers_partial_device(scalars, n_local, offset, dev_out);
     });
 }
 int zkaes_circuit_info(int kind, size_t len, uint64_t out[12]) { return guard([&] { fill_info(compile(kind, len), out); }); }

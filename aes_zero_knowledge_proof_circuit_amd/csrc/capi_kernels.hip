@@ -168,6 +168,22 @@ int zkaes_msm_fold_window_sums_dev(int curve_id, const void *dev_in, int world, 
 int zkaes_g1_sum(int curve_id, const uint8_t *points_xy, const int *inf, size_t n, uint8_t *out_xy, int *out_inf) {
     return guardk([&] { if (curve_id == 381) run_g1_sum<zk::Bls381>(points_xy, inf, n, out_xy, out_inf); else if (curve_id == 377) run_g1_sum<zk::Bls377>(points_xy, inf, n, out_xy, out_inf); else throw std::invalid_argument("curve_id must be 377 or 381"); });
 }
+int zkaes_msm_fold_partials_dev(int curve_id, const void *dev_in, int world, uint8_t *out_xy, int *out_inf) {
+    return guardk([&] {
+        zk::gpu::require_device();
+        if (!dev_in || world < 1) throw std::invalid_argument("zkaes_msm_fold_partials_dev: bad arguments");
+        zk::gpu::stream_t s = zk::gpu::stream_create();
+        auto finish = [&](auto total) {
+            auto a = total.to_affine();
+            if (out_inf) *out_inf = a.is_inf() ? 1 : 0;
+            if (out_xy) { memcpy(out_xy, a.x.l, 48); memcpy(out_xy + 48, a.y.l, 48); }
+        };
+        if (curve_id == 377) finish(zk::gpu::msm_fold_points_device<zk::Bls377>((const zk::XYZZ<zk::Fq377> *)dev_in, world, s));
+        else if (curve_id == 381) finish(zk::gpu::msm_fold_points_device<zk::Bls381>((const zk::XYZZ<zk::Fq381> *)dev_in, world, s));
+        else { zk::gpu::stream_destroy(s); throw std::invalid_argument("curve_id must be 377 or 381"); }
+        zk::gpu::stream_destroy(s);
+    });
+}
 int zkaes_msm_table(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, int window_bits, uint8_t *out_xy, int *out_inf) {
     return guardk([&] { if (curve_id == 381) run_msm_table<zk::Bls381, false>(bases, scalars, n, window_bits, out_xy, out_inf); else if (curve_id == 377) run_msm_table<zk::Bls377, false>(bases, scalars, n, window_bits, out_xy, out_inf); else throw std::invalid_argument("curve_id must be 377 or 381"); });
 }

@@ -86,6 +86,13 @@ void msm_window_sums_device(MsmWorkspace *ws, const Affine28<typename Curve::FqP
                             XYZZ<typename Curve::Fq> *dev_out, stream_t s);
 template <class Curve>
 XYZZ<typename Curve::Fq> msm_fold_window_sums_device(const XYZZ<typename Curve::Fq> *dev_in, int world, size_t n_total, stream_t s);
+// The same sharding on the prover's own path (BLS12-377 SRS on the twisted Edwards model, window tables, ONE bucket set): a rank's share of the MSM is ONE XYZZ point,
+// left in device memory at dev_out; msm_fold_points_device adds `world` such points (rank-major rows of the all-gather) on the device.
+template <class Curve>
+void msm_table_sum_device(MsmWorkspace *ws, const Niels28<typename Curve::FqP> *tables, size_t stride, size_t off, int c, const typename Curve::Fr *scalars, size_t n,
+                          XYZZ<typename Curve::Fq> *dev_out, stream_t s);
+template <class Curve>
+XYZZ<typename Curve::Fq> msm_fold_points_device(const XYZZ<typename Curve::Fq> *dev_in, int world, stream_t s);
 // Precomputed-window variant for FIXED bases (the SRS): tables[j * stride + i] = 2^(c j) * P_i for j < table_windows(c).  With one table copy
 // per window ALL windows share ONE set of 2^(c-1) signed-digit buckets, so the bucket reduction is paid once and c can grow to 20-22
 // (12-13 windows instead of 15): fewer (point, window) pairs = fewer mixed adds in k_accumulate.

@@ -214,9 +214,10 @@ __global__ void __launch_bounds__(ORD_THREADS) k_order_hist(const uint32_t *__re
         atomicAdd(&h[order_key(sz)], 1u);
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < ORD_BINS; b += ORD_THREADS) hist[(size_t)b * gridDim.x + blockIdx.x] = h[b];
+    for (int b = threadIdx.x; b < ORD_BINS; b += ORD_THREADS) hist[(size_t)blockIdx.x * ORD_BINS + b] = h[b];
 }
-// one workgroup, one bin per lane: exclusive scan of the (bin, workgroup) counts in bin-major order; then the overflow list's segment offsets
+// one workgroup, one bin per lane: exclusive scan of the (bin, workgroup) counts in bin-major order (the arrays are workgroup-major, so that the lanes' loads coalesce);
+// then the overflow list's segment offsets
 __global__ void __launch_bounds__(ORD_BINS) k_order_scan(const uint32_t *__restrict__ hist, uint32_t *__restrict__ offs, uint32_t nblk, uint32_t *__restrict__ ctrl,
                                                           const uint32_t *__restrict__ ovf_nseg, uint32_t *__restrict__ ovf_off, uint32_t ovf_cap) {
     __shared__ uint32_t part[ORD_BINS];
@@ -232,11 +233,10 @@ __global__ void __launch_bounds__(ORD_BINS) k_order_scan(const uint32_t *__restr
         }
         return part[t] - v;
     };
-    const uint32_t *row = hist + (size_t)t * nblk;
     uint32_t sum = 0;
-    for (uint32_t i = 0; i < nblk; i++) sum += row[i];
+    for (uint32_t i = 0; i < nblk; i++) sum += hist[(size_t)i * ORD_BINS + t];
     uint32_t run = block_exclusive(sum);
-    for (uint32_t i = 0; i < nblk; i++) { const uint32_t c = row[i]; offs[(size_t)t * nblk + i] = run; run += c; }
+    for (uint32_t i = 0; i < nblk; i++) { const uint32_t c = hist[(size_t)i * ORD_BINS + t]; offs[(size_t)i * ORD_BINS + t] = run; run += c; }
     uint32_t n = ctrl[0];
     if (n > ovf_cap) n = ovf_cap;
     uint32_t base = 0;
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(ORD_THREADS) k_order_scatter(const uint32_t *_
     const uint32_t lo = blockIdx.x * per_block, hi = lo + per_block < nb ? lo + per_block : nb;
     for (uint32_t k = lo + threadIdx.x; k < hi; k += ORD_THREADS) {
         const uint32_t key = order_key(end[k] - start[k]);
-        order[offs[(size_t)key * gridDim.x + blockIdx.x] + atomicAdd(&h[key], 1u)] = k;
+        order[offs[(size_t)blockIdx.x * ORD_BINS + key] + atomicAdd(&h[key], 1u)] = k;
     }
 }
 
@@ -894,6 +894,39 @@ XYZZ<typename Curve::Fq> msm_fold_window_sums_device(const XYZZ<typename Curve::
     return total;
 }
 
+// ---- the same sharding on the prover's own path: tables on the twisted Edwards model, ONE bucket set, hence ONE partial sum per rank (no Horner)
+template <class Curve>
+void msm_table_sum_device(MsmWorkspace *ws_, const Niels28<typename Curve::FqP> *tables, size_t stride, size_t off, int c, const typename Curve::Fr *scalars, size_t n,
+                          XYZZ<typename Curve::Fq> *dev_out, stream_t s_) {
+    using Fq = typename Curve::Fq;
+    hipStream_t s = (hipStream_t)s_;
+    if (n == 0) {             // an empty share contributes the point at infinity (zz = 0)
+        HIP_CHECK(hipMemsetAsync(dev_out, 0, sizeof(XYZZ<Fq>), s));
+        sync((stream_t)s);
+        return;
+    }
+    msm_prepare_table<Curve>(ws_, scalars, n, off, nullptr, 0, 0, c, stride, s_);
+    MsmWorkspace &S = *ws_;
+    float ms = 0;
+    auto t_begin = std::chrono::steady_clock::now();
+    run_buckets<EdwardsLaw<typename Curve::FqP>>(S, tables, S.plan_pairs, S.plan_c - 1, 1, n, S.plan_cap, s, &ms, dev_out);
+    add_stats(ms, n, S.plan_pairs, t_begin);
+}
+template <class Curve>
+XYZZ<typename Curve::Fq> msm_fold_points_device(const XYZZ<typename Curve::Fq> *dev_in, int world, stream_t s_) {
+    using Fq = typename Curve::Fq;
+    hipStream_t s = (hipStream_t)s_;
+    XYZZ<Fq> *d_out = (XYZZ<Fq> *)dmalloc(sizeof(XYZZ<Fq>));
+    hipLaunchKernelGGL((k_fold_ranks<Fq>), dim3(1), dim3(64), 0, s, dev_in, world, 1, d_out);
+    HIP_LAUNCH_CHECK();
+    XYZZ<Fq> r;
+    sync((stream_t)s);
+    HIP_CHECK(hipMemcpyAsync(&r, d_out, sizeof r, hipMemcpyDeviceToHost, s));
+    sync((stream_t)s);
+    dfree(d_out);
+    return r;
+}
+
 template <class Curve>
 int table_windows(int c) { return table_layout(Curve::Fr::BITS + 1, c).nwin; }      // signed digits: one extra bit for the recoding carry
 
@@ -1274,6 +1307,9 @@ template XYZZ<Fq377> msm<Bls377>(MsmWorkspace *, const Niels28<Fq377P> *, const 
 template XYZZ<Fq377> msm_table<Bls377>(MsmWorkspace *, const Niels28<Fq377P> *, size_t, size_t, int, const Fr377 *, size_t, stream_t);
 template bool class_sum<Bls377>(MsmWorkspace *, const Niels28<Fq377P> *, const int8_t *, size_t, XYZZ<Fq377> *, stream_t);
 
+template void msm_table_sum_device<Bls377>(MsmWorkspace *, const Niels28<Fq377P> *, size_t, size_t, int, const Fr377 *, size_t, XYZZ<Fq377> *, stream_t);
+template XYZZ<Fq377> msm_fold_points_device<Bls377>(const XYZZ<Fq377> *, int, stream_t);
+template XYZZ<Fq381> msm_fold_points_device<Bls381>(const XYZZ<Fq381> *, int, stream_t);
 template void msm_sharded_plan<Bls377>(size_t, int *, int *);
 template void msm_sharded_plan<Bls381>(size_t, int *, int *);
 template void msm_window_sums_device<Bls377>(MsmWorkspace *, const Affine28<Fq377P> *, const Fr377 *, size_t, size_t, XYZZ<Fq377> *, stream_t);

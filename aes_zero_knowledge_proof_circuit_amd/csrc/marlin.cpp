@@ -1,5 +1,6 @@
 // csrc/marlin.cpp -- see marlin.hpp.  Host orchestration of the GPU prover + the host verifier.
 #include "marlin.hpp"
+#include "../../include/zkaes.h"   // ZKAES_DEFAULT_CONTEXTS
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -679,9 +680,13 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
     srs_stride = n_plain + n_shift;
     if (use_tables && (uint64_t)n_tab * srs_stride >= (1ull << 30)) { use_tables = false; }
     if (use_tables) {
-        // the tables are an optimisation, not a requirement: skip them when the device is short of memory (copies in the reduced-radix form + two staging
-        // copies in the standard form + ~5 GB per prover context a caller may still create) instead of failing key synthesis
-        const size_t need = n_tab * srs_stride * sizeof(SrsPoint) + 2 * srs_stride * sizeof(G1A) + ((size_t)8 << 30);
+        // the tables are an optimisation, not a requirement: skip them when the device is short of memory instead of failing key synthesis -- or the first multi-proof
+        // call, which creates the prover contexts: the copies in the reduced-radix form + two staging copies in the standard form + the workspaces of the default
+        // number of contexts a caller may still create (alloc_workspace: ~18 |H| + 6 |K| + 6 max(4 |H|, 2 |K|) field elements, plus the MSM scratch of the largest
+        // opening -- 13 windows x 16 B per pair: ~1.2 / 5 GB for the 1- / 6-block key) must all fit
+        const size_t big = std::max(4 * n, 2 * k);
+        const size_t per_context = (18 * n + 6 * k + 6 * big) * sizeof(F) + 13 * big * 16 + ((size_t)256 << 20);
+        const size_t need = n_tab * srs_stride * sizeof(SrsPoint) + 2 * srs_stride * sizeof(G1A) + ZKAES_DEFAULT_CONTEXTS * per_context + ((size_t)2 << 30);
         if (gpu::mem_free_bytes() < need) use_tables = false;
     }
     if (!use_tables) n_tab = 1;
@@ -1041,6 +1046,20 @@ ProvingKey::~ProvingKey() { if (impl) { try { gpu::set_device(impl->device); } c
 const VerifyingKey &ProvingKey::vk() const { return impl->vk; }
 const Circuit &ProvingKey::circuit() const { return impl->circuit; }
 const ProverTimings &ProvingKey::last_timings() const { return impl->last_timings; }
+bool ProvingKey::tables_built(uint64_t *bytes) const {
+    if (bytes) *bytes = impl->use_tables ? (uint64_t)gpu::table_windows<Bls377>(impl->table_c) * impl->srs_stride * sizeof(SrsPoint) : 0;
+    return impl->use_tables;
+}
+void ProvingKey::msm_powers_partial_device(const uint8_t *scalars, size_t n_local, size_t offset, void *dev_out) {
+    gpu::set_device(impl->device);
+    if (!impl->use_tables) throw std::runtime_error("msm_powers_partial_device: this key has no window tables (KEY_NO_TABLES, or the device was short of memory)");
+    if (offset + n_local > impl->supported_degree + 1) throw std::runtime_error("msm_powers_partial_device: range exceeds the committer key");
+    ProverContext &cx = impl->context(0);
+    std::lock_guard<std::mutex> busy(cx.in_use);
+    if (n_local > cx.acc.n) throw std::runtime_error("msm_powers_partial_device: more scalars than a prover context holds");
+    if (n_local) gpu::h2d(cx.acc.p, scalars, n_local * sizeof(F), cx.stream);
+    gpu::msm_table_sum_device<Bls377>(cx.msm_ws, impl->d_powers, impl->srs_stride, offset, impl->table_c, cx.acc.p, n_local, (XYZZ<Fq377> *)dev_out, cx.stream);
+}
 Proof ProvingKey::prove_aes(const uint8_t *message, size_t len, const uint8_t key[16], const uint8_t *zk_seed) {
     if (impl->circuit.kind != CIRCUIT_AES) throw std::invalid_argument("proving key was not synthesized for the AES circuit");
     if (len % 16) throw std::invalid_argument("Input must be 16 bytes length when adding round key");

@@ -78,6 +78,12 @@ class ProvingKey {
     // test / parity hooks: copy an intermediate of the last proof to the host. names: "z" (bytes), "z_a_evals","z_b_evals",
     // polys "w","z_a","z_b","mask_poly","t","g_1","h_1","g_2","h_2" (Montgomery Fr), index "row","col","a_val","b_val","c_val","row_col"
     std::vector<uint8_t> debug_fetch(const std::string &name) const;
+    // were the fixed-base window tables of the SRS built (they are skipped under KEY_NO_TABLES or when device memory is short)?  *bytes = their size
+    bool tables_built(uint64_t *bytes = nullptr) const;
+    // ONE commitment-sized MSM sharded by point range over ranks, on the prover's own path (the key's SRS on the twisted Edwards model, window tables, one bucket set):
+    // sum_i scalars[i] * powers_of_g[offset + i], i < n_local (scalars: host, n_local x 32 B Montgomery Fr), left as ONE XYZZ point (192 B) in device memory at dev_out
+    // -- the rank's row of the all-gather; gpu::msm_fold_points_device adds the ranks' rows.  Needs a key with tables.
+    void msm_powers_partial_device(const uint8_t *scalars, size_t n_local, size_t offset, void *dev_out);
     ProvingKeyImpl *impl;
 };
 

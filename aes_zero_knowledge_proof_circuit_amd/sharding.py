@@ -135,6 +135,27 @@ def msm_sharded_device(curve_id, bases_bytes, scalars_bytes, device):
     return api.msm_fold_window_sums_dev(curve_id, buf.data_ptr(), world, n)
 
 
+def msm_sharded_srs_device(pk, scalars_bytes, device, offset=0):
+    """ONE commitment-sized MSM over a proving key's own SRS, sharded by point range, on the path the prover itself runs (twisted Edwards window tables, one bucket set):
+    every rank's share is ONE XYZZ point (192 B) left in row `rank` of a [world, 192] CUDA tensor, one all_gather_into_tensor over RCCL, one device fold
+    (include/zkaes.h zkaes_pk_msm_partial_dev / zkaes_msm_fold_partials_dev).  scalars_bytes: the WHOLE scalar vector (n x 32 B Montgomery Fr), naming
+    powers_of_g[offset .. offset + n)."""
+    import torch
+    import torch.distributed as dist
+    from . import api
+    n = len(scalars_bytes) // 32
+    rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+    lo, hi = point_range(n, rank, world)
+    buf = torch.zeros((world, 192), dtype=torch.uint8, device=device)
+    torch.cuda.synchronize(device)
+    pk.msm_partial_dev(scalars_bytes[32 * lo:32 * hi], offset + lo, buf[rank].data_ptr())            # returns after its stream has drained
+    if dist.is_available() and dist.is_initialized():
+        mine = buf[rank].clone()
+        dist.all_gather_into_tensor(buf.view(-1), mine)
+        torch.cuda.synchronize(device)
+    return api.msm_fold_partials_dev(377, buf.data_ptr(), world)
+
+
 def msm_sharded(curve_id, bases_bytes, scalars_bytes, local_msm=None, device=None):
     """ONE multi-scalar multiplication sharded by point range over the ranks of the default process group (second row).
 

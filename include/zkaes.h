@@ -82,15 +82,15 @@ int zkaes_encrypt_seeded(const uint8_t *message, size_t message_len, const uint8
  * (the last chunk must be full).  proofs = concatenation, proof_lens[i] = length of proof i (caller array of n_chunks).
  * Zero-knowledge randomness: a FRESH 32-byte seed from the operating system per call (getrandom), proof i drawing from
  * StdRng(Blake2s(seed || i as u64 LE)) -- unlike the reference's encrypt(), whose every call draws from the fixed ark_std::test_rng() seed
- * (src/lib.rs:65), these extensions put hundreds of proofs under one AES key and must not share blinding factors.  ZKAES_PARITY_RNG=1 in the environment
- * restores the fixed stream for every proof (byte-parity with the CPU oracle in tests; not zero-knowledge across proofs). */
+ * (src/lib.rs:65), these extensions put hundreds of proofs under one AES key and must not share blinding factors.  The fixed stream for every proof (byte parity with the CPU
+ * oracle in tests; not zero-knowledge across proofs) is reachable only explicitly: the *_seeded entry points with a NULL seed. */
 int zkaes_encrypt_chunked(const uint8_t *message, size_t message_len, const uint8_t secret_key[16], const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len,
                           size_t *proof_lens, size_t n_chunks);
 /* n independent (message_i, secret_key_i) pairs on one key / one SRS (BASELINE config 5: many small proofs): messages = n x plaintext
  * length bytes, secret_keys = n x 16 bytes.  Up to ZKAES_CONTEXTS (environment; default ZKAES_DEFAULT_CONTEXTS, the configuration bench.py
  * measures) proofs are in flight per call, each on its own pair of HIP streams.  Randomness as zkaes_encrypt_chunked.  This entry point cannot
  * check its buffer lengths: prefer zkaes_encrypt_batch_seeded. */
-#define ZKAES_DEFAULT_CONTEXTS 16
+#define ZKAES_DEFAULT_CONTEXTS 12
 int zkaes_encrypt_batch(size_t n, const uint8_t *messages, const uint8_t *secret_keys, const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens);
 /* the chunked / batch calls with explicit buffer lengths (checked: messages_len == n x plaintext length, secret_keys_len == n x 16) and a
  * caller-supplied 32-byte seed.  Proof i draws from StdRng(Blake2s(zk_seed32 || (first_proof_index + i) as u64 LE)): a caller that splits ONE job over
@@ -165,6 +165,18 @@ int zkaes_g1_sum(int curve_id, const uint8_t *points_xy, const int *inf, size_t 
 int zkaes_msm_sharded_plan(int curve_id, size_t n_total, int *window_bits, int *n_windows, size_t *bytes_per_rank);
 int zkaes_msm_window_sums_dev(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n_local, size_t n_total, void *dev_out, size_t dev_out_bytes);
 int zkaes_msm_fold_window_sums_dev(int curve_id, const void *dev_in, int world, size_t n_total, uint8_t *out_xy, int *out_inf);
+/* The same sharding on the PROVER'S OWN path, for commitments over a key's SRS (src/lib.rs:111 -> KZG10::commit): the key's powers_of_g on the curve's twisted Edwards model,
+ * fixed-base window tables, ONE bucket set -- so a rank's share is ONE partial sum instead of one per window.  Every rank:
+ *   1. zkaes_pk_msm_partial_dev(pk, scalars of ITS slice (n_local x 32 B Montgomery Fr), n_local, offset of the slice in powers_of_g, dev_out, 192): the slice's sum as one XYZZ
+ *      point (192 B) left IN DEVICE MEMORY (row `rank` of a [world, 192] CUDA tensor); an empty share is the point at infinity
+ *   2. one all-gather of the rows over RCCL
+ *   3. zkaes_msm_fold_partials_dev(377, dev_in = the gathered block, world, out): sum over ranks on the device -> the commitment (affine).
+ * Needs a key with tables (zkaes_pk_tables_built).  aes_zero_knowledge_proof_circuit_amd/sharding.py msm_sharded_srs_device is this sequence. */
+int zkaes_pk_msm_partial_dev(const zkaes_pk *pk, const uint8_t *scalars, size_t n_local, size_t offset, void *dev_out, size_t dev_out_bytes);
+int zkaes_msm_fold_partials_dev(int curve_id, const void *dev_in, int world, uint8_t *out_xy, int *out_inf);
+/* *built = 1 when the key holds the fixed-base window tables of its SRS (they are skipped under ZKAES_KEY_NO_TABLES, or when device memory would not also hold the
+ * default number of prover contexts); *table_bytes (may be NULL) = their size in device memory */
+int zkaes_pk_tables_built(const zkaes_pk *pk, int *built, uint64_t *table_bytes);
 /* same sum through the precomputed-window layout the prover uses for the SRS (tables 2^(window offset j) P_i built on the fly here; one bucket set), on the
  * Weierstrass model with XYZZ buckets: correct for ANY curve points, both curves. */
 int zkaes_msm_table(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, int window_bits, uint8_t *out_xy, int *out_inf);

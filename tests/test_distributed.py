@@ -392,3 +392,82 @@ def test_window_sum_fold_of_two_slices_equals_the_whole_msm():
     assert api.msm_fold_window_sums_dev(cid, buf.data_ptr(), 2, n) == _oracle_msm(cid)(bases, scalars)
     with pytest.raises(api.ZkAesError, match="too small"):
         api.msm_window_sums_dev(cid, bases, scalars, n, buf[0].data_ptr(), 100)
+
+
+# ---- the same sharding on the PROVER'S OWN path: a key's SRS on the twisted Edwards model with window tables, one partial sum per rank
+def _srs_msm_case(n, off, seed):
+    """scalars (Montgomery bytes) over powers_of_g[off .. off + n) and the expected sum from the (public, test_rng-derived) trapdoor: (sum s_i beta^(off + i)) g,
+    computed with Python big integers (tools/curve_math.py) -- independent of every kernel and of the C oracle"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import curve_math as cm
+    from oracle import zko
+    rs = np.random.RandomState(seed)
+    vals = [int.from_bytes(rs.bytes(32), "little") % zko.FR[377] for _ in range(n)]
+    vals[0], vals[1] = 0, zko.FR[377] - 1
+    beta, g, _, _ = cm.ark_kzg10_setup_points()
+    acc, pw = 0, pow(beta, off, zko.FR[377])
+    for v in vals:
+        acc = (acc + v * pw) % zko.FR[377]
+        pw = pw * beta % zko.FR[377]
+    return zko.fr_pack(vals), cm.ec_mul(acc, g, cm.Q377)
+
+
+@pytest.mark.gpu
+def test_srs_path_sharded_msm_fold_of_two_slices_equals_the_trapdoor_product():
+    """zkaes_pk_msm_partial_dev on two slices of one MSM over the 16-byte key's SRS (Edwards tables, ONE bucket set -> one XYZZ point per slice, left in device memory)
+    + zkaes_msm_fold_partials_dev == (sum s_i beta^i) g; an empty share is the point at infinity; a range beyond the committer key is refused"""
+    from aes_zero_knowledge_proof_circuit_amd import api
+    from oracle import zko
+    pk, _ = api.synthesize_keys(16)
+    built, nbytes = pk.tables_built()
+    assert built and nbytes > (1 << 30)
+    n, off, cut = 520_003, 12_345, 200_000
+    scalars, want = _srs_msm_case(n, off, 11)
+    buf = torch.zeros((2, 192), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    pk.msm_partial_dev(scalars[:32 * cut], off, buf[0].data_ptr())
+    pk.msm_partial_dev(scalars[32 * cut:], off + cut, buf[1].data_ptr())
+    got, inf = api.msm_fold_partials_dev(377, buf.data_ptr(), 2)
+    assert not inf and zko.pt_unpack(got)[0] == want
+    pk.msm_partial_dev(scalars, off, buf[0].data_ptr())
+    pk.msm_partial_dev(b"", 0, buf[1].data_ptr())
+    got, inf = api.msm_fold_partials_dev(377, buf.data_ptr(), 2)
+    assert not inf and zko.pt_unpack(got)[0] == want
+    with pytest.raises(api.ZkAesError, match="exceeds the committer key"):
+        pk.msm_partial_dev(scalars, 1 << 22, buf[0].data_ptr())
+    with pytest.raises(api.ZkAesError, match="too small"):
+        pk.msm_partial_dev(scalars, off, buf[0].data_ptr(), 100)
+    nt_pk, _ = api.synthesize_keys(16, flags=api.KEY_NO_TABLES)
+    assert nt_pk.tables_built() == (False, 0)
+    with pytest.raises(api.ZkAesError, match="no window tables"):
+        nt_pk.msm_partial_dev(scalars[:3200], 0, buf[0].data_ptr())
+
+
+def _srs_msm_device_worker(rank, world, port, n, off, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dev = rank if world > 1 else 0
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    from aes_zero_knowledge_proof_circuit_amd import api
+    api.set_device(dev)
+    pk, _ = api.synthesize_keys(16)
+    scalars, _ = _srs_msm_case(n, off, 12)
+    out[rank] = sharding.msm_sharded_srs_device(pk, scalars, torch.device("cuda", dev), offset=off)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_srs_path_sharded_msm_through_rccl():
+    """sharding.msm_sharded_srs_device end to end: partial sums in HBM, all_gather_into_tensor over RCCL, device fold -- on as many ranks as the box has GPUs
+    (one here; RCCL refuses two ranks on one device)"""
+    from oracle import zko
+    world = 2 if torch.cuda.device_count() >= 2 else 1
+    n, off, port = 500_500, 7, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_srs_msm_device_worker, args=(world, port, n, off, out), nprocs=world, join=True)
+    _, want = _srs_msm_case(n, off, 12)
+    for r in range(world):
+        got, inf = out[r]
+        assert not inf and zko.pt_unpack(got)[0] == want

@@ -164,6 +164,89 @@ __global__ void k_fmul52d(double *out, double seed, int iters) {
     double s = 0; for (int i = 0; i < 8; i++) s += x.l[i] + y.l[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+// ---- MFMA probe: the idle matrix pipe for the CONSTANT half of a Montgomery product.  k_accumulate sits at the floor of its VALU formulation; the
+// reduction's m x p is a constant-matrix product (Toeplitz(p) x [digits x 64 lanes]) -- an int8 MFMA shape that would run beside the VALU.  This is an OPTIMISTIC RATE
+// PROBE, not a field implementation: per product it issues the VALU half (a x b: 196 v_mad_u64_u32 into 28 columns), packs the 14 low limbs into 49 byte digits,
+// moves them through LDS into MFMA operand layout (element e's digits are needed by lanes e % 16 + 16 q), runs the 28 v_mfma_i32_16x16x64_i8 of a [64 lanes x 64 digits]
+// x [64 x 112 columns] product (7 column tiles x 4 element groups), moves the 98 i32 columns per element back through LDS, recombines them into the 64-bit columns and
+// normalises.  Left OUT, all in the probe's favour: computing m = -T_lo p^-1 mod 2^392 at all (a second, dependent 49 x 49 constant product with its own two transposes
+// and a serial 49-digit carry chain between the two), signed-digit recoding for the signed i8 operands, any validation.  Kill criterion: < 1.25 x the ff28 product rate.
+typedef int v4i __attribute__((ext_vector_type(4)));
+constexpr int MF_COLS = 116;          // 112 columns padded to a 16-byte multiple that spreads the lanes' rows over the LDS banks
+__global__ void __launch_bounds__(64) k_fmul_mfma_probe(uint32_t *out, uint32_t seed, int iters) {
+    __shared__ uint32_t lds_in[64 * 16];                 // 64 bytes of digits per element
+    __shared__ uint32_t lds_out[64 * MF_COLS];
+    const uint32_t lane = threadIdx.x, MASK = (1u << 28) - 1;
+    uint32_t a[14], b[14];
+    for (int i = 0; i < 14; i++) { a[i] = (seed * (i + 3) + lane * 2654435761u) & MASK; b[i] = (seed * (i + 7) + 12345u) & MASK; }
+    v4i toep[7];                                         // this lane's fragment of the constant Toeplitz matrix, one per column tile (7 x 4 VGPRs)
+    for (int t = 0; t < 7; t++) for (int j = 0; j < 4; j++) toep[t][j] = (int)((seed + 0x01010101u * (t * 4 + j + lane)) & 0x7f7f7f7fu);
+    for (int it = 0; it < iters; it++) {
+        uint64_t t[28];
+#pragma unroll
+        for (int i = 0; i < 28; i++) t[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 14; i++)
+#pragma unroll
+            for (int j = 0; j < 14; j++) t[i + j] += (uint64_t)a[j] * b[i];
+        // low half: carry-normalise the 14 columns (a real reduction needs the limbs of T mod R), then 13 dwords of byte digits (28-bit limbs packed contiguously, as
+        // Fp28::pack does), pretending they were m
+        uint32_t lo[16];
+        {
+            uint64_t cl = 0;
+#pragma unroll
+            for (int i = 0; i < 14; i++) { uint64_t v = t[i] + cl; lo[i] = (uint32_t)v & MASK; cl = v >> 28; }
+            t[14] += cl;
+            lo[14] = lo[15] = 0;
+        }
+        uint32_t w[16];
+#pragma unroll
+        for (int k = 0; k < 13; k++) {
+            const int bit = 32 * k, i = bit / 28, sh = bit % 28;
+            uint64_t v = lo[i] >> sh;
+            v |= (uint64_t)lo[i + 1] << (28 - sh);
+            if (28 - sh + 28 < 32) v |= (uint64_t)lo[i + 2] << (56 - sh);
+            w[k] = (uint32_t)v & 0x7f7f7f7fu;
+        }
+        w[13] = w[14] = w[15] = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) *reinterpret_cast<uint4 *>(&lds_in[lane * 16 + k]) = make_uint4(w[k], w[k + 1], w[k + 2], w[k + 3]);
+        __syncthreads();
+        v4i acc[4][7];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 d = *reinterpret_cast<const uint4 *>(&lds_in[(q * 16 + (lane & 15)) * 16 + (lane >> 4) * 4]);
+            v4i bf; bf[0] = (int)d.x; bf[1] = (int)d.y; bf[2] = (int)d.z; bf[3] = (int)d.w;
+#pragma unroll
+            for (int tl = 0; tl < 7; tl++) {
+                v4i z = {0, 0, 0, 0};
+                acc[q][tl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(toep[tl], bf, z, 0, 0, 0);
+            }
+        }
+        // D[row = column within the tile][col = element within the group]: lane holds rows 4 (lane / 16) .. + 3 of column lane % 16
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int tl = 0; tl < 7; tl++)
+                *reinterpret_cast<uint4 *>(&lds_out[(q * 16 + (lane & 15)) * MF_COLS + tl * 16 + (lane >> 4) * 4]) =
+                    make_uint4((uint32_t)acc[q][tl][0], (uint32_t)acc[q][tl][1], (uint32_t)acc[q][tl][2], (uint32_t)acc[q][tl][3]);
+        __syncthreads();
+        uint32_t c[100];
+#pragma unroll
+        for (int k = 0; k < 100; k += 4) { const uint4 v = *reinterpret_cast<const uint4 *>(&lds_out[lane * MF_COLS + k]); c[k] = v.x; c[k + 1] = v.y; c[k + 2] = v.z; c[k + 3] = v.w; }
+        // byte-weighted columns back into the 28-bit-spaced 64-bit columns, then the carry normalisation of the high half
+#pragma unroll
+        for (int j = 0; j < 98; j++) if ((8 * j) / 28 >= 14) t[(8 * j) / 28] += (uint64_t)c[j] << ((8 * j) % 28);      // (the columns below R are not needed: see cy)
+        uint64_t cy = lo[13] != 0;             // the low half of T + m p is zero mod R: only its carry reaches the result
+#pragma unroll
+        for (int i = 0; i < 14; i++) { uint64_t v = t[14 + i] + cy; a[i] = (uint32_t)v & MASK; cy = v >> 28; }
+#pragma unroll
+        for (int i = 0; i < 14; i++) b[i] = (b[i] + a[(i + 1) % 14]) & MASK;
+        __syncthreads();
+    }
+    uint32_t s = 0; for (int i = 0; i < 14; i++) s ^= a[i] ^ b[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 // ---- global-atomic rate on 2^19 counters with uniformly random keys (would a counting scatter beat the radix sort of the MSM's (bucket, point) pairs?)
 __global__ void k_atomic_slots(uint32_t *cnt, uint32_t *slots, uint32_t nkeys_per_thread, uint32_t mask, uint32_t stride) {
     uint32_t x = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u;
@@ -230,5 +313,11 @@ int main() {
     printf("Fq377 FP64 16x24-bit limbs (rate probe): %.2f Gmul/s (%.3f ms)\n", lanes * 400 / ms / 1e6, ms);
     ms = timeit([&] { hipLaunchKernelGGL(k_fmul52d, dim3(blocks), dim3(threads), 0, 0, (double *)buf, 1000.0, 200); });
     printf("Fq377 FP64 8x52-bit limbs, split FMAs + int64 sums (rate probe): %.2f Gmul/s (%.3f ms)\n", lanes * 400 / ms / 1e6, ms);
+    {
+        const int mblocks = 256 * 24, mit = 200;          // one wave per workgroup (30 KB of LDS each: 5 per CU)
+        ms = timeit([&] { hipLaunchKernelGGL(k_fmul_mfma_probe, dim3(mblocks), dim3(64), 0, 0, (uint32_t *)buf, 0x9e3779b9u, mit); });
+        printf("Fq377 28-bit limbs, a x b on the VALU + m x p on v_mfma_i32_16x16x64_i8 incl. digit packing and both LDS transposes, m itself assumed free "
+               "(optimistic rate probe): %.2f Gmul/s (%.3f ms)\n", (double)mblocks * 64 * mit / ms / 1e6, ms);
+    }
     return 0;
 }
