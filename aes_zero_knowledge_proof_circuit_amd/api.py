@@ -274,6 +274,13 @@ def ntt(field_id, data_mont_bytes, inverse=False):
     return buf.raw
 
 
+def ntt_coset(field_id, data_mont_bytes, coset_c, lg_big, inverse=False):
+    n = len(data_mont_bytes) // 32
+    buf = C.create_string_buffer(bytes(data_mont_bytes), len(data_mont_bytes))
+    _check(lib().zkaes_ntt_coset(int(field_id), buf, C.c_size_t(n), 1 if inverse else 0, int(coset_c), int(lg_big)))
+    return buf.raw
+
+
 def msm(curve_id, bases_bytes, scalars_bytes):
     n = len(scalars_bytes) // 32
     out = C.create_string_buffer(96)

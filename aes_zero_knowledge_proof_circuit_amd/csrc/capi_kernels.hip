@@ -32,7 +32,7 @@ template <class Fn> int guardk(Fn &&fn) {
     catch (const std::exception &e) { zk::capi_set_error(e.what()); return 1; }
     catch (...) { zk::capi_set_error("unknown error"); return 1; }
 }
-template <class Fr> void run_ntt(uint8_t *data, size_t n, int inverse) {
+template <class Fr> void run_ntt(uint8_t *data, size_t n, int inverse, int coset_c, int lg_big) {
     int lg = 0;
     while (((size_t)1 << lg) < n) lg++;
     if (((size_t)1 << lg) != n) throw std::invalid_argument("zkaes_ntt: n must be a power of two");
@@ -40,7 +40,8 @@ template <class Fr> void run_ntt(uint8_t *data, size_t n, int inverse) {
     zk::gpu::stream_t s = zk::gpu::stream_create();
     Fr *a = (Fr *)zk::gpu::dmalloc(n * sizeof(Fr)), *b = (Fr *)zk::gpu::dmalloc(n * sizeof(Fr));
     zk::gpu::h2d(a, data, n * sizeof(Fr), s);
-    zk::gpu::ntt<Fr>(b, a, n, lg, inverse != 0, s);
+    if (coset_c) zk::gpu::ntt_coset<Fr>(b, a, n, lg, inverse != 0, coset_c, lg_big, s);
+    else zk::gpu::ntt<Fr>(b, a, n, lg, inverse != 0, s);
     zk::gpu::d2h(data, b, n * sizeof(Fr), s);
     zk::gpu::dfree(a); zk::gpu::dfree(b); zk::gpu::stream_destroy(s);
 }
@@ -192,7 +193,13 @@ int zkaes_msm_table_srs(const uint8_t *bases, const uint8_t *scalars, size_t n, 
 }
 int zkaes_set_device(int ordinal) { return guardk([&] { HIP_CHECK(hipSetDevice(ordinal)); }); }
 int zkaes_ntt(int field_id, uint8_t *data, size_t n, int inverse) {
-    return guardk([&] { if (field_id == 381) run_ntt<zk::Fr381>(data, n, inverse); else if (field_id == 377) run_ntt<zk::Fr377>(data, n, inverse); else throw std::invalid_argument("field_id must be 377 or 381"); });
+    return guardk([&] { if (field_id == 381) run_ntt<zk::Fr381>(data, n, inverse, 0, 0); else if (field_id == 377) run_ntt<zk::Fr377>(data, n, inverse, 0, 0); else throw std::invalid_argument("field_id must be 377 or 381"); });
+}
+int zkaes_ntt_coset(int field_id, uint8_t *data, size_t n, int inverse, int coset_c, int lg_big) {
+    return guardk([&] {
+        if (coset_c <= 0) throw std::invalid_argument("zkaes_ntt_coset: coset index must be positive");
+        if (field_id == 381) run_ntt<zk::Fr381>(data, n, inverse, coset_c, lg_big); else if (field_id == 377) run_ntt<zk::Fr377>(data, n, inverse, coset_c, lg_big); else throw std::invalid_argument("field_id must be 377 or 381");
+    });
 }
 int zkaes_msm(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, uint8_t *out_xy, int *out_inf) {
     return guardk([&] { if (curve_id == 381) run_msm<zk::Bls381>(bases, scalars, n, out_xy, out_inf, 0, nullptr, nullptr); else if (curve_id == 377) run_msm<zk::Bls377>(bases, scalars, n, out_xy, out_inf, 0, nullptr, nullptr); else throw std::invalid_argument("curve_id must be 377 or 381"); });

@@ -45,6 +45,10 @@ void event_destroy(void *ev);
 // dst <- NTT(src zero-padded from in_len to 2^lg); dst may equal src only if in_len == 2^lg is NOT required (out of place first pass
 // reads src completely before any tile of dst is written only when dst != src; pass distinct buffers).
 template <class Fr> void ntt(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, stream_t s);
+// The same transform on the coset g D of the size-2^lg domain D, g = W^coset_c with W the primitive root of the domain of size 2^lg_big (lg_big > lg, 0 < coset_c < 2^(lg_big - lg)):
+// forward: dst[i] = p(g w^i) for the coefficients src[0 .. in_len); inverse: the coefficients of the polynomial of degree < 2^lg with those values.  No extra pass: the scaling
+// by g^(+-k) rides on the first pass's gather / the last pass's store.  (Together, cosets 0 .. 2^(lg_big - lg) - 1 are the larger domain.)
+template <class Fr> void ntt_coset(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, int coset_c, int lg_big, stream_t s);
 template <class Fr> const Fr *domain_elements(int lg);   // device table g^i, i < 2^lg  (built lazily)
 
 // ---- MSM (kernels_msm.hip): sum_i scalars[i] * bases[i]; scalars in Montgomery form; result returned to the host (syncs the stream)
@@ -184,6 +188,13 @@ uint64_t chacha_field_stream(F *out, size_t count, const uint32_t key[8], int ro
 void mask_fixup(F *p, size_t n, stream_t s);
 // e_ra[i] = e_ra[i] * (eta_a za + eta_b zb + eta_c za zb)[i] - t[i] * z[i]
 void q1_pointwise(F *e_ra, const F *e_za, const F *e_zb, const F *e_t, const F *e_z, const F &eta_a, const F &eta_b, const F &eta_c, size_t n, stream_t s);
+// Round 2 on cosets of H (marlin.cpp second round): out[i] = r[i] (eta_a A + eta_b B + eta_c A B) - t[i] Z with A = za[i] + ca, B = zb[i] + cb, Z = z[i] + cz (the constants are
+// the blinding terms rho (X^|H| - 1), constant on a coset); z_evals_h = the full assignment on H as field elements; q1_combine turns the interpolants Q0 (on H), Q1, Q3 (on the
+// cosets W H, W^3 H) of q_1 - mask into h_1 (2n coefficients) and g_1 (n - 1), adding the mask's own quotient and remainder by X^n - 1.
+void q1_coset_pointwise(F *out, const F *r, const F *za, const F *zb, const F *t, const F *z, const F &ca, const F &cb, const F &cz, const F &eta_a, const F &eta_b, const F &eta_c,
+                        size_t n, stream_t s);
+void z_evals_h(F *out, const uint8_t *z, uint32_t n, uint32_t m, uint32_t num_witness, stream_t s);
+void q1_combine(F *h1, F *g1, const F *q0, const F *q1, const F *q3, const F *mask, const F &inv2, const F &inv2zeta, size_t n, stream_t s);
 void round3_den(F *den, const F *row, const F *col, const F &alpha, const F &beta, size_t k, stream_t s);     // (beta - row)(alpha - col)
 void mul_pointwise(F *out, const F *a, const F *b, size_t n, stream_t s);                                       // out = a * b
 void mul_sub(F *acc, const F *b, const F *f, size_t n, stream_t s);

@@ -37,9 +37,13 @@ __global__ void k_twiddles29(const Fr *__restrict__ tw, uint32_t n, Fp29<typenam
 // grow -- bounded statically: every pass starts from canonical inputs (< p); in its first three stages the butterflies with twiddle 1 skip the
 // product (y is still small: bounds 1, 3, 7 p -> K = 1, 4, 8 in x - y + K p), from then on every y is multiplied, so the bound grows by 2 p per
 // stage: < 29 p after ten stages, far below R' = 2^261 >= 64 p.  The store peels 16 p, 8 p, ..., p and re-packs canonical 8 x 32-bit words.
+// Coset transforms (ntt_coset): the points are g w^i with g = W^c, W a primitive root of a LARGER power-of-two domain of size cs_mask + 1 -- the cosets of H inside the
+// 4|H| domain the prover's round 2 evaluates on.  Forward: coefficient k is scaled by g^k while pass 1 gathers it (one more product per element, from the larger
+// domain's twiddle table: W^e for e < half, -W^(e - half) above); inverse: coefficient k is scaled by g^-k (and 1/n) at the last pass's store.
 template <class Fr, int TILE_LG>
 __global__ void __launch_bounds__(256) k_ntt_pass(Fr *dst, const Fr *src, uint32_t in_len, int lg, int s0, int S, int L,
-                                                   const Fp29<typename Fr::Params> *__restrict__ tw, bool bitrev_load, bool scale, Fp29<typename Fr::Params> scale_by) {
+                                                   const Fp29<typename Fr::Params> *__restrict__ tw, bool bitrev_load, bool scale, Fp29<typename Fr::Params> scale_by,
+                                                   const Fp29<typename Fr::Params> *__restrict__ cs_tw, uint32_t cs_c, uint32_t cs_mask) {
     using G = Fp29<typename Fr::Params>;
     constexpr int N = G::N;
     constexpr uint32_t TILE = 1u << TILE_LG;
@@ -60,6 +64,12 @@ __global__ void __launch_bounds__(256) k_ntt_pass(Fr *dst, const Fr *src, uint32
             v = src[gi];
         }
         G g = G::split(v.l);
+        if (bitrev_load && cs_tw && !scale) {         // forward coset transform (scale marks the inverse's last pass): x_k g^k, back to the canonical range the stage bounds start from
+            const uint32_t sidx = __brev(gi) >> (32 - lg), ex = (cs_c * sidx) & cs_mask, half = (cs_mask >> 1) + 1;
+            G t = g * cs_tw[ex & (half - 1)];
+            if (ex >= half) t = G::zero().template sub<2>(t);
+            g = t.template canonical<1>();
+        }
 #pragma unroll
         for (int k = 0; k < N; k++) lds[k][e] = g.l[k];
     }
@@ -96,7 +106,12 @@ __global__ void __launch_bounds__(256) k_ntt_pass(Fr *dst, const Fr *src, uint32
 #pragma unroll
         for (int k = 0; k < N; k++) g.l[k] = lds[k][e];
         Fr v;
-        if (scale) (g * scale_by).template canonical<1>().pack(v.l);
+        if (scale && cs_tw) {                         // inverse coset transform: coefficient gi times g^-gi / n
+            const uint32_t ex = (cs_c * gi) & cs_mask, half = (cs_mask >> 1) + 1;
+            G t = (g * scale_by) * cs_tw[ex & (half - 1)];
+            if (ex >= half) t = G::zero().template sub<2>(t);
+            t.template canonical<1>().pack(v.l);
+        } else if (scale) (g * scale_by).template canonical<1>().pack(v.l);
         else g.template canonical<4>().pack(v.l);
         dst[gi] = v;
     }
@@ -162,17 +177,29 @@ const Fr *domain_elements(int lg) {
 }
 
 template <class Fr>
-void ntt(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, stream_t s_) {
+static void ntt_impl(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, int coset_c, int lg_big, stream_t s_) {
+    using G = Fp29<typename Fr::Params>;
     hipStream_t s = (hipStream_t)s_;
     if (lg > RootOf<Fr>::TWO_ADICITY || lg > 30) throw GpuError("ntt: domain too large");
     const uint32_t n = 1u << lg;
     if (in_len > n) in_len = n;
     if (dst == src) throw GpuError("ntt: dst must differ from src (first pass gathers bit-reversed)");
-    if (lg == 0) { HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(Fr) * (in_len ? 1 : 0), hipMemcpyDeviceToDevice, s)); if (!in_len) HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(Fr), s)); return; }
+    if (lg == 0 && !coset_c) { HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(Fr) * (in_len ? 1 : 0), hipMemcpyDeviceToDevice, s)); if (!in_len) HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(Fr), s)); return; }
+    if (lg == 0) throw GpuError("ntt_coset: domain of size one");
     Fr w = Tables<Fr>::gen(lg);
     const Fr *tw_std = inverse ? tables<Fr>().powers(tables<Fr>().inv, lg, w.inverse(), n / 2) : tables<Fr>().powers(tables<Fr>().fwd, lg, w, n / 2);
-    const Fp29<typename Fr::Params> *tw = twiddles29<Fr>(inverse ? tables<Fr>().inv29 : tables<Fr>().fwd29, lg, tw_std, n / 2);
-    Fp29<typename Fr::Params> n_inv = Fp29<typename Fr::Params>::twiddle_from_std(Fr::from_u64(n).inverse());
+    const G *tw = twiddles29<Fr>(inverse ? tables<Fr>().inv29 : tables<Fr>().fwd29, lg, tw_std, n / 2);
+    G n_inv = G::twiddle_from_std(Fr::from_u64(n).inverse());
+    const G *cs_tw = nullptr;
+    uint32_t cs_mask = 0;
+    if (coset_c) {        // powers of the larger domain's root (its forward or inverse twiddle table: W^(+-e), e < 2^(lg_big - 1))
+        if (lg_big <= lg || lg_big > RootOf<Fr>::TWO_ADICITY || lg_big > 30) throw GpuError("ntt_coset: the coset generator must come from a larger domain");
+        const uint32_t nb = 1u << lg_big;
+        Fr wb = Tables<Fr>::gen(lg_big);
+        const Fr *big_std = inverse ? tables<Fr>().powers(tables<Fr>().inv, lg_big, wb.inverse(), nb / 2) : tables<Fr>().powers(tables<Fr>().fwd, lg_big, wb, nb / 2);
+        cs_tw = twiddles29<Fr>(inverse ? tables<Fr>().inv29 : tables<Fr>().fwd29, lg_big, big_std, nb / 2);
+        cs_mask = nb - 1;
+    }
     // pass plan: pass 1 covers min(lg, 10) stages on contiguous 1024-element tiles; the remaining R stages are split EVENLY over
     // ceil(R / 8) passes, each on full 1024-element tiles made of 2^S strided runs of 2^L = 2^(10 - S) contiguous elements (>= 128 B runs),
     // so that every pass keeps all 256 lanes busy (a lopsided 10 + 8 + 4 plan left the last pass with 64-element tiles and made it the slowest).
@@ -185,7 +212,8 @@ void ntt(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, stream_t s
     int remaining = lg - S1;
     {
         bool last = remaining == 0;
-        hipLaunchKernelGGL((k_ntt_pass<Fr, 10>), dim3(n >> S1), dim3(256), 0, s, dst, src, (uint32_t)in_len, lg, 0, S1, 0, tw, true, inverse && last, n_inv);
+        hipLaunchKernelGGL((k_ntt_pass<Fr, 10>), dim3(n >> S1), dim3(256), 0, s, dst, src, (uint32_t)in_len, lg, 0, S1, 0, tw, true, inverse && last, n_inv,
+                           (!inverse || last) ? cs_tw : (const G *)nullptr, (uint32_t)coset_c, cs_mask);
         HIP_LAUNCH_CHECK();
         s0 = S1;
     }
@@ -196,7 +224,8 @@ void ntt(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, stream_t s
         if (L > s0) L = s0;
         if (L < 2) L = 2;
         bool last = remaining == S;
-        hipLaunchKernelGGL((k_ntt_pass<Fr, 10>), dim3(n >> (S + L)), dim3(256), 0, s, dst, (const Fr *)dst, n, lg, s0, S, L, tw, false, inverse && last, n_inv);
+        hipLaunchKernelGGL((k_ntt_pass<Fr, 10>), dim3(n >> (S + L)), dim3(256), 0, s, dst, (const Fr *)dst, n, lg, s0, S, L, tw, false, inverse && last, n_inv,
+                           (inverse && last) ? cs_tw : (const G *)nullptr, (uint32_t)coset_c, cs_mask);
         HIP_LAUNCH_CHECK();
         s0 += S;
         remaining -= S;
@@ -204,9 +233,18 @@ void ntt(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, stream_t s
     }
     }
 }
+template <class Fr>
+void ntt(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, stream_t s) { ntt_impl<Fr>(dst, src, in_len, lg, inverse, 0, 0, s); }
+template <class Fr>
+void ntt_coset(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, int coset_c, int lg_big, stream_t s) {
+    if (coset_c <= 0 || coset_c >= (1 << (lg_big - lg))) throw GpuError("ntt_coset: coset index out of range");
+    ntt_impl<Fr>(dst, src, in_len, lg, inverse, coset_c, lg_big, s);
+}
 
 template void ntt<Fr377>(Fr377 *, const Fr377 *, size_t, int, bool, stream_t);
 template void ntt<Fr381>(Fr381 *, const Fr381 *, size_t, int, bool, stream_t);
+template void ntt_coset<Fr377>(Fr377 *, const Fr377 *, size_t, int, bool, int, int, stream_t);
+template void ntt_coset<Fr381>(Fr381 *, const Fr381 *, size_t, int, bool, int, int, stream_t);
 template const Fr377 *domain_elements<Fr377>(int);
 template const Fr381 *domain_elements<Fr381>(int);
 

@@ -161,10 +161,19 @@ F poly_eval(const F *p, size_t len, const F &x, F *scratch, stream_t s_) {
     if (len == 0) return F::zero();
     size_t nch = (len + 63) / 64;
     hipLaunchKernelGGL(k_eval_chunks, GRID(nch), 0, s, p, len, x, scratch); HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_eval_combine, dim3(1), dim3(256), 0, s, scratch, nch, x.pow_u64(64), scratch + nch); HIP_LAUNCH_CHECK();
+    F y = x.pow_u64(64);
+    F *part = scratch;
+    if (nch > 2048) {
+        // a second level of 64-partial Horner chunks: the one-workgroup combine below walks its partials serially per lane (two dependent products each) --
+        // 256 steps for a 2^22-coefficient polynomial were 0.3 ms of pure latency per evaluation (profiles/r03_kernel_stats_serial.md: k_eval_combine)
+        const size_t nch2 = (nch + 63) / 64;
+        hipLaunchKernelGGL(k_eval_chunks, GRID(nch2), 0, s, (const F *)scratch, nch, y, scratch + nch); HIP_LAUNCH_CHECK();
+        part = scratch + nch; nch = nch2; y = y.pow_u64(64);
+    }
+    hipLaunchKernelGGL(k_eval_combine, dim3(1), dim3(256), 0, s, (const F *)part, nch, y, part + nch); HIP_LAUNCH_CHECK();
     F out;
     sync((stream_t)s);        // drain first (sleeps in throughput mode): the pageable device-to-host copies below wait actively inside HIP
-    HIP_CHECK(hipMemcpyAsync(&out, scratch + nch, sizeof(F), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(&out, part + nch, sizeof(F), hipMemcpyDeviceToHost, s));
     sync((stream_t)s);
     return out;
 }
@@ -241,6 +250,48 @@ __global__ void k_q1(F *__restrict__ e_ra, const F *__restrict__ za, const F *__
 }
 void q1_pointwise(F *e_ra, const F *e_za, const F *e_zb, const F *e_t, const F *e_z, const F &ea, const F &eb, const F &ec, size_t n, stream_t s) {
     hipLaunchKernelGGL(k_q1, GRID(n), 0, (hipStream_t)s, e_ra, e_za, e_zb, e_t, e_z, ea, eb, ec, n); HIP_LAUNCH_CHECK();
+}
+__global__ void k_q1_coset(F *__restrict__ out, const F *__restrict__ r, const F *__restrict__ za, const F *__restrict__ zb, const F *__restrict__ t, const F *__restrict__ z,
+                           F ca, F cb, F cz, F ea, F eb, F ec, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F a = za[i] + ca, b = zb[i] + cb;
+    F sum = ec * (a * b) + ea * a + eb * b;
+    out[i] = r[i] * sum - t[i] * (z[i] + cz);
+}
+void q1_coset_pointwise(F *out, const F *r, const F *za, const F *zb, const F *t, const F *z, const F &ca, const F &cb, const F &cz, const F &ea, const F &eb, const F &ec, size_t n, stream_t s) {
+    hipLaunchKernelGGL(k_q1_coset, GRID(n), 0, (hipStream_t)s, out, r, za, zb, t, z, ca, cb, cz, ea, eb, ec, n); HIP_LAUNCH_CHECK();
+}
+// the assignment on H: instance values at the multiples of |H| / |X|, witness values in between (the index map of k_w_evals)
+__global__ void k_z_evals_h(F *__restrict__ out, const uint8_t *__restrict__ z, uint32_t n, uint32_t m, uint32_t num_witness) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t ratio = n / m;
+    uint8_t bit;
+    if (k % ratio == 0) bit = z[k / ratio];
+    else { const uint32_t wi = k - k / ratio - 1; bit = wi < num_witness ? z[m + wi] : 0; }
+    out[k] = bit ? F::one() : F::zero();
+}
+void z_evals_h(F *out, const uint8_t *z, uint32_t n, uint32_t m, uint32_t num_witness, stream_t s) {
+    hipLaunchKernelGGL(k_z_evals_h, GRID(n), 0, (hipStream_t)s, out, z, n, m, num_witness); HIP_LAUNCH_CHECK();
+}
+// q = q_1 - mask = q_lo + X^n q_mid + X^2n q_hi (each of degree < n) has the interpolants Q0 = q_lo + q_mid + q_hi on H, Q1 = q_lo + zeta q_mid - q_hi on W H and
+// Q3 = q_lo - zeta q_mid - q_hi on W^3 H (zeta = W^n, zeta^2 = -1).  Dividing by v_H = X^n - 1 in coefficient space: quotient (q_mid + q_hi) + X^n q_hi, remainder Q0;
+// the mask m_lo + X^n m_mid + X^2n m_hi divides the same way.  h_1 = the quotient (2n coefficients), x g_1 = the remainder (its constant term vanishes: sumcheck).
+__global__ void k_q1_combine(F *__restrict__ h1, F *__restrict__ g1, const F *__restrict__ q0, const F *__restrict__ q1, const F *__restrict__ q3, const F *__restrict__ mask,
+                             F inv2, F inv2zeta, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const F a = q1[i], b = q3[i], c = q0[i];
+    const F q_mid = (a - b) * inv2zeta;
+    const F q_hi = ((c - q_mid) - (a + b) * inv2) * inv2;
+    const F m_lo = mask[i], m_mid = mask[n + i], m_hi = mask[2 * n + i];
+    h1[i] = q_mid + q_hi + m_mid + m_hi;
+    h1[n + i] = q_hi + m_hi;
+    if (i >= 1) g1[i - 1] = c + m_lo + m_mid + m_hi;
+}
+void q1_combine(F *h1, F *g1, const F *q0, const F *q1, const F *q3, const F *mask, const F &inv2, const F &inv2zeta, size_t n, stream_t s) {
+    hipLaunchKernelGGL(k_q1_combine, GRID(n), 0, (hipStream_t)s, h1, g1, q0, q1, q3, mask, inv2, inv2zeta, n); HIP_LAUNCH_CHECK();
 }
 __global__ void k_r3_den(F *__restrict__ den, const F *__restrict__ row, const F *__restrict__ col, F alpha, F beta, size_t k) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

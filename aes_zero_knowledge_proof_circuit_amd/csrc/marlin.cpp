@@ -917,17 +917,33 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     gpu::ntt<F>(poly[4].p, tmp_n.p, n, lg_n, true, s); poly_len[4] = n;
     gpu::ntt<F>(ra_poly.p, ra_ev.p, n, lg_n, true, s);
     gpu::z_poly_from_w(zpoly.p, poly[0].p, poly_len[0], x_poly.p, (uint32_t)m, n, s);
-    gpu::ntt<F>(e[0].p, poly[1].p, n + 1, lg_n4, false, s);
-    gpu::ntt<F>(e[1].p, poly[2].p, n + 1, lg_n4, false, s);
-    gpu::ntt<F>(e[2].p, ra_poly.p, n, lg_n4, false, s);
-    gpu::ntt<F>(e[3].p, poly[4].p, n, lg_n4, false, s);
-    gpu::ntt<F>(e[4].p, zpoly.p, n + 1, lg_n4, false, s);
-    gpu::q1_pointwise(e[2].p, e[0].p, e[1].p, e[3].p, e[4].p, eta_a, eta_b, eta_c, n4, s);
-    gpu::ntt<F>(big_tmp.p, e[2].p, n4, lg_n4, true, s);
-    gpu::poly_axpy(big_tmp.p, poly[3].p, Fr::one(), 3 * n, s);               // q_1 = mask + rhs  (degree <= 3|H| - 1)
-    gpu::divide_by_vanishing(poly[6].p, e[0].p, big_tmp.p, 3 * n, n, s);     // h_1 (2|H| coeffs), remainder = x * g_1
-    poly_len[6] = 2 * n;
-    gpu::d2d(poly[5].p, e[0].p + 1, (n - 1) * sizeof(F), s); poly_len[5] = n - 1;
+    // q = q_1 - mask = r(alpha, X) (eta_A z_A + eta_B z_B + eta_C z_A z_B) - t z has degree < 3|H|; instead of five zero-padded transforms to the 4|H| domain, a pointwise
+    // product there and a 4|H|-point inverse (18 passes over 4|H| elements), it is taken on THREE cosets of H inside that domain: on H itself every factor is already known
+    // (the evaluation vectors of round 1 -- the blinding terms rho v_H vanish there), on W H and W^3 H (W the 4|H|-th root) each factor costs one |H|-point coset transform, where
+    // rho (X^|H| - 1) is the constant rho (zeta^c - 1), zeta = W^|H|.  Three |H|-point inverses give the interpolants Q0, Q1, Q3; q_1_combine solves for q's three |H|-coefficient
+    // thirds and divides by v_H = X^|H| - 1 in coefficient space, mask included: 13 |H|-point transforms (26 passes over |H| elements), no 4|H| buffer traffic, no division kernel.
+    {
+        const Fr zeta = domain_gen(lg_n4).pow_u64(n);                    // primitive 4th root of unity
+        const Fr inv2 = Fr::from_u64(2).inverse(), inv2zeta = (zeta + zeta).inverse(), zero = Fr::zero();
+        F *Q0 = e[1].p, *Q1 = e[1].p + n, *Q3 = e[1].p + 2 * n;
+        F *cA = e[2].p, *cB = e[2].p + n, *cR = e[2].p + 2 * n, *cT = e[2].p + 3 * n, *cZ = e[3].p, *cq = e[3].p + n;
+        gpu::z_evals_h(cZ, d_z, (uint32_t)n, (uint32_t)m, (uint32_t)c.num_witness, s);
+        gpu::q1_coset_pointwise(cq, ra_ev.p, za_ev.p, zb_ev.p, tmp_n.p, cZ, zero, zero, zero, eta_a, eta_b, eta_c, n, s);
+        gpu::ntt<F>(Q0, cq, n, lg_n, true, s);
+        for (int cs : {1, 3}) {
+            const Fr zc = cs == 1 ? zeta : zeta.neg();                   // zeta^cs: the value of X^|H| on the coset
+            gpu::ntt_coset<F>(cA, poly[1].p, n, lg_n, false, cs, lg_n4, s);
+            gpu::ntt_coset<F>(cB, poly[2].p, n, lg_n, false, cs, lg_n4, s);
+            gpu::ntt_coset<F>(cR, ra_poly.p, n, lg_n, false, cs, lg_n4, s);
+            gpu::ntt_coset<F>(cT, poly[4].p, n, lg_n, false, cs, lg_n4, s);
+            gpu::ntt_coset<F>(cZ, zpoly.p, n, lg_n, false, cs, lg_n4, s);
+            // the coefficient of X^|H| (rho of z_A, z_B; rho_w for z = w v_X + x) contributes rho zeta^cs everywhere on the coset
+            gpu::q1_coset_pointwise(cq, cR, cA, cB, cT, cZ, rhos[1] * zc, rhos[2] * zc, rhos[0] * zc, eta_a, eta_b, eta_c, n, s);
+            gpu::ntt_coset<F>(cs == 1 ? Q1 : Q3, cq, n, lg_n, true, cs, lg_n4, s);
+        }
+        gpu::q1_combine(poly[6].p, poly[5].p, Q0, Q1, Q3, poly[3].p, inv2, inv2zeta, n, s);     // h_1 (2|H| coefficients), g_1 = remainder / X
+        poly_len[6] = 2 * n; poly_len[5] = n - 1;
+    }
     for (auto &lp : r2) draw_rand(lp, zk);
     {
         Jobs jobs;

@@ -32,6 +32,28 @@ def test_ntt_matches_oracle(zko, api, cid, lg):
         assert api.ntt(cid, data, inverse=inverse) == ref.raw
 
 
+@pytest.mark.parametrize("cid", [377, 381])
+@pytest.mark.parametrize("lg,lg_big,c", [(3, 5, 1), (8, 10, 3), (10, 12, 1), (11, 13, 3), (13, 15, 1), (18, 20, 3), (12, 13, 1)])
+def test_ntt_on_a_coset_matches_the_oracle_transform_of_scaled_coefficients(zko, api, cid, lg, lg_big, c):
+    """ntt_coset (the scaling by g^k rides on the first pass / last store) == the oracle's plain transform of the coefficients scaled by g^k in Python, g = W^c with W
+    the oracle's generator of the 2^lg_big domain; the inverse undoes it.  One-pass (lg <= 10), two- and three-pass plans, both fields, odd cosets of the 4x and 2x domains."""
+    n, p = 1 << lg, zko.FR[cid]
+    coeffs = zko.fr_unpack(rand_fr_mont(n, p, 4000 + lg + c), cid)
+    gb = C.create_string_buffer(32)
+    zko.lib().zko_api_domain_gen(cid, C.c_size_t(1 << lg_big), gb)
+    g = pow(zko.fr_unpack(gb.raw, cid)[0], c, p)
+    scaled, pw = [], 1
+    for v in coeffs:
+        scaled.append(v * pw % p)
+        pw = pw * g % p
+    ref = C.create_string_buffer(zko.fr_pack(scaled, cid), 32 * n)
+    assert zko.lib().zko_api_ntt(cid, ref, C.c_size_t(n), 0) == 0
+    data = zko.fr_pack(coeffs, cid)
+    got = api.ntt_coset(cid, data, c, lg_big)
+    assert got == ref.raw
+    assert api.ntt_coset(cid, got, c, lg_big, inverse=True) == data
+
+
 def test_ntt_full_size_roundtrip_and_linearity(zko, api):
     # BASELINE sizes: |K| = 2^20 and the 2^22 product domain; size-independent properties instead of an oracle run
     p = zko.R377
