@@ -131,6 +131,12 @@ class ProvingKey:
         _check(lib().zkaes_pk_debug_fetch(self._p, name.encode(), C.byref(out), C.byref(n)))
         return _take(out, n)
 
+    def serialize_ark_to_file(self, path):
+        """ark-serialize image of the arkworks IndexProverKey (index_vk, matrices, index polynomials + evaluations, committer key) streamed to `path`; returns its size"""
+        n = C.c_uint64()
+        _check(lib().zkaes_pk_serialize_ark_to_file(self._p, os.fsencode(path), C.byref(n)))
+        return int(n.value)
+
     def tables_built(self):
         """(built, bytes): does the key hold the fixed-base window tables of its SRS?"""
         b, n = C.c_int(), C.c_uint64()

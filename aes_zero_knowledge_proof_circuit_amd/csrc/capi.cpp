@@ -216,6 +216,13 @@ int zkaes_pk_info(const zkaes_pk *pk, uint64_t out[12]) {
         out[9] = pk->pk->vk().num_non_zero; out[10] = next_pow2(pk->pk->vk().num_constraints); out[11] = next_pow2(pk->pk->vk().num_non_zero);
     });
 }
+int zkaes_pk_serialize_ark_to_file(const zkaes_pk *pk, const char *path, uint64_t *bytes_written) {
+    return guard([&] {
+        if (!pk || !path) throw std::invalid_argument("null argument");
+        uint64_t n = pk->pk->serialize_ark_to_file(path);
+        if (bytes_written) *bytes_written = n;
+    });
+}
 int zkaes_pk_tables_built(const zkaes_pk *pk, int *built, uint64_t *table_bytes) {
     return guard([&] {
         if (!pk || !built) throw std::invalid_argument("null argument");

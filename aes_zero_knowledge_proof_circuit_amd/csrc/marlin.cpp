@@ -2,6 +2,7 @@
 #include "marlin.hpp"
 #include "../../include/zkaes.h"   // ZKAES_DEFAULT_CONTEXTS
 #include <algorithm>
+#include <cstdio>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -1164,6 +1165,92 @@ Proof ProvingKey::prove_ops(uint32_t x, uint32_t y, const uint8_t *zk_seed) {
     for (int i = 0; i < 8; i++) trace[8 + i] = (uint8_t)(r >> (8 * i));
     return impl->prove(impl->context(0), trace, nullptr, 0, nullptr, zk_seed);
 }
+// ark-serialize 0.3 compressed image of ark_marlin::IndexProverKey<Fr, MarlinKZG10<Bls12_377, DensePolynomial<Fr>>> [RECALL: the pinned ark-marlin fork is not under
+// /root/reference; field order as in arkworks marlin after the joint-matrix arithmetization, ark-poly-commit 0.3.0, ark-poly 0.3.0 -- SURVEY.md A.4 / A.5]:
+//   index_vk         : IndexVerifierKey (serialize_vk_ark)
+//   index_comm_rands : Vec<marlin_pc::Randomness> = u64 len 6, each { rand: kzg10::Randomness { blinding_polynomial: DensePolynomial = Vec<Fr> (empty) }, shifted_rand: None }
+//   index            : Index { index_info (4 x u64), a, b, c : Matrix = Vec<Vec<(Fr, usize)>> (padded, rows in constraint order, entries (coeff 32 B, column u64)),
+//                      joint_arith : { row, col, val_a, val_b, val_c, row_col : LabeledPolynomial { label: String, polynomial: Vec<Fr>, degree_bound: None, hiding_bound: None },
+//                                      evals_on_K : { row, col, row_col, val_a, val_b, val_c : Evaluations { evals: Vec<Fr>, domain: GeneralEvaluationDomain (u8 variant 0 = Radix2,
+//                                      size u64, log_size u32, size_as_field_element, size_inv, group_gen, group_gen_inv, generator_inv) } } } }
+//   committer_key    : marlin_pc::CommitterKey { powers: Vec<G1 compressed>, shifted_powers: Some(Vec<G1>), powers_of_gamma_g: Vec<G1> (3), enforced_degree_bounds: Some(Vec<usize>),
+//                      max_degree: usize }
+// Streamed to a file (0.65 GB for the one-block key, 2.6 GB for a four-block one); the SRS powers are re-made on the device in chunks (the key keeps them only in the
+// Edwards form k_accumulate gathers).  What this buys: `synthesize_keys` here takes seconds where the reference's takes minutes, and the image lets the reference's own CPU
+// `encrypt()` run on a GPU-made key (integration/check_on_cargo_box.sh).
+namespace {
+struct FileSink {
+    FILE *f; uint64_t n = 0; Bytes buf;
+    explicit FileSink(const std::string &path) : f(fopen(path.c_str(), "wb")) { if (!f) throw std::runtime_error("cannot open " + path + " for writing"); }
+    ~FileSink() { if (f) fclose(f); }
+    void flush() { if (!buf.b.empty()) { if (fwrite(buf.b.data(), 1, buf.b.size(), f) != buf.b.size()) throw std::runtime_error("short write (disk full?)"); n += buf.b.size(); buf.b.clear(); } }
+    void maybe_flush() { if (buf.b.size() > (8u << 20)) flush(); }
+    void u32(uint32_t v) { for (int i = 0; i < 4; i++) buf.u8((uint8_t)(v >> (8 * i))); }
+    void fr_vec(const std::vector<Fr> &v, size_t len) { buf.u64(len); for (size_t i = 0; i < len; i++) { buf.field(v[i]); maybe_flush(); } }
+    void label(const char *s) { size_t l = strlen(s); buf.u64(l); buf.put(s, l); }
+};
+Fr fr_from_small(int64_t c) { return c >= 0 ? Fr::from_u64((uint64_t)c) : Fr::from_u64((uint64_t)(-c)).neg(); }
+}  // namespace
+uint64_t ProvingKey::serialize_ark_to_file(const std::string &path) const {
+    ProvingKeyImpl &K = *impl;
+    gpu::set_device(K.device);
+    ProverContext &cx = K.context(0);
+    std::lock_guard<std::mutex> busy(cx.in_use);
+    gpu::stream_t s = cx.stream;
+    FileSink o(path);
+    { auto v = serialize_vk_ark(K.vk); o.buf.put(v.data(), v.size()); }
+    o.buf.u64(6);
+    for (int i = 0; i < 6; i++) { o.buf.u64(0); o.buf.u8(0); }                      // Randomness::empty(): zero blinding polynomial, no shifted_rand
+    o.buf.u64(K.vk.num_variables); o.buf.u64(K.vk.num_constraints); o.buf.u64(K.vk.num_non_zero); o.buf.u64(K.vk.num_instance);
+    for (const CsrMatrix *M : {&K.circuit.A, &K.circuit.B, &K.circuit.C}) {
+        o.buf.u64(M->rows());
+        for (size_t r = 0; r < M->rows(); r++) {
+            o.buf.u64(M->rowptr[r + 1] - M->rowptr[r]);
+            for (uint32_t i = M->rowptr[r]; i < M->rowptr[r + 1]; i++) { o.buf.field(fr_from_small(M->coeff[i])); o.buf.u64(M->col[i]); }
+            o.maybe_flush();
+        }
+    }
+    std::vector<Fr> host(K.k);
+    static const char *labels[6] = {"row", "col", "a_val", "b_val", "c_val", "row_col"};
+    for (int i = 0; i < 6; i++) {                                                  // LabeledPolynomial: label, coefficients (DensePolynomial drops leading zero coefficients), no bounds
+        gpu::d2h(host.data(), K.ix_co[i].p, K.k * sizeof(F), s);
+        size_t len = K.k;
+        while (len && host[len - 1].is_zero()) len--;
+        o.label(labels[i]);
+        o.fr_vec(host, len);
+        o.buf.u8(0); o.buf.u8(0);
+    }
+    const Fr kgen = domain_gen(K.lg_k);
+    for (int i : {0, 1, 5, 2, 3, 4}) {                                             // MatrixEvals field order: row, col, row_col, val_a, val_b, val_c
+        gpu::d2h(host.data(), K.ix_ev[i].p, K.k * sizeof(F), s);
+        o.fr_vec(host, K.k);
+        o.buf.u8(0);                                                               // GeneralEvaluationDomain::Radix2
+        o.buf.u64(K.k); o.u32((uint32_t)K.lg_k);
+        o.buf.field(Fr::from_u64(K.k)); o.buf.field(Fr::from_u64(K.k).inverse()); o.buf.field(kgen); o.buf.field(kgen.inverse()); o.buf.field(K.coset_g_inv);
+    }
+    // committer key: the powers in the standard affine form, re-made on the device chunk by chunk
+    auto write_powers = [&](size_t from, size_t count) {
+        const size_t CH = (size_t)1 << 20;
+        G1A *d = (G1A *)gpu::dmalloc(CH * sizeof(G1A));
+        std::vector<G1A> h(CH);
+        o.buf.u64(count);
+        for (size_t off = 0; off < count; off += CH) {
+            const size_t m_ = std::min(CH, count - off);
+            gpu::fixed_base_powers<Bls377>(d, K.vk.g, K.srs_beta, from + off, m_, s);
+            gpu::d2h(h.data(), d, m_ * sizeof(G1A), s);
+            for (size_t i = 0; i < m_; i++) { o.buf.g1_compressed(h[i]); o.maybe_flush(); }
+        }
+        gpu::dfree(d);
+    };
+    write_powers(0, K.supported_degree + 1);
+    o.buf.u8(1); write_powers(K.lowest_shift, K.bounds[1] + 1);
+    o.buf.u64(3); for (int i = 0; i < 3; i++) o.buf.g1_compressed(K.gamma_powers[i]);
+    o.buf.u8(1); o.buf.u64(2); o.buf.u64(K.bounds[0]); o.buf.u64(K.bounds[1]);
+    o.buf.u64(K.max_degree);
+    o.flush();
+    return o.n;
+}
+
 std::vector<uint8_t> ProvingKey::debug_fetch(const std::string &name) const {
     static const char *pn[9] = {"w", "z_a", "z_b", "mask_poly", "t", "g_1", "h_1", "g_2", "h_2"};
     static const char *in[6] = {"row", "col", "a_val", "b_val", "c_val", "row_col"};

@@ -80,6 +80,8 @@ class ProvingKey {
     std::vector<uint8_t> debug_fetch(const std::string &name) const;
     // were the fixed-base window tables of the SRS built (they are skipped under KEY_NO_TABLES or when device memory is short)?  *bytes = their size
     bool tables_built(uint64_t *bytes = nullptr) const;
+    // ark-serialize (compressed) image of the arkworks IndexProverKey this key corresponds to, streamed to `path`; returns the bytes written (marlin.cpp has the layout)
+    uint64_t serialize_ark_to_file(const std::string &path) const;
     // ONE commitment-sized MSM sharded by point range over ranks, on the prover's own path (the key's SRS on the twisted Edwards model, window tables, one bucket set):
     // sum_i scalars[i] * powers_of_g[offset + i], i < n_local (scalars: host, n_local x 32 B Montgomery Fr), left as ONE XYZZ point (192 B) in device memory at dev_out
     // -- the rank's row of the all-gather; gpu::msm_fold_points_device adds the ranks' rows.  Needs a key with tables.

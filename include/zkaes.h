@@ -177,6 +177,11 @@ int zkaes_msm_fold_window_sums_dev(int curve_id, const void *dev_in, int world, 
  * Needs a key with tables (zkaes_pk_tables_built).  aes_zero_knowledge_proof_circuit_amd/sharding.py msm_sharded_srs_device is this sequence. */
 int zkaes_pk_msm_partial_dev(const zkaes_pk *pk, const uint8_t *scalars, size_t n_local, size_t offset, void *dev_out, size_t dev_out_bytes);
 int zkaes_msm_fold_partials_dev(int curve_id, const void *dev_in, int world, uint8_t *out_xy, int *out_inf);
+/* The proving key as the reference would hold it (src/lib.rs:138-174 returns simpleworks' ProvingKey = ark_marlin::IndexProverKey BY VALUE): its ark-serialize 0.3 compressed
+ * image -- index_vk, index_comm_rands, index (info, the padded matrices A, B, C, the six index polynomials with their evaluations on K), committer key (powers, shifted
+ * powers, powers_of_gamma_g, degree bounds) -- streamed to `path` (0.65 GB for a 16-byte key).  A Rust caller reads it with
+ * IndexProverKey::deserialize_unchecked(BufReader::new(File::open(path)?)) and can run the reference's own CPU encrypt() on a key that was synthesized on the GPU in seconds. */
+int zkaes_pk_serialize_ark_to_file(const zkaes_pk *pk, const char *path, uint64_t *bytes_written);
 /* *built = 1 when the key holds the fixed-base window tables of its SRS (they are skipped under ZKAES_KEY_NO_TABLES, or when device memory would not also hold the
  * default number of prover contexts); *table_bytes (may be NULL) = their size in device memory */
 int zkaes_pk_tables_built(const zkaes_pk *pk, int *built, uint64_t *table_bytes);

@@ -11,6 +11,8 @@
 #    csrc/circuit.cpp).  The first diverging step names the gadget behind the 629,856-vs-866,944 gap; "CONFIRMED" pins the gadget layer.
 # 2. Proof + key formats and the whole Marlin restatement: feeds the committed GPU-made verifying key + proof (tests/golden/gpu_aes16_*.bin) to the
 #    unmodified zk_aes::verify_encryption through integration/rust_verify_harness -- must accept the FIPS-197 ciphertext and reject a flipped one.
+#    With ZKAES_PK_IMAGE=<file made by tools/make_pk_image.py on an MI355X> also the third artefact of SURVEY.md 8 f1: the reference's OWN CPU prover, zk_aes::encrypt
+#    (src/lib.rs:60-114), runs on the GPU-synthesized IndexProverKey image and its proof must verify (rust_verify_harness/src/bin/encrypt_with_gpu_key.rs).
 # 3. The real CPU numbers for BASELINE.md: `cargo criterion --bench benchmark` (reference Makefile:9-10; falls back to `cargo bench`).
 # Every step writes its log under WORKDIR and the script ends with a summary; a failing step does not stop the later ones.
 # ZKAES_CARGO_BOX_DRY_RUN=1 skips everything that needs cargo / git and only runs the log differ on WORKDIR/steps_{16,64}.log (used by
@@ -51,16 +53,20 @@ if [ "$DRY" != "1" ]; then
     printf '\x39\x25\x84\x1d\x02\xdc\x09\xfb\xdc\x11\x85\x97\x19\x6a\x0b\x33' > "$WORK/ct_bad.bin"
     H="$HERE/rust_verify_harness/Cargo.toml"
     G="$REPO/tests/golden"
-    cargo run --release --manifest-path "$H" -- "$G/gpu_aes16_vk_ark.bin" "$G/gpu_aes16_proof.bin" "$WORK/ct_ok.bin" > "$WORK/verify_accept.log" 2>&1
+    cargo run --release --manifest-path "$H" --bin zkaes-verify-harness -- "$G/gpu_aes16_vk_ark.bin" "$G/gpu_aes16_proof.bin" "$WORK/ct_ok.bin" > "$WORK/verify_accept.log" 2>&1
     RESULT[verify_accept]="rc $? (expected 0: the unmodified verifier accepts the GPU-made proof; $WORK/verify_accept.log)"
-    cargo run --release --manifest-path "$H" -- "$G/gpu_aes16_vk_ark.bin" "$G/gpu_aes16_proof.bin" "$WORK/ct_bad.bin" expect-reject > "$WORK/verify_reject.log" 2>&1
+    cargo run --release --manifest-path "$H" --bin zkaes-verify-harness -- "$G/gpu_aes16_vk_ark.bin" "$G/gpu_aes16_proof.bin" "$WORK/ct_bad.bin" expect-reject > "$WORK/verify_reject.log" 2>&1
     RESULT[verify_reject]="rc $? (expected 0: a wrong ciphertext is Ok(false); $WORK/verify_reject.log)"
+    if [ -n "${ZKAES_PK_IMAGE:-}" ]; then
+        cargo run --release --manifest-path "$H" --bin encrypt_with_gpu_key -- "$ZKAES_PK_IMAGE" "${ZKAES_PK_IMAGE}.vk" > "$WORK/encrypt_with_gpu_key.log" 2>&1
+        RESULT[encrypt_with_gpu_key]="rc $? (expected 0: the reference's CPU encrypt() proves with the GPU-made proving key; $WORK/encrypt_with_gpu_key.log)"
+    fi
     ( cd "$WORK/reference" && { cargo criterion --bench benchmark || cargo bench --bench benchmark; } ) > "$WORK/criterion.log" 2>&1
     RESULT[criterion]="rc $? (Encryption/{16,32,64}_message_encryption times for BASELINE.md section 1: $WORK/criterion.log; cores: $(nproc))"
 fi
 
 echo "==== check_on_cargo_box summary ===="
-for k in steps_16 steps_64 verify_accept verify_reject criterion; do
+for k in steps_16 steps_64 verify_accept verify_reject encrypt_with_gpu_key criterion; do
     [ -n "${RESULT[$k]+x}" ] && echo "$k: ${RESULT[$k]}"
 done
 fail=0

@@ -106,6 +106,73 @@ static void by_g1_compressed(bytes *o, const g1a_t *p, const zko_curve *C) {
     if (y_gt) buf[47] |= 1 << 7;
     by_put(o, buf, 48);
 }
+/* ark-serialize image of ark_marlin::IndexProverKey WITHOUT its first field (index_vk: the G2 side lives in the product), streamed to a file -- the checker for the product's
+ * zkaes_pk_serialize_ark_to_file.  Layout [RECALL]: index_comm_rands (6 x empty Randomness), index (info, A, B, C as Vec<Vec<(Fr, usize)>>, six LabeledPolynomials, six
+ * Evaluations in the order row, col, row_col, val_a, val_b, val_c with their Radix2 domain), committer key (powers, Some(shifted_powers), powers_of_gamma_g, Some(bounds), max_degree). */
+static void fl_flush(bytes *o, FILE *f, uint64_t *total, int force) {
+    if (o->n && (force || o->n > (8u << 20))) { if (fwrite(o->b, 1, o->n, f) != o->n) abort(); *total += o->n; o->n = 0; }
+}
+static void by_u32(bytes *o, uint32_t v) { uint8_t t[4]; for (int i = 0; i < 4; i++) t[i] = v >> (8 * i); by_put(o, t, 4); }
+uint64_t zko_pk_serialize_ark_to_file(const zko_index *ix, const char *path) {
+    const zko_curve *C = ix->ck.C;
+    const fr_params *F = C->fr;
+    FILE *f = fopen(path, "wb");
+    if (!f) return 0;
+    bytes o = {0};
+    uint64_t total = 0;
+    by_u64(&o, 6);
+    for (int i = 0; i < 6; i++) { by_u64(&o, 0); uint8_t z = 0; by_put(&o, &z, 1); }
+    by_u64(&o, ix->num_variables); by_u64(&o, ix->num_constraints); by_u64(&o, ix->num_non_zero); by_u64(&o, ix->num_instance);
+    const zko_mat *M[3] = {&ix->cs->A, &ix->cs->B, &ix->cs->C};
+    for (int q = 0; q < 3; q++) {
+        by_u64(&o, M[q]->n);
+        for (size_t r = 0; r < M[q]->n; r++) {
+            by_u64(&o, M[q]->rowptr[r + 1] - M[q]->rowptr[r]);
+            for (size_t i = M[q]->rowptr[r]; i < M[q]->rowptr[r + 1]; i++) {
+                fr_t c; fr_from_i64(&c, M[q]->coeff[i], F);
+                by_fr(&o, &c, F);
+                uint32_t v = M[q]->var[i];
+                by_u64(&o, v < ZKO_WIT_BASE ? v : (uint64_t)ix->cs->num_instance + (v - ZKO_WIT_BASE));
+            }
+            fl_flush(&o, f, &total, 0);
+        }
+    }
+    const zko_poly *P[6] = {&ix->row, &ix->col, &ix->val_a, &ix->val_b, &ix->val_c, &ix->row_col};
+    static const char *labels[6] = {"row", "col", "a_val", "b_val", "c_val", "row_col"};
+    for (int i = 0; i < 6; i++) {
+        size_t len = P[i]->len;
+        while (len && fr_is_zero(&P[i]->c[len - 1])) len--;
+        by_u64(&o, strlen(labels[i])); by_put(&o, labels[i], strlen(labels[i]));
+        by_u64(&o, len);
+        for (size_t j = 0; j < len; j++) { by_fr(&o, &P[i]->c[j], F); fl_flush(&o, f, &total, 0); }
+        uint8_t none[2] = {0, 0}; by_put(&o, none, 2);
+    }
+    const fr_t *E[6] = {ix->row_evals, ix->col_evals, ix->row_col_evals, ix->val_a_evals, ix->val_b_evals, ix->val_c_evals};
+    fr_t cg_inv; fr_inv(&cg_inv, &ix->K.coset_gen, F);
+    for (int i = 0; i < 6; i++) {
+        by_u64(&o, ix->K.size);
+        for (size_t j = 0; j < ix->K.size; j++) { by_fr(&o, &E[i][j], F); fl_flush(&o, f, &total, 0); }
+        uint8_t radix2 = 0; by_put(&o, &radix2, 1);
+        by_u64(&o, ix->K.size); by_u32(&o, (uint32_t)ix->K.log_size);
+        by_fr(&o, &ix->K.size_as_fe, F); by_fr(&o, &ix->K.size_inv, F); by_fr(&o, &ix->K.gen, F); by_fr(&o, &ix->K.gen_inv, F); by_fr(&o, &cg_inv, F);
+    }
+    const zko_ck *ck = &ix->ck;
+    by_u64(&o, ck->supported_degree + 1);
+    for (size_t i = 0; i <= ck->supported_degree; i++) { by_g1_compressed(&o, &ck->powers[i], C); fl_flush(&o, f, &total, 0); }
+    { uint8_t some = 1; by_put(&o, &some, 1); }
+    const size_t nshift = ck->max_degree - ck->lowest_shift + 1;
+    by_u64(&o, nshift);
+    for (size_t i = 0; i < nshift; i++) { by_g1_compressed(&o, &ck->shifted_powers[i], C); fl_flush(&o, f, &total, 0); }
+    by_u64(&o, 3);
+    for (int i = 0; i < 3; i++) by_g1_compressed(&o, &ck->gamma_powers[i], C);
+    { uint8_t some = 1; by_put(&o, &some, 1); }
+    by_u64(&o, 2); by_u64(&o, ck->bounds[0]); by_u64(&o, ck->bounds[1]);
+    by_u64(&o, ck->max_degree);
+    fl_flush(&o, f, &total, 1);
+    free(o.b);
+    fclose(f);
+    return total;
+}
 size_t zko_proof_serialize(const zko_proof *p, const zko_curve *C, uint8_t *out, size_t cap) {
     bytes o = {0};
     static const int round_len[3] = {4, 3, 2};

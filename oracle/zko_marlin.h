@@ -50,6 +50,8 @@ zko_proof *zko_marlin_prove(const zko_index *ix, zko_cs *cs, const uint8_t *zk_s
 void zko_proof_free(zko_proof *p);
 /* ark-serialize 0.3 compressed layout of ark_marlin::Proof; returns length, writes into out (cap bytes) */
 size_t zko_proof_serialize(const zko_proof *p, const zko_curve *C, uint8_t *out, size_t cap);
+/* ark-serialize image of ark_marlin::IndexProverKey minus its first field (index_vk), streamed to `path`; returns the bytes written (0 = cannot open) */
+uint64_t zko_pk_serialize_ark_to_file(const zko_index *ix, const char *path);
 /* IndexVerifierKey pieces the product verifier needs are serialized by the product itself; for tests: */
 void zko_commit_plain(g1a_t *out, const zko_ck *ck, const fr_t *coeffs, size_t len, size_t power_offset_in_shifted, int use_shifted);
 #endif

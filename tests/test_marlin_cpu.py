@@ -254,3 +254,71 @@ def test_vk_ark_roundtrip_verifies_and_rejects_garbage(zko, api, xor_setup):
     flipped = bytearray(raw)
     flipped[40 + 6 * 49 + 96 + 95] ^= 0x80               # sign flag of h: -h is a valid point, the pairing check must now fail
     assert api.VerifyingKey.from_ark_bytes(bytes(flipped)).verify(proof, b"") is False
+
+
+def _parse_pk_image(raw, p, expect_vk_prefix=0):
+    """walk the ark-serialize IndexProverKey image after its index_vk prefix; returns a dict of what it holds and checks that the file ends exactly"""
+    import struct
+    pos = [expect_vk_prefix]
+
+    def u64():
+        v = struct.unpack_from("<Q", raw, pos[0])[0]; pos[0] += 8; return v
+
+    def u8():
+        v = raw[pos[0]]; pos[0] += 1; return v
+
+    def fr():
+        v = int.from_bytes(raw[pos[0]:pos[0] + 32], "little"); pos[0] += 32; assert v < p; return v
+    out = {}
+    assert u64() == 6
+    for _ in range(6):
+        assert u64() == 0 and u8() == 0                       # empty blinding polynomial, no shifted_rand
+    out["info"] = [u64() for _ in range(4)]
+    out["nnz"] = []
+    for _ in range(3):
+        rows = u64(); nnz = 0
+        for _ in range(rows):
+            k = u64()
+            for _ in range(k):
+                fr(); col = u64(); assert col < out["info"][0]; nnz += 1
+        assert rows == out["info"][1]
+        out["nnz"].append(nnz)
+    out["labels"] = []
+    for _ in range(6):
+        n = u64(); out["labels"].append(raw[pos[0]:pos[0] + n].decode()); pos[0] += n
+        ln = u64(); pos[0] += 32 * ln; assert u8() == 0 and u8() == 0
+    for _ in range(6):
+        k = u64(); pos[0] += 32 * k
+        assert u8() == 0 and u64() == k
+        lg = struct.unpack_from("<I", raw, pos[0])[0]; pos[0] += 4; assert 1 << lg == k
+        size_fe, size_inv, gen, gen_inv, cg_inv = fr(), fr(), fr(), fr(), fr()
+        assert size_fe == k and size_fe * size_inv % p == 1 and gen * gen_inv % p == 1 and pow(gen, k, p) == 1 and pow(gen, k // 2, p) == p - 1
+        out["k"] = k; out["coset_gen_inv"] = cg_inv
+    npow = u64(); pos[0] += 48 * npow
+    assert u8() == 1
+    nshift = u64(); pos[0] += 48 * nshift
+    assert u64() == 3; pos[0] += 48 * 3
+    assert u8() == 1 and u64() == 2
+    out["bounds"] = [u64(), u64()]
+    out["max_degree"] = u64()
+    out["powers"], out["shifted"] = npow, nshift
+    assert pos[0] == len(raw), (pos[0], len(raw))
+    return out
+
+
+def test_oracle_pk_image_of_the_xor_circuit_is_well_formed(zko, tmp_path):
+    """the checker's ark-serialize IndexProverKey writer (oracle/zko_marlin.c) on the src/ops.rs xor gate: every length field adds up, the Radix2 domain fields are
+    consistent, labels and field order as ark-marlin's joint arithmetization [RECALL], the file ends where the committer key ends"""
+    cs, _ = zko.synth_ops("xor", 0, 0, field=377)
+    ix = zko.Index(cs, srs=(200, 200, 600))
+    path = str(tmp_path / "pk_xor.bin")
+    size = ix.pk_serialize_ark_to_file(path)
+    raw = open(path, "rb").read()
+    assert size == len(raw) > 0
+    got = _parse_pk_image(raw, zko.R377)
+    info = ix.info()
+    assert got["info"] == [info["num_variables"], info["num_constraints"], info["num_non_zero"], info["num_instance"]]
+    assert got["labels"] == ["row", "col", "a_val", "b_val", "c_val", "row_col"] and got["k"] == info["k"]
+    assert got["powers"] == info["supported_degree"] + 1 and got["max_degree"] == info["max_degree"]
+    assert got["bounds"] == sorted([info["h"] - 2, info["k"] - 2]) and got["shifted"] == max(got["bounds"]) + 1
+    assert got["coset_gen_inv"] * 22 % zko.R377 == 1            # Fr377's multiplicative generator
