@@ -37,14 +37,6 @@ def api():
         from aes_zero_knowledge_proof_circuit_amd import build
         build.build()
     m.lib()
-    # torch bundles its own copy of the HIP runtime: in a process where libzkaes' runtime (/opt/rocm) already holds the device, torch's first CUDA call has been seen to
-    # report "No HIP GPUs are available" -- so on a GPU box torch initialises FIRST (bench.py does the same: torch.cuda.set_device before the first libzkaes call)
-    try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    except Exception:
-        pass
     return m
 
 
