@@ -49,6 +49,10 @@ template <class Fr> void ntt(Fr *dst, const Fr *src, size_t in_len, int lg, bool
 // forward: dst[i] = p(g w^i) for the coefficients src[0 .. in_len); inverse: the coefficients of the polynomial of degree < 2^lg with those values.  No extra pass: the scaling
 // by g^(+-k) rides on the first pass's gather / the last pass's store.  (Together, cosets 0 .. 2^(lg_big - lg) - 1 are the larger domain.)
 template <class Fr> void ntt_coset(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, int coset_c, int lg_big, stream_t s);
+// A coset whose generator g is not a root of unity (round 3 uses the field's multiplicative generator): coset_power_table builds g^i (i < n) once per key in the kernel's
+// reduced-radix form (free with dfree); ntt_scaled(.., table of g^i) evaluates on g D, ntt_scaled(.., inverse = true, table of g^-i) interpolates from there.
+template <class Fr> void *coset_power_table(const Fr &g, size_t n, stream_t s);
+template <class Fr> void ntt_scaled(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, const void *table, stream_t s);
 template <class Fr> const Fr *domain_elements(int lg);   // device table g^i, i < 2^lg  (built lazily)
 
 // ---- MSM (kernels_msm.hip): sum_i scalars[i] * bases[i]; scalars in Montgomery form; result returned to the host (syncs the stream)

@@ -3,8 +3,8 @@
 // Replaces ark-ec 0.3.0 VariableBaseMSM::multi_scalar_mul (one rayon task per window, Cargo.lock:118) behind
 // KZG10::commit / open (ark-poly-commit 0.3.0) -- SURVEY.md §8 a17.  GPU shape:
 //   1. k_digits      : scalars Montgomery -> canonical, split into c-bit window digits, emit (window|digit, index) pairs
-//   2. grouping      : table mode: the digit kernels split the pairs stably on the low 3 bucket bits (k_split_*), rocPRIM's radix sort does the other 16 in two passes;
-//                      per-window mode: one stable radix sort on the bucket bits over all windows at once
+//   2. grouping      : table mode: a two-level bucket partition written for this layout and for instruction count (k_part_*); per-window mode and small instances:
+//                      one stable rocPRIM radix sort on the bucket bits over all windows at once
 //   3. k_bounds      : bucket [start, end) ranges in the sorted pair list (empty buckets filled in on the way: nothing is memset)
 //      k_order_*     : visiting order of the buckets by descending size (counting sort, deterministic) + the list of oversized buckets
 //   4. k_accumulate  : ONE LANE PER BUCKET, XYZZ accumulator, mixed adds of affine bases gathered through the sorted
@@ -527,7 +527,8 @@ struct MsmWorkspace {
     uint32_t *sorted_keys = nullptr, *sorted_vals = nullptr;      // whichever half of the double buffers the radix sort finished in
     uint32_t *order = nullptr, *ovf_slot = nullptr;               // per bucket: visiting order, slot in the overflow list (NO_SLOT for all but oversized buckets)
     uint32_t *ovf_bucket = nullptr, *ovf_nseg = nullptr, *ovf_off = nullptr; void *ovf_partial = nullptr; size_t cap_ovf = 0;    // overflow list + the segments' partial sums
-    uint32_t *split_hist = nullptr, *split_offs = nullptr; size_t cap_split = 0;   // pre-split digits: (class, window, block) counts and their scan
+    uint32_t *part_hist = nullptr, *part_offs = nullptr; size_t cap_part = 0;      // two-level partition: (coarse bin, workgroup) counts and their scan
+    uint32_t *dig = nullptr; size_t cap_dig = 0;                                   // two-level partition: 16 digit words per scalar
     uint32_t *ord_hist = nullptr, *ord_offs = nullptr;            // ORD_BINS x ORD_MAX_BLOCKS counts and their scan
     uint32_t *ctrl = nullptr;                                     // 8 control words (see k_order_hist); armed at zero between MSMs
     bool ctrl_dirty = false;                                      // an exception left the order pass half done: re-arm ctrl before the next one
@@ -576,7 +577,7 @@ MsmWorkspace *msm_workspace_create() { return new MsmWorkspace(); }
 void msm_workspace_destroy(MsmWorkspace *w) {
     if (!w) return;
     for (void *p : {(void *)w->keys_a, (void *)w->keys_b, (void *)w->vals_a, (void *)w->vals_b, (void *)w->start, (void *)w->end, (void *)w->order, (void *)w->ovf_slot,
-                    (void *)w->ovf_bucket, (void *)w->ovf_nseg, (void *)w->ovf_off, w->ovf_partial, (void *)w->split_hist, (void *)w->split_offs, (void *)w->ord_hist, (void *)w->ord_offs,
+                    (void *)w->ovf_bucket, (void *)w->ovf_nseg, (void *)w->ovf_off, w->ovf_partial, (void *)w->part_hist, (void *)w->part_offs, (void *)w->dig, (void *)w->ord_hist, (void *)w->ord_offs,
                     (void *)w->ctrl, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->tmp}) dfree(p);
     if (w->h_res) (void)hipHostFree(w->h_res);
     if (w->ev0) { (void)hipEventDestroy(w->ev0); (void)hipEventDestroy(w->ev1); }
@@ -952,24 +953,38 @@ void table_next(Affine<typename Curve::Fq> *next, const Affine<typename Curve::F
     HIP_LAUNCH_CHECK();
 }
 
-// ---- Pre-split digits: one radix pass less for the table path, with the (window, point index) order inside buckets intact.
-// An LSD radix sort on bucket bits [0, B) is the same as a STABLE split on the low SB = B - 16 bits followed by a stable sort on bits [SB, B).  The digit
-// kernel can do that split itself while it writes the pairs: two launches over the scalars (32 B each) -- k_split_hist counts, per (class = low bits,
-// window, 256-scalar block), how many pairs there are; one scan turns the counts into positions; k_split_scatter recodes the digits again and writes every
-// pair to  position(class, window, block) + its rank inside the block (wave ballots + per-wave counts: stable) -- ~32-element runs per class and window.
-// The radix sort then only covers bits [SB, B): 16 bits = two 8-bit passes instead of three over the 8-byte pairs (7.4 GB less traffic per 6-block proof).
-constexpr int SPLIT_THREADS = 256, SPLIT_WAVES = SPLIT_THREADS / 64, SPLIT_MAXW = 16, SPLIT_MAXCLS = 8;
-// digit words of scalar g: d[w] = bucket | neg << 31 | skip << 30 for w < nwin
+// ---- Two-level bucket partition: the table path's grouping (digits -> bucket-contiguous value list + bucket ranges), written for INSTRUCTION count.
+// Per-kernel VALU accounting of a proof (profiles/r04_valu_by_kernel_mid_round.md) shows the saturated prover is VALU-issue bound as a whole -- k_accumulate already issues at
+// the pipe's limit, so every other kernel costs its instruction count -- and that the generic route (digit kernels that pre-split on 3 bits with wave ballots + two rocPRIM
+// onesweep passes, whose stable ranking is a chain of match-any ballots per item) spent ~470 lane-instructions per (point, window) pair, 13 % of what the bucket
+// additions themselves take.  Nothing here needs a stable sort -- only "bucket-contiguous, and inside a bucket by window" (the lanes of a wave then gather from the same
+// table copy, which the round-3 partition got wrong: 5.7 % slower accumulation) -- so ranks come from LDS atomics, ~70 lane-instructions per pair:
+//   k_part_hist    : one pass over the scalars: window digits (Montgomery -> canonical, carry recoding) stored as 16 words per scalar, LDS histogram of the pairs over the
+//                    COARSE bins (the high bucket bits, <= 1024 bins); fixed tiling over a fixed grid, counts written per (bin, workgroup)
+//   one scan       : every (bin, workgroup) gets its range -- no global atomics, deterministic
+//   k_part_scatter : same tiling, digits re-read (not recomputed): a tile's pairs are ranked by LDS atomics into bin-contiguous runs staged in LDS and written out as
+//                    (value, 13-bit key = fine bucket bits x 16 + window)
+//   k_part_fine    : one workgroup per coarse bin: LDS counts of its 8,192 (fine bucket, window) keys, in-place scan, bucket [start, end) ranges (what k_bounds used to
+//                    find), values scattered to their final place through LDS cursors
+// Zero digits are not emitted.  Skewed scalars (few distinct digits) only make some workgroups of the last pass long; oversized buckets still go through the overflow list.
+constexpr int PART_FINE_BITS = 9, PART_FINE = 1 << PART_FINE_BITS, PART_WBITS = 4, PART_KEYS = PART_FINE << PART_WBITS;
+constexpr int PART_THREADS = 512, PART_SPT = 2, PART_TILE = PART_THREADS * PART_SPT;      // scalars per tile
+constexpr int PART_MAXW = 1 << PART_WBITS;                                                // windows per scalar (c_hi >= 16)
+constexpr int PART_STAGE = PART_TILE * PART_MAXW;                                         // staged pairs per tile (LDS: 8 B each = 128 KB)
+constexpr uint32_t PART_NBIN_MAX = 1024;                                                  // coarse bins (bucket bits <= 19, i.e. c_hi <= 20)
+constexpr uint32_t PART_GRID = 512, PART_NONE = 0xffffffffu;
+constexpr int PART_FINE_THREADS = 1024, PART_FINE_UNROLL = 4;     // the last pass is latency-bound (load -> LDS atomic -> scattered store): many lanes per bin, several loads in flight per lane
+
+// signed window digits of one scalar: d[w] = (|digit| - 1) | neg << 31, PART_NONE for a zero digit or w >= nwin
 template <class Fr>
-__device__ __forceinline__ uint32_t split_digits(const Fr *__restrict__ s1, uint32_t n1, uint32_t off1, const Fr *__restrict__ s2, uint32_t off2, uint32_t g, const TableLayout &L, uint32_t d[SPLIT_MAXW]) {
+__device__ __forceinline__ void part_recode(const Fr &sc, const TableLayout &L, uint32_t d[PART_MAXW]) {
     uint32_t raw[Fr::N + 1];
-    uint32_t base;
-    if (g < n1) { s1[g].to_raw(raw); base = off1 + g; } else { s2[g - n1].to_raw(raw); base = off2 + (g - n1); }
+    sc.to_raw(raw);
     raw[Fr::N] = 0;
     uint32_t carry = 0;
 #pragma unroll
-    for (int w = 0; w < SPLIT_MAXW; w++) {
-        d[w] = VAL_SKIP;
+    for (int w = 0; w < PART_MAXW; w++) {
+        d[w] = PART_NONE;
         if (w < L.nwin) {
             const int c = L.width(w), bit = L.offset(w), limb = bit >> 5, sh = bit & 31;
             const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
@@ -981,79 +996,159 @@ __device__ __forceinline__ uint32_t split_digits(const Fr *__restrict__ s1, uint
             if (v) d[w] = (v - 1) | neg;
         }
     }
-    return base;
 }
-// lanes of the wave whose class equals this lane's (inactive lanes pass cls = ~0 and match nobody active): one ballot per class bit
-__device__ __forceinline__ uint64_t split_same_class(uint32_t cls, int split_bits, bool active) {
-    uint64_t same = __ballot(active);
-    for (int b = 0; b < split_bits; b++) {
-        uint64_t m = __ballot(active && ((cls >> b) & 1));
-        same &= ((cls >> b) & 1) ? m : ~m;
-    }
-    return same;
-}
-template <class Fr>
-__global__ void __launch_bounds__(SPLIT_THREADS) k_split_hist(const Fr *__restrict__ s1, uint32_t n1, uint32_t off1, const Fr *__restrict__ s2, uint32_t n2, uint32_t off2, TableLayout L,
-                                                              int split_bits, uint32_t nblocks, uint32_t *__restrict__ hist) {
-    __shared__ uint32_t cnt[SPLIT_MAXW * SPLIT_MAXCLS];
-    const uint32_t n = n1 + n2, g = blockIdx.x * SPLIT_THREADS + threadIdx.x, ncls = 1u << split_bits, cmask = ncls - 1, lane = threadIdx.x & 63;
-    for (uint32_t i = threadIdx.x; i < SPLIT_MAXW * SPLIT_MAXCLS; i += SPLIT_THREADS) cnt[i] = 0;
+// block-wide exclusive scan of `len` LDS counters (len a multiple of the block size) IN PLACE; the total goes to *total_out (LDS).  Ends with a barrier.
+template <int THREADS>
+__device__ __forceinline__ void part_block_scan(uint32_t *cnt, uint32_t len, uint32_t *wave_sums, uint32_t *total_out) {
+    const uint32_t per = len / THREADS, t = threadIdx.x, base = t * per;
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < per; i++) sum += cnt[base + i];
+    uint32_t incl = sum;                                     // inclusive scan across the 64 lanes of the wave
+    for (int d = 1; d < 64; d <<= 1) { uint32_t v = __shfl_up(incl, d, 64); if ((int)(t & 63) >= d) incl += v; }
+    if ((t & 63) == 63) wave_sums[t >> 6] = incl;
     __syncthreads();
-    uint32_t d[SPLIT_MAXW];
-    const bool active = g < n;
-    if (active) split_digits<Fr>(s1, n1, off1, s2, off2, g, L, d);
-    const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
-#pragma unroll
-    for (int w = 0; w < SPLIT_MAXW; w++) {
-        if (w < L.nwin) {
-            const uint32_t cls = active ? ((d[w] & VAL_SKIP) ? 0u : (d[w] & cmask)) : 0u;
-            const uint64_t same = split_same_class(cls, split_bits, active);
-            if (active && (same & lt) == 0) atomicAdd(&cnt[w * SPLIT_MAXCLS + cls], (uint32_t)__popcll(same));        // the first lane of every class present in the wave
-        }
-    }
+    uint32_t run = incl - sum;
+    for (uint32_t w = 0; w < (t >> 6); w++) run += wave_sums[w];
+    for (uint32_t i = 0; i < per; i++) { const uint32_t c = cnt[base + i]; cnt[base + i] = run; run += c; }
+    if (t == THREADS - 1) *total_out = run;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < (uint32_t)L.nwin * ncls; i += SPLIT_THREADS) {
-        const uint32_t w = i / ncls, k = i % ncls;
-        hist[((size_t)k * L.nwin + w) * nblocks + blockIdx.x] = cnt[w * SPLIT_MAXCLS + k];          // class-major, then window, then block: the order of the split
-    }
 }
 template <class Fr>
-__global__ void __launch_bounds__(SPLIT_THREADS) k_split_scatter(const Fr *__restrict__ s1, uint32_t n1, uint32_t off1, const Fr *__restrict__ s2, uint32_t n2, uint32_t off2, TableLayout L,
-                                                                 uint32_t stride, int split_bits, uint32_t nblocks, const uint32_t *__restrict__ offs, uint32_t *__restrict__ keys,
-                                                                 uint32_t *__restrict__ vals) {
-    __shared__ uint32_t wc[SPLIT_MAXW][SPLIT_WAVES][SPLIT_MAXCLS];
-    const uint32_t n = n1 + n2, g = blockIdx.x * SPLIT_THREADS + threadIdx.x, cmask = (1u << split_bits) - 1;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (uint32_t i = threadIdx.x; i < SPLIT_MAXW * SPLIT_WAVES * SPLIT_MAXCLS; i += SPLIT_THREADS) (&wc[0][0][0])[i] = 0;
+__global__ void __launch_bounds__(PART_THREADS) k_part_hist(const Fr *__restrict__ s1, uint32_t n1, const Fr *__restrict__ s2, uint32_t n2, TableLayout L, uint32_t nbin,
+                                                            uint32_t *__restrict__ dig, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t sh[PART_NBIN_MAX];
+    for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) sh[b] = 0;
     __syncthreads();
-    uint32_t d[SPLIT_MAXW], rank[SPLIT_MAXW];
-    const bool active = g < n;
-    uint32_t base = 0;
-    if (active) base = split_digits<Fr>(s1, n1, off1, s2, off2, g, L, d);
-    const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    // every workgroup takes a CONTIGUOUS range of tiles: a bin's list then runs in (roughly) scalar-index order, which the last pass keeps inside each (bucket, window) group
+    const uint32_t n = n1 + n2, ntiles = (n + PART_TILE - 1) / PART_TILE, per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
+    const uint32_t tile_lo = blockIdx.x * per_wg, tile_hi = tile_lo + per_wg < ntiles ? tile_lo + per_wg : ntiles;
+    for (uint32_t tile = tile_lo; tile < tile_hi; tile++)
+        for (int q = 0; q < PART_SPT; q++) {
+            const uint32_t g = tile * PART_TILE + q * PART_THREADS + threadIdx.x;
+            if (g >= n) continue;
+            uint32_t d[PART_MAXW];
+            part_recode<Fr>(g < n1 ? s1[g] : s2[g - n1], L, d);
 #pragma unroll
-    for (int w = 0; w < SPLIT_MAXW; w++) {
-        rank[w] = 0;
-        if (w < L.nwin) {
-            const uint32_t cls = active ? ((d[w] & VAL_SKIP) ? 0u : (d[w] & cmask)) : 0u;
-            const uint64_t same = split_same_class(cls, split_bits, active);
-            rank[w] = (uint32_t)__popcll(same & lt);                                   // stable: lanes of a class keep their order
-            if (active && rank[w] == 0) wc[w][wave][cls] = (uint32_t)__popcll(same);
+            for (int w = 0; w < PART_MAXW; w++) if (d[w] != PART_NONE) atomicAdd(&sh[(d[w] & 0x7fffffffu) >> PART_FINE_BITS], 1u);
+            uint4 *dst = reinterpret_cast<uint4 *>(dig + (size_t)g * PART_MAXW);
+#pragma unroll
+            for (int k = 0; k < PART_MAXW / 4; k++) dst[k] = make_uint4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
         }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) hist[(size_t)b * gridDim.x + blockIdx.x] = sh[b];      // bin-major: the scan gives every (bin, workgroup) its range
+    if (blockIdx.x == 0 && threadIdx.x == 0) hist[(size_t)nbin * gridDim.x] = 0;                                       // the scan's last entry = the number of pairs
+}
+__global__ void __launch_bounds__(PART_THREADS) k_part_scatter(const uint32_t *__restrict__ dig, uint32_t n, uint32_t n1, uint32_t off1, uint32_t off2, uint32_t stride, uint32_t nbin,
+                                                               const uint32_t *__restrict__ offs, uint32_t *__restrict__ out_val, uint16_t *__restrict__ out_key) {
+    __shared__ uint32_t cursor[PART_NBIN_MAX], cnt[PART_NBIN_MAX], fill[PART_NBIN_MAX], st_val[PART_STAGE], st_key[PART_STAGE];
+    __shared__ uint32_t wave_sums[PART_THREADS / 64], total;
+    for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) cursor[b] = offs[(size_t)b * gridDim.x + blockIdx.x];
+    const uint32_t ntiles = (n + PART_TILE - 1) / PART_TILE, per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
+    const uint32_t tile_lo = blockIdx.x * per_wg, tile_hi = tile_lo + per_wg < ntiles ? tile_lo + per_wg : ntiles;
+    for (uint32_t tile = tile_lo; tile < tile_hi; tile++) {
+        for (uint32_t b = threadIdx.x; b < PART_NBIN_MAX; b += PART_THREADS) { cnt[b] = 0; fill[b] = 0; }
+        __syncthreads();
+        uint32_t d[PART_SPT][PART_MAXW];
+#pragma unroll
+        for (int q = 0; q < PART_SPT; q++) {
+            const uint32_t g = tile * PART_TILE + q * PART_THREADS + threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < PART_MAXW / 4; k++) {
+                uint4 v = make_uint4(PART_NONE, PART_NONE, PART_NONE, PART_NONE);
+                if (g < n) v = reinterpret_cast<const uint4 *>(dig + (size_t)g * PART_MAXW)[k];
+                d[q][4 * k] = v.x; d[q][4 * k + 1] = v.y; d[q][4 * k + 2] = v.z; d[q][4 * k + 3] = v.w;
+            }
+#pragma unroll
+            for (int w = 0; w < PART_MAXW; w++) if (d[q][w] != PART_NONE) atomicAdd(&cnt[(d[q][w] & 0x7fffffffu) >> PART_FINE_BITS], 1u);
+        }
+        __syncthreads();
+        part_block_scan<PART_THREADS>(cnt, PART_NBIN_MAX, wave_sums, &total);           // cnt[b] = the tile-local start of bin b
+#pragma unroll
+        for (int q = 0; q < PART_SPT; q++) {
+            const uint32_t g = tile * PART_TILE + q * PART_THREADS + threadIdx.x;
+            const uint32_t base = g < n1 ? off1 + g : off2 + (g - n1);
+#pragma unroll
+            for (int w = 0; w < PART_MAXW; w++) {
+                if (d[q][w] == PART_NONE) continue;
+                const uint32_t bucket = d[q][w] & 0x7fffffffu, bin = bucket >> PART_FINE_BITS;
+                const uint32_t e = cnt[bin] + atomicAdd(&fill[bin], 1u);
+                st_val[e] = ((uint32_t)w * stride + base) | (d[q][w] & 0x80000000u);
+                st_key[e] = bucket | ((uint32_t)w << 20);
+            }
+        }
+        __syncthreads();
+        const uint32_t tot = total;
+        for (uint32_t e = threadIdx.x; e < tot; e += PART_THREADS) {                      // bin-contiguous runs: consecutive lanes write consecutive addresses
+            const uint32_t key = st_key[e], bucket = key & 0xfffffu, bin = bucket >> PART_FINE_BITS, dst = cursor[bin] + (e - cnt[bin]);
+            out_val[dst] = st_val[e];
+            out_key[dst] = (uint16_t)(((bucket & (PART_FINE - 1)) << PART_WBITS) | (key >> 20));
+        }
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) cursor[b] += fill[b];
+        __syncthreads();
+    }
+}
+// one workgroup per coarse bin
+__global__ void __launch_bounds__(PART_FINE_THREADS) k_part_fine(const uint32_t *__restrict__ offs, uint32_t grid_a, const uint32_t *__restrict__ in_val, const uint16_t *__restrict__ in_key,
+                                                                 uint32_t *__restrict__ out_val, uint32_t *__restrict__ start, uint32_t *__restrict__ end) {
+    __shared__ uint32_t cur[PART_KEYS], wave_sums[PART_FINE_THREADS / 64], total;
+    const uint32_t bin = blockIdx.x, t = threadIdx.x;
+    const uint32_t lo = offs[(size_t)bin * grid_a], hi = offs[(size_t)(bin + 1) * grid_a];
+    for (uint32_t f = t; f < PART_KEYS; f += PART_FINE_THREADS) cur[f] = 0;
+    __syncthreads();
+    for (uint32_t e0 = lo + t; e0 < hi; e0 += PART_FINE_THREADS * PART_FINE_UNROLL) {
+        uint32_t key[PART_FINE_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PART_FINE_UNROLL; u++) { const uint32_t e = e0 + u * PART_FINE_THREADS; key[u] = e < hi ? in_key[e] : PART_NONE; }
+#pragma unroll
+        for (int u = 0; u < PART_FINE_UNROLL; u++) if (key[u] != PART_NONE) atomicAdd(&cur[key[u]], 1u);
     }
     __syncthreads();
-    if (!active) return;
-#pragma unroll
-    for (int w = 0; w < SPLIT_MAXW; w++) {
-        if (w < L.nwin) {
-            const bool skip = (d[w] & VAL_SKIP) != 0;
-            const uint32_t cls = skip ? 0u : (d[w] & cmask);
-            uint32_t pos = offs[((size_t)cls * L.nwin + w) * nblocks + blockIdx.x] + rank[w];
-            for (uint32_t v = 0; v < wave; v++) pos += wc[w][v][cls];
-            keys[pos] = skip ? 0u : (d[w] & VAL_INDEX);
-            vals[pos] = skip ? VAL_SKIP : (((uint32_t)w * stride + base) | (d[w] & (1u << 31)));
-        }
+    part_block_scan<PART_FINE_THREADS>(cur, PART_KEYS, wave_sums, &total);
+    for (uint32_t f = t; f < PART_FINE; f += PART_FINE_THREADS) {
+        const uint32_t k = bin * PART_FINE + f;
+        start[k] = lo + cur[f << PART_WBITS];
+        end[k] = lo + (f + 1 < PART_FINE ? cur[(f + 1) << PART_WBITS] : total);
     }
+    __syncthreads();
+    for (uint32_t e0 = lo + t; e0 < hi; e0 += PART_FINE_THREADS * PART_FINE_UNROLL) {
+        uint32_t key[PART_FINE_UNROLL], val[PART_FINE_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PART_FINE_UNROLL; u++) {
+            const uint32_t e = e0 + u * PART_FINE_THREADS;
+            key[u] = PART_NONE;
+            if (e < hi) { key[u] = in_key[e]; val[u] = in_val[e]; }
+        }
+#pragma unroll
+        for (int u = 0; u < PART_FINE_UNROLL; u++) if (key[u] != PART_NONE) out_val[lo + atomicAdd(&cur[key[u]], 1u)] = val[u];
+    }
+}
+// digits + grouping of the table path; leaves S.sorted_vals / S.start / S.end as prepare_buckets would (bucket-contiguous, by window inside a bucket, zero digits absent)
+template <class Fr>
+static void partition_buckets(MsmWorkspace &S, const Fr *scal1, size_t n1, size_t off1, const Fr *scal2, size_t n2, size_t off2, const TableLayout &L, size_t stride, uint32_t cap, hipStream_t s) {
+    const int B = L.c_hi - 1;                                         // bucket bits
+    const uint32_t nbin = 1u << (B - PART_FINE_BITS), G = PART_GRID;
+    const size_t n = n1 + n2, nb = (size_t)1 << B, nh = (size_t)nbin * G + 1;
+    if (nh > S.cap_part) { dfree(S.part_hist); dfree(S.part_offs); S.part_hist = (uint32_t *)dmalloc(nh * 4); S.part_offs = (uint32_t *)dmalloc(nh * 4); S.cap_part = nh; }
+    if (n > S.cap_dig) { dfree(S.dig); S.dig = (uint32_t *)dmalloc(n * PART_MAXW * 4); S.cap_dig = n; }
+#ifdef ZKAES_MEASURE
+    for (int rep = (knockin() & 1) ? 0 : 1; rep < 2; rep++)
+#endif
+    {
+    hipLaunchKernelGGL((k_part_hist<Fr>), dim3(G), dim3(PART_THREADS), 0, s, scal1, (uint32_t)n1, scal2, (uint32_t)n2, L, nbin, S.dig, S.part_hist);
+    HIP_LAUNCH_CHECK();
+    size_t tb = 0;
+    HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, S.part_hist, S.part_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
+    if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
+    HIP_CHECK(rocprim::exclusive_scan(S.tmp, tb, S.part_hist, S.part_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
+    hipLaunchKernelGGL(k_part_scatter, dim3(G), dim3(PART_THREADS), 0, s, (const uint32_t *)S.dig, (uint32_t)n, (uint32_t)n1, (uint32_t)off1, (uint32_t)off2, (uint32_t)stride, nbin,
+                       (const uint32_t *)S.part_offs, S.vals_a, (uint16_t *)S.keys_a);
+    HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_part_fine, dim3(nbin), dim3(PART_FINE_THREADS), 0, s, (const uint32_t *)S.part_offs, G, (const uint32_t *)S.vals_a, (const uint16_t *)S.keys_a, S.vals_b, S.start, S.end);
+    HIP_LAUNCH_CHECK();
+    }
+    S.sorted_vals = S.vals_b; S.sorted_keys = nullptr;
+    order_buckets(S, nb, cap, s);
 }
 
 // Table-mode Pippenger in the same two steps as the per-window variant.  msm_prepare_table: signed c-bit digits of up to two scalar vectors
@@ -1078,24 +1173,12 @@ void msm_prepare_table(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_
     const size_t nb = (size_t)1 << (L.c_hi - 1);
     S.plan_c = L.c_hi; S.plan_nwin = nwin; S.plan_pairs = pairs; S.plan_table = true; S.plan_cap = BUCKET_CAP_TABLE;
     ensure_scratch(S, pairs, nb, BUCKET_CAP_TABLE);
-    const int B = L.c_hi - 1, split_bits = B > 16 ? (B - 16 < 3 ? B - 16 : 3) : 0;
-    if (split_bits > 0 && nwin <= SPLIT_MAXW && pairs >= ((size_t)1 << 16)) {
-        // the digit kernels already split the pairs (stably) on the low `split_bits` bucket bits: the radix sort starts above them
-        const uint32_t nblocks = (uint32_t)((n + SPLIT_THREADS - 1) / SPLIT_THREADS);
-        const size_t nh = ((size_t)nwin << split_bits) * nblocks;
-        if (nh > S.cap_split) { dfree(S.split_hist); dfree(S.split_offs); S.split_hist = (uint32_t *)dmalloc(nh * 4); S.split_offs = (uint32_t *)dmalloc(nh * 4); S.cap_split = nh; }
-        hipLaunchKernelGGL((k_split_hist<Fr>), dim3(nblocks), dim3(SPLIT_THREADS), 0, s, scal1, (uint32_t)n1, (uint32_t)off1, scal2, (uint32_t)n2, (uint32_t)off2, L, split_bits, nblocks, S.split_hist);
-        HIP_LAUNCH_CHECK();
-        size_t tb = 0;
-        HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, S.split_hist, S.split_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
-        if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
-        HIP_CHECK(rocprim::exclusive_scan(S.tmp, tb, S.split_hist, S.split_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
-        hipLaunchKernelGGL((k_split_scatter<Fr>), dim3(nblocks), dim3(SPLIT_THREADS), 0, s, scal1, (uint32_t)n1, (uint32_t)off1, scal2, (uint32_t)n2, (uint32_t)off2, L, (uint32_t)stride, split_bits,
-                           nblocks, (const uint32_t *)S.split_offs, S.keys_a, S.vals_a);
-        HIP_LAUNCH_CHECK();
-        prepare_buckets<typename Curve::FqP>(S, pairs, B, 1, B, BUCKET_CAP_TABLE, s, split_bits);
+    const int B = L.c_hi - 1;
+    if (B > PART_FINE_BITS && (1u << (B - PART_FINE_BITS)) <= PART_NBIN_MAX && nwin <= PART_MAXW && pairs >= ((size_t)1 << 16)) {
+        partition_buckets<Fr>(S, scal1, n1, off1, scal2, n2, off2, L, stride, BUCKET_CAP_TABLE, s);
         return;
     }
+    // small instances and window plans outside the partition's limits: digits + one stable radix sort over the bucket bits
     if (n1) { hipLaunchKernelGGL((k_digits_table<Fr>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, scal1, (uint32_t)n1, 0u, (uint32_t)n, (uint32_t)off1, L, (uint32_t)stride, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
     if (n2) { hipLaunchKernelGGL((k_digits_table<Fr>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, scal2, (uint32_t)n2, (uint32_t)n1, (uint32_t)n, (uint32_t)off2, L, (uint32_t)stride, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
     prepare_buckets<typename Curve::FqP>(S, pairs, L.c_hi - 1, 1, L.c_hi - 1, BUCKET_CAP_TABLE, s);

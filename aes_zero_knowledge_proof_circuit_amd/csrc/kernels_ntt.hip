@@ -177,14 +177,14 @@ const Fr *domain_elements(int lg) {
 }
 
 template <class Fr>
-static void ntt_impl(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, int coset_c, int lg_big, stream_t s_) {
+static void ntt_impl(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, int coset_c, int lg_big, stream_t s_, const void *scale_table = nullptr) {
     using G = Fp29<typename Fr::Params>;
     hipStream_t s = (hipStream_t)s_;
     if (lg > RootOf<Fr>::TWO_ADICITY || lg > 30) throw GpuError("ntt: domain too large");
     const uint32_t n = 1u << lg;
     if (in_len > n) in_len = n;
     if (dst == src) throw GpuError("ntt: dst must differ from src (first pass gathers bit-reversed)");
-    if (lg == 0 && !coset_c) { HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(Fr) * (in_len ? 1 : 0), hipMemcpyDeviceToDevice, s)); if (!in_len) HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(Fr), s)); return; }
+    if (lg == 0 && !coset_c && !scale_table) { HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(Fr) * (in_len ? 1 : 0), hipMemcpyDeviceToDevice, s)); if (!in_len) HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(Fr), s)); return; }
     if (lg == 0) throw GpuError("ntt_coset: domain of size one");
     Fr w = Tables<Fr>::gen(lg);
     const Fr *tw_std = inverse ? tables<Fr>().powers(tables<Fr>().inv, lg, w.inverse(), n / 2) : tables<Fr>().powers(tables<Fr>().fwd, lg, w, n / 2);
@@ -192,7 +192,8 @@ static void ntt_impl(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse
     G n_inv = G::twiddle_from_std(Fr::from_u64(n).inverse());
     const G *cs_tw = nullptr;
     uint32_t cs_mask = 0;
-    if (coset_c) {        // powers of the larger domain's root (its forward or inverse twiddle table: W^(+-e), e < 2^(lg_big - 1))
+    if (scale_table) { cs_tw = (const G *)scale_table; coset_c = 1; cs_mask = 0xffffffffu; }      // an explicit table g^(+-k), k < 2^lg (coset_power_table): no wrap, no sign
+    else if (coset_c) {   // powers of the larger domain's root (its forward or inverse twiddle table: W^(+-e), e < 2^(lg_big - 1))
         if (lg_big <= lg || lg_big > RootOf<Fr>::TWO_ADICITY || lg_big > 30) throw GpuError("ntt_coset: the coset generator must come from a larger domain");
         const uint32_t nb = 1u << lg_big;
         Fr wb = Tables<Fr>::gen(lg_big);
@@ -241,6 +242,28 @@ void ntt_coset(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, int 
     ntt_impl<Fr>(dst, src, in_len, lg, inverse, coset_c, lg_big, s);
 }
 
+// g^i R' for i < n as reduced-radix limbs: the scaling table of a coset whose generator is NOT a root of unity (the field's multiplicative generator in round 3)
+template <class Fr>
+void *coset_power_table(const Fr &g, size_t n, stream_t s_) {
+    using G = Fp29<typename Fr::Params>;
+    hipStream_t s = (hipStream_t)s_;
+    Fr *tmp = (Fr *)dmalloc(n * sizeof(Fr));
+    G *out = (G *)dmalloc(n * sizeof(G));
+    hipLaunchKernelGGL((k_fill_powers<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, (uint32_t)n, tmp);
+    HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_twiddles29<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const Fr *)tmp, (uint32_t)n, out);
+    HIP_LAUNCH_CHECK();
+    sync(s_);
+    dfree(tmp);
+    return out;
+}
+template <class Fr>
+void ntt_scaled(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, const void *table, stream_t s) {
+    if (!table) throw GpuError("ntt_scaled: null table");
+    ntt_impl<Fr>(dst, src, in_len, lg, inverse, 0, 0, s, table);
+}
+template void *coset_power_table<Fr377>(const Fr377 &, size_t, stream_t);
+template void ntt_scaled<Fr377>(Fr377 *, const Fr377 *, size_t, int, bool, const void *, stream_t);
 template void ntt<Fr377>(Fr377 *, const Fr377 *, size_t, int, bool, stream_t);
 template void ntt<Fr381>(Fr381 *, const Fr381 *, size_t, int, bool, stream_t);
 template void ntt_coset<Fr377>(Fr377 *, const Fr377 *, size_t, int, bool, int, int, stream_t);

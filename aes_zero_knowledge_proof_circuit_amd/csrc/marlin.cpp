@@ -487,9 +487,11 @@ class ProvingKeyImpl {
     // device: index polynomials (evaluations on K and coefficients); order row col a_val b_val c_val row_col
     DevBuf ix_ev[6], ix_co[6], ix_cs[6];       // index polynomials: values on K, coefficients, values on the coset g K (round 3)
     Fr coset_g, coset_g_inv, coset_vk_inv;     // g = the field's multiplicative generator, 1 / (g^|K| - 1)
+    void *coset_tab = nullptr, *coset_tab_inv = nullptr;   // g^i and g^-i, i < |K|, in the NTT's reduced-radix form: round 3's coset scalings ride on its two transforms
     ProverTimings last_timings;
 
     ~ProvingKeyImpl() {
+        gpu::dfree(coset_tab); gpu::dfree(coset_tab_inv);
         gpu::dfree(d_powers); gpu::dfree(d_lag_h); gpu::dfree(d_lag_w); gpu::dfree(d_desc); gpu::dfree(d_sbox_in); gpu::dfree(d_sbox_tmpl);
         gpu::dfree(d_a_rowptr); gpu::dfree(d_a_col); gpu::dfree(d_b_rowptr); gpu::dfree(d_b_col); gpu::dfree(d_a_coeff); gpu::dfree(d_b_coeff);
         gpu::dfree(d_t_heavy); gpu::dfree(d_t_colptr); gpu::dfree(d_t_seg_start); gpu::dfree(d_t_seg_end); gpu::dfree(d_t_row); gpu::dfree(d_t_mat); gpu::dfree(d_t_coeff);
@@ -820,6 +822,8 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
         }
         gpu::sync(stream);
         gpu::dfree(tmp);
+        coset_tab = gpu::coset_power_table<F>(coset_g, k, stream);
+        coset_tab_inv = gpu::coset_power_table<F>(coset_g_inv, k, stream);
     }
     // ---- workspace of context 0 (further contexts are created on demand)
     alloc_workspace(*cx0);
@@ -966,11 +970,9 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     gpu::d2d(poly[7].p, f_poly.p + 1, (k - 1) * sizeof(F), s); poly_len[7] = k - 1;   // g_2 = (f - f(0)) / X
     // h_2 = (a - b f) / v_K with a = sum eta_M v_H(alpha) v_H(beta) val_M, b = (beta - row)(alpha - col) expanded with row_col: degree <= |K| - 2,
     // so it is interpolated from ONE coset of K, where v_K is the constant g^|K| - 1 and a, b come from the key's precomputed coset values
-    gpu::coset_scale(e[1].p, f_poly.p, coset_g, k, k, s);
-    gpu::ntt<F>(e[2].p, e[1].p, k, lg_k, false, s);                           // f on g K
+    gpu::ntt_scaled<F>(e[2].p, f_poly.p, k, lg_k, false, coset_tab, s);       // f on g K (the scaling by g^i rides on the transform's first pass)
     gpu::h2_coset(e[0].p, ix_cs[0].p, ix_cs[1].p, ix_cs[2].p, ix_cs[3].p, ix_cs[4].p, ix_cs[5].p, e[2].p, alpha, beta, alpha_beta, ea_vv, eb_vv, ec_vv, coset_vk_inv, k, s);
-    gpu::ntt<F>(big_tmp.p, e[0].p, k, lg_k, true, s);                         // coefficients of h_2(g X)
-    gpu::coset_scale(poly[8].p, big_tmp.p, coset_g_inv, k - 1, k - 1, s);     // h_2 (the coefficient of X^(|K|-1) is zero for a satisfied instance)
+    gpu::ntt_scaled<F>(poly[8].p, e[0].p, k, lg_k, true, coset_tab_inv, s);   // h_2: interpolated from g K, scaled back by g^-i at the last pass's store (the coefficient of X^(|K|-1) is zero for a satisfied instance)
     poly_len[8] = k - 1;
     for (auto &lp : r3) draw_rand(lp, zk);
     {
