@@ -514,6 +514,164 @@ __global__ void __launch_bounds__(256) k_reduce_window(const A *__restrict__ par
     }
 }
 
+// ---- The reduction behind k_reduce_l1 on the Edwards law: a 2-D decomposition with four lanes per point operation (te28.cuh te_add_quad / te_dbl_quad).
+// k_reduce_l1 leaves, per 8-bucket segment g of a bucket set, S_g = sum B and W_g = sum (d + 1) B; the set's sum is  sum_g W_g + 8 sum_g g S_g.  With g = r C + c
+// (G = R C segments, both powers of two):  sum_g g S_g = sum_c c CS_c + C sum_r r RS_r, where CS_c (column sums) and RS_r (row sums) are PLAIN sums -- trees, no running
+// sums, no scalar products on thousands of lanes (k_reduce_l2's second role did a 16-bit double-and-add per 64 buckets).
+//   k_reduce_rc    : one 64-quad workgroup per plain sum: the R row sums of W (their total is sum_g W_g), the R row sums RS_r and the C column sums CS_c of S
+//   k_reduce_final : three workgroups per set (total of the W sums; sum_c c CS_c; sum_r r RS_r -- an index-weighted sum of <= 256 points is split 16 x 16 once more,
+//                    then taken bit plane by bit plane), the last one to finish (ticket) combines  T + 8 (U1 + C U2)  and converts to the Weierstrass XYZZ form.
+// Depth of the whole reduction: 16 sequential additions in k_reduce_l1, then ~40 quad operations of 2-3 product-times each, instead of ~70 whole additions.
+constexpr int RQ_THREADS = 256, RQ_QUADS = RQ_THREADS / 4;          // k_reduce_rc
+constexpr int RF_THREADS = 1024, RF_QUADS = RF_THREADS / 4;         // k_reduce_final: up to 256 points per weighted sum
+constexpr int PT_WORDS = 4 * FpMsm<Fq377P>::N;                      // one extended point: 4 coordinates x 14 limbs (224 B: sizeof(AccTE))
+template <class P> __device__ __forceinline__ FpMsm<P> quad_load(const uint32_t *pt, int q) {
+    FpMsm<P> r;
+#pragma unroll
+    for (int i = 0; i < FpMsm<P>::N; i++) r.l[i] = pt[q * FpMsm<P>::N + i];
+    return r;
+}
+template <class P> __device__ __forceinline__ void quad_store(uint32_t *pt, int q, const FpMsm<P> &v) {
+#pragma unroll
+    for (int i = 0; i < FpMsm<P>::N; i++) pt[q * FpMsm<P>::N + i] = v.l[i];
+}
+// sum of pt[0 .. count) (count a power of two <= the number of quads) into pt[0]; every lane of the workgroup must call it.  Ends with a barrier.
+template <class P>
+__device__ __forceinline__ void quad_tree_sum(uint32_t *pt, uint32_t count, uint32_t quad, int q) {
+    for (uint32_t half = count >> 1; half >= 1; half >>= 1) {
+        if (quad < half) quad_store<P>(pt + quad * PT_WORDS, q, te_add_quad<P>(quad_load<P>(pt + quad * PT_WORDS, q), quad_load<P>(pt + (quad + half) * PT_WORDS, q), q));
+        __syncthreads();
+    }
+}
+// jobs per set: [0, R) row sums of W, [R, 2R) row sums of S, [2R, 2R + C) column sums of S; out[set][job]
+template <class P>
+__global__ void __launch_bounds__(RQ_THREADS) k_reduce_rc(const AccTE<P> *__restrict__ seg_s, const AccTE<P> *__restrict__ seg_w, int lgR, int lgC, AccTE<P> *__restrict__ out) {
+    __shared__ uint32_t pt[RQ_QUADS * PT_WORDS];
+    const uint32_t R = 1u << lgR, C = 1u << lgC, jobs = 2 * R + C;
+    const uint32_t set = blockIdx.x / jobs, job = blockIdx.x % jobs, quad = threadIdx.x >> 2;
+    const int q = threadIdx.x & 3;
+    const AccTE<P> *src = (job < R ? seg_w : seg_s) + ((size_t)set << (lgR + lgC));
+    uint32_t first, stride, len;
+    if (job < 2 * R) { first = (job < R ? job : job - R) << lgC; stride = 1; len = C; }
+    else { first = job - 2 * R; stride = C; len = R; }
+    FpMsm<P> acc = te_identity_quad<P>(q);
+    for (uint32_t i = quad; i < len; i += RQ_QUADS)
+        acc = te_add_quad<P>(acc, quad_load<P>(reinterpret_cast<const uint32_t *>(src + first + (size_t)i * stride), q), q);
+    quad_store<P>(pt + quad * PT_WORDS, q, acc);
+    __syncthreads();
+    quad_tree_sum<P>(pt, RQ_QUADS, quad, q);
+    if (quad == 0) quad_store<P>(reinterpret_cast<uint32_t *>(out + (size_t)set * jobs + job), q, quad_load<P>(pt, q));
+}
+// index-weighted sum  sum_i i E_i  of n <= 16 points E_i = pt[i * stride] (n a power of two), bit plane by bit plane: plane b = the sum of the points whose index has bit b set
+// (n / 2 points: a tree), then Horner over the planes.  Planes and their trees live in `scratch` (>= 16 points).  Result in scratch[0]; all lanes call it; ends with a barrier.
+template <class P>
+__device__ __forceinline__ void quad_weighted_small(const uint32_t *pt, uint32_t stride, uint32_t n, uint32_t *scratch, uint32_t quad, int q) {
+    int lg = 0;
+    while ((1u << lg) < n) lg++;
+    if (lg == 0) { if (quad == 0) quad_store<P>(scratch, q, te_identity_quad<P>(q)); __syncthreads(); return; }       // one point, weight 0
+    const uint32_t half = n >> 1;                      // points per plane; plane b occupies scratch[b * 4 .. b * 4 + half / 2) after the first level (half <= 8)
+    // first level: quad (b, j) adds the plane's points 2j and 2j + 1 (or copies the single point when half == 1)
+    {
+        const uint32_t per = half > 1 ? half >> 1 : 1, b = quad / per, j = quad % per;
+        if (b < (uint32_t)lg) {
+            auto member = [&](uint32_t i) { const uint32_t lo = i & ((1u << b) - 1), hi = i >> b; return (hi << (b + 1)) | (1u << b) | lo; };      // i-th index with bit b set
+            FpMsm<P> v = quad_load<P>(pt + (size_t)member(half > 1 ? 2 * j : 0) * stride * PT_WORDS, q);
+            if (half > 1) v = te_add_quad<P>(v, quad_load<P>(pt + (size_t)member(2 * j + 1) * stride * PT_WORDS, q), q);
+            quad_store<P>(scratch + (b * 4 + j) * PT_WORDS, q, v);
+        }
+        __syncthreads();
+    }
+    for (uint32_t cnt = half >> 1; cnt > 1; cnt >>= 1) {          // remaining tree levels of all planes side by side
+        const uint32_t h2 = cnt >> 1, b = quad / h2, j = quad % h2;
+        if (b < (uint32_t)lg) quad_store<P>(scratch + (b * 4 + j) * PT_WORDS, q, te_add_quad<P>(quad_load<P>(scratch + (b * 4 + j) * PT_WORDS, q), quad_load<P>(scratch + (b * 4 + j + h2) * PT_WORDS, q), q));
+        __syncthreads();
+    }
+    if (quad == 0) {                                               // Horner: ((p_top 2 + p_next) 2 + ...) + p_0
+        FpMsm<P> acc = quad_load<P>(scratch + (size_t)(lg - 1) * 4 * PT_WORDS, q);
+        for (int b = lg - 2; b >= 0; b--) acc = te_add_quad<P>(te_dbl_quad<P>(acc, q), quad_load<P>(scratch + (size_t)b * 4 * PT_WORDS, q), q);
+        quad_store<P>(scratch, q, acc);
+    }
+    __syncthreads();
+}
+// sum_i i E_i over M <= 256 points loaded into bufA AND bufB (M a power of two): M = r1 x c1, i = r c1 + c  =>  sum_c c (column sums) + c1 sum_r r (row sums).  Result in bufA[0].
+template <class P>
+__device__ __forceinline__ void quad_weighted(uint32_t *bufA, uint32_t *bufB, uint32_t M, uint32_t *scratch, uint32_t quad, int q) {
+    int m = 0;
+    while ((1u << m) < M) m++;
+    if (M <= 16) {
+        quad_weighted_small<P>(bufA, 1, M, scratch, quad, q);
+        if (quad == 0) quad_store<P>(bufA, q, quad_load<P>(scratch, q));
+        __syncthreads();
+        return;
+    }
+    const int lc = (m + 1) / 2;
+    const uint32_t c1 = 1u << lc, r1 = M >> lc;
+    // column sums in bufA (tree over the rows) and row sums in bufB (tree inside every row), side by side: quads [0, M / 2) and [M / 2, M)
+    for (uint32_t lvl = 0;; lvl++) {
+        const uint32_t hr = (r1 >> 1) >> lvl, hc = (c1 >> 1) >> lvl;          // halves of the two trees at this level (0 once a tree is done)
+        if (hr == 0 && hc == 0) break;
+        if (quad < hr * c1) quad_store<P>(bufA + quad * PT_WORDS, q, te_add_quad<P>(quad_load<P>(bufA + quad * PT_WORDS, q), quad_load<P>(bufA + (quad + hr * c1) * PT_WORDS, q), q));
+        else if (quad >= RF_QUADS / 2 && quad - RF_QUADS / 2 < hc * r1) {
+            const uint32_t k = quad - RF_QUADS / 2, r = k / hc, c = k % hc, at = r * c1 + c;
+            quad_store<P>(bufB + at * PT_WORDS, q, te_add_quad<P>(quad_load<P>(bufB + at * PT_WORDS, q), quad_load<P>(bufB + (at + hc) * PT_WORDS, q), q));
+        }
+        __syncthreads();
+    }
+    // V1 = sum_c c bufA[c] (c1 points), V2 = sum_r r bufB[r c1] (r1 points): both <= 16 points
+    quad_weighted_small<P>(bufA, 1, c1, scratch, quad, q);
+    FpMsm<P> v1 = quad_load<P>(scratch, q);                        // (every quad reads it; quad 0 uses it)
+    __syncthreads();
+    quad_weighted_small<P>(bufB, c1, r1, scratch, quad, q);
+    if (quad == 0) {
+        FpMsm<P> v2 = quad_load<P>(scratch, q);
+        for (int i = 0; i < lc; i++) v2 = te_dbl_quad<P>(v2, q);
+        quad_store<P>(bufA, q, te_add_quad<P>(v1, v2, q));
+    }
+    __syncthreads();
+}
+template <class P>
+__global__ void __launch_bounds__(RF_THREADS) k_reduce_final(const AccTE<P> *__restrict__ rc, int lgR, int lgC, AccTE<P> *__restrict__ part, uint32_t *__restrict__ tickets,
+                                                              XYZZ<Fp<P>> *__restrict__ out, XYZZ<Fp<P>> *__restrict__ out2) {
+    __shared__ uint32_t bufA[RF_QUADS * PT_WORDS], bufB[RF_QUADS * PT_WORDS], scratch[16 * PT_WORDS];
+    __shared__ uint32_t ticket;
+    const uint32_t R = 1u << lgR, C = 1u << lgC, jobs = 2 * R + C;
+    const uint32_t set = blockIdx.x / 3, role = blockIdx.x % 3, quad = threadIdx.x >> 2;
+    const int q = threadIdx.x & 3;
+    const AccTE<P> *src = rc + (size_t)set * jobs + (role == 0 ? 0 : (role == 1 ? 2 * R : R));        // W row sums | column sums of S | row sums of S
+    const uint32_t M = role == 1 ? C : R;
+    {
+        FpMsm<P> v = quad < M ? quad_load<P>(reinterpret_cast<const uint32_t *>(src + quad), q) : te_identity_quad<P>(q);
+        quad_store<P>(bufA + quad * PT_WORDS, q, v);
+        if (role != 0) quad_store<P>(bufB + quad * PT_WORDS, q, v);
+    }
+    __syncthreads();
+    if (role == 0) quad_tree_sum<P>(bufA, RF_QUADS, quad, q);
+    else quad_weighted<P>(bufA, bufB, M, scratch, quad, q);
+    if (quad == 0) quad_store<P>(reinterpret_cast<uint32_t *>(part + (size_t)set * 3 + role), q, quad_load<P>(bufA, q));
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = atomicAdd(&tickets[set], 1u);
+    __syncthreads();
+    if (ticket != 2) return;
+    __threadfence();
+    if (threadIdx.x == 0) tickets[set] = 0;                         // re-armed for the next MSM of this workspace
+    if (quad == 0) {
+        const AccTE<P> *pp = part + (size_t)set * 3;
+        FpMsm<P> t = quad_load<P>(reinterpret_cast<const uint32_t *>(pp + 0), q), u1 = quad_load<P>(reinterpret_cast<const uint32_t *>(pp + 1), q),
+                 u2 = quad_load<P>(reinterpret_cast<const uint32_t *>(pp + 2), q);
+        for (int i = 0; i < lgC; i++) u2 = te_dbl_quad<P>(u2, q);
+        FpMsm<P> u = te_add_quad<P>(u1, u2, q);
+        for (int i = 0; i < 3; i++) u = te_dbl_quad<P>(u, q);        // x RED_L1
+        quad_store<P>(scratch, q, te_add_quad<P>(t, u, q));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const auto r = te_to_std_point<P>(*reinterpret_cast<const AccTE<P> *>(scratch));
+        out[set] = r;
+        if (out2) out2[set] = r;
+    }
+}
+
 template <class A> __global__ void k_sum_tree(const A *__restrict__ in, uint32_t total, uint32_t per, A *__restrict__ out);
 
 constexpr uint32_t DEFERRED_CAP = 1u << 20;
@@ -531,6 +689,7 @@ struct MsmWorkspace {
     uint32_t *dig = nullptr; size_t cap_dig = 0;                                   // two-level partition: 16 digit words per scalar
     uint32_t *ord_hist = nullptr, *ord_offs = nullptr;            // ORD_BINS x ORD_MAX_BLOCKS counts and their scan
     uint32_t *ctrl = nullptr;                                     // 8 control words (see k_order_hist); armed at zero between MSMs
+    uint32_t *tickets = nullptr;                                  // k_reduce_final's per-set workgroup tickets (re-armed by the kernel itself)
     bool ctrl_dirty = false;                                      // an exception left the order pass half done: re-arm ctrl before the next one
     size_t plan_n = 0, plan_pairs = 0; int plan_c = 0, plan_nwin = 0;     // state between msm_prepare and msm_finish
     bool plan_table = false; uint32_t plan_cap = BUCKET_CAP;
@@ -548,6 +707,8 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
         S.ord_hist = (uint32_t *)dmalloc((size_t)ORD_BINS * ORD_MAX_BLOCKS * 4); S.ord_offs = (uint32_t *)dmalloc((size_t)ORD_BINS * ORD_MAX_BLOCKS * 4);
         S.ctrl = (uint32_t *)dmalloc(32);
         HIP_CHECK(hipMemset(S.ctrl, 0, 32));
+        S.tickets = (uint32_t *)dmalloc(MAX_WSUMS * 4);
+        HIP_CHECK(hipMemset(S.tickets, 0, MAX_WSUMS * 4));
         HIP_CHECK(hipHostMalloc(&S.h_res, RES_BYTES, hipHostMallocMapped));
         HIP_CHECK(hipHostGetDevicePointer(&S.d_res, S.h_res, 0));
     }
@@ -578,7 +739,7 @@ void msm_workspace_destroy(MsmWorkspace *w) {
     if (!w) return;
     for (void *p : {(void *)w->keys_a, (void *)w->keys_b, (void *)w->vals_a, (void *)w->vals_b, (void *)w->start, (void *)w->end, (void *)w->order, (void *)w->ovf_slot,
                     (void *)w->ovf_bucket, (void *)w->ovf_nseg, (void *)w->ovf_off, w->ovf_partial, (void *)w->part_hist, (void *)w->part_offs, (void *)w->dig, (void *)w->ord_hist, (void *)w->ord_offs,
-                    (void *)w->ctrl, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->tmp}) dfree(p);
+                    (void *)w->ctrl, (void *)w->tickets, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->tmp}) dfree(p);
     if (w->h_res) (void)hipHostFree(w->h_res);
     if (w->ev0) { (void)hipEventDestroy(w->ev0); (void)hipEventDestroy(w->ev1); }
     delete w;
@@ -661,11 +822,22 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
     hipLaunchKernelGGL((k_reduce_l1<A>), dim3((unsigned)((segs * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.buckets, c, nsets, (A *)S.seg_s, (A *)S.seg_w,
                        S.ovf_slot, S.ovf_off, max_seg, (const A *)S.ovf_partial);
     HIP_LAUNCH_CHECK();
+    if constexpr (Law::edwards) {
+        // Edwards law: plain row / column sums of the segment sums, then three quad-cooperative workgroups per set (k_reduce_rc / k_reduce_final above)
+        const int lgG = c - 3 > 0 ? c - 3 : 0, lgC = (lgG + 1) / 2, lgR = lgG - lgC;
+        if (lgC > 8) throw GpuError("msm: more than 2^19 buckets per set");
+        const unsigned jobs = 2u * (1u << lgR) + (1u << lgC);
+        A *rc = (A *)S.partial, *part = rc + (size_t)nsets * jobs;
+        hipLaunchKernelGGL((k_reduce_rc<P>), dim3((unsigned)nsets * jobs), dim3(RQ_THREADS), 0, s, (const A *)S.seg_s, (const A *)S.seg_w, lgR, lgC, rc);
+        HIP_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_reduce_final<P>), dim3(3u * (unsigned)nsets), dim3(RF_THREADS), 0, s, (const A *)rc, lgR, lgC, part, S.tickets, res, dev_wsum_out);
+        HIP_LAUNCH_CHECK();
+    } else {
     hipLaunchKernelGGL((k_reduce_l2<A>), dim3(2u * (unsigned)((groups * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.seg_s, (const A *)S.seg_w, c, nsets, (A *)S.partial);
     HIP_LAUNCH_CHECK();
     const uint32_t parts = 2 * groups;                 // two partials per group (k_reduce_l2's two roles)
     if (nsets == 1 && parts > 2048) {
-        // one big bucket set (table mode): 256-partial blocks first, so the final LDS tree does not walk tens of thousands of partials serially
+        // one big bucket set: 256-partial blocks first, so the final LDS tree does not walk tens of thousands of partials serially
         uint32_t mid = (parts + 255) / 256;
         hipLaunchKernelGGL((k_sum_tree<A>), dim3(mid), dim3(256), 0, s, (const A *)S.partial, parts, 256u, (A *)S.seg_s);
         HIP_LAUNCH_CHECK();
@@ -674,6 +846,7 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
         hipLaunchKernelGGL((k_reduce_window<A>), dim3((unsigned)nsets), dim3(256), 0, s, (const A *)S.partial, parts, res, dev_wsum_out);
     }
     HIP_LAUNCH_CHECK();
+    }
     }
     std::vector<XYZZ<Fq>> ws(nsets);
     uint32_t n_deferred = 0;

@@ -181,6 +181,63 @@ ZK_HD Niels28<Fq377P> niels_from_weierstrass(const Affine<Fp<Fq377P>> &p, bool *
     return te_niels_finish(m, m.den.inverse());
 }
 
+#if defined(__HIPCC__)
+// ---- FOUR LANES PER POINT OPERATION (the narrow stages of the bucket reduction).  A lane running a whole te_add alone issues its ~4,700 instructions one after the other
+// (~12 us); where few points are left and most lanes idle anyway, a quad of lanes shares one operation instead: lane q of the quad holds coordinate q (x, y, z, t: the
+// AccTE order) and multiplies one of the operation's independent products, so an addition is THREE product-times (9 products over 4 lanes; the t lane also multiplies by 2d)
+// and a doubling TWO, with the operands exchanged inside the quad by DPP quad_perm moves (no LDS, no barrier).  Same formulas and value bounds as te_add / te_dbl, same results.
+template <int CTRL> __device__ __forceinline__ uint32_t quad_dpp(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+#else
+    return v;            // (host pass of hipcc: never executed)
+#endif
+}
+template <int CTRL, class G> __device__ __forceinline__ G quad_move(const G &v) {
+    G r;
+#pragma unroll
+    for (int i = 0; i < G::N; i++) r.l[i] = quad_dpp<CTRL>(v.l[i]);
+    return r;
+}
+constexpr int QP_LANE0 = 0x00, QP_LANE1 = 0x55, QP_LANE2 = 0xAA, QP_LANE3 = 0xFF, QP_SWAP_PAIRS = 0xB1;      // quad_perm: broadcast lane k; [1, 0, 3, 2]
+template <class G> __device__ __forceinline__ G quad_pick(int q, const G &v0, const G &v1, const G &v2, const G &v3) {
+    G r;
+#pragma unroll
+    for (int i = 0; i < G::N; i++) r.l[i] = q == 0 ? v0.l[i] : (q == 1 ? v1.l[i] : (q == 2 ? v2.l[i] : v3.l[i]));
+    return r;
+}
+// second level shared by addition and doubling: from A, B, C, D (one per lane) to X3 = E F, Y3 = G H, Z3 = F G, T3 = E H
+template <class P>
+__device__ __forceinline__ FpMsm<P> te_quad_finish(int q, const FpMsm<P> &E, const FpMsm<P> &F, const FpMsm<P> &Gg, const FpMsm<P> &H) {
+    return quad_pick(q, E, Gg, F, E) * quad_pick(q, F, H, Gg, H);
+}
+// my coordinate of a + b, given my coordinate of a and of b
+template <class P>
+__device__ __forceinline__ FpMsm<P> te_add_quad(const FpMsm<P> &a, const FpMsm<P> &b, int q) {
+    using G = FpMsm<P>;
+    const G oa = quad_move<QP_SWAP_PAIRS>(a), ob = quad_move<QP_SWAP_PAIRS>(b);             // the x and y lanes see each other's coordinate
+    // x lane: (Y1 - X1)(Y2 - X2); y lane: (Y1 + X1)(Y2 + X2); z lane: Z1 Z2; t lane: T1 T2 (then times 2d)
+    const G u = quad_pick(q, oa.template sub<3>(a), a + oa, a, a), v = quad_pick(q, ob.template sub<3>(b), b + ob, b, b);
+    G m = u * v;
+    const G mk = m * Te377::k2d();
+    m = quad_pick(q, m, m, m, mk);
+    const G A = quad_move<QP_LANE0>(m), B = quad_move<QP_LANE1>(m), D = quad_move<QP_LANE2>(m).dbl(), C = quad_move<QP_LANE3>(m);
+    return te_quad_finish<P>(q, B.template sub<2>(A), D.template sub<2>(C), D + C, B + A);
+}
+template <class P>
+__device__ __forceinline__ FpMsm<P> te_dbl_quad(const FpMsm<P> &a, int q) {
+    using G = FpMsm<P>;
+    const G X = quad_move<QP_LANE0>(a), Y = quad_move<QP_LANE1>(a);
+    const G m = quad_pick(q, a, a, a, X + Y).sqr();                                          // X^2, Y^2, Z^2, (X + Y)^2
+    const G A = quad_move<QP_LANE0>(m), B = quad_move<QP_LANE1>(m), C = quad_move<QP_LANE2>(m).dbl(), S = quad_move<QP_LANE3>(m);
+    const G AB = A + B, Gg = B.template sub<2>(A);
+    return te_quad_finish<P>(q, S.template sub<3>(AB), Gg.template sub<3>(C), Gg, G::zero().template sub<3>(AB));
+}
+// coordinate q of the identity (0 : 1 : 1 : 0)
+template <class P>
+__device__ __forceinline__ FpMsm<P> te_identity_quad(int q) { return (q == 1 || q == 2) ? FpMsm<P>::k_one() : FpMsm<P>::zero(); }
+#endif
+
 // ---- one vocabulary for the bucket-reduction kernels over either accumulator type
 template <class A> struct PtOps;
 template <class P> struct PtOps<Acc28<P>> {
