@@ -520,7 +520,8 @@ __global__ void __launch_bounds__(256) k_reduce_window(const A *__restrict__ par
 // sums, no scalar products on thousands of lanes (k_reduce_l2's second role did a 16-bit double-and-add per 64 buckets).
 //   k_reduce_rc    : one 64-quad workgroup per plain sum: the R row sums of W (their total is sum_g W_g), the R row sums RS_r and the C column sums CS_c of S
 //   k_reduce_final : three workgroups per set (total of the W sums; sum_c c CS_c; sum_r r RS_r -- an index-weighted sum of <= 256 points is split 16 x 16 once more,
-//                    then taken bit plane by bit plane), the last one to finish (ticket) combines  T + 8 (U1 + C U2)  and converts to the Weierstrass XYZZ form.
+//                    then taken bit plane by bit plane; the row term is scaled by C where it is made), the last one to finish (ticket) combines  T + 8 (U1 + C U2)  and
+//                    converts to the Weierstrass XYZZ form.
 // Depth of the whole reduction: 16 sequential additions in k_reduce_l1, then ~40 quad operations of 2-3 product-times each, instead of ~70 whole additions.
 constexpr int RQ_THREADS = 256, RQ_QUADS = RQ_THREADS / 4;          // k_reduce_rc
 constexpr int RF_THREADS = 1024, RF_QUADS = RF_THREADS / 4;         // k_reduce_final: up to 256 points per weighted sum
@@ -562,53 +563,57 @@ __global__ void __launch_bounds__(RQ_THREADS) k_reduce_rc(const AccTE<P> *__rest
     quad_tree_sum<P>(pt, RQ_QUADS, quad, q);
     if (quad == 0) quad_store<P>(reinterpret_cast<uint32_t *>(out + (size_t)set * jobs + job), q, quad_load<P>(pt, q));
 }
-// index-weighted sum  sum_i i E_i  of n <= 16 points E_i = pt[i * stride] (n a power of two), bit plane by bit plane: plane b = the sum of the points whose index has bit b set
-// (n / 2 points: a tree), then Horner over the planes.  Planes and their trees live in `scratch` (>= 16 points).  Result in scratch[0]; all lanes call it; ends with a barrier.
+// index-weighted sums  sum_i i E_i  of n <= 16 points E_i = pt[i * stride] (n a power of two), TWO of them side by side (problem 0 on quads [0, 16), problem 1 on quads
+// [RF_QUADS / 2, RF_QUADS / 2 + 16)), bit plane by bit plane: plane b = the sum of the points whose index has bit b set (n / 2 points: a tree), then Horner over the planes.
+// Planes and their trees live in the problem's `scratch` (>= 16 points); result in scratch[0].  All lanes call it (uniform barriers); ends with a barrier.
+struct QuadWeighted { const uint32_t *pt; uint32_t stride, n; uint32_t *scratch; };
 template <class P>
-__device__ __forceinline__ void quad_weighted_small(const uint32_t *pt, uint32_t stride, uint32_t n, uint32_t *scratch, uint32_t quad, int q) {
+__device__ __forceinline__ void quad_weighted_small2(const QuadWeighted &p0, const QuadWeighted &p1, uint32_t quad, int q) {
+    const bool second = quad >= RF_QUADS / 2;
+    const QuadWeighted &pr = second ? p1 : p0;
+    const uint32_t lq = second ? quad - RF_QUADS / 2 : quad, n = pr.n, nmax = p0.n > p1.n ? p0.n : p1.n;
     int lg = 0;
     while ((1u << lg) < n) lg++;
-    if (lg == 0) { if (quad == 0) quad_store<P>(scratch, q, te_identity_quad<P>(q)); __syncthreads(); return; }       // one point, weight 0
     const uint32_t half = n >> 1;                      // points per plane; plane b occupies scratch[b * 4 .. b * 4 + half / 2) after the first level (half <= 8)
     // first level: quad (b, j) adds the plane's points 2j and 2j + 1 (or copies the single point when half == 1)
-    {
-        const uint32_t per = half > 1 ? half >> 1 : 1, b = quad / per, j = quad % per;
+    if (lg > 0) {
+        const uint32_t per = half > 1 ? half >> 1 : 1, b = lq / per, j = lq % per;
         if (b < (uint32_t)lg) {
             auto member = [&](uint32_t i) { const uint32_t lo = i & ((1u << b) - 1), hi = i >> b; return (hi << (b + 1)) | (1u << b) | lo; };      // i-th index with bit b set
-            FpMsm<P> v = quad_load<P>(pt + (size_t)member(half > 1 ? 2 * j : 0) * stride * PT_WORDS, q);
-            if (half > 1) v = te_add_quad<P>(v, quad_load<P>(pt + (size_t)member(2 * j + 1) * stride * PT_WORDS, q), q);
-            quad_store<P>(scratch + (b * 4 + j) * PT_WORDS, q, v);
+            FpMsm<P> v = quad_load<P>(pr.pt + (size_t)member(half > 1 ? 2 * j : 0) * pr.stride * PT_WORDS, q);
+            if (half > 1) v = te_add_quad<P>(v, quad_load<P>(pr.pt + (size_t)member(2 * j + 1) * pr.stride * PT_WORDS, q), q);
+            quad_store<P>(pr.scratch + (b * 4 + j) * PT_WORDS, q, v);
+        }
+    }
+    __syncthreads();
+    for (uint32_t cmax = nmax >> 2, cnt = half >> 1; cmax > 1; cmax >>= 1, cnt >>= 1) {       // remaining tree levels of all planes side by side (trip count of the larger problem)
+        if (cnt > 1) {
+            const uint32_t h2 = cnt >> 1, b = lq / h2, j = lq % h2;
+            if (b < (uint32_t)lg) quad_store<P>(pr.scratch + (b * 4 + j) * PT_WORDS, q, te_add_quad<P>(quad_load<P>(pr.scratch + (b * 4 + j) * PT_WORDS, q), quad_load<P>(pr.scratch + (b * 4 + j + h2) * PT_WORDS, q), q));
         }
         __syncthreads();
     }
-    for (uint32_t cnt = half >> 1; cnt > 1; cnt >>= 1) {          // remaining tree levels of all planes side by side
-        const uint32_t h2 = cnt >> 1, b = quad / h2, j = quad % h2;
-        if (b < (uint32_t)lg) quad_store<P>(scratch + (b * 4 + j) * PT_WORDS, q, te_add_quad<P>(quad_load<P>(scratch + (b * 4 + j) * PT_WORDS, q), quad_load<P>(scratch + (b * 4 + j + h2) * PT_WORDS, q), q));
-        __syncthreads();
-    }
-    if (quad == 0) {                                               // Horner: ((p_top 2 + p_next) 2 + ...) + p_0
-        FpMsm<P> acc = quad_load<P>(scratch + (size_t)(lg - 1) * 4 * PT_WORDS, q);
-        for (int b = lg - 2; b >= 0; b--) acc = te_add_quad<P>(te_dbl_quad<P>(acc, q), quad_load<P>(scratch + (size_t)b * 4 * PT_WORDS, q), q);
-        quad_store<P>(scratch, q, acc);
+    if (lq == 0) {                                                 // Horner: ((p_top 2 + p_next) 2 + ...) + p_0; a single point has weight 0
+        FpMsm<P> acc = te_identity_quad<P>(q);
+        if (lg > 0) {
+            acc = quad_load<P>(pr.scratch + (size_t)(lg - 1) * 4 * PT_WORDS, q);
+            for (int b = lg - 2; b >= 0; b--) acc = te_add_quad<P>(te_dbl_quad<P>(acc, q), quad_load<P>(pr.scratch + (size_t)b * 4 * PT_WORDS, q), q);
+        }
+        quad_store<P>(pr.scratch, q, acc);
     }
     __syncthreads();
 }
-// sum_i i E_i over M <= 256 points loaded into bufA AND bufB (M a power of two): M = r1 x c1, i = r c1 + c  =>  sum_c c (column sums) + c1 sum_r r (row sums).  Result in bufA[0].
+// sum_i i E_i over M <= 256 points loaded into bufA AND bufB (M a power of two), times 2^shift: M = r1 x c1, i = r c1 + c  =>  sum_c c (column sums) + c1 sum_r r (row sums).
+// Result in bufA[0].
 template <class P>
-__device__ __forceinline__ void quad_weighted(uint32_t *bufA, uint32_t *bufB, uint32_t M, uint32_t *scratch, uint32_t quad, int q) {
+__device__ __forceinline__ void quad_weighted(uint32_t *bufA, uint32_t *bufB, uint32_t M, int shift, uint32_t *scratch, uint32_t quad, int q) {
     int m = 0;
     while ((1u << m) < M) m++;
-    if (M <= 16) {
-        quad_weighted_small<P>(bufA, 1, M, scratch, quad, q);
-        if (quad == 0) quad_store<P>(bufA, q, quad_load<P>(scratch, q));
-        __syncthreads();
-        return;
-    }
-    const int lc = (m + 1) / 2;
+    const int lc = M <= 16 ? m : (m + 1) / 2;
     const uint32_t c1 = 1u << lc, r1 = M >> lc;
-    // column sums in bufA (tree over the rows) and row sums in bufB (tree inside every row), side by side: quads [0, M / 2) and [M / 2, M)
+    // column sums in bufA (tree over the rows) and row sums in bufB (tree inside every row), side by side: quads [0, M / 2) and [RF_QUADS / 2, RF_QUADS / 2 + M / 2)
     for (uint32_t lvl = 0;; lvl++) {
-        const uint32_t hr = (r1 >> 1) >> lvl, hc = (c1 >> 1) >> lvl;          // halves of the two trees at this level (0 once a tree is done)
+        const uint32_t hr = (r1 >> 1) >> lvl, hc = r1 > 1 ? (c1 >> 1) >> lvl : 0;          // halves of the two trees at this level (0 once a tree is done; one row: no row sums)
         if (hr == 0 && hc == 0) break;
         if (quad < hr * c1) quad_store<P>(bufA + quad * PT_WORDS, q, te_add_quad<P>(quad_load<P>(bufA + quad * PT_WORDS, q), quad_load<P>(bufA + (quad + hr * c1) * PT_WORDS, q), q));
         else if (quad >= RF_QUADS / 2 && quad - RF_QUADS / 2 < hc * r1) {
@@ -617,22 +622,21 @@ __device__ __forceinline__ void quad_weighted(uint32_t *bufA, uint32_t *bufB, ui
         }
         __syncthreads();
     }
-    // V1 = sum_c c bufA[c] (c1 points), V2 = sum_r r bufB[r c1] (r1 points): both <= 16 points
-    quad_weighted_small<P>(bufA, 1, c1, scratch, quad, q);
-    FpMsm<P> v1 = quad_load<P>(scratch, q);                        // (every quad reads it; quad 0 uses it)
-    __syncthreads();
-    quad_weighted_small<P>(bufB, c1, r1, scratch, quad, q);
+    // V1 = sum_c c bufA[c] (c1 points) and V2 = sum_r r bufB[r c1] (r1 points), both <= 16 points, side by side
+    quad_weighted_small2<P>(QuadWeighted{bufA, 1, c1, scratch}, QuadWeighted{bufB, c1, r1, scratch + 16 * PT_WORDS}, quad, q);
     if (quad == 0) {
-        FpMsm<P> v2 = quad_load<P>(scratch, q);
+        FpMsm<P> v2 = quad_load<P>(scratch + 16 * PT_WORDS, q);
         for (int i = 0; i < lc; i++) v2 = te_dbl_quad<P>(v2, q);
-        quad_store<P>(bufA, q, te_add_quad<P>(v1, v2, q));
+        FpMsm<P> v = te_add_quad<P>(quad_load<P>(scratch, q), v2, q);
+        for (int i = 0; i < shift; i++) v = te_dbl_quad<P>(v, q);
+        quad_store<P>(bufA, q, v);
     }
     __syncthreads();
 }
 template <class P>
 __global__ void __launch_bounds__(RF_THREADS) k_reduce_final(const AccTE<P> *__restrict__ rc, int lgR, int lgC, AccTE<P> *__restrict__ part, uint32_t *__restrict__ tickets,
                                                               XYZZ<Fp<P>> *__restrict__ out, XYZZ<Fp<P>> *__restrict__ out2) {
-    __shared__ uint32_t bufA[RF_QUADS * PT_WORDS], bufB[RF_QUADS * PT_WORDS], scratch[16 * PT_WORDS];
+    __shared__ uint32_t bufA[RF_QUADS * PT_WORDS], bufB[RF_QUADS * PT_WORDS], scratch[32 * PT_WORDS];
     __shared__ uint32_t ticket;
     const uint32_t R = 1u << lgR, C = 1u << lgC, jobs = 2 * R + C;
     const uint32_t set = blockIdx.x / 3, role = blockIdx.x % 3, quad = threadIdx.x >> 2;
@@ -646,7 +650,7 @@ __global__ void __launch_bounds__(RF_THREADS) k_reduce_final(const AccTE<P> *__r
     }
     __syncthreads();
     if (role == 0) quad_tree_sum<P>(bufA, RF_QUADS, quad, q);
-    else quad_weighted<P>(bufA, bufB, M, scratch, quad, q);
+    else quad_weighted<P>(bufA, bufB, M, role == 2 ? lgC : 0, scratch, quad, q);       // the row term carries the factor C: applied here, beside the column term's workgroup
     if (quad == 0) quad_store<P>(reinterpret_cast<uint32_t *>(part + (size_t)set * 3 + role), q, quad_load<P>(bufA, q));
     __threadfence();
     __syncthreads();
@@ -659,7 +663,6 @@ __global__ void __launch_bounds__(RF_THREADS) k_reduce_final(const AccTE<P> *__r
         const AccTE<P> *pp = part + (size_t)set * 3;
         FpMsm<P> t = quad_load<P>(reinterpret_cast<const uint32_t *>(pp + 0), q), u1 = quad_load<P>(reinterpret_cast<const uint32_t *>(pp + 1), q),
                  u2 = quad_load<P>(reinterpret_cast<const uint32_t *>(pp + 2), q);
-        for (int i = 0; i < lgC; i++) u2 = te_dbl_quad<P>(u2, q);
         FpMsm<P> u = te_add_quad<P>(u1, u2, q);
         for (int i = 0; i < 3; i++) u = te_dbl_quad<P>(u, q);        // x RED_L1
         quad_store<P>(scratch, q, te_add_quad<P>(t, u, q));
