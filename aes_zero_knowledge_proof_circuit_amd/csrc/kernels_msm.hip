@@ -947,7 +947,6 @@ void msm_prepare(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_t n1, 
     int c = lg - 2;                               // signed digits: 2^(c-1) buckets per window
     if (c < 7) c = 7;
     if (c > 17) c = 17;
-    if (const char *e = getenv("ZKAES_MSM_C")) { int v = atoi(e); if (v >= 4 && v <= 22) c = v; }   // tuning knob (tools/ubench/msm_sweep.py)
     if (force_c >= 4 && force_c <= 22) c = force_c;     // ranks sharing one MSM by point range must cut the scalars into the same windows
     const int nwin = (Fr::BITS + 1 + c - 1) / c;  // one extra bit for the recoding carry
     size_t pairs = n * (size_t)nwin;

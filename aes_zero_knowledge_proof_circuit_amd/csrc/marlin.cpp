@@ -469,14 +469,14 @@ class ProvingKeyImpl {
     SrsPoint *d_powers = nullptr, *d_shifted = nullptr;
     size_t srs_stride = 0, n_plain = 0;
     size_t table_min_n = 500000;    // MSMs below this many points keep the per-window buckets (their own, smaller c)
-    // Lagrange-basis SRS over H (ZKAES_LAGRANGE=0 disables): L_k(beta) G for z_A, z_B; L_k(beta)/v_X(beta) G (zero on X) for w;
+    // Lagrange-basis SRS over H: L_k(beta) G for z_A, z_B; L_k(beta)/v_X(beta) G (zero on X) for w;
     // P_j for the public-input part of w; v_H(beta) G and (v_H/v_X)(beta) G for the blinding terms
     bool use_lagrange = true;
     SrsPoint *d_lag_h = nullptr, *d_lag_w = nullptr;
     std::vector<G1A> lag_pj;
     G1A lag_vh, lag_vw;
     int table_c = 22;
-    bool use_tables = false;   // window tables for the large MSMs (default on when |K| >= 2^20: ZKAES_MSM_TABLES=0/1 overrides)
+    bool use_tables = false;   // window tables for the large MSMs (on when |K| >= 2^20, memory allows and the key was not made with KEY_NO_TABLES)
     // device: circuit
     uint32_t *d_desc = nullptr, *d_sbox_in = nullptr, *d_sbox_tmpl = nullptr;
     uint32_t *d_a_rowptr = nullptr, *d_a_col = nullptr, *d_b_rowptr = nullptr, *d_b_col = nullptr;
@@ -537,9 +537,8 @@ class ProvingKeyImpl {
     // Window tables: 13 balanced windows over ONE bucket set instead of 15 windows with their own buckets.  Round 2 kept them away from a lone encrypt() call
     // (the short top window of that layout cost ~2 ms of serial segment chains per MSM); with balanced windows they win there too
     // (profiles/r03_latency.json: 16 B 36.4 -> 34.3 ms, 64 B 98.6 -> 91.4 ms), so every MSM of at least table_min_n points uses them.
-    // ZKAES_MSM_TABLES=0 builds no tables, =3 keeps lone calls on the per-window buckets (A/B measurements).
-    bool table_ok(const ProverContext &cx, size_t len) const { return use_tables && (cx.throughput || !lone_calls_without_tables) && len >= table_min_n; }
-    bool lone_calls_without_tables = false;
+    // (KEY_NO_TABLES builds no tables.)
+    bool table_ok(const ProverContext &, size_t len) const { return use_tables && len >= table_min_n; }
     using Lane = ProverContext::Lane;
     // MSM against powers_of_g starting at `off` (plain or shifted range); device scalars
     XYZZ<Fq377> msm_powers(ProverContext &cx, Lane &ln, bool shifted, size_t off, const F *scalars, size_t len) {
@@ -668,12 +667,9 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
     kzg_setup_points(srs_beta, g, gamma_g, srs_h);
     // window tables pay from the one-block key (|K| = 2^20: 35.5 -> 38.2 proofs/s in batch mode) upwards; tiny circuits keep per-window buckets only
     use_tables = lg_k >= 20 && !(flags & KEY_NO_TABLES);
-    if (const char *e = getenv("ZKAES_MSM_TABLES")) { use_tables = atoi(e) != 0 && !(flags & KEY_NO_TABLES); lone_calls_without_tables = atoi(e) == 3; }
     // c = 20: 13 signed windows instead of 15 and 2^19 buckets in ONE set (the 15 x 2^16 per-window buckets cost more to reduce).  c = 22 saves one more
     // window but its 2^21 buckets triple k_reduce_l1 (1.95 ms vs 0.67 ms per MSM): measured slower (profiles/r02_msm_tables.md)
     table_c = 20;
-    if (const char *e = getenv("ZKAES_MSM_TABLE_C")) { int v = atoi(e); if (v >= 8 && v <= 24) table_c = v; }
-    if (const char *e = getenv("ZKAES_MSM_TABLE_MIN")) table_min_n = (size_t)atoll(e);
     // (the windows are balanced since round 3 -- 254 = 7 x 20 + 6 x 19 bits at c = 20, kernels_msm.hip TableLayout -- so no window is short and any c is safe)
     size_t n_tab = use_tables ? (size_t)gpu::table_windows<Bls377>(table_c) : 1;
     // powers_of_g[0..=supported_degree] and the shifted range live in ONE reduced-radix array (shifted part right after the plain part), so
@@ -709,7 +705,6 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
         gpu::dfree(stage[0]); gpu::dfree(stage[1]);
         d_shifted = d_powers + n_plain;
     }
-    if (const char *e = getenv("ZKAES_LAGRANGE")) use_lagrange = atoi(e) != 0;
     if (const char *e = getenv("ZKAES_LANES")) use_lanes = atoi(e) != 0;
     if (use_lagrange) {
         // With the (public, test_rng-derived) trapdoor the Lagrange-basis points are direct fixed-base products; a trapdoor-free universal SRS
