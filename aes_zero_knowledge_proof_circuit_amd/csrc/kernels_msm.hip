@@ -1129,7 +1129,7 @@ void table_next(Affine<typename Curve::Fq> *next, const Affine<typename Curve::F
 }
 
 // ---- Two-level bucket partition: the table path's grouping (digits -> bucket-contiguous value list + bucket ranges), written for INSTRUCTION count.
-// Per-kernel VALU accounting of a proof (profiles/r04_valu_by_kernel_mid_round.md) shows the saturated prover is VALU-issue bound as a whole -- k_accumulate already issues at
+// Per-kernel VALU accounting of a proof (profiles/r04_valu_by_kernel_before_partition.md) shows the saturated prover is VALU-issue bound as a whole -- k_accumulate already issues at
 // the pipe's limit, so every other kernel costs its instruction count -- and that the generic route (digit kernels that pre-split on 3 bits with wave ballots + two rocPRIM
 // onesweep passes, whose stable ranking is a chain of match-any ballots per item) spent ~470 lane-instructions per (point, window) pair, 13 % of what the bucket
 // additions themselves take.  Nothing here needs a stable sort -- only "bucket-contiguous, and inside a bucket by window" (the lanes of a wave then gather from the same

@@ -366,7 +366,7 @@ def run(args, api, dist_env=None):
         achieved = (bytes_per_launch / 1e9) / (chip_ms / 1e3) if chip_ms > 0 else 0.0
         kernel_ms_per_step = launches / max(args.steps, 1) * chip_ms
         traffic = traffic_src = None
-        for name in ("r03_pmc_k_accumulate_tables.json", "r02_pmc_k_accumulate_tables.json", "r02_pmc_k_accumulate.json"):
+        for name in ("r04_pmc_k_accumulate_tables.json", "r03_pmc_k_accumulate_tables.json", "r02_pmc_k_accumulate_tables.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 traffic = round(pmc["hbm_bytes_per_point_window"] * pairs_per_launch)

@@ -27,6 +27,8 @@ extern "C" {
                              proof_lens: *mut usize, n_chunks: usize) -> c_int;
     fn zkaes_encrypt_chunked_seeded_at(message: *const u8, message_len: usize, secret_key: *const u8, pk: *const zkaes_pk, zk_seed32: *const u8, first_proof_index: u64,
                                        proofs: *mut *mut u8, proofs_len: *mut usize, proof_lens: *mut usize, n_chunks: usize) -> c_int;
+    fn zkaes_pk_serialize_ark_to_file(pk: *const zkaes_pk, path: *const c_char, bytes_written: *mut u64) -> c_int;
+    fn zkaes_pk_tables_built(pk: *const zkaes_pk, built: *mut c_int, table_bytes: *mut u64) -> c_int;
     fn zkaes_vk_serialize_ark(vk: *const zkaes_vk, out: *mut *mut u8, out_len: *mut usize) -> c_int;
     fn zkaes_vk_deserialize_ark(bytes: *const u8, len: usize, vk: *mut *mut zkaes_vk) -> c_int;
 }
@@ -57,6 +59,23 @@ impl Drop for VkHandle { fn drop(&mut self) { unsafe { zkaes_vk_free(self.0) } }
 pub struct ProvingKey(Arc<PkHandle>);
 #[derive(Clone)]
 pub struct VerifyingKey(Arc<VkHandle>);
+
+impl ProvingKey {
+    /// Streams the ark-serialize image of the arkworks `IndexProverKey` this key corresponds to (0.65 GB for a 16-byte key) -- read it back with
+    /// `simpleworks::marlin::ProvingKey::deserialize_unchecked(BufReader::new(File::open(path)?))` to run the reference's CPU `encrypt()` (src/lib.rs:60) on a GPU-made key.
+    pub fn serialize_ark_to_file(&self, path: &std::path::Path) -> Result<u64> {
+        let c = std::ffi::CString::new(path.to_string_lossy().as_bytes()).map_err(|_| anyhow::anyhow!("path contains a NUL byte"))?;
+        let mut n = 0u64;
+        if unsafe { zkaes_pk_serialize_ark_to_file((self.0).0, c.as_ptr(), &mut n) } != 0 { return Err(last_error()); }
+        Ok(n)
+    }
+    /// (built, bytes): whether the key holds the fixed-base window tables of its SRS (skipped under KEY_NO_TABLES or when device memory is short)
+    pub fn tables_built(&self) -> Result<(bool, u64)> {
+        let (mut b, mut n) = (0 as c_int, 0u64);
+        if unsafe { zkaes_pk_tables_built((self.0).0, &mut b, &mut n) } != 0 { return Err(last_error()); }
+        Ok((b != 0, n))
+    }
+}
 
 impl VerifyingKey {
     /// ark-serialize bytes of `ark_marlin::IndexVerifierKey` -- feed to `simpleworks::marlin::VerifyingKey::deserialize`

@@ -9,7 +9,7 @@ window_bits: 20 = the prover's table path (13 balanced windows, one bucket set, 
 Three separate rocprofv3 runs of `tools/ubench/msm_one.py <lg_n>` (FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ counters in a third), each with
 `--pmc ... --kernel-trace --output-format csv` only (MI355X_MICROARCH.md, HBM / rocprofv3 sections).  The absolute FETCH_SIZE scale is calibrated on
 kernels of the same run whose byte counts are known exactly: k_convert_bases / k_convert_bases_te (reads 96 B, writes 112 B / 168 B per point, 16 B-per-lane
-array-of-structures access -- the pattern of k_accumulate's gathers) and k_digits / k_digits_table (reads 32 B per scalar, fully coalesced).
+array-of-structures access -- the pattern of k_accumulate's gathers) and k_digits / k_part_hist (reads 32 B per scalar, fully coalesced).
 """
 import csv
 import json
@@ -42,7 +42,7 @@ def collect(name, counters):
     rows = {}
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"]
-        short = "k_accumulate" if "k_accumulate<" in k else ("k_convert_bases" if "k_convert_bases" in k else ("k_digits" if ("k_digits" in k or "k_split_hist" in k) else None))   # k_split_hist: the pre-split path's pass over the scalars (reads 32 B each, writes counts only)
+        short = "k_accumulate" if "k_accumulate<" in k else ("k_convert_bases" if "k_convert_bases" in k else ("k_digits" if ("k_digits" in k or "k_part_hist" in k) else None))   # k_part_hist: the partition's pass over the scalars (reads 32 B each, coalesced; its writes are not in FETCH_SIZE)
         if short:
             rows.setdefault((short, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in rows.items()}, {k: len(v) for k, v in rows.items()}
