@@ -149,7 +149,7 @@ void poly_lincomb_n(F *out, size_t n, const F *const *polys, const size_t *lens,
 void poly_lincomb3(F *out, const F *a, const F *b, const F *c, const F &sa, const F &sb, const F &sc, size_t n, stream_t s);
 // q = p / (X^m - 1) (len - m coefficients), rem = remainder (m coefficients); requires len > m
 void divide_by_vanishing(F *q, F *rem, const F *p, size_t len, size_t m, stream_t s);
-// q = p / (X - z) (len - 1 coefficients, remainder dropped); scratch >= divide_by_linear_scratch(len) elements (power tables + scan temp)
+// q = p / (X - z) (len - 1 coefficients, remainder dropped); scratch >= divide_by_linear_scratch(len) elements (block values and carries of the blocked recurrence)
 void divide_by_linear(F *q, const F *p, size_t len, const F &z, F *scratch, size_t scratch_elems, stream_t s);
 size_t divide_by_linear_scratch(size_t len);   // field elements of scratch a division of `len` coefficients needs
 // p(x) returned to the host (synchronizes); scratch >= ceil(len/64) + 1 elements
