@@ -109,6 +109,43 @@ struct Fp29 {
         r.l[N - 1] = (uint32_t)(t[2 * N - 1] + c);
         return r;
     }
+    // sum_{i < N} a[i] b[i] / R' with ONE Montgomery reduction: the N x 81 limb products accumulate in the same 64-bit columns.  N <= 4 (36 limb products of < 2^58 plus
+    // the reduction's 9 per column stay below 2^64); limbs normalized.  For a[i] < A_i p, b[i] < B_i p the result is < (sum A_i B_i / 256 + 1) p  (p / R' < 2^-8).
+    template <int N>
+    ZK_HD static Fp29 dot(const Fp29 *a, const Fp29 *b) {
+        static_assert(N >= 1 && N <= 4, "column accumulators hold at most four products per limb pair");
+        static_assert(mod29(0) == 1u && PINV == MASK, "written for p = 1 (mod 2^29)");
+        uint64_t t[2 * Fp29::N];
+#pragma unroll
+        for (int i = 0; i < 2 * Fp29::N; i++) t[i] = 0;
+#pragma unroll
+        for (int i = 0; i < Fp29::N; i++) {
+#pragma unroll
+            for (int n = 0; n < N; n++)
+#pragma unroll
+                for (int j = 0; j < Fp29::N; j++) t[i + j] += (uint64_t)a[n].l[j] * b[n].l[i];
+            const uint64_t u = t[i] + MASK;
+            const uint32_t m = ~(uint32_t)u & MASK;
+#pragma unroll
+            for (int j = 1; j < Fp29::N; j++) t[i + j] += (uint64_t)m * mod29(j);
+            t[i + 1] += u >> B;
+        }
+        Fp29 r;
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < Fp29::N - 1; i++) { uint64_t v = t[Fp29::N + i] + c; r.l[i] = (uint32_t)v & MASK; c = v >> B; }
+        r.l[Fp29::N - 1] = (uint32_t)(t[2 * Fp29::N - 1] + c);
+        return r;
+    }
+    // 32 x: the limbs shifted up by five bits (x < 2^256: the result fits the 261 bits of nine limbs).  For the product of two values that are BOTH in the standard
+    // form x R, y R (R = 2^256 = R' / 32):  mul(shl5(x R), y R) = x y R.
+    ZK_HD Fp29 shl5() const {
+        Fp29 r;
+        r.l[0] = (l[0] << 5) & MASK;
+#pragma unroll
+        for (int i = 1; i < N; i++) r.l[i] = ((l[i] << 5) | (l[i - 1] >> (B - 5))) & (i == N - 1 ? 0xffffffffu : MASK);
+        return r;
+    }
     // fully reduce a value < 2^(LOG + 1) p to [0, p): peel 2^LOG p, ..., 2 p, p
     template <int LOG>
     ZK_HD Fp29 canonical() const {

@@ -5,6 +5,7 @@
 // KZG10::open call.  All are HBM-streaming: one 32-byte element per lane per access.
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
+#include "ff29.cuh"
 #include "hip_util.hpp"
 
 namespace zk {
@@ -23,29 +24,40 @@ __global__ void k_axpy(F *__restrict__ acc, const F *__restrict__ p, F sc, size_
 void poly_axpy(F *acc, const F *p, const F &sc, size_t n, stream_t s) { if (!n) return; hipLaunchKernelGGL(k_axpy, GRID(n), 0, (hipStream_t)s, acc, p, sc, n); HIP_LAUNCH_CHECK(); }
 __global__ void k_scale(F *p, F sc, size_t n) { size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = p[i] * sc; }
 void poly_scale(F *p, const F &sc, size_t n, stream_t s) { if (!n) return; hipLaunchKernelGGL(k_scale, GRID(n), 0, (hipStream_t)s, p, sc, n); HIP_LAUNCH_CHECK(); }
-__global__ void k_lincomb3(F *__restrict__ out, const F *__restrict__ a, const F *__restrict__ b, const F *__restrict__ c, F sa, F sb, F sc, size_t n) {
+// ---- linear combinations and the pointwise kernels of rounds 2 / 3 on the NTT's reduced-radix field (ff29.cuh): data is only re-limbed (x R stays x R), scalars travel as
+// s R' ("twiddle form", converted on the host), and a SUM of up to four products shares ONE Montgomery reduction (Fp29::dot) -- an 8-term combination is 8 x 81 + 2 x 81
+// multiply-accumulates instead of 8 full 8 x 32-bit CIOS products with their carry fix-ups (~3x fewer instructions; exact arithmetic, identical results).
+using G29 = Fp29<Fr377P>;
+__device__ __forceinline__ G29 ld29(const F &x) { return G29::split(x.l); }
+__device__ __forceinline__ F st29(const G29 &g) { F r; g.template canonical<1>().pack(r.l); return r; }        // values < 4 p
+__global__ void k_lincomb3(F *__restrict__ out, const F *__restrict__ a, const F *__restrict__ b, const F *__restrict__ c, G29 sa, G29 sb, G29 sc, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = sa * a[i] + sb * b[i] + sc * c[i];
+    if (i >= n) return;
+    const G29 v[3] = {ld29(a[i]), ld29(b[i]), ld29(c[i])}, w[3] = {sa, sb, sc};
+    out[i] = st29(G29::dot<3>(v, w));
 }
 void poly_lincomb3(F *out, const F *a, const F *b, const F *c, const F &sa, const F &sb, const F &sc, size_t n, stream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_lincomb3, GRID(n), 0, (hipStream_t)s, out, a, b, c, sa, sb, sc, n); HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_lincomb3, GRID(n), 0, (hipStream_t)s, out, a, b, c, G29::twiddle_from_std(sa), G29::twiddle_from_std(sb), G29::twiddle_from_std(sc), n); HIP_LAUNCH_CHECK();
 }
-// out[i] = sum_j sc[j] * p[j][i] over the (up to 8) polynomials long enough to have a coefficient i: the opening combinations in ONE pass
-struct LincombArgs { const F *p[8]; size_t len[8]; F sc[8]; int count; };
+// out[i] = sum_j sc[j] * p[j][i] over the (up to 8) polynomials long enough to have a coefficient i: the opening combinations in ONE pass, two dot products of four terms
+struct LincombArgs { const F *p[8]; size_t len[8]; G29 sc[8]; int count; };
 __global__ void k_lincomb_n(F *__restrict__ out, LincombArgs a, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    F acc = F::zero();
-    for (int j = 0; j < a.count; j++) if (i < a.len[j]) acc = acc + a.sc[j] * a.p[j][i];
-    out[i] = acc;
+    G29 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = (j < a.count && i < a.len[j]) ? ld29(a.p[j][i]) : G29::zero();
+    G29 acc = G29::dot<4>(v, a.sc);
+    if (a.count > 4) acc = acc + G29::dot<4>(v + 4, a.sc + 4);
+    out[i] = st29(acc);
 }
 void poly_lincomb_n(F *out, size_t n, const F *const *polys, const size_t *lens, const F *scalars, int count, stream_t s) {
     if (!n) return;
     if (count < 1 || count > 8) throw GpuError("poly_lincomb_n: 1..8 terms");
     LincombArgs a;
     a.count = count;
-    for (int j = 0; j < 8; j++) { a.p[j] = j < count ? polys[j] : nullptr; a.len[j] = j < count ? lens[j] : 0; a.sc[j] = j < count ? scalars[j] : F::zero(); }
+    for (int j = 0; j < 8; j++) { a.p[j] = j < count ? polys[j] : nullptr; a.len[j] = j < count ? lens[j] : 0; a.sc[j] = j < count ? G29::twiddle_from_std(scalars[j]) : G29::zero(); }
     hipLaunchKernelGGL(k_lincomb_n, GRID(n), 0, (hipStream_t)s, out, a, n); HIP_LAUNCH_CHECK();
 }
 __global__ void k_sub_from_scalar(F *__restrict__ out, const F *__restrict__ v, F sc, size_t n) { size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = sc - v[i]; }
@@ -253,15 +265,18 @@ void q1_pointwise(F *e_ra, const F *e_za, const F *e_zb, const F *e_t, const F *
     hipLaunchKernelGGL(k_q1, GRID(n), 0, (hipStream_t)s, e_ra, e_za, e_zb, e_t, e_z, ea, eb, ec, n); HIP_LAUNCH_CHECK();
 }
 __global__ void k_q1_coset(F *__restrict__ out, const F *__restrict__ r, const F *__restrict__ za, const F *__restrict__ zb, const F *__restrict__ t, const F *__restrict__ z,
-                           F ca, F cb, F cz, F ea, F eb, F ec, size_t n) {
+                           F ca, F cb, F cz, G29 ea, G29 eb, G29 ec, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    F a = za[i] + ca, b = zb[i] + cb;
-    F sum = ec * (a * b) + ea * a + eb * b;
-    out[i] = r[i] * sum - t[i] * (z[i] + cz);
+    // (all in the standard form x R; a product of two such values goes through the five-bit shift: mul(shl5(x R), y R) = x y R)
+    const G29 a = ld29(za[i]) + ld29(ca), b = ld29(zb[i]) + ld29(cb), zz = ld29(z[i]) + ld29(cz);        // < 2 p each
+    const G29 v[3] = {a.shl5() * b, a, b}, w[3] = {ec, ea, eb};                                             // a b < 1.5 p
+    const G29 sum = G29::dot<3>(v, w);                                                                      // eta_c a b + eta_a a + eta_b b     < 1.1 p
+    const G29 l[2] = {ld29(r[i]).shl5(), ld29(t[i]).shl5()}, m[2] = {sum, G29::zero().template sub<2>(zz)};  // r sum + t (2 p - z)
+    out[i] = st29(G29::dot<2>(l, m));
 }
 void q1_coset_pointwise(F *out, const F *r, const F *za, const F *zb, const F *t, const F *z, const F &ca, const F &cb, const F &cz, const F &ea, const F &eb, const F &ec, size_t n, stream_t s) {
-    hipLaunchKernelGGL(k_q1_coset, GRID(n), 0, (hipStream_t)s, out, r, za, zb, t, z, ca, cb, cz, ea, eb, ec, n); HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_q1_coset, GRID(n), 0, (hipStream_t)s, out, r, za, zb, t, z, ca, cb, cz, G29::twiddle_from_std(ea), G29::twiddle_from_std(eb), G29::twiddle_from_std(ec), n); HIP_LAUNCH_CHECK();
 }
 // the assignment on H: instance values at the multiples of |H| / |X|, witness values in between (the index map of k_w_evals)
 __global__ void k_z_evals_h(F *__restrict__ out, const uint8_t *__restrict__ z, uint32_t n, uint32_t m, uint32_t num_witness) {
@@ -321,16 +336,20 @@ void coset_scale(F *out, const F *in, const F &g, size_t in_len, size_t n, strea
 // values of h_2 on the coset from the coset values of the six index polynomials and of f:
 //   a = ea va + eb vb + ec vc,  b = alpha beta - alpha row - beta col + row_col,  out = (a - b f) * vinv
 __global__ void k_h2_coset(F *__restrict__ out, const F *__restrict__ row, const F *__restrict__ col, const F *__restrict__ va, const F *__restrict__ vb,
-                           const F *__restrict__ vc, const F *__restrict__ rc, const F *__restrict__ f, F alpha, F beta, F alpha_beta, F ea, F eb, F ec, F vinv, size_t k) {
+                           const F *__restrict__ vc, const F *__restrict__ rc, const F *__restrict__ f, G29 alpha, G29 beta, F alpha_beta, G29 ea, G29 eb, G29 ec, G29 vinv, size_t k) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= k) return;
-    F a = ea * va[i] + eb * vb[i] + ec * vc[i];
-    F b = alpha_beta - alpha * row[i] - beta * col[i] + rc[i];
-    out[i] = (a - b * f[i]) * vinv;
+    const G29 v3[3] = {ld29(va[i]), ld29(vb[i]), ld29(vc[i])}, w3[3] = {ea, eb, ec};
+    const G29 a = G29::dot<3>(v3, w3);                                                     // < 1.02 p
+    const G29 v2[2] = {ld29(row[i]), ld29(col[i])}, w2[2] = {alpha, beta};
+    const G29 b = (ld29(alpha_beta) + ld29(rc[i])).template sub<2>(G29::dot<2>(v2, w2));    // alpha beta + row_col - (alpha row + beta col) + 2 p   < 4 p
+    const G29 bf = b.shl5() * ld29(f[i]);                                                   // < 1.5 p
+    out[i] = st29(a.template sub<2>(bf) * vinv);
 }
 void h2_coset(F *out, const F *row, const F *col, const F *va, const F *vb, const F *vc, const F *rc, const F *f, const F &alpha, const F &beta, const F &alpha_beta,
               const F &ea, const F &eb, const F &ec, const F &vinv, size_t k, stream_t s) {
-    hipLaunchKernelGGL(k_h2_coset, GRID(k), 0, (hipStream_t)s, out, row, col, va, vb, vc, rc, f, alpha, beta, alpha_beta, ea, eb, ec, vinv, k); HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_h2_coset, GRID(k), 0, (hipStream_t)s, out, row, col, va, vb, vc, rc, f, G29::twiddle_from_std(alpha), G29::twiddle_from_std(beta), alpha_beta,
+                       G29::twiddle_from_std(ea), G29::twiddle_from_std(eb), G29::twiddle_from_std(ec), G29::twiddle_from_std(vinv), k); HIP_LAUNCH_CHECK();
 }
 // z_poly = w * (X^m - 1) + x_poly : zp[i] = (i >= m ? w[i-m] : 0) - (i < wlen ? w[i] : 0) + (i < m ? x[i] : 0), i <= n
 __global__ void k_z_poly(F *__restrict__ zp, const F *__restrict__ w, size_t wlen, const F *__restrict__ x, uint32_t m, size_t n1) {

@@ -4,6 +4,8 @@ import random
 import sys
 
 import pytest
+import torch  # noqa: F401  -- BEFORE libzkaes.so: torch's wheel bundles its own ROCm runtime; whichever HIP runtime a process loads first is the one that sees the GPU,
+#                and the C-ABI library binds to an already-loaded one by SONAME while torch does not ("one process, two HIP runtimes")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

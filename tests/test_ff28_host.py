@@ -151,6 +151,21 @@ template <class P> int run(const char *name) {
         bad += !(x.template to_std_relimb<4>() == xs);
         bad += !(y.template to_std_relimb<4>() == ys);
         bad += !((x * W).template to_std_relimb<1>() == xs * b);
+        // dot products with one reduction (the polynomial kernels' linear combinations): data x scalar-in-twiddle-form terms, lazy operands (< 2 p, < 4 p), and
+        // data x data through the five-bit shift: mul(shl5(a R), b R) = a b R
+        {
+            F c = a * a + b, d2 = b * b - a;
+            G C = G::from_std_relimb(c), D2 = G::from_std_relimb(d2), WC = G::twiddle_from_std(c), WA = G::twiddle_from_std(a);
+            G av[4] = {A, B, C, D2}, bv[4] = {W, WC, WA, W};
+            bad += !(G::template dot<4>(av, bv).template to_std_relimb<1>() == a * b + b * c + c * a + d2 * b);
+            bad += !(G::template dot<3>(av, bv).template to_std_relimb<1>() == a * b + b * c + c * a);
+            bad += !(G::template dot<1>(av, bv).template to_std_relimb<1>() == a * b);
+            G lazy[2] = {A + B, (C + D2).template sub<2>(B)}, wv[2] = {WC, WA};
+            bad += !(G::template dot<2>(lazy, wv).template to_std_relimb<1>() == (a + b) * c + (c + d2 - b) * a);
+            bad += !((A.shl5() * B).template to_std_relimb<1>() == a * b);
+            G s5[2] = {A.shl5(), (C + C).shl5()}, dd[2] = {B, G::zero().template sub<2>(D2 + D2)};
+            bad += !(G::template dot<2>(s5, dd).template to_std_relimb<1>() == a * b - (c + c) * (d2 + d2));
+        }
     }
     printf("%s %d\n", name, bad);
     return bad;
@@ -161,7 +176,8 @@ int main() { return run<Fr377P>("fr377") + run<Fr381P>("fr381"); }
 
 def test_reduced_radix_scalar_field_matches_montgomery_reference():
     """csrc/ff29.cuh (9 x 29-bit limbs, the NTT butterflies' arithmetic) against the 8 x 32-bit Montgomery field, including the lazy value growth
-    of a ten-stage pass (K = 1, 4, 8 product-free stages, then multiplied stages) and the final canonicalisation."""
+    of a ten-stage pass (K = 1, 4, 8 product-free stages, then multiplied stages) and the final canonicalisation; dot products of up to four terms with one reduction
+    and the five-bit shift that multiplies two standard-form values (the polynomial kernels of rounds 2-3 and the openings)."""
     with tempfile.TemporaryDirectory() as d:
         src, exe = os.path.join(d, "t.cpp"), os.path.join(d, "t")
         open(src, "w").write(SRC29)
