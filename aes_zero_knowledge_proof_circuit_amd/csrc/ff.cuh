@@ -168,13 +168,45 @@ struct Fp {
         return acc;
     }
     ZK_HD Fp pow_u64(uint64_t e) const { uint32_t w[2] = {(uint32_t)e, (uint32_t)(e >> 32)}; return pow(w, 2); }
-    // Fermat inverse; inverse(0) = 0
-    ZK_HD Fp inverse() const {
+    // Fermat inverse; inverse(0) = 0.  ~1.5 BITS field products in ONE dependent chain (~380 for the scalar fields): kept as the cross-check of inverse()
+    ZK_HD Fp inverse_fermat() const {
         uint32_t e[N];
         uint64_t br = 2;
         for (int i = 0; i < N; i++) { uint64_t d = (uint64_t)P::mod(i) - br; e[i] = (uint32_t)d; br = (d >> 32) & 1; }
         return pow(e, N);
     }
+    // inverse(0) = 0.  Kaliski's almost-Montgomery inverse (binary extended Euclid: shifts, additions and subtractions only, at most 2 BITS rounds of ~6 N
+    // instructions) followed by modular doublings: for the stored value a = x R it ends with r = -a^-1 2^k (mod p), BITS <= k <= 2 BITS, and
+    // (p - r) 2^(64 N - k) = x^-1 R^-1 R^2 = x^-1 R.  ~6 x fewer instructions than the Fermat chain -- it is the serial tail of every batch inversion
+    // (kernels_poly.hip k_batch_inverse: one lane per workgroup) and of every host-side to_affine.  Invariant u s + v r = p keeps s <= p, r <= 2 p.
+    ZK_HD Fp inverse() const {
+        if (is_zero()) return zero();
+        uint32_t u[N], v[N], r[N], s[N];
+        for (int i = 0; i < N; i++) { u[i] = P::mod(i); v[i] = l[i]; r[i] = 0; s[i] = 0; }
+        s[0] = 1;
+        int k = 0;
+        for (;;) {
+            uint32_t nz = 0;
+            for (int i = 0; i < N; i++) nz |= v[i];
+            if (!nz) break;
+            if (!(u[0] & 1)) { raw_shr1(u); raw_shl1(s); }
+            else if (!(v[0] & 1)) { raw_shr1(v); raw_shl1(r); }
+            else if (raw_gt(u, v)) { raw_sub(u, v); raw_shr1(u); raw_add(r, s); raw_shl1(s); }
+            else { raw_sub(v, u); raw_shr1(v); raw_add(s, r); raw_shl1(r); }
+            k++;
+        }
+        if (geq_mod(r)) sub_mod_inplace(r);
+        Fp x;
+        uint64_t br = 0;
+        for (int i = 0; i < N; i++) { uint64_t d = (uint64_t)P::mod(i) - r[i] - br; x.l[i] = (uint32_t)d; br = (d >> 32) & 1; }
+        for (int i = k; i < 64 * N; i++) x = x + x;
+        return x;
+    }
+    ZK_HD static void raw_shr1(uint32_t *x) { for (int i = 0; i < N - 1; i++) x[i] = (x[i] >> 1) | (x[i + 1] << 31); x[N - 1] >>= 1; }
+    ZK_HD static void raw_shl1(uint32_t *x) { for (int i = N - 1; i > 0; i--) x[i] = (x[i] << 1) | (x[i - 1] >> 31); x[0] <<= 1; }
+    ZK_HD static void raw_add(uint32_t *x, const uint32_t *y) { uint64_t c = 0; for (int i = 0; i < N; i++) { c += (uint64_t)x[i] + y[i]; x[i] = (uint32_t)c; c >>= 32; } }
+    ZK_HD static void raw_sub(uint32_t *x, const uint32_t *y) { uint64_t br = 0; for (int i = 0; i < N; i++) { uint64_t d = (uint64_t)x[i] - y[i] - br; x[i] = (uint32_t)d; br = (d >> 32) & 1; } }
+    ZK_HD static bool raw_gt(const uint32_t *x, const uint32_t *y) { for (int i = N - 1; i >= 0; i--) { if (x[i] > y[i]) return true; if (x[i] < y[i]) return false; } return false; }
 };
 
 using Fr377 = Fp<Fr377P>;

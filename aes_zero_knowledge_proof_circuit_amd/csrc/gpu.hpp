@@ -80,6 +80,9 @@ template <class Curve>
 XYZZ<typename Curve::Fq> msm(MsmWorkspace *ws, const Niels28<typename Curve::FqP> *bases, const typename Curve::Fr *scalars, size_t n, stream_t s);
 template <class Curve>
 XYZZ<typename Curve::Fq> msm_finish(MsmWorkspace *ws, const Niels28<typename Curve::FqP> *bases, stream_t s);
+// the prepared scalars against TWO base arrays (plain + shifted powers of a degree-bounded commitment): both accumulations back to back, one reduction, one host wait
+template <class Curve>
+void msm_finish2(MsmWorkspace *ws, const Niels28<typename Curve::FqP> *bases, const Niels28<typename Curve::FqP> *bases2, XYZZ<typename Curve::Fq> *out, stream_t s);
 template <class Curve>
 XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws, const Niels28<typename Curve::FqP> *tables, size_t stride, size_t off, int c, const typename Curve::Fr *scalars, size_t n, stream_t s);
 template <class Curve>
@@ -148,12 +151,15 @@ void poly_scale(F *p, const F &sc, size_t n, stream_t s);                     //
 void poly_lincomb_n(F *out, size_t n, const F *const *polys, const size_t *lens, const F *scalars, int count, stream_t s);
 void poly_lincomb3(F *out, const F *a, const F *b, const F *c, const F &sa, const F &sb, const F &sc, size_t n, stream_t s);
 // q = p / (X^m - 1) (len - m coefficients), rem = remainder (m coefficients); requires len > m
-void divide_by_vanishing(F *q, F *rem, const F *p, size_t len, size_t m, stream_t s);
+void divide_by_vanishing(F *q, F *rem, const F *p, size_t len, size_t m, stream_t s, F *scratch = nullptr, size_t scratch_len = 0);
 // q = p / (X - z) (len - 1 coefficients, remainder dropped); scratch >= divide_by_linear_scratch(len) elements (block values and carries of the blocked recurrence)
 void divide_by_linear(F *q, const F *p, size_t len, const F &z, F *scratch, size_t scratch_elems, stream_t s);
 size_t divide_by_linear_scratch(size_t len);   // field elements of scratch a division of `len` coefficients needs
 // p(x) returned to the host (synchronizes); scratch >= ceil(len/64) + 1 elements
-F poly_eval(const F *p, size_t len, const F &x, F *scratch, stream_t s);
+F poly_eval(const F *p, size_t len, const F &x, F *scratch, stream_t s);       // scratch: 8 + poly_eval_scratch(len) elements
+size_t poly_eval_scratch(size_t len);
+// out[i] = p[i](x[i]), 1..8 polynomials: all launches, then one wait and one copy.  scratch: 8 + sum poly_eval_scratch(len[i]) elements
+void poly_eval_multi(const F *const *p, const size_t *len, const F *x, int count, F *out, F *scratch, size_t scratch_elems, stream_t s);
 // in-place batch inversion, zeros stay zero; every output optionally multiplied by `post`
 void batch_inverse(F *v, size_t n, const F *post_or_null, stream_t s);
 void sub_from_scalar(F *out, const F *v, const F &sc, size_t n, stream_t s);  // out[i] = sc - v[i]

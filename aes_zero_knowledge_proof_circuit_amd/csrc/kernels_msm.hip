@@ -414,8 +414,10 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_tail(const typename Law::B
 // bucket k with its overflow partials folded in (the reduction's load)
 template <class A>
 __device__ __forceinline__ A load_bucket(const A *__restrict__ buckets, size_t k, const uint32_t *__restrict__ ovf_slot, const uint32_t *__restrict__ ovf_off, uint32_t max_segments,
-                                         const A *__restrict__ partial) {
+                                         const A *__restrict__ partial, size_t period = ~(size_t)0, size_t partial_stride = 0) {
     A acc = buckets[k];
+    // (two accumulations over ONE prepared state -- plain + shifted powers: the second one's bucket sets follow the first's; same overflow list, own partials)
+    if (k >= period) { k -= period; partial += partial_stride; }
     const uint32_t q = ovf_slot[k];
     if (q != NO_SLOT) {
         uint32_t a = ovf_off[q], b = ovf_off[q + 1];
@@ -434,7 +436,8 @@ __device__ __forceinline__ A load_bucket(const A *__restrict__ buckets, size_t k
 constexpr int RED_L1 = 8, RED_L2 = 8;
 template <class A>
 __global__ void __launch_bounds__(64) k_reduce_l1(const A *__restrict__ buckets, int c, int nwin, A *__restrict__ seg_s, A *__restrict__ seg_w,
-                                                   const uint32_t *__restrict__ ovf_slot, const uint32_t *__restrict__ ovf_off, uint32_t max_segments, const A *__restrict__ ovf_partial) {
+                                                   const uint32_t *__restrict__ ovf_slot, const uint32_t *__restrict__ ovf_off, uint32_t max_segments, const A *__restrict__ ovf_partial,
+                                                   size_t ovf_period, size_t ovf_stride) {
     uint32_t segs = (1u << c) / RED_L1;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= segs * (uint32_t)nwin) return;
@@ -442,7 +445,7 @@ __global__ void __launch_bounds__(64) k_reduce_l1(const A *__restrict__ buckets,
     const size_t k0 = ((size_t)w << c) + (size_t)g * RED_L1;
     A run = PtOps<A>::identity(), tot = PtOps<A>::identity();
     for (int d = RED_L1 - 1; d >= 0; d--) {
-        A b = load_bucket<A>(buckets, k0 + d, ovf_slot, ovf_off, max_segments, ovf_partial);
+        A b = load_bucket<A>(buckets, k0 + d, ovf_slot, ovf_off, max_segments, ovf_partial, ovf_period, ovf_stride);
         PtOps<A>::add(run, b);
         PtOps<A>::add(tot, run);
     }
@@ -683,7 +686,7 @@ static_assert(sizeof(Acc28<Fq381P>) == ACC_BYTES, "bucket size differs between t
 static_assert(sizeof(AccTE<Fq377P>) == ACC_BYTES, "the Edwards accumulator must fit the XYZZ bucket slots");
 constexpr int MAX_WSUMS = 64;                                // window sums per MSM (per-window mode: <= 37 windows)
 struct MsmWorkspace {
-    size_t cap_pairs = 0, cap_buckets = 0, cap_tmp = 0;
+    size_t cap_pairs = 0, cap_buckets = 0, cap_tmp = 0, cap_result = 0;
     uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr, *start = nullptr, *end = nullptr;
     uint32_t *sorted_keys = nullptr, *sorted_vals = nullptr;      // whichever half of the double buffers the radix sort finished in
     uint32_t *order = nullptr, *ovf_slot = nullptr;               // per bucket: visiting order, slot in the overflow list (NO_SLOT for all but oversized buckets)
@@ -702,6 +705,15 @@ struct MsmWorkspace {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 constexpr size_t RES_BYTES = 192 * MAX_WSUMS + 64;
+// the accumulators and the reduction's levels, sized by the number of buckets ACCUMULATED (twice the prepared ones when one prepared state serves two base arrays at once)
+static void ensure_result(MsmWorkspace &S, size_t buckets) {
+    if (buckets <= S.cap_result) return;
+    dfree(S.buckets); dfree(S.partial); dfree(S.seg_s); dfree(S.seg_w);
+    S.cap_result = buckets;
+    S.buckets = dmalloc(buckets * ACC_BYTES);
+    S.seg_s = dmalloc((buckets / RED_L1 + 64) * ACC_BYTES); S.seg_w = dmalloc((buckets / RED_L1 + 64) * ACC_BYTES);
+    S.partial = dmalloc((2 * (buckets / (RED_L1 * RED_L2)) + 2 * 64 * 64) * ACC_BYTES);
+}
 static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t cap) {
     if (cap == 0) cap = BUCKET_CAP;
     if (!S.ev0) {
@@ -718,7 +730,7 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
     if (pairs / cap + 64 > S.cap_ovf) {
         dfree(S.ovf_partial); dfree(S.ovf_bucket); dfree(S.ovf_nseg); dfree(S.ovf_off);
         S.cap_ovf = pairs / cap + 64;
-        S.ovf_partial = dmalloc(S.cap_ovf * ACC_BYTES);
+        S.ovf_partial = dmalloc(2 * S.cap_ovf * ACC_BYTES);          // (x 2: run_buckets with a second base array)
         S.ovf_bucket = (uint32_t *)dmalloc(S.cap_ovf * 4); S.ovf_nseg = (uint32_t *)dmalloc(S.cap_ovf * 4); S.ovf_off = (uint32_t *)dmalloc((S.cap_ovf + 1) * 4);
     }
     if (pairs > S.cap_pairs) {
@@ -728,14 +740,12 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
         S.vals_a = (uint32_t *)dmalloc(pairs * 4); S.vals_b = (uint32_t *)dmalloc(pairs * 4);
     }
     if (buckets > S.cap_buckets) {
-        dfree(S.start); dfree(S.end); dfree(S.buckets); dfree(S.partial); dfree(S.seg_s); dfree(S.seg_w); dfree(S.order); dfree(S.ovf_slot);
+        dfree(S.start); dfree(S.end); dfree(S.order); dfree(S.ovf_slot);
         S.cap_buckets = buckets;
         S.start = (uint32_t *)dmalloc(buckets * 4); S.end = (uint32_t *)dmalloc(buckets * 4);
         S.order = (uint32_t *)dmalloc(buckets * 4); S.ovf_slot = (uint32_t *)dmalloc(buckets * 4);
-        S.buckets = dmalloc(buckets * ACC_BYTES);
-        S.seg_s = dmalloc((buckets / RED_L1 + 64) * ACC_BYTES); S.seg_w = dmalloc((buckets / RED_L1 + 64) * ACC_BYTES);
-        S.partial = dmalloc((2 * (buckets / (RED_L1 * RED_L2)) + 2 * 64 * 64) * ACC_BYTES);
     }
+    ensure_result(S, buckets);
 }
 MsmWorkspace *msm_workspace_create() { return new MsmWorkspace(); }
 void msm_workspace_destroy(MsmWorkspace *w) {
@@ -791,13 +801,18 @@ static void prepare_buckets(MsmWorkspace &S, size_t pairs, int c, int nsets, int
 // shared tail over prepared buckets: accumulate from `bases`, fold overflow segments and deferred degenerate additions, reduce; returns the
 // nsets window sums.  May be called several times on one prepared state with different base arrays (same scalars, e.g. plain + shifted powers).
 template <class Law>
-static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, const typename Law::Base *bases, size_t pairs, int c, int nsets, size_t n_points, uint32_t cap, hipStream_t s, float *acc_ms,
-                                            XYZZ<Fp<typename Law::Params>> *dev_wsum_out = nullptr) {
+static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, const typename Law::Base *bases, size_t pairs, int c, int nsets_one, size_t n_points, uint32_t cap, hipStream_t s, float *acc_ms,
+                                            XYZZ<Fp<typename Law::Params>> *dev_wsum_out = nullptr, const typename Law::Base *bases2 = nullptr) {
     using P = typename Law::Params;
     using A = typename Law::Acc;
     using Fq = Fp<P>;
+    // `bases2` (Edwards law): the same prepared scalars against a second base array (plain + shifted powers of a degree-bounded commitment).  Both accumulations are
+    // launched back to back into consecutive bucket sets and ONE reduction (and one host wait) serves both: the returned sums are [sets of bases..., sets of bases2...]
+    const int nrep = bases2 ? 2 : 1, nsets = nsets_one * nrep;
+    if (bases2 && !Law::edwards) throw GpuError("msm: two base arrays per prepared state need the Edwards law");
     if (nsets > MAX_WSUMS) throw GpuError("msm: too many windows");
-    size_t nb = (size_t)nsets << c;
+    const size_t nb = (size_t)nsets_one << c;
+    ensure_result(S, nb * nrep);
     if constexpr (!Law::edwards) HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 8, s));        // [0] deferred pairs, [1] the tail kernel's workgroup ticket (the Edwards law defers nothing)
 #ifdef ZKAES_MEASURE
     if (knockin() & 8) {        // (measurement builds only) one extra, untimed launch
@@ -807,15 +822,18 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
     }
 #endif
     HIP_CHECK(hipEventRecord(S.ev0, s));
-    hipLaunchKernelGGL((k_accumulate<Law>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, bases, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb, cap,
-                       (A *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
-    HIP_LAUNCH_CHECK();
-    HIP_CHECK(hipEventRecord(S.ev1, s));
     uint32_t max_seg = (uint32_t)(pairs / cap + 1);
-    // oversized buckets + deferred degenerate additions (none for uniformly distributed digits: every lane exits at once)
-    hipLaunchKernelGGL((k_accumulate_tail<Law>), dim3((max_seg + 63) / 64), dim3(64), 0, s, bases, S.sorted_vals, S.start, S.end, S.ctrl, S.ovf_bucket, S.ovf_off, max_seg, cap,
-                       (A *)S.ovf_partial, (A *)S.buckets, S.deferred, DEFERRED_CAP, S.deferred_count);
-    HIP_LAUNCH_CHECK();
+    for (int rep = 0; rep < nrep; rep++) {
+        const typename Law::Base *src = rep ? bases2 : bases;
+        hipLaunchKernelGGL((k_accumulate<Law>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, src, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb, cap,
+                           (A *)S.buckets + rep * nb, S.deferred, DEFERRED_CAP, S.deferred_count);
+        HIP_LAUNCH_CHECK();
+        if (rep == 0) HIP_CHECK(hipEventRecord(S.ev1, s));
+        // oversized buckets + deferred degenerate additions (none for uniformly distributed digits: every lane exits at once)
+        hipLaunchKernelGGL((k_accumulate_tail<Law>), dim3((max_seg + 63) / 64), dim3(64), 0, s, src, S.sorted_vals, S.start, S.end, S.ctrl, S.ovf_bucket, S.ovf_off, max_seg, cap,
+                           (A *)S.ovf_partial + rep * S.cap_ovf, (A *)S.buckets + rep * nb, S.deferred, DEFERRED_CAP, S.deferred_count);
+        HIP_LAUNCH_CHECK();
+    }
     XYZZ<Fq> *res = (XYZZ<Fq> *)S.d_res;
     uint32_t segs = (1u << c) / RED_L1, groups = (segs + RED_L2 - 1) / RED_L2;
 #ifdef ZKAES_MEASURE
@@ -823,7 +841,7 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
 #endif
     {
     hipLaunchKernelGGL((k_reduce_l1<A>), dim3((unsigned)((segs * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.buckets, c, nsets, (A *)S.seg_s, (A *)S.seg_w,
-                       S.ovf_slot, S.ovf_off, max_seg, (const A *)S.ovf_partial);
+                       S.ovf_slot, S.ovf_off, max_seg, (const A *)S.ovf_partial, nrep == 2 ? nb : ~(size_t)0, S.cap_ovf);
     HIP_LAUNCH_CHECK();
     if constexpr (Law::edwards) {
         // Edwards law: plain row / column sums of the segment sums, then three quad-cooperative workgroups per set (k_reduce_rc / k_reduce_final above)
@@ -959,36 +977,53 @@ void msm_prepare(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_t n1, 
     prepare_buckets<typename Curve::FqP>(S, pairs, c - 1, nwin, c - 1, BUCKET_CAP, s);
 }
 template <class Curve, class Law>
-static XYZZ<typename Curve::Fq> msm_finish_impl(MsmWorkspace *ws_, const typename Law::Base *bases, stream_t s_) {
+static XYZZ<typename Curve::Fq> msm_finish_impl(MsmWorkspace *ws_, const typename Law::Base *bases, stream_t s_, const typename Law::Base *bases2 = nullptr,
+                                                XYZZ<typename Curve::Fq> *out2 = nullptr) {
     using Fq = typename Curve::Fq;
     static_assert(sizeof(XYZZ<Fq>) == 192, "XYZZ layout");
     hipStream_t s = (hipStream_t)s_;
     if (!ws_) throw GpuError("msm: null workspace");
     MsmWorkspace &S = *ws_;
+    if (out2) *out2 = XYZZ<Fq>::inf();
     if (S.plan_n == 0) return XYZZ<Fq>::inf();
     auto t_begin = std::chrono::steady_clock::now();
     const int c = S.plan_c, nwin = S.plan_nwin;
     float ms = 0;
     if (S.plan_table) {      // `bases` = table copy 0 (+ a constant index shift): the window weights live in the copies, ONE bucket set, no Horner
-        std::vector<XYZZ<Fq>> one = run_buckets<Law>(S, bases, S.plan_pairs, c - 1, 1, S.plan_n, S.plan_cap, s, &ms);
+        std::vector<XYZZ<Fq>> one = run_buckets<Law>(S, bases, S.plan_pairs, c - 1, 1, S.plan_n, S.plan_cap, s, &ms, nullptr, bases2);
         add_stats(ms, S.plan_n, S.plan_pairs, t_begin);
+        if (bases2) *out2 = one[1];
         return one[0];
     }
-    std::vector<XYZZ<Fq>> ws = run_buckets<Law>(S, bases, S.plan_pairs, c - 1, nwin, S.plan_n, S.plan_cap, s, &ms);
+    if (bases2 && 2 * nwin > MAX_WSUMS) {      // (more window sums than one reduction returns: one after the other)
+        *out2 = msm_finish_impl<Curve, Law>(ws_, bases2, s_);
+        bases2 = nullptr;
+    }
+    std::vector<XYZZ<Fq>> ws = run_buckets<Law>(S, bases, S.plan_pairs, c - 1, nwin, S.plan_n, S.plan_cap, s, &ms, nullptr, bases2);
     if (getenv("ZKAES_MSM_DEBUG")) {
         for (int w = 0; w < nwin; w++) {
             Affine<Fq> a = ws[w].to_affine();
             fprintf(stderr, "window %d inf=%d x0=%08x y0=%08x\n", w, (int)a.is_inf(), a.x.l[0], a.y.l[0]);
         }
     }
-    XYZZ<Fq> total = XYZZ<Fq>::inf();
-    for (int w = nwin - 1; w >= 1; w--) {
-        total.add(ws[w]);
-        for (int k = 0; k < c; k++) total = total.dbl();
+    XYZZ<Fq> total[2];
+    for (int rep = 0; rep < (bases2 ? 2 : 1); rep++) {
+        XYZZ<Fq> t = XYZZ<Fq>::inf();
+        for (int w = nwin - 1; w >= 1; w--) {
+            t.add(ws[rep * nwin + w]);
+            for (int k = 0; k < c; k++) t = t.dbl();
+        }
+        t.add(ws[rep * nwin]);
+        total[rep] = t;
     }
-    total.add(ws[0]);
+    if (bases2) *out2 = total[1];
     add_stats(ms, S.plan_n, S.plan_pairs, t_begin);
-    return total;
+    return total[0];
+}
+// plain + shifted powers of one degree-bounded commitment: out[0] = sum over `bases`, out[1] = sum over `bases2`, one reduction and one host wait for both
+template <class Curve>
+void msm_finish2(MsmWorkspace *ws_, const Niels28<typename Curve::FqP> *bases, const Niels28<typename Curve::FqP> *bases2, XYZZ<typename Curve::Fq> *out, stream_t s_) {
+    out[0] = msm_finish_impl<Curve, EdwardsLaw<typename Curve::FqP>>(ws_, bases, s_, bases2, out + 1);
 }
 template <class Curve>
 XYZZ<typename Curve::Fq> msm_finish(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *bases, stream_t s_) { return msm_finish_impl<Curve, WeierLaw<typename Curve::FqP>>(ws_, bases, s_); }
@@ -1561,6 +1596,7 @@ bool class_sum(MsmWorkspace *ws_, const Niels28<typename Curve::FqP> *bases, con
     return class_sum_impl<Curve, EdwardsLaw<typename Curve::FqP>>(ws_, bases, vals, n, out, s_);
 }
 template XYZZ<Fq377> msm_finish<Bls377>(MsmWorkspace *, const Niels28<Fq377P> *, stream_t);
+template void msm_finish2<Bls377>(MsmWorkspace *, const Niels28<Fq377P> *, const Niels28<Fq377P> *, XYZZ<Fq377> *, stream_t);
 template XYZZ<Fq377> msm<Bls377>(MsmWorkspace *, const Niels28<Fq377P> *, const Fr377 *, size_t, stream_t);
 template XYZZ<Fq377> msm_table<Bls377>(MsmWorkspace *, const Niels28<Fq377P> *, size_t, size_t, int, const Fr377 *, size_t, stream_t);
 template bool class_sum<Bls377>(MsmWorkspace *, const Niels28<Fq377P> *, const int8_t *, size_t, XYZZ<Fq377> *, stream_t);

@@ -80,8 +80,38 @@ __global__ void k_div_vanishing(F *__restrict__ q, F *__restrict__ rem, const F 
     }
     if (rem) rem[j] = (j < len ? p[j] : F::zero()) + carry;
 }
-void divide_by_vanishing(F *q, F *rem, const F *p, size_t len, size_t m, stream_t s) {
+// A SMALL divisor (round 1 divides by the input domain's v_X, m = 64 against |H| + 1 coefficients) makes the m chains long and few: cut every chain into S segments of
+// C steps -- k_divvan_sums leaves the segment sums, k_divvan_apply starts every segment from the sum of the segments above it.  (One lane per residue class took
+// 524 us of a lone 16-byte encrypt(): 64 lanes x 4,096 dependent steps.)  Additions only: the same values in the same order class by class, bit-identical.
+__global__ void k_divvan_sums(F *__restrict__ part, const F *__restrict__ p, size_t qlen, size_t m, size_t C, size_t S) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * m) return;
+    const size_t seg = idx / m, j = idx % m;
+    F sum = F::zero();
+    for (size_t t = seg * C; t < (seg + 1) * C; t++) { size_t i = j + t * m; if (i < qlen) sum = sum + p[i + m]; }
+    part[idx] = sum;
+}
+__global__ void k_divvan_apply(F *__restrict__ q, F *__restrict__ rem, const F *__restrict__ p, const F *__restrict__ part, size_t len, size_t m, size_t C, size_t S) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * m) return;
+    const size_t seg = idx / m, j = idx % m, qlen = len - m;
+    F carry = F::zero();
+    for (size_t u = S; u-- > seg + 1;) carry = carry + part[u * m + j];
+    for (size_t t = (seg + 1) * C; t-- > seg * C;) { size_t i = j + t * m; if (i < qlen) { carry = carry + p[i + m]; q[i] = carry; } }
+    if (seg == 0 && rem) rem[j] = (j < len ? p[j] : F::zero()) + carry;
+}
+// `scratch` (optional, `scratch_len` elements, must not overlap q / rem / p): the segment sums of the small-divisor path
+void divide_by_vanishing(F *q, F *rem, const F *p, size_t len, size_t m, stream_t s, F *scratch, size_t scratch_len) {
     if (len <= m) throw GpuError("divide_by_vanishing: dividend shorter than divisor");
+    const size_t chain = (len - m + m - 1) / m;            // steps of the longest residue class
+    size_t S = 1;
+    while (S * S < chain) S <<= 1;
+    if (chain >= 64 && scratch && S * m <= scratch_len) {
+        const size_t C = (chain + S - 1) / S;
+        hipLaunchKernelGGL(k_divvan_sums, GRID(S * m), 0, (hipStream_t)s, scratch, p, len - m, m, C, S); HIP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_divvan_apply, GRID(S * m), 0, (hipStream_t)s, q, rem, p, (const F *)scratch, len, m, C, S); HIP_LAUNCH_CHECK();
+        return;
+    }
     hipLaunchKernelGGL(k_div_vanishing, GRID(m), 0, (hipStream_t)s, q, rem, p, len, m); HIP_LAUNCH_CHECK();
 }
 
@@ -149,12 +179,15 @@ void divide_by_linear(F *q, const F *p, size_t len, const F &z, F *scratch, size
     divlin_rec(q, p, len, z, scratch, s);
 }
 
-// ---- evaluation: chunks of 64 coefficients by Horner, then sum_t partial_t * (x^64)^t
+// ---- evaluation: chunks of EV_CHUNK coefficients by Horner, level by level (the partials of one level are the coefficients of the next, in x^EV_CHUNK) until one
+// workgroup can combine what is left: sum_t partial_t * y^t.  Short chunks: a lane's chain of dependent products is what a lone proof waits for (64-coefficient chunks:
+// 100 us per level at |H| = 2^18 on 16 workgroups); the extra partial traffic is 1/16 of reading the polynomial.
+constexpr size_t EV_CHUNK = 16, EV_COMBINE_MAX = 1024;
 __global__ void k_eval_chunks(const F *__restrict__ p, size_t len, F x, F *__restrict__ partial) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t nch = (len + 63) / 64;
+    size_t nch = (len + EV_CHUNK - 1) / EV_CHUNK;
     if (t >= nch) return;
-    size_t s0 = t * 64, e = s0 + 64 < len ? s0 + 64 : len;
+    size_t s0 = t * EV_CHUNK, e = s0 + EV_CHUNK < len ? s0 + EV_CHUNK : len;
     F acc = F::zero();
     for (size_t i = e; i-- > s0;) acc = acc * x + p[i];
     partial[t] = acc;
@@ -169,25 +202,49 @@ __global__ void __launch_bounds__(256) k_eval_combine(const F *__restrict__ part
     for (int s = 128; s > 0; s >>= 1) { if ((int)t < s) sh[t] = sh[t] + sh[t + s]; __syncthreads(); }
     if (t == 0) out[0] = sh[0];
 }
-F poly_eval(const F *p, size_t len, const F &x, F *scratch, stream_t s_) {
+size_t poly_eval_scratch(size_t len) {
+    size_t tot = 0, n = len;
+    do { n = (n + EV_CHUNK - 1) / EV_CHUNK; tot += n; } while (n > EV_COMBINE_MAX);
+    return tot;
+}
+// launches only: the value lands in *out (device)
+static void eval_launch(const F *p, size_t len, F x, F *scratch, F *out, hipStream_t s) {
+    const F *src = p;
+    size_t n = len;
+    F y = x;
+    do {
+        size_t nch = (n + EV_CHUNK - 1) / EV_CHUNK;
+        hipLaunchKernelGGL(k_eval_chunks, GRID(nch), 0, s, src, n, y, scratch); HIP_LAUNCH_CHECK();
+        src = scratch; scratch += nch; n = nch; y = y.pow_u64(EV_CHUNK);
+    } while (n > EV_COMBINE_MAX);
+    hipLaunchKernelGGL(k_eval_combine, dim3(1), dim3(256), 0, s, src, n, y, out); HIP_LAUNCH_CHECK();
+}
+// out[i] = p[i](x[i]) for up to 8 polynomials: every launch first, then ONE wait and one copy (the four evaluations of a proof go into the transcript together)
+void poly_eval_multi(const F *const *p, const size_t *len, const F *x, int count, F *out, F *scratch, size_t scratch_elems, stream_t s_) {
     hipStream_t s = (hipStream_t)s_;
-    if (len == 0) return F::zero();
-    size_t nch = (len + 63) / 64;
-    hipLaunchKernelGGL(k_eval_chunks, GRID(nch), 0, s, p, len, x, scratch); HIP_LAUNCH_CHECK();
-    F y = x.pow_u64(64);
-    F *part = scratch;
-    if (nch > 2048) {
-        // a second level of 64-partial Horner chunks: the one-workgroup combine below walks its partials serially per lane (two dependent products each) --
-        // 256 steps for a 2^22-coefficient polynomial were 0.3 ms of pure latency per evaluation (profiles/r03_kernel_stats_serial.md: k_eval_combine)
-        const size_t nch2 = (nch + 63) / 64;
-        hipLaunchKernelGGL(k_eval_chunks, GRID(nch2), 0, s, (const F *)scratch, nch, y, scratch + nch); HIP_LAUNCH_CHECK();
-        part = scratch + nch; nch = nch2; y = y.pow_u64(64);
+    if (count < 1 || count > 8) throw GpuError("poly_eval_multi: 1..8 polynomials");
+    size_t need = 8;
+    for (int i = 0; i < count; i++) need += poly_eval_scratch(len[i]);
+    if (need > scratch_elems) throw GpuError("poly_eval_multi: scratch too small");
+    F *res = scratch, *at = scratch + 8;
+    bool any = false;
+    for (int i = 0; i < count; i++) {
+        if (!len[i]) continue;
+        eval_launch(p[i], len[i], x[i], at, res + i, s);
+        at += poly_eval_scratch(len[i]); any = true;
     }
-    hipLaunchKernelGGL(k_eval_combine, dim3(1), dim3(256), 0, s, (const F *)part, nch, y, part + nch); HIP_LAUNCH_CHECK();
+    F host[8];
+    if (any) {
+        sync((stream_t)s);        // drain first (sleeps in throughput mode): the pageable device-to-host copy below waits actively inside HIP
+        HIP_CHECK(hipMemcpyAsync(host, res, count * sizeof(F), hipMemcpyDeviceToHost, s));
+        sync((stream_t)s);
+    }
+    for (int i = 0; i < count; i++) out[i] = len[i] ? host[i] : F::zero();
+}
+// (`scratch`: 8 + poly_eval_scratch(len) elements)
+F poly_eval(const F *p, size_t len, const F &x, F *scratch, stream_t s_) {
     F out;
-    sync((stream_t)s);        // drain first (sleeps in throughput mode): the pageable device-to-host copies below wait actively inside HIP
-    HIP_CHECK(hipMemcpyAsync(&out, part + nch, sizeof(F), hipMemcpyDeviceToHost, s));
-    sync((stream_t)s);
+    poly_eval_multi(&p, &len, &x, 1, &out, scratch, 8 + poly_eval_scratch(len), s_);
     return out;
 }
 

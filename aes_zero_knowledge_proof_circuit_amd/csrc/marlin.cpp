@@ -525,7 +525,7 @@ class ProvingKeyImpl {
         size_t big = std::max(n4, k2);
         for (auto &b : cx.e) b.alloc(big);
         cx.big_tmp.alloc(big); cx.f_poly.alloc(k);
-        cx.acc.alloc(std::max(3 * n, k) + 1); cx.wit.alloc(std::max(3 * n, k) + 1); cx.wit2.alloc(std::max(n, k) + 1); cx.scratch.alloc(std::max(std::max(3 * n, k) / 32 + 1024, gpu::divide_by_linear_scratch(std::max(3 * n, k) + 1)));
+        cx.acc.alloc(std::max(3 * n, k) + 1); cx.wit.alloc(std::max(3 * n, k) + 1); cx.wit2.alloc(std::max(n, k) + 1); cx.scratch.alloc(std::max(8 + 3 * gpu::poly_eval_scratch(n + 1) + gpu::poly_eval_scratch(k), gpu::divide_by_linear_scratch(std::max(3 * n, k) + 1)));
     }
 
     template <class T> static T *upload(const std::vector<T> &v, gpu::stream_t s) {
@@ -585,11 +585,11 @@ class ProvingKeyImpl {
         if (len > supported_degree + 1 || off + len > bounds[1] + 1) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
         if (table_ok(cx, len)) gpu::msm_prepare_table<Bls377>(ln.ws, coeffs, len, 0, nullptr, 0, 0, table_c, srs_stride, ln.stream);
         else gpu::msm_prepare<Bls377>(ln.ws, coeffs, len, nullptr, 0, 0, ln.stream);
-        XYZZ<Fq377> c1 = gpu::msm_finish<Bls377>(ln.ws, d_powers, ln.stream);
-        hide(c1, lp.rand);
-        XYZZ<Fq377> c2 = gpu::msm_finish<Bls377>(ln.ws, d_shifted + off, ln.stream);     // table mode: every copy's index shifts by n_plain + off
-        hide(c2, lp.shifted_rand);
-        lp.comm.comm = c1.to_affine(); lp.comm.shifted = c2.to_affine(); lp.comm.has_shifted = true;
+        XYZZ<Fq377> c12[2];
+        gpu::msm_finish2<Bls377>(ln.ws, d_powers, d_shifted + off, c12, ln.stream);       // table mode: every copy's index shifts by n_plain + off
+        hide(c12[0], lp.rand);
+        hide(c12[1], lp.shifted_rand);
+        lp.comm.comm = c12[0].to_affine(); lp.comm.shifted = c12[1].to_affine(); lp.comm.has_shifted = true;
     }
     // opening witness = MSM(powers, wit) + MSM(shifted powers from shift_off, swit) as ONE Pippenger instance over the contiguous SRS array
     XYZZ<Fq377> msm_opening(ProverContext &cx, Lane &ln, const F *wit, size_t wlen, const F *swit, size_t slen, size_t shift_off) {
@@ -874,7 +874,7 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     Fr rhos[3];
     Fr rho = zk.rand_field<Fr>(); rhos[0] = rho;
     gpu::poly_add_at(e[0].p, 0, rho.neg(), s); gpu::poly_set_at(e[0].p, n, rho, s);   // + rho * v_H
-    gpu::divide_by_vanishing(poly[0].p, e[1].p, e[0].p, n + 1, m, s);       // / v_X ; remainder must vanish
+    gpu::divide_by_vanishing(poly[0].p, e[1].p, e[0].p, n + 1, m, s, e[1].p + m, n);       // / v_X ; remainder must vanish
     poly_len[0] = n + 1 - m;
     gpu::ntt<F>(poly[1].p, za_ev.p, n, lg_n, true, s);
     rho = zk.rand_field<Fr>(); rhos[1] = rho;
@@ -980,11 +980,13 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     timings.round3_ms = ms_since(t0); t0 = Clock::now();
     // ---- evaluations, opening challenge
     Proof pf;
-    Fr g1_b = gpu::poly_eval(poly[5].p, poly_len[5], beta, scratch.p, s);
-    Fr g2_g = gpu::poly_eval(poly[7].p, poly_len[7], gamma, scratch.p, s);
-    Fr t_b = gpu::poly_eval(poly[4].p, poly_len[4], beta, scratch.p, s);
-    Fr zb_b = gpu::poly_eval(poly[2].p, poly_len[2], beta, scratch.p, s);
-    pf.evals[0] = g1_b; pf.evals[1] = g2_g; pf.evals[2] = t_b; pf.evals[3] = zb_b;
+    {
+        const F *ps[4] = {poly[5].p, poly[7].p, poly[4].p, poly[2].p};
+        const size_t ls[4] = {poly_len[5], poly_len[7], poly_len[4], poly_len[2]};
+        const Fr at[4] = {beta, gamma, beta, beta};
+        gpu::poly_eval_multi(ps, ls, at, 4, pf.evals, scratch.p, scratch.n, s);     // g_1(beta), g_2(gamma), t(beta), z_b(beta)
+    }
+    const Fr g1_b = pf.evals[0], g2_g = pf.evals[1], t_b = pf.evals[2], zb_b = pf.evals[3];
     { Bytes o; for (auto &v : pf.evals) o.field(v); fs.absorb(o.b); }
     Fr ch;
     { uint64_t lo = fs.rng().next_u64(), hi = fs.rng().next_u64(); uint32_t raw[8] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32), 0, 0, 0, 0}; ch = Fr::from_raw(raw); }

@@ -185,3 +185,48 @@ def test_reduced_radix_scalar_field_matches_montgomery_reference():
         out = subprocess.run([exe], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout + out.stderr
         assert out.stdout.split() == ["fr377", "0", "fr381", "0"]
+
+
+SRC_INV = r'''
+#include "ff.cuh"
+#include <cstdio>
+#include <cstdlib>
+using namespace zk;
+template <class F> int run(const char *name) {
+    srand(23);
+    int bad = 0;
+    for (int it = 0; it < 600; it++) {
+        uint32_t raw[F::N];
+        for (int i = 0; i < F::N; i++) raw[i] = (uint32_t)rand() * 2654435761u ^ (uint32_t)rand();
+        raw[F::N - 1] &= (1u << ((F::BITS - 2) % 32)) - 1;        // < p
+        F a = F::from_raw(raw);
+        if (it == 0) a = F::zero();
+        if (it == 1) a = F::one();
+        if (it == 2) a = F::one().neg();
+        if (it == 3) a = F::one() + F::one();
+        if (it == 4) a = (F::one() + F::one()).inverse_fermat();                 // (p + 1) / 2
+        if (it >= 5 && it < 40) a = F::from_u64(1ull << (it - 5)) ;              // powers of two: the longest runs of halvings
+        if (it >= 40 && it < 80) a = F::from_u64((uint64_t)it * 0x9e3779b97f4a7c15ull).neg();
+        F i1 = a.inverse(), i2 = a.inverse_fermat();
+        bad += !(i1 == i2);
+        if (!a.is_zero()) bad += !(i1 * a == F::one());
+        for (int i = 0; i < F::N; i++) raw[i] = i1.l[i];
+        bad += !a.is_zero() && F::geq_mod(raw);                                   // canonical
+    }
+    printf("%s %d\n", name, bad);
+    return bad;
+}
+int main() { return run<Fr377>("fr377") + run<Fr381>("fr381") + run<Fq377>("fq377") + run<Fq381>("fq381"); }
+'''
+
+
+def test_euclid_inverse_matches_fermat():
+    """Fp::inverse (csrc/ff.cuh: Kaliski's almost-Montgomery inverse + doublings) against the Fermat chain on all four fields: zero, +-1, 2, 1/2, powers of two,
+    negated small values and random elements; the result is canonical and a * a^-1 = 1."""
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "t.cpp"), os.path.join(d, "t")
+        open(src, "w").write(SRC_INV)
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", CSRC, src, "-o", exe])
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert out.stdout.split() == ["fr377", "0", "fr381", "0", "fq377", "0", "fq381", "0"], out.stdout
