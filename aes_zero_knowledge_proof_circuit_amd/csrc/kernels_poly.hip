@@ -121,8 +121,9 @@ void divide_by_vanishing(F *q, F *rem, const F *p, size_t len, size_t m, stream_
 // C_t = sum_{t' > t} V_t' (z^B)^(t' - t - 1) -- the same division applied to V at the point z^B, DL_B times shorter; k_divlin_apply then adds z^(end - 1 - i) C_t to every
 // coefficient of the block (one more product).  Two products per coefficient and a few tiny launches for the upper levels, against four products per coefficient plus the
 // operator applications of a generic device scan over scaled terms (rounds 1-3: ~600 M wave-instructions per proof, 2 % of everything the saturated prover issues).
-// Field arithmetic is exact, so the result is bit-identical to the recurrence.
-constexpr int DL_B = 64;
+// Field arithmetic is exact, so the result is bit-identical to the recurrence.  Short blocks: a lane's chain of DL_B dependent products is what a lone proof waits for
+// at every level (64-coefficient blocks: 125 us per level, 0.83 ms for the two divisions of an opening; 16: four cheap levels more, a third of the wait).
+constexpr int DL_B = 16;
 __global__ void k_divlin_local(F *__restrict__ q, const F *__restrict__ p, size_t len, F z, F *__restrict__ v, F *__restrict__ zp) {
     if (blockIdx.x == 0 && threadIdx.x < DL_B) zp[threadIdx.x] = z.pow_u64(threadIdx.x);        // the level's power table z^0 .. z^(B-1) for k_divlin_apply (next launch but one)
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, s0 = t * DL_B;

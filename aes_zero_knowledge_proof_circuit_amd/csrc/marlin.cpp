@@ -574,30 +574,34 @@ class ProvingKeyImpl {
         const F *coeffs = cx.poly[lp.idx].p;
         size_t len = cx.poly_len[lp.idx];
         lp.comm.has_shifted = false;
-        if (lp.bound < 0) {
-            XYZZ<Fq377> c = msm_powers(cx, ln, false, 0, coeffs, len);
-            hide(c, lp.rand);
-            lp.comm.comm = c.to_affine();
-            return;
+        const bool bounded = lp.bound >= 0;
+        // degree-bounded polynomial: the plain and the shifted commitment have the same scalars -> one digit / sort pass, two accumulations, one reduction
+        const size_t off = bounded ? (max_degree - (size_t)lp.bound) - lowest_shift : 0;
+        if (len > supported_degree + 1 || (bounded && off + len > bounds[1] + 1)) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
+        if (len) {
+            if (table_ok(cx, len)) gpu::msm_prepare_table<Bls377>(ln.ws, coeffs, len, 0, nullptr, 0, 0, table_c, srs_stride, ln.stream);
+            else gpu::msm_prepare<Bls377>(ln.ws, coeffs, len, nullptr, 0, 0, ln.stream);
         }
-        // degree-bounded polynomial: the plain and the shifted commitment have the same scalars -> one digit / sort pass, two accumulations
-        size_t off = (max_degree - (size_t)lp.bound) - lowest_shift;
-        if (len > supported_degree + 1 || off + len > bounds[1] + 1) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
-        if (table_ok(cx, len)) gpu::msm_prepare_table<Bls377>(ln.ws, coeffs, len, 0, nullptr, 0, 0, table_c, srs_stride, ln.stream);
-        else gpu::msm_prepare<Bls377>(ln.ws, coeffs, len, nullptr, 0, 0, ln.stream);
-        XYZZ<Fq377> c12[2];
-        gpu::msm_finish2<Bls377>(ln.ws, d_powers, d_shifted + off, c12, ln.stream);       // table mode: every copy's index shifts by n_plain + off
-        hide(c12[0], lp.rand);
-        hide(c12[1], lp.shifted_rand);
-        lp.comm.comm = c12[0].to_affine(); lp.comm.shifted = c12[1].to_affine(); lp.comm.has_shifted = true;
+        // the hiding terms are host work (comb-table products): done while the device groups the digits, not after the wait for its sums
+        XYZZ<Fq377> c12[2] = {XYZZ<Fq377>::inf(), XYZZ<Fq377>::inf()}, h12[2] = {XYZZ<Fq377>::inf(), XYZZ<Fq377>::inf()};
+        hide(h12[0], lp.rand);
+        if (bounded) hide(h12[1], lp.shifted_rand);
+        if (len) {
+            if (bounded) gpu::msm_finish2<Bls377>(ln.ws, d_powers, d_shifted + off, c12, ln.stream);       // table mode: every copy's index shifts by n_plain + off
+            else c12[0] = gpu::msm_finish<Bls377>(ln.ws, d_powers, ln.stream);
+        }
+        c12[0].add(h12[0]);
+        lp.comm.comm = c12[0].to_affine();
+        if (bounded) { c12[1].add(h12[1]); lp.comm.shifted = c12[1].to_affine(); lp.comm.has_shifted = true; }
     }
     // opening witness = MSM(powers, wit) + MSM(shifted powers from shift_off, swit) as ONE Pippenger instance over the contiguous SRS array
-    XYZZ<Fq377> msm_opening(ProverContext &cx, Lane &ln, const F *wit, size_t wlen, const F *swit, size_t slen, size_t shift_off) {
+    // (two steps: the digit grouping is launched and returns; the caller does its host-side share of the witness, then waits for the sum)
+    void msm_opening_prepare(ProverContext &cx, Lane &ln, const F *wit, size_t wlen, const F *swit, size_t slen, size_t shift_off) {
         if (wlen > supported_degree + 1 || shift_off + slen > bounds[1] + 1) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
         if (table_ok(cx, wlen + slen)) gpu::msm_prepare_table<Bls377>(ln.ws, wit, wlen, 0, swit, slen, n_plain + shift_off, table_c, srs_stride, ln.stream);
         else gpu::msm_prepare<Bls377>(ln.ws, wit, wlen, swit, slen, n_plain + shift_off, ln.stream);
-        return gpu::msm_finish<Bls377>(ln.ws, d_powers, ln.stream);
     }
+    XYZZ<Fq377> msm_opening_finish(Lane &ln) { return gpu::msm_finish<Bls377>(ln.ws, d_powers, ln.stream); }
     // Run the independent jobs of one prover step.  Throughput calls (several proofs in flight) and ZKAES_LANES=0 run them one after the other on lane 0;
     // a lone encrypt() call gives each job its own lane (stream + MSM scratch) and a host thread, after the main stream has produced their inputs.
     bool use_lanes = true;
@@ -841,6 +845,30 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     ChaChaRng zk(zk_seed ? zk_seed : ark_test_rng_seed(), 12);
     const size_t n4 = next_pow2(3 * n + 1), k2 = 2 * k;
     const int lg_n4 = log2_exact(n4), lg_k2 = log2_exact(k2);
+    // ---- the prover's own randomness first: none of it depends on the witness.  Upstream's draw order is rho_w, rho_zA, rho_zB, the 3|H| mask coefficients, then the
+    // commitments' blinding scalars label by label -- kept -- but the mask polynomial and its commitment (the one full-width MSM of round 1, and the round's critical
+    // path in a lone call: 2.9 of 26.8 ms at 16 bytes) start NOW on a lane of their own, under the witness generation and the round's transforms.
+    Labeled r1[4] = {{0, -1, true}, {1, -1, true}, {2, -1, true}, {3, -1, false}};
+    Fr rhos[3];
+    for (auto &r : rhos) r = zk.rand_field<Fr>();
+    {   // mask polynomial: degree 3|H| + 2 zk_bound - 3, sum over H forced to zero.  The 3|H| coefficients are the next 3|H| Fr::rand draws
+        // of the prover RNG: generated on the device from the same ChaCha12 key stream, then the host RNG skips past them.
+        uint64_t next = gpu::chacha_field_stream(poly[3].p, 3 * n, zk.key_words(), zk.rounds(), zk.word_pos(), cx.d_rng, cx.rng_bytes, s);
+        zk.set_word_pos(next);
+        gpu::mask_fixup(poly[3].p, n, s);
+        poly_len[3] = 3 * n;
+    }
+    for (auto &lp : r1) draw_rand(lp, zk);
+    const bool early_mask = !cx.throughput && use_lanes;
+    std::thread mask_thread;
+    std::string mask_err;
+    struct JoinGuard { std::thread &t; ~JoinGuard() { if (t.joinable()) t.join(); } } mask_guard{mask_thread};       // (an exception below must not leave the thread running on this context)
+    if (early_mask) {
+        cx.ensure_lanes();
+        gpu::sync(s);                    // the mask polynomial is in place (nothing else is on the stream yet)
+        const int dev = device;
+        mask_thread = std::thread([&, dev] { try { gpu::set_device(dev); mpc_commit(cx, cx.lane[3], r1[3]); } catch (const std::exception &e) { mask_err = e.what(); if (mask_err.empty()) mask_err = "error"; } });
+    }
     // ---- witness: trace -> z (bytes) -> z_A, z_B
     if (host_trace) gpu::h2d(d_trace, host_trace, c.trace_bytes, s);
     else {
@@ -865,42 +893,35 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
         fs.initialize(o.b);
     }
     // ---- first round
-    Labeled r1[4] = {{0, -1, true}, {1, -1, true}, {2, -1, true}, {3, -1, false}};
     gpu::bits_to_field(x_tmp.p, d_z, m, s);
     gpu::ntt<F>(x_poly.p, x_tmp.p, m, lg_m, true, s);
     gpu::ntt<F>(x_evals.p, x_poly.p, m, lg_n, false, s);
     gpu::w_evals(tmp_n.p, d_z, x_evals.p, (uint32_t)n, (uint32_t)m, (uint32_t)c.num_witness, s);
     gpu::ntt<F>(e[0].p, tmp_n.p, n, lg_n, true, s);                         // interpolate
-    Fr rhos[3];
-    Fr rho = zk.rand_field<Fr>(); rhos[0] = rho;
+    Fr rho = rhos[0];
     gpu::poly_add_at(e[0].p, 0, rho.neg(), s); gpu::poly_set_at(e[0].p, n, rho, s);   // + rho * v_H
     gpu::divide_by_vanishing(poly[0].p, e[1].p, e[0].p, n + 1, m, s, e[1].p + m, n);       // / v_X ; remainder must vanish
     poly_len[0] = n + 1 - m;
     gpu::ntt<F>(poly[1].p, za_ev.p, n, lg_n, true, s);
-    rho = zk.rand_field<Fr>(); rhos[1] = rho;
+    rho = rhos[1];
     gpu::poly_add_at(poly[1].p, 0, rho.neg(), s); gpu::poly_set_at(poly[1].p, n, rho, s); poly_len[1] = n + 1;
     gpu::ntt<F>(poly[2].p, zb_ev.p, n, lg_n, true, s);
-    rho = zk.rand_field<Fr>(); rhos[2] = rho;
+    rho = rhos[2];
     gpu::poly_add_at(poly[2].p, 0, rho.neg(), s); gpu::poly_set_at(poly[2].p, n, rho, s); poly_len[2] = n + 1;
-    {   // mask polynomial: degree 3|H| + 2 zk_bound - 3, sum over H forced to zero.  The 3|H| coefficients are the next 3|H| Fr::rand draws
-        // of the prover RNG: generated on the device from the same ChaCha12 key stream, then the host RNG skips past them.
-        uint64_t next = gpu::chacha_field_stream(poly[3].p, 3 * n, zk.key_words(), zk.rounds(), zk.word_pos(), cx.d_rng, cx.rng_bytes, s);
-        zk.set_word_pos(next);
-        gpu::mask_fixup(poly[3].p, n, s);
-        poly_len[3] = 3 * n;
-    }
     using Jobs = std::vector<std::function<void(Lane &)>>;
-    for (auto &lp : r1) draw_rand(lp, zk);
     {
         Jobs jobs;
         for (auto &lp_ : r1) {
             Labeled *lp = &lp_;
+            if (early_mask && lp->idx == 3) continue;          // (already under way on lane 3)
             jobs.push_back([&, lp](Lane &ln) {
                 if (use_lagrange && lp->idx < 3 && lagrange_commit(cx, ln, lp->idx, inst, rhos[lp->idx], lp->rand, lp->comm.comm)) { lp->comm.has_shifted = false; return; }
                 mpc_commit(cx, ln, *lp);
             });
         }
         run_jobs(cx, jobs);
+        if (mask_thread.joinable()) mask_thread.join();
+        if (!mask_err.empty()) throw std::runtime_error(mask_err);
     }
     { Bytes o; for (auto &lp : r1) o.commitment_tobytes(lp.comm); fs.absorb(o.b); }
     auto sample_outside_h = [&]() { Fr t; do { t = fs.rng().rand_field<Fr>(); } while (eval_vanishing(n, t).is_zero()); return t; };
@@ -1022,14 +1043,18 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
         // shifted part (g_1, degree bound |H| - 2) rides in the same Pippenger instance
         gpu::divide_by_linear(wit2.p, poly[5].p, poly_len[5], beta, scratch.p, scratch.n, ls_);
         gpu::poly_scale(wit2.p, chp[1], poly_len[5] - 1, ls_);
-        XYZZ<Fq377> w = msm_opening(cx, ln, wit.p, plen - 1, wit2.p, poly_len[5] - 1, bounds[1] - (n - 2));
+        msm_opening_prepare(cx, ln, wit.p, plen - 1, wit2.p, poly_len[5] - 1, bounds[1] - (n - 2));
+        // (the blinding part of the witness is host work: under the device's digit grouping, not after the wait for its sum)
+        XYZZ<Fq377> hw = XYZZ<Fq377>::inf();
         Fr rq[2]; host_divide_by_linear(rq, rb, beta);
-        for (int i = 0; i < 2; i++) w.add(gamma_tab[i].mul(rq[i]));
+        for (int i = 0; i < 2; i++) hw.add(gamma_tab[i].mul(rq[i]));
         Fr rv = host_eval3(rb, beta);
         Fr srb[3]; for (int i = 0; i < 3; i++) srb[i] = chp[1] * r2[1].shifted_rand.b[i];
         host_divide_by_linear(rq, srb, beta);
-        for (int i = 0; i < 2; i++) w.add(gamma_tab[i].mul(rq[i]));
+        for (int i = 0; i < 2; i++) hw.add(gamma_tab[i].mul(rq[i]));
         rv = rv + host_eval3(srb, beta);
+        XYZZ<Fq377> w = msm_opening_finish(ln);
+        w.add(hw);
         pf.w_beta = w.to_affine(); pf.random_v_beta = rv;
     });
     open_jobs.push_back([&](Lane &ln) {   // open at gamma: g_2 (ch^0; shifted ch^1), inner_sumcheck (ch^2)
@@ -1045,7 +1070,8 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
         gpu::divide_by_linear(wit_.p, acc_.p, plen, gamma, scr_.p, scr_.n, ls_);
         gpu::divide_by_linear(wit2_.p, poly[7].p, poly_len[7], gamma, scr_.p, scr_.n, ls_);
         gpu::poly_scale(wit2_.p, chp[1], poly_len[7] - 1, ls_);
-        XYZZ<Fq377> w = msm_opening(cx, ln, wit_.p, plen - 1, wit2_.p, poly_len[7] - 1, bounds[1] - (k - 2));
+        msm_opening_prepare(cx, ln, wit_.p, plen - 1, wit2_.p, poly_len[7] - 1, bounds[1] - (k - 2));
+        XYZZ<Fq377> w = msm_opening_finish(ln);
         pf.w_gamma = w.to_affine();
     });
     run_jobs(cx, open_jobs);
