@@ -49,6 +49,9 @@ template <class Fr> void ntt(Fr *dst, const Fr *src, size_t in_len, int lg, bool
 // forward: dst[i] = p(g w^i) for the coefficients src[0 .. in_len); inverse: the coefficients of the polynomial of degree < 2^lg with those values.  No extra pass: the scaling
 // by g^(+-k) rides on the first pass's gather / the last pass's store.  (Together, cosets 0 .. 2^(lg_big - lg) - 1 are the larger domain.)
 template <class Fr> void ntt_coset(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, int coset_c, int lg_big, stream_t s);
+// up to 12 independent transforms of ONE shape (size, direction, input length) in shared launches; coset_c = 0: plain transform, > 0: the coset W^c H as in ntt_coset
+template <class Fr> struct NttJob { Fr *dst; const Fr *src; int coset_c; };
+template <class Fr> void ntt_batch(const NttJob<Fr> *jobs, int count, size_t in_len, int lg, bool inverse, int lg_big, stream_t s);
 // A coset whose generator g is not a root of unity (round 3 uses the field's multiplicative generator): coset_power_table builds g^i (i < n) once per key in the kernel's
 // reduced-radix form (free with dfree); ntt_scaled(.., table of g^i) evaluates on g D, ntt_scaled(.., inverse = true, table of g^-i) interpolates from there.
 template <class Fr> void *coset_power_table(const Fr &g, size_t n, stream_t s);

@@ -678,7 +678,7 @@ __global__ void __launch_bounds__(RF_THREADS) k_reduce_final(const AccTE<P> *__r
     }
 }
 
-template <class A> __global__ void k_sum_tree(const A *__restrict__ in, uint32_t total, uint32_t per, A *__restrict__ out);
+template <class A> __global__ void k_sum_tree(const A *__restrict__ in, uint32_t total, uint32_t per, A *__restrict__ out, uint32_t in_stride, uint32_t out_stride);
 
 constexpr uint32_t DEFERRED_CAP = 1u << 20;
 constexpr size_t ACC_BYTES = sizeof(Acc28<Fq377P>);          // one bucket in the reduced-radix form: 224 B, XYZZ and extended Edwards alike, same for both curves
@@ -860,7 +860,7 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
     if (nsets == 1 && parts > 2048) {
         // one big bucket set: 256-partial blocks first, so the final LDS tree does not walk tens of thousands of partials serially
         uint32_t mid = (parts + 255) / 256;
-        hipLaunchKernelGGL((k_sum_tree<A>), dim3(mid), dim3(256), 0, s, (const A *)S.partial, parts, 256u, (A *)S.seg_s);
+        hipLaunchKernelGGL((k_sum_tree<A>), dim3(mid), dim3(256), 0, s, (const A *)S.partial, parts, 256u, (A *)S.seg_s, 0u, 0u);
         HIP_LAUNCH_CHECK();
         hipLaunchKernelGGL((k_reduce_window<A>), dim3(1), dim3(256), 0, s, (const A *)S.seg_s, mid, res, dev_wsum_out);
     } else {
@@ -1531,17 +1531,21 @@ __global__ void __launch_bounds__(64, 2) k_class_partials(const typename Law::Ba
     part2[t] = inf2 ? inf28<P>() : a2;
     }
 }
-// out[b] = sum of in[b * per .. (b+1) * per)   (one block of 256 lanes per output)
+// out[b] = sum of in[b * per .. (b+1) * per)   (one block of 256 lanes per output); blockIdx.y selects one of several independent arrays laid out at fixed strides
+// (the two classes of class_sum share a launch).  The LDS tree starts at the width that holds data: 64 partials take six levels, not eight.
 template <class A>
-__global__ void __launch_bounds__(256) k_sum_tree(const A *__restrict__ in, uint32_t total, uint32_t per, A *__restrict__ out) {
+__global__ void __launch_bounds__(256) k_sum_tree(const A *__restrict__ in, uint32_t total, uint32_t per, A *__restrict__ out, uint32_t in_stride, uint32_t out_stride) {
     __shared__ A sh[256];
+    in += (size_t)blockIdx.y * in_stride; out += (size_t)blockIdx.y * out_stride;
     uint32_t b = blockIdx.x, t = threadIdx.x;
     uint32_t lo = b * per, hi = lo + per < total ? lo + per : total;
     A acc = PtOps<A>::identity();
     for (uint32_t i = lo + t; i < hi; i += 256) PtOps<A>::add(acc, in[i]);
     sh[t] = acc;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    int width = 256;
+    while (width > 2 && (uint32_t)(width >> 1) >= hi - lo) width >>= 1;          // lanes >= hi - lo hold the identity
+    for (int s = width >> 1; s > 0; s >>= 1) {
         if ((int)t < s) { A a = sh[t]; PtOps<A>::add(a, sh[t + s]); sh[t] = a; }
         __syncthreads();
     }
@@ -1571,10 +1575,9 @@ static bool class_sum_impl(MsmWorkspace *ws_, const typename Law::Base *bases, c
     A *p1 = (A *)S.buckets, *p2 = p1 + chunks, *m1 = p2 + chunks, *m2 = m1 + mid, *fin = m2 + mid;
     hipLaunchKernelGGL((k_class_partials<Law>), dim3((chunks + 63) / 64), dim3(64), 0, s, bases, vals, (uint32_t)n, p1, p2, S.ctrl + 3);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_sum_tree<A>), dim3(mid), dim3(256), 0, s, (const A *)p1, chunks, 256u, m1); HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_sum_tree<A>), dim3(mid), dim3(256), 0, s, (const A *)p2, chunks, 256u, m2); HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_sum_tree<A>), dim3(1), dim3(256), 0, s, (const A *)m1, mid, mid, fin); HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_sum_tree<A>), dim3(1), dim3(256), 0, s, (const A *)m2, mid, mid, fin + 1); HIP_LAUNCH_CHECK();
+    (void)p2; (void)m2;          // (class 2's arrays follow class 1's at the strides below)
+    hipLaunchKernelGGL((k_sum_tree<A>), dim3(mid, 2), dim3(256), 0, s, (const A *)p1, chunks, 256u, m1, chunks, mid); HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_sum_tree<A>), dim3(1, 2), dim3(256), 0, s, (const A *)m1, mid, mid, fin, mid, 1u); HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_class_result<A>), dim3(1), dim3(64), 0, s, (const A *)fin, S.ctrl + 3, (XYZZ<Fq> *)S.d_res); HIP_LAUNCH_CHECK();
     XYZZ<Fq> r[2];
     uint32_t flags = 0;

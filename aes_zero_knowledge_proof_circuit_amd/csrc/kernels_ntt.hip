@@ -40,11 +40,19 @@ __global__ void k_twiddles29(const Fr *__restrict__ tw, uint32_t n, Fp29<typenam
 // Coset transforms (ntt_coset): the points are g w^i with g = W^c, W a primitive root of a LARGER power-of-two domain of size cs_mask + 1 -- the cosets of H inside the
 // 4|H| domain the prover's round 2 evaluates on.  Forward: coefficient k is scaled by g^k while pass 1 gathers it (one more product per element, from the larger
 // domain's twiddle table: W^e for e < half, -W^(e - half) above); inverse: coefficient k is scaled by g^-k (and 1/n) at the last pass's store.
+// Several independent transforms of one shape (same size, direction and input length) share a launch: blockIdx.y names the job (destination, source, coset index).
+// A lone proof's |H|-point passes are latency-bound (30 us for 8 MB): round 2's fifteen transforms are six launches instead of thirty.
+constexpr int NTT_MAX_BATCH = 12;
+template <class Fr> struct NttBatchArgs { Fr *dst[NTT_MAX_BATCH]; const Fr *src[NTT_MAX_BATCH]; uint32_t cs_c[NTT_MAX_BATCH]; };
 template <class Fr, int TILE_LG>
-__global__ void __launch_bounds__(256) k_ntt_pass(Fr *dst, const Fr *src, uint32_t in_len, int lg, int s0, int S, int L,
+__global__ void __launch_bounds__(256) k_ntt_pass(NttBatchArgs<Fr> batch, bool from_dst, uint32_t in_len, int lg, int s0, int S, int L,
                                                    const Fp29<typename Fr::Params> *__restrict__ tw, bool bitrev_load, bool scale, Fp29<typename Fr::Params> scale_by,
-                                                   const Fp29<typename Fr::Params> *__restrict__ cs_tw, uint32_t cs_c, uint32_t cs_mask) {
+                                                   const Fp29<typename Fr::Params> *__restrict__ cs_tw_all, uint32_t cs_mask) {
     using G = Fp29<typename Fr::Params>;
+    Fr *dst = batch.dst[blockIdx.y];
+    const Fr *src = from_dst ? (const Fr *)dst : batch.src[blockIdx.y];
+    const uint32_t cs_c = batch.cs_c[blockIdx.y];
+    const G *__restrict__ cs_tw = cs_c ? cs_tw_all : nullptr;          // (a plain transform inside a batch of coset transforms)
     constexpr int N = G::N;
     constexpr uint32_t TILE = 1u << TILE_LG;
     __shared__ uint32_t lds[N][TILE];
@@ -177,14 +185,26 @@ const Fr *domain_elements(int lg) {
 }
 
 template <class Fr>
-static void ntt_impl(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, int coset_c, int lg_big, stream_t s_, const void *scale_table = nullptr) {
+static void ntt_impl(const NttJob<Fr> *jobs, int count, size_t in_len, int lg, bool inverse, int lg_big, stream_t s_, const void *scale_table = nullptr) {
     using G = Fp29<typename Fr::Params>;
     hipStream_t s = (hipStream_t)s_;
+    if (count < 1 || count > NTT_MAX_BATCH) throw GpuError("ntt: 1..12 transforms per batch");
     if (lg > RootOf<Fr>::TWO_ADICITY || lg > 30) throw GpuError("ntt: domain too large");
     const uint32_t n = 1u << lg;
     if (in_len > n) in_len = n;
-    if (dst == src) throw GpuError("ntt: dst must differ from src (first pass gathers bit-reversed)");
-    if (lg == 0 && !coset_c && !scale_table) { HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(Fr) * (in_len ? 1 : 0), hipMemcpyDeviceToDevice, s)); if (!in_len) HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(Fr), s)); return; }
+    NttBatchArgs<Fr> batch;
+    bool any_coset = scale_table != nullptr;
+    for (int i = 0; i < NTT_MAX_BATCH; i++) {
+        const NttJob<Fr> &j = jobs[i < count ? i : 0];
+        if (j.dst == j.src) throw GpuError("ntt: dst must differ from src (first pass gathers bit-reversed)");
+        if (j.coset_c < 0 || (j.coset_c > 0 && (lg_big <= lg || j.coset_c >= (1 << (lg_big - lg))))) throw GpuError("ntt_coset: coset index out of range");
+        batch.dst[i] = j.dst; batch.src[i] = j.src; batch.cs_c[i] = scale_table ? 1u : (uint32_t)j.coset_c;
+        any_coset = any_coset || j.coset_c > 0;
+    }
+    if (lg == 0 && !any_coset) {
+        for (int i = 0; i < count; i++) { HIP_CHECK(hipMemcpyAsync(jobs[i].dst, jobs[i].src, sizeof(Fr) * (in_len ? 1 : 0), hipMemcpyDeviceToDevice, s)); if (!in_len) HIP_CHECK(hipMemsetAsync(jobs[i].dst, 0, sizeof(Fr), s)); }
+        return;
+    }
     if (lg == 0) throw GpuError("ntt_coset: domain of size one");
     Fr w = Tables<Fr>::gen(lg);
     const Fr *tw_std = inverse ? tables<Fr>().powers(tables<Fr>().inv, lg, w.inverse(), n / 2) : tables<Fr>().powers(tables<Fr>().fwd, lg, w, n / 2);
@@ -192,8 +212,8 @@ static void ntt_impl(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse
     G n_inv = G::twiddle_from_std(Fr::from_u64(n).inverse());
     const G *cs_tw = nullptr;
     uint32_t cs_mask = 0;
-    if (scale_table) { cs_tw = (const G *)scale_table; coset_c = 1; cs_mask = 0xffffffffu; }      // an explicit table g^(+-k), k < 2^lg (coset_power_table): no wrap, no sign
-    else if (coset_c) {   // powers of the larger domain's root (its forward or inverse twiddle table: W^(+-e), e < 2^(lg_big - 1))
+    if (scale_table) { cs_tw = (const G *)scale_table; cs_mask = 0xffffffffu; }      // an explicit table g^(+-k), k < 2^lg (coset_power_table): no wrap, no sign
+    else if (any_coset) {   // powers of the larger domain's root (its forward or inverse twiddle table: W^(+-e), e < 2^(lg_big - 1))
         if (lg_big <= lg || lg_big > RootOf<Fr>::TWO_ADICITY || lg_big > 30) throw GpuError("ntt_coset: the coset generator must come from a larger domain");
         const uint32_t nb = 1u << lg_big;
         Fr wb = Tables<Fr>::gen(lg_big);
@@ -213,8 +233,8 @@ static void ntt_impl(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse
     int remaining = lg - S1;
     {
         bool last = remaining == 0;
-        hipLaunchKernelGGL((k_ntt_pass<Fr, 10>), dim3(n >> S1), dim3(256), 0, s, dst, src, (uint32_t)in_len, lg, 0, S1, 0, tw, true, inverse && last, n_inv,
-                           (!inverse || last) ? cs_tw : (const G *)nullptr, (uint32_t)coset_c, cs_mask);
+        hipLaunchKernelGGL((k_ntt_pass<Fr, 10>), dim3(n >> S1, count), dim3(256), 0, s, batch, false, (uint32_t)in_len, lg, 0, S1, 0, tw, true, inverse && last, n_inv,
+                           (!inverse || last) ? cs_tw : (const G *)nullptr, cs_mask);
         HIP_LAUNCH_CHECK();
         s0 = S1;
     }
@@ -225,8 +245,8 @@ static void ntt_impl(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse
         if (L > s0) L = s0;
         if (L < 2) L = 2;
         bool last = remaining == S;
-        hipLaunchKernelGGL((k_ntt_pass<Fr, 10>), dim3(n >> (S + L)), dim3(256), 0, s, dst, (const Fr *)dst, n, lg, s0, S, L, tw, false, inverse && last, n_inv,
-                           (inverse && last) ? cs_tw : (const G *)nullptr, (uint32_t)coset_c, cs_mask);
+        hipLaunchKernelGGL((k_ntt_pass<Fr, 10>), dim3(n >> (S + L), count), dim3(256), 0, s, batch, true, n, lg, s0, S, L, tw, false, inverse && last, n_inv,
+                           (inverse && last) ? cs_tw : (const G *)nullptr, cs_mask);
         HIP_LAUNCH_CHECK();
         s0 += S;
         remaining -= S;
@@ -234,6 +254,13 @@ static void ntt_impl(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse
     }
     }
 }
+template <class Fr>
+static void ntt_impl(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, int coset_c, int lg_big, stream_t s, const void *scale_table = nullptr) {
+    NttJob<Fr> j{dst, src, coset_c};
+    ntt_impl<Fr>(&j, 1, in_len, lg, inverse, lg_big, s, scale_table);
+}
+template <class Fr>
+void ntt_batch(const NttJob<Fr> *jobs, int count, size_t in_len, int lg, bool inverse, int lg_big, stream_t s) { ntt_impl<Fr>(jobs, count, in_len, lg, inverse, lg_big, s); }
 template <class Fr>
 void ntt(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, stream_t s) { ntt_impl<Fr>(dst, src, in_len, lg, inverse, 0, 0, s); }
 template <class Fr>
@@ -265,6 +292,8 @@ void ntt_scaled(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, con
 template void *coset_power_table<Fr377>(const Fr377 &, size_t, stream_t);
 template void ntt_scaled<Fr377>(Fr377 *, const Fr377 *, size_t, int, bool, const void *, stream_t);
 template void ntt<Fr377>(Fr377 *, const Fr377 *, size_t, int, bool, stream_t);
+template void ntt_batch<Fr377>(const NttJob<Fr377> *, int, size_t, int, bool, int, stream_t);
+template void ntt_batch<Fr381>(const NttJob<Fr381> *, int, size_t, int, bool, int, stream_t);
 template void ntt<Fr381>(Fr381 *, const Fr381 *, size_t, int, bool, stream_t);
 template void ntt_coset<Fr377>(Fr377 *, const Fr377 *, size_t, int, bool, int, int, stream_t);
 template void ntt_coset<Fr381>(Fr381 *, const Fr381 *, size_t, int, bool, int, int, stream_t);

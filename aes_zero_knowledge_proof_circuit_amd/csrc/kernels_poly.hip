@@ -249,11 +249,14 @@ F poly_eval(const F *p, size_t len, const F &x, F *scratch, stream_t s_) {
     return out;
 }
 
-// ---- batch inversion (Montgomery's trick) with ONE Fermat inversion per 512-lane workgroup: 16 elements per lane, the 512 lane products are
+// ---- batch inversion (Montgomery's trick) with ONE inversion per 512-lane workgroup: BI_CHUNK elements per lane, the 512 lane products are
 // combined by prefix / suffix product scans in LDS, lane 0 inverts the block product, every lane recovers the inverse of its own product as
 // inv_total * prefix(lane-1) * suffix(lane+1).  ~4 field products per element instead of 27 (one 380-product Fermat chain per 16 elements);
 // the chain left over is latency, not ALU throughput, so it hides beside other proofs' kernels.  Exact arithmetic: results are identical.
-constexpr int BI_CHUNK = 16, BI_BLOCK = 512;
+// BI_CHUNK: 16 elements per lane when proofs overlap (the scans cost 18 / BI_CHUNK products per element); 4 for a lone call on a small vector, where the lane's chain
+// of dependent products (3 BI_CHUNK + 18 + the inversion) is the kernel's duration and 16-element chunks leave most of the chip without a workgroup.
+constexpr int BI_BLOCK = 512;
+template <int BI_CHUNK>
 __global__ void __launch_bounds__(BI_BLOCK) k_batch_inverse(F *__restrict__ v, size_t n, bool has_post, F post) {
     __shared__ F pre_s[BI_BLOCK], suf_s[BI_BLOCK];
     __shared__ F inv_total;
@@ -291,8 +294,14 @@ __global__ void __launch_bounds__(BI_BLOCK) k_batch_inverse(F *__restrict__ v, s
 }
 void batch_inverse(F *v, size_t n, const F *post, stream_t s) {
     if (!n) return;
-    size_t threads = (n + BI_CHUNK - 1) / BI_CHUNK;
-    hipLaunchKernelGGL(k_batch_inverse, dim3((unsigned)((threads + BI_BLOCK - 1) / BI_BLOCK)), dim3(BI_BLOCK), 0, (hipStream_t)s, v, n, post != nullptr, post ? *post : F::one()); HIP_LAUNCH_CHECK();
+    const F post_v = post ? *post : F::one();
+    if (throughput_mode() || n > ((size_t)1 << 21)) {
+        size_t threads = (n + 15) / 16;
+        hipLaunchKernelGGL(k_batch_inverse<16>, dim3((unsigned)((threads + BI_BLOCK - 1) / BI_BLOCK)), dim3(BI_BLOCK), 0, (hipStream_t)s, v, n, post != nullptr, post_v); HIP_LAUNCH_CHECK();
+    } else {
+        size_t threads = (n + 3) / 4;
+        hipLaunchKernelGGL(k_batch_inverse<4>, dim3((unsigned)((threads + BI_BLOCK - 1) / BI_BLOCK)), dim3(BI_BLOCK), 0, (hipStream_t)s, v, n, post != nullptr, post_v); HIP_LAUNCH_CHECK();
+    }
 }
 
 __global__ void k_count_nonzero(const F *__restrict__ p, size_t n, unsigned long long *out) {

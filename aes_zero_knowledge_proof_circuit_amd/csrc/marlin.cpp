@@ -897,17 +897,15 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     gpu::ntt<F>(x_poly.p, x_tmp.p, m, lg_m, true, s);
     gpu::ntt<F>(x_evals.p, x_poly.p, m, lg_n, false, s);
     gpu::w_evals(tmp_n.p, d_z, x_evals.p, (uint32_t)n, (uint32_t)m, (uint32_t)c.num_witness, s);
-    gpu::ntt<F>(e[0].p, tmp_n.p, n, lg_n, true, s);                         // interpolate
-    Fr rho = rhos[0];
-    gpu::poly_add_at(e[0].p, 0, rho.neg(), s); gpu::poly_set_at(e[0].p, n, rho, s);   // + rho * v_H
+    {   // interpolate w v_X + x (then / v_X), z_A, z_B: three transforms, shared launches
+        const gpu::NttJob<F> interp[3] = {{e[0].p, tmp_n.p, 0}, {poly[1].p, za_ev.p, 0}, {poly[2].p, zb_ev.p, 0}};
+        gpu::ntt_batch<F>(interp, 3, n, lg_n, true, 0, s);
+    }
+    gpu::poly_add_at(e[0].p, 0, rhos[0].neg(), s); gpu::poly_set_at(e[0].p, n, rhos[0], s);   // + rho * v_H
     gpu::divide_by_vanishing(poly[0].p, e[1].p, e[0].p, n + 1, m, s, e[1].p + m, n);       // / v_X ; remainder must vanish
     poly_len[0] = n + 1 - m;
-    gpu::ntt<F>(poly[1].p, za_ev.p, n, lg_n, true, s);
-    rho = rhos[1];
-    gpu::poly_add_at(poly[1].p, 0, rho.neg(), s); gpu::poly_set_at(poly[1].p, n, rho, s); poly_len[1] = n + 1;
-    gpu::ntt<F>(poly[2].p, zb_ev.p, n, lg_n, true, s);
-    rho = rhos[2];
-    gpu::poly_add_at(poly[2].p, 0, rho.neg(), s); gpu::poly_set_at(poly[2].p, n, rho, s); poly_len[2] = n + 1;
+    gpu::poly_add_at(poly[1].p, 0, rhos[1].neg(), s); gpu::poly_set_at(poly[1].p, n, rhos[1], s); poly_len[1] = n + 1;
+    gpu::poly_add_at(poly[2].p, 0, rhos[2].neg(), s); gpu::poly_set_at(poly[2].p, n, rhos[2], s); poly_len[2] = n + 1;
     using Jobs = std::vector<std::function<void(Lane &)>>;
     {
         Jobs jobs;
@@ -935,33 +933,36 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     gpu::sub_from_scalar(ra_ev.p, elems, alpha, n, s);
     gpu::batch_inverse(ra_ev.p, n, &vh_alpha, s);                            // r(alpha, h) = v_H(alpha) / (alpha - h)
     gpu::t_evals(tmp_n.p, (uint32_t)n, t_partial.p, t_nseg, d_t_colptr, d_t_seg_start, d_t_seg_end, d_t_heavy, t_nheavy, d_t_row, d_t_mat, d_t_coeff, ra_ev.p, eta_a, eta_b, eta_c, s);
-    gpu::ntt<F>(poly[4].p, tmp_n.p, n, lg_n, true, s); poly_len[4] = n;
-    gpu::ntt<F>(ra_poly.p, ra_ev.p, n, lg_n, true, s);
-    gpu::z_poly_from_w(zpoly.p, poly[0].p, poly_len[0], x_poly.p, (uint32_t)m, n, s);
     // q = q_1 - mask = r(alpha, X) (eta_A z_A + eta_B z_B + eta_C z_A z_B) - t z has degree < 3|H|; instead of five zero-padded transforms to the 4|H| domain, a pointwise
     // product there and a 4|H|-point inverse (18 passes over 4|H| elements), it is taken on THREE cosets of H inside that domain: on H itself every factor is already known
     // (the evaluation vectors of round 1 -- the blinding terms rho v_H vanish there), on W H and W^3 H (W the 4|H|-th root) each factor costs one |H|-point coset transform, where
     // rho (X^|H| - 1) is the constant rho (zeta^c - 1), zeta = W^|H|.  Three |H|-point inverses give the interpolants Q0, Q1, Q3; q_1_combine solves for q's three |H|-coefficient
-    // thirds and divides by v_H = X^|H| - 1 in coefficient space, mask included: 13 |H|-point transforms (26 passes over |H| elements), no 4|H| buffer traffic, no division kernel.
+    // thirds and divides by v_H = X^|H| - 1 in coefficient space, mask included: 15 |H|-point transforms in all, no 4|H| buffer traffic, no division kernel -- and since
+    // transforms of one shape share their launches (ntt_batch), six launches: {t, r, Q0} inverse, {z_A, z_B, r, t, z} x {W H, W^3 H} forward, {Q1, Q3} inverse.
     {
+        using Job = gpu::NttJob<F>;
         const Fr zeta = domain_gen(lg_n4).pow_u64(n);                    // primitive 4th root of unity
         const Fr inv2 = Fr::from_u64(2).inverse(), inv2zeta = (zeta + zeta).inverse(), zero = Fr::zero();
-        F *Q0 = e[1].p, *Q1 = e[1].p + n, *Q3 = e[1].p + 2 * n;
-        F *cA = e[2].p, *cB = e[2].p + n, *cR = e[2].p + 2 * n, *cT = e[2].p + 3 * n, *cZ = e[3].p, *cq = e[3].p + n;
-        gpu::z_evals_h(cZ, d_z, (uint32_t)n, (uint32_t)m, (uint32_t)c.num_witness, s);
-        gpu::q1_coset_pointwise(cq, ra_ev.p, za_ev.p, zb_ev.p, tmp_n.p, cZ, zero, zero, zero, eta_a, eta_b, eta_c, n, s);
-        gpu::ntt<F>(Q0, cq, n, lg_n, true, s);
-        for (int cs : {1, 3}) {
-            const Fr zc = cs == 1 ? zeta : zeta.neg();                   // zeta^cs: the value of X^|H| on the coset
-            gpu::ntt_coset<F>(cA, poly[1].p, n, lg_n, false, cs, lg_n4, s);
-            gpu::ntt_coset<F>(cB, poly[2].p, n, lg_n, false, cs, lg_n4, s);
-            gpu::ntt_coset<F>(cR, ra_poly.p, n, lg_n, false, cs, lg_n4, s);
-            gpu::ntt_coset<F>(cT, poly[4].p, n, lg_n, false, cs, lg_n4, s);
-            gpu::ntt_coset<F>(cZ, zpoly.p, n, lg_n, false, cs, lg_n4, s);
+        F *Q0 = e[1].p, *Q1 = e[1].p + n, *Q3 = e[1].p + 2 * n, *zH = e[0].p, *qH = e[0].p + n;
+        gpu::z_evals_h(zH, d_z, (uint32_t)n, (uint32_t)m, (uint32_t)c.num_witness, s);
+        gpu::q1_coset_pointwise(qH, ra_ev.p, za_ev.p, zb_ev.p, tmp_n.p, zH, zero, zero, zero, eta_a, eta_b, eta_c, n, s);
+        const Job inv0[3] = {{poly[4].p, tmp_n.p, 0}, {ra_poly.p, ra_ev.p, 0}, {Q0, qH, 0}};
+        gpu::ntt_batch<F>(inv0, 3, n, lg_n, true, 0, s); poly_len[4] = n;
+        gpu::z_poly_from_w(zpoly.p, poly[0].p, poly_len[0], x_poly.p, (uint32_t)m, n, s);
+        // per coset: z_A, z_B, r, t in e[2 | 3], z and the product in e[4]
+        F *cs_buf[2][6];
+        for (int i = 0; i < 2; i++) { for (int j = 0; j < 4; j++) cs_buf[i][j] = e[2 + i].p + j * n; cs_buf[i][4] = e[4].p + i * n; cs_buf[i][5] = e[4].p + (2 + i) * n; }
+        const F *srcs[5] = {poly[1].p, poly[2].p, ra_poly.p, poly[4].p, zpoly.p};
+        Job fwd[10];
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 5; j++) fwd[5 * i + j] = Job{cs_buf[i][j], srcs[j], i == 0 ? 1 : 3};
+        gpu::ntt_batch<F>(fwd, 10, n, lg_n, false, lg_n4, s);
+        for (int i = 0; i < 2; i++) {
+            const Fr zc = i == 0 ? zeta : zeta.neg();                    // zeta^cs: the value of X^|H| on the coset
             // the coefficient of X^|H| (rho of z_A, z_B; rho_w for z = w v_X + x) contributes rho zeta^cs everywhere on the coset
-            gpu::q1_coset_pointwise(cq, cR, cA, cB, cT, cZ, rhos[1] * zc, rhos[2] * zc, rhos[0] * zc, eta_a, eta_b, eta_c, n, s);
-            gpu::ntt_coset<F>(cs == 1 ? Q1 : Q3, cq, n, lg_n, true, cs, lg_n4, s);
+            gpu::q1_coset_pointwise(cs_buf[i][5], cs_buf[i][2], cs_buf[i][0], cs_buf[i][1], cs_buf[i][3], cs_buf[i][4], rhos[1] * zc, rhos[2] * zc, rhos[0] * zc, eta_a, eta_b, eta_c, n, s);
         }
+        const Job inv13[2] = {{Q1, cs_buf[0][5], 1}, {Q3, cs_buf[1][5], 3}};
+        gpu::ntt_batch<F>(inv13, 2, n, lg_n, true, lg_n4, s);
         gpu::q1_combine(poly[6].p, poly[5].p, Q0, Q1, Q3, poly[3].p, inv2, inv2zeta, n, s);     // h_1 (2|H| coefficients), g_1 = remainder / X
         poly_len[6] = 2 * n; poly_len[5] = n - 1;
     }
