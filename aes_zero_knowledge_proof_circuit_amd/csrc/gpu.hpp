@@ -34,6 +34,7 @@ void sync(stream_t s);                    // wait for the stream: spins (lone ca
 bool throughput_mode();                   // true while a ThroughputWaits scope is alive (a multi-proof call is in flight): kernels may pick the throughput variant of a step
 struct ThroughputWaits { explicit ThroughputWaits(bool on); ~ThroughputWaits(); ThroughputWaits(const ThroughputWaits &) = delete; ThroughputWaits &operator=(const ThroughputWaits &) = delete; private: bool on_; };
 stream_t stream_create();
+stream_t stream_create_background();      // lowest device priority: its kernels yield workgroup slots to every other stream's
 void stream_destroy(stream_t s);
 // event timing on a stream (ms)
 void *event_create();

@@ -81,7 +81,7 @@ __global__ void k_div_vanishing(F *__restrict__ q, F *__restrict__ rem, const F 
     if (rem) rem[j] = (j < len ? p[j] : F::zero()) + carry;
 }
 // A SMALL divisor (round 1 divides by the input domain's v_X, m = 64 against |H| + 1 coefficients) makes the m chains long and few: cut every chain into S segments of
-// C steps -- k_divvan_sums leaves the segment sums, k_divvan_apply starts every segment from the sum of the segments above it.  (One lane per residue class took
+// C = 16 steps -- k_divvan_sums leaves the segment sums, k_divvan_apply starts every segment from the sum of the segments above it.  (One lane per residue class took
 // 524 us of a lone 16-byte encrypt(): 64 lanes x 4,096 dependent steps.)  Additions only: the same values in the same order class by class, bit-identical.
 __global__ void k_divvan_sums(F *__restrict__ part, const F *__restrict__ p, size_t qlen, size_t m, size_t C, size_t S) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,10 +104,8 @@ __global__ void k_divvan_apply(F *__restrict__ q, F *__restrict__ rem, const F *
 void divide_by_vanishing(F *q, F *rem, const F *p, size_t len, size_t m, stream_t s, F *scratch, size_t scratch_len) {
     if (len <= m) throw GpuError("divide_by_vanishing: dividend shorter than divisor");
     const size_t chain = (len - m + m - 1) / m;            // steps of the longest residue class
-    size_t S = 1;
-    while (S * S < chain) S <<= 1;
+    const size_t C = 16, S = (chain + C - 1) / C;          // 16 dependent steps per lane; the carry of a segment is a sum of up to S segment sums (independent loads)
     if (chain >= 64 && scratch && S * m <= scratch_len) {
-        const size_t C = (chain + S - 1) / S;
         hipLaunchKernelGGL(k_divvan_sums, GRID(S * m), 0, (hipStream_t)s, scratch, p, len - m, m, C, S); HIP_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_divvan_apply, GRID(S * m), 0, (hipStream_t)s, q, rem, p, (const F *)scratch, len, m, C, S); HIP_LAUNCH_CHECK();
         return;
@@ -280,7 +278,9 @@ __global__ void __launch_bounds__(BI_BLOCK) k_batch_inverse(F *__restrict__ v, s
         if (hb) suf_s[lane] = suf_s[lane] * b;
         __syncthreads();
     }
-    if (lane == 0) { F iv = suf_s[0].inverse(); inv_total = has_post ? iv * post : iv; }
+    // the lone-call variant takes the Euclidean inverse (a third of the Fermat chain's latency); between overlapping proofs the cost of the step is its instruction
+    // count, and there the branchy shift-and-subtract loop issues ~1.5 x what the 380 products do (SQ_INSTS_VALU, profiles/r04_valu_by_kernel.md): Fermat
+    if (lane == 0) { F iv = BI_CHUNK == 4 ? suf_s[0].inverse() : suf_s[0].inverse_fermat(); inv_total = has_post ? iv * post : iv; }
     __syncthreads();
     acc = inv_total;
     if (lane > 0) acc = acc * pre_s[lane - 1];

@@ -433,7 +433,8 @@ struct ProverContext {
     DevBuf acc_b, wit_b, wit2_b, scratch_b;             // second set of opening buffers (the two openings run side by side on the latency path)
     bool throughput = false;           // set per proof: several proofs in flight (chunked / batch calls) -> window tables; a lone encrypt() call -> per-window buckets
     ProverContext() { stream = gpu::stream_create(); msm_ws = gpu::msm_workspace_create(); lane[0].stream = stream; lane[0].ws = msm_ws; }
-    void ensure_lanes() { for (int i = 1; i < 4; i++) if (!lane[i].stream) { lane[i].stream = gpu::stream_create(); lane[i].ws = gpu::msm_workspace_create(); } }
+    // (lane 3 is the background lane: the early mask commitment of round 1 runs there, under the witness generation on the main stream)
+    void ensure_lanes() { for (int i = 1; i < 4; i++) if (!lane[i].stream) { lane[i].stream = i == 3 ? gpu::stream_create_background() : gpu::stream_create(); lane[i].ws = gpu::msm_workspace_create(); } }
     ~ProverContext() {
         gpu::dfree(d_trace); gpu::dfree(d_z); gpu::dfree(d_msg); gpu::dfree(d_key);
         for (auto p : d_cls) gpu::dfree(p);

@@ -81,6 +81,15 @@ stream_t stream_create() {
     HIP_CHECK(hipStreamCreate(&s));
     return (stream_t)s;
 }
+// a stream whose kernels yield to every other stream's when workgroup slots free up (the lowest priority the device offers): background work of a lone proof --
+// the mask polynomial's commitment runs under the witness generation and must not starve it
+stream_t stream_create_background() {
+    int least = 0, greatest = 0;
+    HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t s;
+    HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamDefault, least));
+    return (stream_t)s;
+}
 void stream_destroy(stream_t s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
 void *event_create() { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return (void *)e; }
 void event_record(void *ev, stream_t s) { HIP_CHECK(hipEventRecord((hipEvent_t)ev, (hipStream_t)s)); }

@@ -273,19 +273,8 @@ def run(args, api, dist_env=None):
                 small_keys[nbytes] = api.synthesize_keys(nbytes)
             return small_keys[nbytes]
 
-        if args.alt_proofs > 0 and chunk != ALT_CHUNK:
-            apk, avk = key_for(16 * ALT_CHUNK)
-            amsg = synthetic(16 * ALT_CHUNK * args.alt_proofs, 0x5EED + 4242)
-            apk.encrypt_chunked(amsg[:16 * ALT_CHUNK * min(contexts, args.alt_proofs)], key)          # warm-up: this key's prover contexts
-            ta = time.perf_counter()
-            aproofs = apk.encrypt_chunked(amsg, key)
-            ta = time.perf_counter() - ta
-            act = zko.aes_encrypt(amsg, key)
-            aok = sum(pool.map(lambda j: bool(api.verify_encryption(avk, aproofs[j], act[16 * ALT_CHUNK * j:16 * ALT_CHUNK * (j + 1)])), range(len(aproofs))))
-            ainfo = apk.info()
-            alt = {"chunk_blocks": ALT_CHUNK, "value": round(ALT_CHUNK * len(aproofs) / ta, 4), "unit": "blocks/s", "proofs": len(aproofs), "proofs_verified": "%d/%d" % (aok, len(aproofs)),
-                   "elapsed_s": round(ta, 3), "h": int(ainfo["h"]), "k": int(ainfo["k"]),
-                   "note": "measured in this run after the timed region, same contexts; the headline value is what this prover does at %d blocks per chunk-proof" % chunk}
+        # (latency leg first: the 16- and 32-byte keys are synthesized while the device still has room for their window tables -- the library skips the tables of a key
+        #  when the default number of contexts could not be created beside them -- and are released before the alt leg creates its contexts on the 4-block key)
         if args.latency_samples > 0:
             latency, lat_ok = {}, True
             for nbytes in LATENCY_BYTES:
@@ -299,9 +288,24 @@ def run(args, api, dist_env=None):
                     ts.append(time.perf_counter() - tl)
                 lat_ok = lat_ok and bool(api.verify_encryption(lvk, lp, zko.aes_encrypt(lmsg, key)))
                 latency[str(nbytes)] = round(1e3 * sorted(ts)[len(ts) // 2], 2)
+                latency.setdefault("min", {})[str(nbytes)] = round(1e3 * min(ts), 2)
+                latency.setdefault("window_tables", {})[str(nbytes)] = bool(lpk.tables_built()[0])      # (skipped by the library when the device is short of memory)
             latency["samples"] = args.latency_samples
             latency["verified"] = lat_ok
         small_keys.clear()
+        if args.alt_proofs > 0 and chunk != ALT_CHUNK:
+            apk, avk = key_for(16 * ALT_CHUNK)
+            amsg = synthetic(16 * ALT_CHUNK * args.alt_proofs, 0x5EED + 4242)
+            apk.encrypt_chunked(amsg[:16 * ALT_CHUNK * min(contexts, args.alt_proofs)], key)          # warm-up: this key's prover contexts
+            ta = time.perf_counter()
+            aproofs = apk.encrypt_chunked(amsg, key)
+            ta = time.perf_counter() - ta
+            act = zko.aes_encrypt(amsg, key)
+            aok = sum(pool.map(lambda j: bool(api.verify_encryption(avk, aproofs[j], act[16 * ALT_CHUNK * j:16 * ALT_CHUNK * (j + 1)])), range(len(aproofs))))
+            ainfo = apk.info()
+            alt = {"chunk_blocks": ALT_CHUNK, "value": round(ALT_CHUNK * len(aproofs) / ta, 4), "unit": "blocks/s", "proofs": len(aproofs), "proofs_verified": "%d/%d" % (aok, len(aproofs)),
+                   "elapsed_s": round(ta, 3), "h": int(ainfo["h"]), "k": int(ainfo["k"]),
+                   "note": "measured in this run after the timed region, same contexts; the headline value is what this prover does at %d blocks per chunk-proof" % chunk}
 
     # ---- acceptance: every timed proof must verify (host), the wrong-ciphertext negative must be rejected
 

@@ -64,6 +64,9 @@ class _StubKey:
     def timings(self):
         return dict(witness_ms=0.0, round1_ms=0.0, round2_ms=0.0, round3_ms=0.0, open_ms=0.0, total_ms=0.0)
 
+    def tables_built(self):
+        return True, 0
+
     @staticmethod
     def make(ct):
         import hashlib
@@ -217,7 +220,8 @@ def test_bench_one_rank_reports_the_measured_alt_and_latency_legs():
     line = json.loads(buf.getvalue())
     assert "error" not in res and res["proofs_verified"] == "7/7" and line["alt"] == res["alt"]
     assert res["alt"]["chunk_blocks"] == 4 and res["alt"]["proofs_verified"] == "5/5" and res["alt"]["value"] > 0
-    assert set(res["latency_ms"]) == {"16", "32", "64", "samples", "verified"} and res["latency_ms"]["verified"] is True
+    assert set(res["latency_ms"]) == {"16", "32", "64", "min", "window_tables", "samples", "verified"} and res["latency_ms"]["verified"] is True
+    assert set(res["latency_ms"]["min"]) == {"16", "32", "64"} and res["latency_ms"]["window_tables"] == {"16": True, "32": True, "64": True}
     assert [e for e in api.log if e[0] == "lone"] == [("lone", n, 1) for n in (16, 32, 64) for _ in range(3)]     # one warm-up + two timed calls per size
     assert ("chunked", 64, 5) in api.log                                                                          # the timed alt call: five 4-block chunk-proofs
     src = open(bench.__file__).read()

@@ -19,5 +19,5 @@ for nbytes in (16, 32, 64, 96):
     assert api.verify_encryption(vk, proof, zko.aes_encrypt(msg, key))
     ts.sort()
     info = pk.info()
-    out["%d_message_encryption" % nbytes] = {"median_ms": round(1e3 * ts[len(ts) // 2], 2), "min_ms": round(1e3 * ts[0], 2), "h": info["h"], "k": info["k"], "phase_ms": {k: round(v, 2) for k, v in pk.timings().items()}}
+    out["%d_message_encryption" % nbytes] = {"median_ms": round(1e3 * ts[len(ts) // 2], 2), "min_ms": round(1e3 * ts[0], 2), "sorted_ms": [round(1e3 * t, 1) for t in ts], "h": info["h"], "k": info["k"], "phase_ms": {k: round(v, 2) for k, v in pk.timings().items()}}
 print(json.dumps(out))
