@@ -287,6 +287,17 @@ def ntt_coset(field_id, data_mont_bytes, coset_c, lg_big, inverse=False):
     return buf.raw
 
 
+def ntt_batch(field_id, vectors, cosets=None, lg_big=0, inverse=False):
+    """several transforms of one size in shared launches: vectors = list of equal-length Montgomery byte strings, cosets[i] = 0 (plain) or the coset index of vector i"""
+    count, n = len(vectors), len(vectors[0]) // 32
+    if any(len(v) != 32 * n for v in vectors):
+        raise ZkAesError("ntt_batch: vectors of one length")
+    buf = C.create_string_buffer(b"".join(bytes(v) for v in vectors), 32 * n * count)
+    cs = (C.c_int * count)(*[int(c) for c in cosets]) if cosets is not None else None
+    _check(lib().zkaes_ntt_batch(int(field_id), buf, C.c_size_t(n), count, 1 if inverse else 0, cs, int(lg_big)))
+    return [buf.raw[32 * n * i:32 * n * (i + 1)] for i in range(count)]
+
+
 def msm(curve_id, bases_bytes, scalars_bytes):
     n = len(scalars_bytes) // 32
     out = C.create_string_buffer(96)

@@ -45,6 +45,21 @@ template <class Fr> void run_ntt(uint8_t *data, size_t n, int inverse, int coset
     zk::gpu::d2h(data, b, n * sizeof(Fr), s);
     zk::gpu::dfree(a); zk::gpu::dfree(b); zk::gpu::stream_destroy(s);
 }
+template <class Fr> void run_ntt_batch(uint8_t *data, size_t n, int count, int inverse, const int *coset_c, int lg_big) {
+    int lg = 0;
+    while (((size_t)1 << lg) < n) lg++;
+    if (((size_t)1 << lg) != n) throw std::invalid_argument("zkaes_ntt_batch: n must be a power of two");
+    if (count < 1 || count > 12) throw std::invalid_argument("zkaes_ntt_batch: 1..12 transforms");
+    zk::gpu::require_device();
+    zk::gpu::stream_t s = zk::gpu::stream_create();
+    Fr *a = (Fr *)zk::gpu::dmalloc((size_t)count * n * sizeof(Fr)), *b = (Fr *)zk::gpu::dmalloc((size_t)count * n * sizeof(Fr));
+    zk::gpu::h2d(a, data, (size_t)count * n * sizeof(Fr), s);
+    zk::gpu::NttJob<Fr> jobs[12];
+    for (int i = 0; i < count; i++) jobs[i] = zk::gpu::NttJob<Fr>{b + (size_t)i * n, a + (size_t)i * n, coset_c ? coset_c[i] : 0};
+    zk::gpu::ntt_batch<Fr>(jobs, count, n, lg, inverse != 0, lg_big, s);
+    zk::gpu::d2h(data, b, (size_t)count * n * sizeof(Fr), s);
+    zk::gpu::dfree(a); zk::gpu::dfree(b); zk::gpu::stream_destroy(s);
+}
 template <class Curve> void run_msm(const uint8_t *bases, const uint8_t *scalars, size_t n, uint8_t *out_xy, int *out_inf, int reps, double *ms_total, double *ms_acc) {
     using Fq = typename Curve::Fq; using Fr = typename Curve::Fr;
     zk::gpu::require_device();
@@ -199,6 +214,12 @@ int zkaes_ntt_coset(int field_id, uint8_t *data, size_t n, int inverse, int cose
     return guardk([&] {
         if (coset_c <= 0) throw std::invalid_argument("zkaes_ntt_coset: coset index must be positive");
         if (field_id == 381) run_ntt<zk::Fr381>(data, n, inverse, coset_c, lg_big); else if (field_id == 377) run_ntt<zk::Fr377>(data, n, inverse, coset_c, lg_big); else throw std::invalid_argument("field_id must be 377 or 381");
+    });
+}
+int zkaes_ntt_batch(int field_id, uint8_t *data, size_t n, int count, int inverse, const int *coset_c, int lg_big) {
+    return guardk([&] {
+        if (field_id == 381) run_ntt_batch<zk::Fr381>(data, n, count, inverse, coset_c, lg_big); else if (field_id == 377) run_ntt_batch<zk::Fr377>(data, n, count, inverse, coset_c, lg_big);
+        else throw std::invalid_argument("field_id must be 377 or 381");
     });
 }
 int zkaes_msm(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, uint8_t *out_xy, int *out_inf) {

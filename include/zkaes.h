@@ -151,6 +151,9 @@ int zkaes_ntt(int field_id, uint8_t *data, size_t n, int inverse);
 /* the same transform on the coset g D of the size-n domain D, g = W^coset_c with W the primitive 2^lg_big-th root (2^lg_big > n, 0 < coset_c < 2^lg_big / n): forward =
  * the values p(g w^i) of the coefficient vector, inverse = the coefficients from those values.  The prover's second round runs on such cosets of H inside the 4|H| domain. */
 int zkaes_ntt_coset(int field_id, uint8_t *data, size_t n, int inverse, int coset_c, int lg_big);
+/* `count` (1..12) transforms of one shape in shared launches, as the prover's rounds 1 and 2 issue them: data = count x n x 32 B, transformed in place; coset_c[i] = 0 for a
+ * plain transform, > 0 for the coset W^coset_c[i] D (coset_c may be NULL: all plain; lg_big as in zkaes_ntt_coset, ignored when no job is a coset transform). */
+int zkaes_ntt_batch(int field_id, uint8_t *data, size_t n, int count, int inverse, const int *coset_c, int lg_big);
 /* curve_id 377 / 381.  bases: n x 96 B affine (x||y Montgomery), scalars: n x 32 B Montgomery Fr; out_xy 96 B, *out_inf = 1 if infinity */
 int zkaes_msm(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, uint8_t *out_xy, int *out_inf);
 /* host-side sum of n affine points (n x 96 B, inf[i] != 0 marks the point at infinity; inf may be NULL): the local EC add that follows the

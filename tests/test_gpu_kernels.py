@@ -54,6 +54,30 @@ def test_ntt_on_a_coset_matches_the_oracle_transform_of_scaled_coefficients(zko,
     assert api.ntt_coset(cid, got, c, lg_big, inverse=True) == data
 
 
+def fast_fr_mont(n, seed):
+    """n pseudo-random 32-byte values below 2^252 (< p for both scalar fields) without a Python loop"""
+    a = np.random.RandomState(seed).randint(0, 256, size=(n, 32), dtype=np.uint8)
+    a[:, 31] &= 0x0f
+    return a.tobytes()
+
+
+@pytest.mark.parametrize("cid", [377, 381])
+@pytest.mark.parametrize("lg,inverse,count", [(6, False, 12), (12, False, 12), (12, True, 12), (16, True, 12), (19, False, 4), (19, True, 4)])
+def test_batched_transforms_equal_the_same_transforms_one_by_one(api, cid, lg, inverse, count):
+    """ntt_batch (up to 12 (destination, source, coset) jobs per launch: how rounds 1 and 2 of the prover issue their transforms) == the same transforms issued alone,
+    for a mix of plain jobs and both odd cosets of the 4x domain, one-, two- and three-pass plans, both directions; sub-batches down to one job; 13 jobs are refused."""
+    n = 1 << lg
+    cosets = [0, 1, 3, 1, 0, 3, 3, 1, 0, 0, 1, 3][:count]
+    vecs = [fast_fr_mont(n, 7000 + 13 * lg + i) for i in range(count)]
+    single = [api.ntt(cid, v, inverse=inverse) if c == 0 else api.ntt_coset(cid, v, c, lg + 2, inverse=inverse) for v, c in zip(vecs, cosets)]
+    assert api.ntt_batch(cid, vecs, cosets, lg + 2, inverse=inverse) == single
+    assert api.ntt_batch(cid, vecs[:3], cosets[:3], lg + 2, inverse=inverse) == single[:3]
+    assert api.ntt_batch(cid, vecs[0:1], None, 0, inverse=inverse) == single[0:1]
+    if count == 12:
+        with pytest.raises(api.ZkAesError):
+            api.ntt_batch(cid, vecs + vecs[:1], cosets + [0], lg + 2)
+
+
 def test_ntt_full_size_roundtrip_and_linearity(zko, api):
     # BASELINE sizes: |K| = 2^20 and the 2^22 product domain; size-independent properties instead of an oracle run
     p = zko.R377
