@@ -443,12 +443,15 @@ __global__ void __launch_bounds__(64) k_reduce_l1(const A *__restrict__ buckets,
     if (t >= segs * (uint32_t)nwin) return;
     uint32_t w = t / segs, g = t % segs;
     const size_t k0 = ((size_t)w << c) + (size_t)g * RED_L1;
-    A run = PtOps<A>::identity(), tot = PtOps<A>::identity();
-    for (int d = RED_L1 - 1; d >= 0; d--) {
+    // run_d = B_7 + ... + B_d, W = sum_d run_d.  The running sum starts from the top bucket itself and the sum of the running sums lags one step behind it: 14 additions instead
+    // of 16 (nothing is added to an identity), and the two additions of a step are independent of each other -- tot takes the PREVIOUS running sum while the next one forms
+    A run = load_bucket<A>(buckets, k0 + RED_L1 - 1, ovf_slot, ovf_off, max_segments, ovf_partial, ovf_period, ovf_stride), tot = run;
+    for (int d = RED_L1 - 2; d >= 0; d--) {
         A b = load_bucket<A>(buckets, k0 + d, ovf_slot, ovf_off, max_segments, ovf_partial, ovf_period, ovf_stride);
-        PtOps<A>::add(run, b);
-        PtOps<A>::add(tot, run);
+        if (d != RED_L1 - 2) PtOps<A>::add_inline(tot, run);   // + run_{d+1}  (tot already holds run_7 when d = 6)
+        PtOps<A>::add_inline(run, b);                           // run_d
     }
+    PtOps<A>::add(tot, run);                                    // + run_0
     seg_s[t] = run;
     seg_w[t] = tot;
 }

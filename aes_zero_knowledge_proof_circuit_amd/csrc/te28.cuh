@@ -103,9 +103,11 @@ ZK_HD void te_madd_hot(AccTE<P> &a, Niels28<P> &n, bool neg, const Niels28<P> *n
     for (int i = 0; i < G::N; i++) { F.l[i] = neg ? V.l[i] : U.l[i]; Gg.l[i] = neg ? U.l[i] : V.l[i]; }
     a.x = G::mul_biased(E, F, bias); a.y = G::mul_biased(Gg, H, bias); a.t = G::mul_biased(E, H, bias); a.z = G::mul_biased(F, Gg, bias);
 }
-// a += b, unified (add-2008-hwcd-3): nine products
+// a += b, unified (add-2008-hwcd-3): nine products.  te_add_inline is the body for the one kernel that wants two additions of a step in ONE instruction stream
+// (k_reduce_l1: a lone wave per SIMD issues dependent multiply-adds at half rate; the two independent additions of its running sums interleave); te_add is the call
+// everything else makes (code size: ~4,000 instructions per copy).
 template <class P>
-ZK_EC_FN void te_add(AccTE<P> &a, const AccTE<P> &b) {
+ZK_HD void te_add_inline(AccTE<P> &a, const AccTE<P> &b) {
     using G = FpMsm<P>;
     G A = a.y.template sub<3>(a.x) * b.y.template sub<3>(b.x);
     G B = (a.y + a.x) * (b.y + b.x);
@@ -115,6 +117,8 @@ ZK_EC_FN void te_add(AccTE<P> &a, const AccTE<P> &b) {
     G F = D.template sub<2>(C), Gg = D + C;
     a.x = E * F; a.y = Gg * H; a.t = E * H; a.z = F * Gg;
 }
+template <class P>
+ZK_EC_FN void te_add(AccTE<P> &a, const AccTE<P> &b) { te_add_inline<P>(a, b); }
 // a = 2 a (dbl-2008-hwcd with a = -1): four squarings + four products
 template <class P>
 ZK_EC_FN void te_dbl(AccTE<P> &a) {
@@ -244,6 +248,7 @@ template <class P> struct PtOps<Acc28<P>> {
     using Params = P;
     ZK_HD static Acc28<P> identity() { return inf28<P>(); }
     ZK_HD static void add(Acc28<P> &a, const Acc28<P> &b) { add28<P>(a, b); }
+    ZK_HD static void add_inline(Acc28<P> &a, const Acc28<P> &b) { add28<P>(a, b); }
     ZK_HD static void dbl(Acc28<P> &a) { dbl28<P>(a); }
     ZK_HD static Acc28<P> neg(const Acc28<P> &a) { return neg28<P>(a); }
     ZK_HD static XYZZ<Fp<P>> to_std(const Acc28<P> &a) { return to_std_point<P>(a); }
@@ -252,6 +257,7 @@ template <class P> struct PtOps<AccTE<P>> {
     using Params = P;
     ZK_HD static AccTE<P> identity() { return te_identity<P>(); }
     ZK_HD static void add(AccTE<P> &a, const AccTE<P> &b) { te_add<P>(a, b); }
+    ZK_HD static void add_inline(AccTE<P> &a, const AccTE<P> &b) { te_add_inline<P>(a, b); }
     ZK_HD static void dbl(AccTE<P> &a) { te_dbl<P>(a); }
     ZK_HD static AccTE<P> neg(const AccTE<P> &a) { return te_neg<P>(a); }
     ZK_HD static XYZZ<Fp<P>> to_std(const AccTE<P> &a) { return te_to_std_point<P>(a); }
