@@ -455,6 +455,33 @@ __global__ void __launch_bounds__(64) k_reduce_l1(const A *__restrict__ buckets,
     seg_s[t] = run;
     seg_w[t] = tot;
 }
+// The same first level for the Edwards law with LANE-INTERLEAVED segments: lane g of a set takes buckets d G + g, d < 8 (G = 2^c / 8 lanes per set), so for every d the 64
+// lanes of a wave read 64 consecutive 224-byte buckets -- one contiguous 14 KB stretch per wave and load step instead of 16-byte pieces of 64 lines 1,792 B apart (the
+// consecutive-bucket layout above spent ~130 of its 290 us on those loads, profiles/r04_reduce_scan.txt).  With j = d G + g:
+//     sum_j (j + 1) B_j  =  G sum_g W'_g  +  sum_g g S_g  +  sum_g S_g,      S_g = sum_d B_{d,g},   W'_g = sum_d d B_{d,g}
+// -- the same row / column decomposition of sum_g g S_g behind it (k_reduce_rc), one more plain sum and lg G doublings in k_reduce_final.  13 additions per lane.
+template <class A>
+__global__ void __launch_bounds__(64) k_reduce_l1_interleaved(const A *__restrict__ buckets, int c, int nwin, A *__restrict__ seg_s, A *__restrict__ seg_w,
+                                                               const uint32_t *__restrict__ ovf_slot, const uint32_t *__restrict__ ovf_off, uint32_t max_segments, const A *__restrict__ ovf_partial,
+                                                               size_t ovf_period, size_t ovf_stride) {
+    const uint32_t segs = (1u << c) / RED_L1;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= segs * (uint32_t)nwin) return;
+    const uint32_t w = t / segs, g = t % segs;
+    const size_t k0 = ((size_t)w << c) + g;
+    // run_d = B_7 + ... + B_d;  W' = run_7 + ... + run_1 (lagging one step behind the running sum, as in k_reduce_l1);  S = run_1 + B_0
+    A run = load_bucket<A>(buckets, k0 + (size_t)(RED_L1 - 1) * segs, ovf_slot, ovf_off, max_segments, ovf_partial, ovf_period, ovf_stride), tot = run;
+    for (int d = RED_L1 - 2; d >= 1; d--) {
+        A b = load_bucket<A>(buckets, k0 + (size_t)d * segs, ovf_slot, ovf_off, max_segments, ovf_partial, ovf_period, ovf_stride);
+        if (d != RED_L1 - 2) PtOps<A>::add_inline(tot, run);
+        PtOps<A>::add_inline(run, b);
+    }
+    PtOps<A>::add(tot, run);
+    A b0 = load_bucket<A>(buckets, k0, ovf_slot, ovf_off, max_segments, ovf_partial, ovf_period, ovf_stride);
+    PtOps<A>::add(run, b0);
+    seg_s[t] = run;
+    seg_w[t] = tot;
+}
 // Two roles per group (whole 64-lane workgroups take one role, so nobody diverges): a lane's time is its NUMBER of point operations, and one lane doing both the
 // running sums (29 operations) and the scalar product (8 + up to 28) was the longest chain of the whole reduction (630 us of the 1.36 ms a bucket reduction costs
 // a lone encrypt() call).  Role 0 writes sw + L1 (tot2 - run) to partial[.. 2h], role 1 sums its S_g again and writes (L1 g0) run to partial[.. 2h + 1]; the trees behind
@@ -521,13 +548,13 @@ __global__ void __launch_bounds__(256) k_reduce_window(const A *__restrict__ par
 }
 
 // ---- The reduction behind k_reduce_l1 on the Edwards law: a 2-D decomposition with four lanes per point operation (te28.cuh te_add_quad / te_dbl_quad).
-// k_reduce_l1 leaves, per 8-bucket segment g of a bucket set, S_g = sum B and W_g = sum (d + 1) B; the set's sum is  sum_g W_g + 8 sum_g g S_g.  With g = r C + c
-// (G = R C segments, both powers of two):  sum_g g S_g = sum_c c CS_c + C sum_r r RS_r, where CS_c (column sums) and RS_r (row sums) are PLAIN sums -- trees, no running
+// k_reduce_l1_interleaved leaves, per segment g of a bucket set (8 buckets G apart), S_g = sum B and W'_g = sum d B; the set's sum is  G sum_g W'_g + sum_g g S_g + sum_g S_g.
+// With g = r C + c (G = R C segments, both powers of two):  sum_g g S_g = sum_c c CS_c + C sum_r r RS_r, where CS_c (column sums) and RS_r (row sums) are PLAIN sums -- trees, no running
 // sums, no scalar products on thousands of lanes (k_reduce_l2's second role did a 16-bit double-and-add per 64 buckets).
 //   k_reduce_rc    : one 64-quad workgroup per plain sum: the R row sums of W (their total is sum_g W_g), the R row sums RS_r and the C column sums CS_c of S
-//   k_reduce_final : three workgroups per set (total of the W sums; sum_c c CS_c; sum_r r RS_r -- an index-weighted sum of <= 256 points is split 16 x 16 once more,
-//                    then taken bit plane by bit plane; the row term is scaled by C where it is made), the last one to finish (ticket) combines  T + 8 (U1 + C U2)  and
-//                    converts to the Weierstrass XYZZ form.
+//   k_reduce_final : four workgroups per set (G x the total of the W' sums; sum_c c CS_c; sum_r r RS_r -- an index-weighted sum of <= 256 points is split 16 x 16 once more,
+//                    then taken bit plane by bit plane; the row term is scaled by C where it is made; the total of the row sums), the last one to finish (ticket) adds the
+//                    four and converts to the Weierstrass XYZZ form.
 // Depth of the whole reduction: 16 sequential additions in k_reduce_l1, then ~40 quad operations of 2-3 product-times each, instead of ~70 whole additions.
 constexpr int RQ_THREADS = 256, RQ_QUADS = RQ_THREADS / 4;          // k_reduce_rc
 constexpr int RF_THREADS = 1024, RF_QUADS = RF_THREADS / 4;         // k_reduce_final: up to 256 points per weighted sum
@@ -645,33 +672,37 @@ __global__ void __launch_bounds__(RF_THREADS) k_reduce_final(const AccTE<P> *__r
     __shared__ uint32_t bufA[RF_QUADS * PT_WORDS], bufB[RF_QUADS * PT_WORDS], scratch[32 * PT_WORDS];
     __shared__ uint32_t ticket;
     const uint32_t R = 1u << lgR, C = 1u << lgC, jobs = 2 * R + C;
-    const uint32_t set = blockIdx.x / 3, role = blockIdx.x % 3, quad = threadIdx.x >> 2;
+    const uint32_t set = blockIdx.x / 4, role = blockIdx.x % 4, quad = threadIdx.x >> 2;
     const int q = threadIdx.x & 3;
-    const AccTE<P> *src = rc + (size_t)set * jobs + (role == 0 ? 0 : (role == 1 ? 2 * R : R));        // W row sums | column sums of S | row sums of S
+    const AccTE<P> *src = rc + (size_t)set * jobs + (role == 0 ? 0 : (role == 1 ? 2 * R : R));        // W' row sums | column sums of S | row sums of S (roles 2 and 3)
     const uint32_t M = role == 1 ? C : R;
     {
         FpMsm<P> v = quad < M ? quad_load<P>(reinterpret_cast<const uint32_t *>(src + quad), q) : te_identity_quad<P>(q);
         quad_store<P>(bufA + quad * PT_WORDS, q, v);
-        if (role != 0) quad_store<P>(bufB + quad * PT_WORDS, q, v);
+        if (role == 1 || role == 2) quad_store<P>(bufB + quad * PT_WORDS, q, v);
     }
     __syncthreads();
-    if (role == 0) quad_tree_sum<P>(bufA, RF_QUADS, quad, q);
-    else quad_weighted<P>(bufA, bufB, M, role == 2 ? lgC : 0, scratch, quad, q);       // the row term carries the factor C: applied here, beside the column term's workgroup
-    if (quad == 0) quad_store<P>(reinterpret_cast<uint32_t *>(part + (size_t)set * 3 + role), q, quad_load<P>(bufA, q));
+    if (role == 0 || role == 3) {
+        quad_tree_sum<P>(bufA, RF_QUADS, quad, q);
+        if (role == 0 && quad == 0) {                       // the W' term carries the factor G = R C
+            FpMsm<P> v = quad_load<P>(bufA, q);
+            for (int i = 0; i < lgR + lgC; i++) v = te_dbl_quad<P>(v, q);
+            quad_store<P>(bufA, q, v);
+        }
+    } else quad_weighted<P>(bufA, bufB, M, role == 2 ? lgC : 0, scratch, quad, q);       // the row term carries the factor C: applied here, beside the column term's workgroup
+    if (quad == 0) quad_store<P>(reinterpret_cast<uint32_t *>(part + (size_t)set * 4 + role), q, quad_load<P>(bufA, q));
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) ticket = atomicAdd(&tickets[set], 1u);
     __syncthreads();
-    if (ticket != 2) return;
+    if (ticket != 3) return;
     __threadfence();
     if (threadIdx.x == 0) tickets[set] = 0;                         // re-armed for the next MSM of this workspace
-    if (quad == 0) {
-        const AccTE<P> *pp = part + (size_t)set * 3;
+    if (quad == 0) {                                                // G sum W' + sum_c c CS_c + C sum_r r RS_r + sum_r RS_r
+        const AccTE<P> *pp = part + (size_t)set * 4;
         FpMsm<P> t = quad_load<P>(reinterpret_cast<const uint32_t *>(pp + 0), q), u1 = quad_load<P>(reinterpret_cast<const uint32_t *>(pp + 1), q),
-                 u2 = quad_load<P>(reinterpret_cast<const uint32_t *>(pp + 2), q);
-        FpMsm<P> u = te_add_quad<P>(u1, u2, q);
-        for (int i = 0; i < 3; i++) u = te_dbl_quad<P>(u, q);        // x RED_L1
-        quad_store<P>(scratch, q, te_add_quad<P>(t, u, q));
+                 u2 = quad_load<P>(reinterpret_cast<const uint32_t *>(pp + 2), q), st = quad_load<P>(reinterpret_cast<const uint32_t *>(pp + 3), q);
+        quad_store<P>(scratch, q, te_add_quad<P>(te_add_quad<P>(t, st, q), te_add_quad<P>(u1, u2, q), q));
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -843,18 +874,22 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
     for (int rep = (knockin() & 2) ? 0 : 1; rep < 2; rep++)
 #endif
     {
-    hipLaunchKernelGGL((k_reduce_l1<A>), dim3((unsigned)((segs * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.buckets, c, nsets, (A *)S.seg_s, (A *)S.seg_w,
-                       S.ovf_slot, S.ovf_off, max_seg, (const A *)S.ovf_partial, nrep == 2 ? nb : ~(size_t)0, S.cap_ovf);
+    if constexpr (Law::edwards)
+        hipLaunchKernelGGL((k_reduce_l1_interleaved<A>), dim3((unsigned)((segs * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.buckets, c, nsets, (A *)S.seg_s, (A *)S.seg_w,
+                           S.ovf_slot, S.ovf_off, max_seg, (const A *)S.ovf_partial, nrep == 2 ? nb : ~(size_t)0, S.cap_ovf);
+    else
+        hipLaunchKernelGGL((k_reduce_l1<A>), dim3((unsigned)((segs * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.buckets, c, nsets, (A *)S.seg_s, (A *)S.seg_w,
+                           S.ovf_slot, S.ovf_off, max_seg, (const A *)S.ovf_partial, nrep == 2 ? nb : ~(size_t)0, S.cap_ovf);
     HIP_LAUNCH_CHECK();
     if constexpr (Law::edwards) {
-        // Edwards law: plain row / column sums of the segment sums, then three quad-cooperative workgroups per set (k_reduce_rc / k_reduce_final above)
+        // Edwards law: plain row / column sums of the segment sums, then four quad-cooperative workgroups per set (k_reduce_rc / k_reduce_final above)
         const int lgG = c - 3 > 0 ? c - 3 : 0, lgC = (lgG + 1) / 2, lgR = lgG - lgC;
         if (lgC > 8) throw GpuError("msm: more than 2^19 buckets per set");
         const unsigned jobs = 2u * (1u << lgR) + (1u << lgC);
         A *rc = (A *)S.partial, *part = rc + (size_t)nsets * jobs;
         hipLaunchKernelGGL((k_reduce_rc<P>), dim3((unsigned)nsets * jobs), dim3(RQ_THREADS), 0, s, (const A *)S.seg_s, (const A *)S.seg_w, lgR, lgC, rc);
         HIP_LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_reduce_final<P>), dim3(3u * (unsigned)nsets), dim3(RF_THREADS), 0, s, (const A *)rc, lgR, lgC, part, S.tickets, res, dev_wsum_out);
+        hipLaunchKernelGGL((k_reduce_final<P>), dim3(4u * (unsigned)nsets), dim3(RF_THREADS), 0, s, (const A *)rc, lgR, lgC, part, S.tickets, res, dev_wsum_out);
         HIP_LAUNCH_CHECK();
     } else {
     hipLaunchKernelGGL((k_reduce_l2<A>), dim3(2u * (unsigned)((groups * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.seg_s, (const A *)S.seg_w, c, nsets, (A *)S.partial);
