@@ -80,6 +80,12 @@ class VerifyingKey:
         _check(lib().zkaes_vk_serialize_ark(self._p, C.byref(out), C.byref(n)))
         return _take(out, n)
 
+    def to_ark_bytes_uncompressed(self):
+        """serialize_uncompressed's image of the IndexVerifierKey (96-byte G1, 192-byte G2): what deserialize_unchecked reads"""
+        out, n = C.c_void_p(), C.c_size_t()
+        _check(lib().zkaes_vk_serialize_ark_uncompressed(self._p, C.byref(out), C.byref(n)))
+        return _take(out, n)
+
     @staticmethod
     def from_ark_bytes(b):
         p = C.c_void_p()
@@ -131,11 +137,37 @@ class ProvingKey:
         _check(lib().zkaes_pk_debug_fetch(self._p, name.encode(), C.byref(out), C.byref(n)))
         return _take(out, n)
 
-    def serialize_ark_to_file(self, path):
-        """ark-serialize image of the arkworks IndexProverKey (index_vk, matrices, index polynomials + evaluations, committer key) streamed to `path`; returns its size"""
+    def serialize_ark_to_file(self, path, uncompressed=False):
+        """ark-serialize image of the arkworks IndexProverKey (index_vk, matrices, index polynomials + evaluations, committer key) streamed to `path`; returns its size.
+        uncompressed=True: serialize_uncompressed's image (96-byte points) -- what IndexProverKey::deserialize_unchecked reads"""
         n = C.c_uint64()
-        _check(lib().zkaes_pk_serialize_ark_to_file(self._p, os.fsencode(path), C.byref(n)))
+        _check(lib().zkaes_pk_serialize_ark_to_file_ex(self._p, os.fsencode(path), 1 if uncompressed else 0, C.byref(n)))
         return int(n.value)
+
+    def set_contexts(self, n):
+        """proofs in flight per multi-proof call on this key (1..64; 0 = the process default)"""
+        _check(lib().zkaes_pk_set_contexts(self._p, C.c_size_t(int(n))))
+
+    def contexts(self):
+        n = C.c_size_t()
+        _check(lib().zkaes_pk_get_contexts(self._p, C.byref(n)))
+        return int(n.value)
+
+    def srs_info(self):
+        """the universal SRS behind the key (one per process, device and SRS literals, shared by every key over it)"""
+        out, secs = (C.c_uint64 * 6)(), (C.c_double * 2)()
+        _check(lib().zkaes_pk_srs_info(self._p, out, secs))
+        d = dict(zip(["max_degree", "points_per_copy", "copies", "bytes", "keys_sharing", "lagrange_bytes"], [int(v) for v in out]))
+        d["srs_build_s"], d["setup_s"] = float(secs[0]), float(secs[1])
+        return d
+
+    def op_lists(self, message, secret_key, throughput_path=True):
+        """the transforms and MSMs the library ACTUALLY launches for one proof on this key (zkaes_pk_op_lists): dict with "ntt" [[points, transforms per launch], ...] and
+        "msm" [[points, kind], ...] + the circuit sizes.  Process-global recorder: no other proof may be in flight."""
+        import json
+        out, n = C.c_void_p(), C.c_size_t()
+        _check(lib().zkaes_pk_op_lists(self._p, bytes(message), C.c_size_t(len(message)), bytes(secret_key), 1 if throughput_path else 0, C.byref(out), C.byref(n)))
+        return json.loads(_take(out, n).decode())
 
     def tables_built(self):
         """(built, bytes): does the key hold the fixed-base window tables of its SRS?"""
@@ -377,6 +409,13 @@ def stream_copy_bench(nbytes=1 << 30, reps=20):
     g = C.c_double()
     _check(lib().zkaes_stream_copy_bench(C.c_size_t(nbytes), int(reps), C.byref(g)))
     return g.value
+
+
+def mem_info():
+    """(free, total) bytes of the current device"""
+    f, t = C.c_uint64(), C.c_uint64()
+    _check(lib().zkaes_mem_info(C.byref(f), C.byref(t)))
+    return int(f.value), int(t.value)
 
 
 def msm_stats(reset=False):

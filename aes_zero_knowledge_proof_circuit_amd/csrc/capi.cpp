@@ -72,11 +72,6 @@ int zkaes_encrypt_seeded(const uint8_t *msg, size_t len, const uint8_t key[16], 
 int zkaes_encrypt(const uint8_t *msg, size_t len, const uint8_t key[16], const zkaes_pk *pk, uint8_t **proof, size_t *proof_len) {
     return zkaes_encrypt_seeded(msg, len, key, pk, nullptr, proof, proof_len);
 }
-static size_t default_contexts() {
-    size_t n_ctx = ZKAES_DEFAULT_CONTEXTS;
-    if (const char *e = getenv("ZKAES_CONTEXTS")) n_ctx = (size_t)std::max(1, atoi(e));
-    return n_ctx;
-}
 static void pack_proofs(const std::vector<zk::Proof> &ps, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens) {
     std::vector<uint8_t> all;
     for (size_t i = 0; i < ps.size(); i++) {
@@ -94,7 +89,7 @@ int zkaes_encrypt_chunked_seeded_at(const uint8_t *msg, size_t len, const uint8_
         if (!pk || !proofs || !proofs_len || !key || (!msg && len)) throw std::invalid_argument("null argument");
         size_t chunk = pk->pk->circuit().n_blocks * 16;
         if (chunk == 0 || len % chunk || len / chunk != n_chunks) throw std::invalid_argument("message length must be n_chunks * the key's plaintext length");
-        pack_proofs(pk->pk->prove_aes_chunked(msg, len, key, default_contexts(), zk_seed32, first_proof_index), proofs, proofs_len, proof_lens);
+        pack_proofs(pk->pk->prove_aes_chunked(msg, len, key, pk->pk->contexts(), zk_seed32, first_proof_index), proofs, proofs_len, proof_lens);
     });
 }
 int zkaes_encrypt_chunked_seeded(const uint8_t *msg, size_t len, const uint8_t key[16], const zkaes_pk *pk, const uint8_t *zk_seed32, uint8_t **proofs, size_t *proofs_len,
@@ -113,7 +108,7 @@ int zkaes_encrypt_batch_seeded_at(size_t n, const uint8_t *messages, size_t mess
         size_t chunk = pk->pk->circuit().n_blocks * 16;
         if (messages_len != n * chunk) throw std::invalid_argument("messages must hold n x " + std::to_string(chunk) + " bytes (the key's plaintext length)");
         if (secret_keys_len != n * 16) throw std::invalid_argument("secret_keys must hold n x 16 bytes");
-        pack_proofs(pk->pk->prove_aes_batch(messages, secret_keys, n, default_contexts(), zk_seed32, first_proof_index), proofs, proofs_len, proof_lens);
+        pack_proofs(pk->pk->prove_aes_batch(messages, secret_keys, n, pk->pk->contexts(), zk_seed32, first_proof_index), proofs, proofs_len, proof_lens);
     });
 }
 int zkaes_encrypt_batch_seeded(size_t n, const uint8_t *messages, size_t messages_len, const uint8_t *secret_keys, size_t secret_keys_len, const zkaes_pk *pk,
@@ -169,6 +164,13 @@ int zkaes_vk_serialize_ark(const zkaes_vk *vk, uint8_t **out, size_t *out_len) {
         *out = give(b); *out_len = b.size();
     });
 }
+int zkaes_vk_serialize_ark_uncompressed(const zkaes_vk *vk, uint8_t **out, size_t *out_len) {
+    return guard([&] {
+        if (!vk || !out || !out_len) throw std::invalid_argument("null argument");
+        auto b = zk::serialize_vk_ark(vk->vk, true);
+        *out = give(b); *out_len = b.size();
+    });
+}
 int zkaes_vk_deserialize_ark(const uint8_t *bytes, size_t len, zkaes_vk **vk) {
     return guard([&] {
         if (!bytes || !vk) throw std::invalid_argument("null argument");
@@ -216,11 +218,37 @@ int zkaes_pk_info(const zkaes_pk *pk, uint64_t out[12]) {
         out[9] = pk->pk->vk().num_non_zero; out[10] = next_pow2(pk->pk->vk().num_constraints); out[11] = next_pow2(pk->pk->vk().num_non_zero);
     });
 }
-int zkaes_pk_serialize_ark_to_file(const zkaes_pk *pk, const char *path, uint64_t *bytes_written) {
+int zkaes_pk_serialize_ark_to_file_ex(const zkaes_pk *pk, const char *path, int uncompressed, uint64_t *bytes_written) {
     return guard([&] {
         if (!pk || !path) throw std::invalid_argument("null argument");
-        uint64_t n = pk->pk->serialize_ark_to_file(path);
+        uint64_t n = pk->pk->serialize_ark_to_file(path, uncompressed != 0);
         if (bytes_written) *bytes_written = n;
+    });
+}
+int zkaes_pk_serialize_ark_to_file(const zkaes_pk *pk, const char *path, uint64_t *bytes_written) { return zkaes_pk_serialize_ark_to_file_ex(pk, path, 0, bytes_written); }
+int zkaes_pk_set_contexts(zkaes_pk *pk, size_t n) {
+    return guard([&] {
+        if (!pk) throw std::invalid_argument("null argument");
+        pk->pk->set_contexts(n);
+    });
+}
+int zkaes_pk_get_contexts(const zkaes_pk *pk, size_t *n) {
+    return guard([&] {
+        if (!pk || !n) throw std::invalid_argument("null argument");
+        *n = pk->pk->contexts();
+    });
+}
+int zkaes_pk_srs_info(const zkaes_pk *pk, uint64_t out[6], double secs[2]) {
+    return guard([&] {
+        if (!pk || !out) throw std::invalid_argument("null argument");
+        pk->pk->srs_info(out, secs);
+    });
+}
+int zkaes_pk_op_lists(const zkaes_pk *pk, const uint8_t *msg, size_t len, const uint8_t key[16], int throughput_path, uint8_t **json, size_t *json_len) {
+    return guard([&] {
+        if (!pk || !json || !json_len || !key || (!msg && len)) throw std::invalid_argument("null argument");
+        std::string o = pk->pk->op_lists_json(msg, len, key, throughput_path != 0);
+        *json = give(std::vector<uint8_t>(o.begin(), o.end())); *json_len = o.size();
     });
 }
 int zkaes_pk_tables_built(const zkaes_pk *pk, int *built, uint64_t *table_bytes) {

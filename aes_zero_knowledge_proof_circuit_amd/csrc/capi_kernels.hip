@@ -32,49 +32,61 @@ template <class Fn> int guardk(Fn &&fn) {
     catch (const std::exception &e) { zk::capi_set_error(e.what()); return 1; }
     catch (...) { zk::capi_set_error("unknown error"); return 1; }
 }
-template <class Fr> void run_ntt(uint8_t *data, size_t n, int inverse, int coset_c, int lg_big) {
+using zk::gpu::DevPtr; using zk::gpu::StreamGuard; using zk::gpu::WorkspaceGuard; using zk::gpu::EventGuard;
+// Every helper below validates its arguments BEFORE it allocates and owns its temporaries through RAII guards (gpu.hpp): a GpuError in the middle of a call -- a bad coset
+// index, an MSM whose n x windows exceeds the sort's 2^31 pairs, a device fault -- releases the stream, the buffers and the MSM workspace on the way out
+// (tests/test_gpu_kernels.py::test_error_paths_release_device_memory).
+int exact_log2(size_t n, const char *who) {
     int lg = 0;
     while (((size_t)1 << lg) < n) lg++;
-    if (((size_t)1 << lg) != n) throw std::invalid_argument("zkaes_ntt: n must be a power of two");
+    if (n == 0 || ((size_t)1 << lg) != n) throw std::invalid_argument(std::string(who) + ": n must be a power of two");
+    return lg;
+}
+template <class Fr> void run_ntt(uint8_t *data, size_t n, int inverse, int coset_c, int lg_big) {
+    const int lg = exact_log2(n, "zkaes_ntt");
+    if (!data) throw std::invalid_argument("zkaes_ntt: null data");
     zk::gpu::require_device();
-    zk::gpu::stream_t s = zk::gpu::stream_create();
-    Fr *a = (Fr *)zk::gpu::dmalloc(n * sizeof(Fr)), *b = (Fr *)zk::gpu::dmalloc(n * sizeof(Fr));
+    StreamGuard s;
+    DevPtr<Fr> a(n), b(n);
     zk::gpu::h2d(a, data, n * sizeof(Fr), s);
     if (coset_c) zk::gpu::ntt_coset<Fr>(b, a, n, lg, inverse != 0, coset_c, lg_big, s);
     else zk::gpu::ntt<Fr>(b, a, n, lg, inverse != 0, s);
     zk::gpu::d2h(data, b, n * sizeof(Fr), s);
-    zk::gpu::dfree(a); zk::gpu::dfree(b); zk::gpu::stream_destroy(s);
 }
 template <class Fr> void run_ntt_batch(uint8_t *data, size_t n, int count, int inverse, const int *coset_c, int lg_big) {
-    int lg = 0;
-    while (((size_t)1 << lg) < n) lg++;
-    if (((size_t)1 << lg) != n) throw std::invalid_argument("zkaes_ntt_batch: n must be a power of two");
+    const int lg = exact_log2(n, "zkaes_ntt_batch");
     if (count < 1 || count > 12) throw std::invalid_argument("zkaes_ntt_batch: 1..12 transforms");
+    if (!data) throw std::invalid_argument("zkaes_ntt_batch: null data");
     zk::gpu::require_device();
-    zk::gpu::stream_t s = zk::gpu::stream_create();
-    Fr *a = (Fr *)zk::gpu::dmalloc((size_t)count * n * sizeof(Fr)), *b = (Fr *)zk::gpu::dmalloc((size_t)count * n * sizeof(Fr));
+    StreamGuard s;
+    DevPtr<Fr> a((size_t)count * n), b((size_t)count * n);
     zk::gpu::h2d(a, data, (size_t)count * n * sizeof(Fr), s);
     zk::gpu::NttJob<Fr> jobs[12];
     for (int i = 0; i < count; i++) jobs[i] = zk::gpu::NttJob<Fr>{b + (size_t)i * n, a + (size_t)i * n, coset_c ? coset_c[i] : 0};
     zk::gpu::ntt_batch<Fr>(jobs, count, n, lg, inverse != 0, lg_big, s);
     zk::gpu::d2h(data, b, (size_t)count * n * sizeof(Fr), s);
-    zk::gpu::dfree(a); zk::gpu::dfree(b); zk::gpu::stream_destroy(s);
+}
+template <class Fq> void give_affine(const zk::Affine<Fq> &a, uint8_t *out_xy, int *out_inf) {
+    if (out_inf) *out_inf = a.is_inf() ? 1 : 0;
+    if (out_xy) { memcpy(out_xy, a.x.l, 48); memcpy(out_xy + 48, a.y.l, 48); }
 }
 template <class Curve> void run_msm(const uint8_t *bases, const uint8_t *scalars, size_t n, uint8_t *out_xy, int *out_inf, int reps, double *ms_total, double *ms_acc) {
     using Fq = typename Curve::Fq; using Fr = typename Curve::Fr;
+    if (n && (!bases || !scalars)) throw std::invalid_argument("zkaes_msm: null argument");
+    if (n >= ((size_t)1 << 30)) throw std::invalid_argument("zkaes_msm: too many points");
     zk::gpu::require_device();
-    zk::gpu::stream_t s = zk::gpu::stream_create();
-    zk::Affine<Fq> *db = (zk::Affine<Fq> *)zk::gpu::dmalloc(n * 96);
-    Fr *ds = (Fr *)zk::gpu::dmalloc(n * 32);
+    StreamGuard s;
+    DevPtr<zk::Affine<Fq>> db(n);
+    DevPtr<Fr> ds(n);
     zk::gpu::h2d(db, bases, n * 96, s); zk::gpu::h2d(ds, scalars, n * 32, s);
-    zk::Affine28<typename Curve::FqP> *db28 = (zk::Affine28<typename Curve::FqP> *)zk::gpu::dmalloc(n * sizeof(zk::Affine28<typename Curve::FqP>));
+    DevPtr<zk::Affine28<typename Curve::FqP>> db28(n);
     zk::gpu::convert_bases<Curve>(db28, db, n, s);
     zk::gpu::sync(s);
-    zk::gpu::MsmWorkspace *ws = zk::gpu::msm_workspace_create();
+    WorkspaceGuard ws;
     zk::XYZZ<Fq> r = zk::gpu::msm<Curve>(ws, db28, ds, n, s);   // warm-up / result
     if (reps > 0) {
         zk::gpu::MsmStats before = zk::gpu::msm_stats(false);
-        void *e0 = zk::gpu::event_create(), *e1 = zk::gpu::event_create();
+        EventGuard e0, e1;
         zk::gpu::event_record(e0, s);
         for (int i = 0; i < reps; i++) r = zk::gpu::msm<Curve>(ws, db28, ds, n, s);
         zk::gpu::event_record(e1, s);
@@ -82,44 +94,35 @@ template <class Curve> void run_msm(const uint8_t *bases, const uint8_t *scalars
         zk::gpu::MsmStats after = zk::gpu::msm_stats(false);
         if (ms_total) *ms_total = ms / reps;
         if (ms_acc) *ms_acc = (after.accumulate_ms - before.accumulate_ms) / reps;
-        zk::gpu::event_destroy(e0); zk::gpu::event_destroy(e1);
     }
-    zk::Affine<Fq> a = r.to_affine();
-    if (out_inf) *out_inf = a.is_inf() ? 1 : 0;
-    if (out_xy) { memcpy(out_xy, a.x.l, 48); memcpy(out_xy + 48, a.y.l, 48); }
-    zk::gpu::msm_workspace_destroy(ws);
-    zk::gpu::dfree(db28);
-    zk::gpu::dfree(db); zk::gpu::dfree(ds); zk::gpu::stream_destroy(s);
+    give_affine(r.to_affine(), out_xy, out_inf);
 }
 // EDWARDS (377 only): the prover's SRS path -- tables on the curve's twisted Edwards model; the bases must lie in the prime-order subgroup.  Otherwise the
 // Weierstrass law (any curve point).
 template <class Curve, bool EDWARDS> void run_msm_table(const uint8_t *bases, const uint8_t *scalars, size_t n, int c, uint8_t *out_xy, int *out_inf) {
     using Fq = typename Curve::Fq; using Fr = typename Curve::Fr;
-    zk::gpu::require_device();
     if (c < 2 || c > 22) throw std::invalid_argument("window bits must be in [2, 22]");
-    zk::gpu::stream_t s = zk::gpu::stream_create();
+    if (n && (!bases || !scalars)) throw std::invalid_argument("zkaes_msm_table: null argument");
+    zk::gpu::require_device();
     const size_t nt = (size_t)zk::gpu::table_windows<Curve>(c);
-    zk::Affine<Fq> *tab = (zk::Affine<Fq> *)zk::gpu::dmalloc(nt * n * 96);
-    Fr *ds = (Fr *)zk::gpu::dmalloc(n * 32);
+    if ((uint64_t)nt * n >= (1ull << 30)) throw std::invalid_argument("zkaes_msm_table: n x table copies exceeds the 2^30 base indices of one MSM");
+    StreamGuard s;
+    DevPtr<zk::Affine<Fq>> tab(nt * n);
+    DevPtr<Fr> ds(n);
     zk::gpu::h2d(tab, bases, n * 96, s); zk::gpu::h2d(ds, scalars, n * 32, s);
     zk::gpu::build_window_tables<Curve>(tab, n, c, s);
-    zk::gpu::MsmWorkspace *ws = zk::gpu::msm_workspace_create();
+    WorkspaceGuard ws;
     zk::Affine<Fq> a;
     if constexpr (EDWARDS) {
-        zk::Niels28<typename Curve::FqP> *tabte = (zk::Niels28<typename Curve::FqP> *)zk::gpu::dmalloc(nt * n * sizeof(zk::Niels28<typename Curve::FqP>));
+        DevPtr<zk::Niels28<typename Curve::FqP>> tabte(nt * n);
         zk::gpu::convert_bases_te<Curve>(tabte, tab, nt * n, s);
         a = zk::gpu::msm_table<Curve>(ws, tabte, n, 0, c, ds, n, s).to_affine();
-        zk::gpu::dfree(tabte);
     } else {
-        zk::Affine28<typename Curve::FqP> *tab28 = (zk::Affine28<typename Curve::FqP> *)zk::gpu::dmalloc(nt * n * sizeof(zk::Affine28<typename Curve::FqP>));
+        DevPtr<zk::Affine28<typename Curve::FqP>> tab28(nt * n);
         zk::gpu::convert_bases<Curve>(tab28, tab, nt * n, s);
         a = zk::gpu::msm_table<Curve>(ws, tab28, n, 0, c, ds, n, s).to_affine();
-        zk::gpu::dfree(tab28);
     }
-    if (out_inf) *out_inf = a.is_inf() ? 1 : 0;
-    if (out_xy) { memcpy(out_xy, a.x.l, 48); memcpy(out_xy + 48, a.y.l, 48); }
-    zk::gpu::msm_workspace_destroy(ws);
-    zk::gpu::dfree(tab); zk::gpu::dfree(ds); zk::gpu::stream_destroy(s);
+    give_affine(a, out_xy, out_inf);
 }
 template <class Curve> void run_msm_window_sums_dev(const uint8_t *bases, const uint8_t *scalars, size_t n_local, size_t n_total, void *dev_out, size_t dev_out_bytes) {
     using Fq = typename Curve::Fq; using Fr = typename Curve::Fr;
@@ -128,26 +131,23 @@ template <class Curve> void run_msm_window_sums_dev(const uint8_t *bases, const 
     zk::gpu::msm_sharded_plan<Curve>(n_total, &c, &nwin);
     if (!dev_out || dev_out_bytes < (size_t)nwin * sizeof(zk::XYZZ<Fq>)) throw std::invalid_argument("zkaes_msm_window_sums_dev: device buffer too small for the window sums");
     if (n_local > n_total) throw std::invalid_argument("zkaes_msm_window_sums_dev: n_local > n_total");
-    zk::gpu::stream_t s = zk::gpu::stream_create();
-    zk::Affine<Fq> *db = (zk::Affine<Fq> *)zk::gpu::dmalloc(n_local * 96);
-    Fr *ds = (Fr *)zk::gpu::dmalloc(n_local * 32);
+    if (n_local && (!bases || !scalars)) throw std::invalid_argument("zkaes_msm_window_sums_dev: null argument");
+    StreamGuard s;
+    DevPtr<zk::Affine<Fq>> db(n_local);
+    DevPtr<Fr> ds(n_local);
     zk::gpu::h2d(db, bases, n_local * 96, s); zk::gpu::h2d(ds, scalars, n_local * 32, s);
-    zk::Affine28<typename Curve::FqP> *db28 = (zk::Affine28<typename Curve::FqP> *)zk::gpu::dmalloc(n_local * sizeof(zk::Affine28<typename Curve::FqP>));
+    DevPtr<zk::Affine28<typename Curve::FqP>> db28(n_local);
     zk::gpu::convert_bases<Curve>(db28, db, n_local, s);
-    zk::gpu::MsmWorkspace *ws = zk::gpu::msm_workspace_create();
+    WorkspaceGuard ws;
     zk::gpu::msm_window_sums_device<Curve>(ws, db28, ds, n_local, n_total, (zk::XYZZ<Fq> *)dev_out, s);    // synchronizes the stream
-    zk::gpu::msm_workspace_destroy(ws);
-    zk::gpu::dfree(db28); zk::gpu::dfree(db); zk::gpu::dfree(ds); zk::gpu::stream_destroy(s);
 }
+constexpr int MAX_FOLD_WORLD = 4096;        // ranks whose partial sums one fold call adds (an 8-GPU node needs 8)
 template <class Curve> void run_msm_fold_dev(const void *dev_in, int world, size_t n_total, uint8_t *out_xy, int *out_inf) {
     using Fq = typename Curve::Fq;
+    if (!dev_in || world < 1 || world > MAX_FOLD_WORLD) throw std::invalid_argument("zkaes_msm_fold_window_sums_dev: bad arguments (world must be 1..4096)");
     zk::gpu::require_device();
-    if (!dev_in || world < 1) throw std::invalid_argument("zkaes_msm_fold_window_sums_dev: bad arguments");
-    zk::gpu::stream_t s = zk::gpu::stream_create();
-    zk::Affine<Fq> a = zk::gpu::msm_fold_window_sums_device<Curve>((const zk::XYZZ<Fq> *)dev_in, world, n_total, s).to_affine();
-    zk::gpu::stream_destroy(s);
-    if (out_inf) *out_inf = a.is_inf() ? 1 : 0;
-    if (out_xy) { memcpy(out_xy, a.x.l, 48); memcpy(out_xy + 48, a.y.l, 48); }
+    StreamGuard s;
+    give_affine(zk::gpu::msm_fold_window_sums_device<Curve>((const zk::XYZZ<Fq> *)dev_in, world, n_total, s).to_affine(), out_xy, out_inf);
 }
 // host-side sum of a handful of affine partial results: the "local EC add" after the all-gather of a point-range-sharded MSM
 template <class Curve> void run_g1_sum(const uint8_t *points_xy, const int *inf, size_t n, uint8_t *out_xy, int *out_inf) {
@@ -186,18 +186,12 @@ int zkaes_g1_sum(int curve_id, const uint8_t *points_xy, const int *inf, size_t 
 }
 int zkaes_msm_fold_partials_dev(int curve_id, const void *dev_in, int world, uint8_t *out_xy, int *out_inf) {
     return guardk([&] {
+        if (!dev_in || world < 1 || world > MAX_FOLD_WORLD) throw std::invalid_argument("zkaes_msm_fold_partials_dev: bad arguments (world must be 1..4096)");
+        if (curve_id != 377 && curve_id != 381) throw std::invalid_argument("curve_id must be 377 or 381");
         zk::gpu::require_device();
-        if (!dev_in || world < 1) throw std::invalid_argument("zkaes_msm_fold_partials_dev: bad arguments");
-        zk::gpu::stream_t s = zk::gpu::stream_create();
-        auto finish = [&](auto total) {
-            auto a = total.to_affine();
-            if (out_inf) *out_inf = a.is_inf() ? 1 : 0;
-            if (out_xy) { memcpy(out_xy, a.x.l, 48); memcpy(out_xy + 48, a.y.l, 48); }
-        };
-        if (curve_id == 377) finish(zk::gpu::msm_fold_points_device<zk::Bls377>((const zk::XYZZ<zk::Fq377> *)dev_in, world, s));
-        else if (curve_id == 381) finish(zk::gpu::msm_fold_points_device<zk::Bls381>((const zk::XYZZ<zk::Fq381> *)dev_in, world, s));
-        else { zk::gpu::stream_destroy(s); throw std::invalid_argument("curve_id must be 377 or 381"); }
-        zk::gpu::stream_destroy(s);
+        StreamGuard s;
+        if (curve_id == 377) give_affine(zk::gpu::msm_fold_points_device<zk::Bls377>((const zk::XYZZ<zk::Fq377> *)dev_in, world, s).to_affine(), out_xy, out_inf);
+        else give_affine(zk::gpu::msm_fold_points_device<zk::Bls381>((const zk::XYZZ<zk::Fq381> *)dev_in, world, s).to_affine(), out_xy, out_inf);
     });
 }
 int zkaes_msm_table(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, int window_bits, uint8_t *out_xy, int *out_inf) {
@@ -234,69 +228,70 @@ int zkaes_msm_bench(int curve_id, const uint8_t *bases, const uint8_t *scalars, 
 int zkaes_msm_bench_synth(size_t n, int window_bits, int reps, double *ms_total, double *ms_accumulate, uint8_t *out_xy) {
     return guardk([&] {
         using Fq = zk::Fq377; using Fr = zk::Fr377;
+        if (!ms_total || !ms_accumulate || reps < 1 || n == 0 || window_bits > 22) throw std::invalid_argument("zkaes_msm_bench_synth: bad arguments");
         zk::gpu::require_device();
-        zk::gpu::stream_t s = zk::gpu::stream_create();
         const size_t nt = window_bits > 0 ? (size_t)zk::gpu::table_windows<zk::Bls377>(window_bits) : 1;
-        zk::Affine<Fq> *tab = (zk::Affine<Fq> *)zk::gpu::dmalloc(nt * n * 96);
+        if ((uint64_t)nt * n >= (1ull << 30)) throw std::invalid_argument("zkaes_msm_bench_synth: n x table copies exceeds the 2^30 base indices of one MSM");
+        StreamGuard s;
+        DevPtr<zk::Affine<Fq>> tab(nt * n);
         zk::Affine<Fq> g; for (int i = 0; i < 12; i++) { g.x.l[i] = G1_377_X_MONT[i]; g.y.l[i] = G1_377_Y_MONT[i]; }
         Fr beta = Fr::from_u64(0x9e3779b97f4a7c15ull) * Fr::from_u64(0xc2b2ae3d27d4eb4full);
         zk::gpu::fixed_base_powers<zk::Bls377>(tab, g, beta, 1, n, s);
         if (window_bits > 0) zk::gpu::build_window_tables<zk::Bls377>(tab, n, window_bits, s);
         // window_bits == 0: the generic path (Weierstrass model, XYZZ buckets, 112-byte bases); < 0 or > 0: the prover's SRS path on the twisted Edwards model
         const bool edwards = window_bits != 0;
-        zk::Affine28<zk::Fq377P> *tab28 = nullptr;
-        zk::Niels28<zk::Fq377P> *tabte = nullptr;
-        if (edwards) { tabte = (zk::Niels28<zk::Fq377P> *)zk::gpu::dmalloc(nt * n * sizeof(zk::Niels28<zk::Fq377P>)); zk::gpu::convert_bases_te<zk::Bls377>(tabte, tab, nt * n, s); }
-        if (!edwards) { tab28 = (zk::Affine28<zk::Fq377P> *)zk::gpu::dmalloc(nt * n * sizeof(zk::Affine28<zk::Fq377P>)); zk::gpu::convert_bases<zk::Bls377>(tab28, tab, nt * n, s); }
+        DevPtr<zk::Affine28<zk::Fq377P>> tab28;
+        DevPtr<zk::Niels28<zk::Fq377P>> tabte;
+        if (edwards) { tabte.alloc(nt * n); zk::gpu::convert_bases_te<zk::Bls377>(tabte, tab, nt * n, s); }
+        else { tab28.alloc(nt * n); zk::gpu::convert_bases<zk::Bls377>(tab28, tab, nt * n, s); }
         std::vector<Fr> sc(n);
         uint64_t x = 88172645463325252ull;
         for (size_t i = 0; i < n; i++) { for (int k = 0; k < 8; k += 2) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; sc[i].l[k] = (uint32_t)x; sc[i].l[k + 1] = (uint32_t)(x >> 32); } sc[i].l[7] &= 0x0fffffffu; }
-        Fr *ds = (Fr *)zk::gpu::dmalloc(n * 32);
+        DevPtr<Fr> ds(n);
         zk::gpu::h2d(ds, sc.data(), n * 32, s);
         zk::gpu::sync(s);
-        zk::gpu::MsmWorkspace *ws = zk::gpu::msm_workspace_create();
+        WorkspaceGuard ws;
         auto run = [&]() -> zk::XYZZ<Fq> {
-            if (edwards) return window_bits > 0 ? zk::gpu::msm_table<zk::Bls377>(ws, tabte, n, 0, window_bits, ds, n, s) : zk::gpu::msm<zk::Bls377>(ws, tabte, ds, n, s);
-            return window_bits > 0 ? zk::gpu::msm_table<zk::Bls377>(ws, tab28, n, 0, window_bits, ds, n, s) : zk::gpu::msm<zk::Bls377>(ws, tab28, ds, n, s);
+            if (edwards) return window_bits > 0 ? zk::gpu::msm_table<zk::Bls377>(ws, tabte, n, 0, window_bits, ds, n, s) : zk::gpu::msm<zk::Bls377>(ws, tabte.get(), ds.get(), n, s);
+            return window_bits > 0 ? zk::gpu::msm_table<zk::Bls377>(ws, tab28, n, 0, window_bits, ds, n, s) : zk::gpu::msm<zk::Bls377>(ws, tab28.get(), ds.get(), n, s);
         };
-        {
-            zk::Affine<Fq> a = run().to_affine();
-            if (out_xy) { memcpy(out_xy, a.x.l, 48); memcpy(out_xy + 48, a.y.l, 48); }
-        }
+        give_affine(run().to_affine(), out_xy, nullptr);
         zk::gpu::MsmStats before = zk::gpu::msm_stats(false);
-        void *e0 = zk::gpu::event_create(), *e1 = zk::gpu::event_create();
+        EventGuard e0, e1;
         zk::gpu::event_record(e0, s);
         for (int i = 0; i < reps; i++) run();
         zk::gpu::event_record(e1, s);
         float ms = zk::gpu::event_elapsed_ms(e0, e1);
         zk::gpu::MsmStats after = zk::gpu::msm_stats(false);
         *ms_total = ms / reps; *ms_accumulate = (after.accumulate_ms - before.accumulate_ms) / reps;
-        zk::gpu::event_destroy(e0); zk::gpu::event_destroy(e1);
-        zk::gpu::msm_workspace_destroy(ws);
-        zk::gpu::dfree(tab28);
-        zk::gpu::dfree(tabte);
-        zk::gpu::dfree(tab); zk::gpu::dfree(ds); zk::gpu::stream_destroy(s);
     });
 }
 
 int zkaes_stream_copy_bench(size_t bytes, int reps, double *gb_per_s) {
     return guardk([&] {
+        if (bytes < 4096 || reps < 1 || !gb_per_s) throw std::invalid_argument("zkaes_stream_copy_bench: bytes >= 4096, reps >= 1");
         zk::gpu::require_device();
-        if (bytes < 4096 || reps < 1) throw std::invalid_argument("zkaes_stream_copy_bench: bytes >= 4096, reps >= 1");
-        zk::gpu::stream_t s = zk::gpu::stream_create();
+        StreamGuard s;
         const size_t n16 = bytes / 16;
-        uint4 *a = (uint4 *)zk::gpu::dmalloc(n16 * 16), *b = (uint4 *)zk::gpu::dmalloc(n16 * 16);
+        DevPtr<uint4> a(n16), b(n16);
         zk::gpu::dzero(a, n16 * 16, s);
-        hipStream_t hs = (hipStream_t)s;
+        hipStream_t hs = (hipStream_t)s.s;
         k_stream_copy<<<(unsigned)((n16 + 1023) / 1024), 256, 0, hs>>>(b, a, n16);
-        void *e0 = zk::gpu::event_create(), *e1 = zk::gpu::event_create();
+        EventGuard e0, e1;
         zk::gpu::event_record(e0, s);
-        for (int i = 0; i < reps; i++) k_stream_copy<<<(unsigned)((n16 + 1023) / 1024), 256, 0, hs>>>(i & 1 ? a : b, i & 1 ? b : a, n16);
+        for (int i = 0; i < reps; i++) k_stream_copy<<<(unsigned)((n16 + 1023) / 1024), 256, 0, hs>>>(i & 1 ? a.get() : b.get(), i & 1 ? b.get() : a.get(), n16);
         zk::gpu::event_record(e1, s);
         float ms = zk::gpu::event_elapsed_ms(e0, e1);
         *gb_per_s = 2.0 * (double)(n16 * 16) * reps / 1e9 / (ms / 1e3);   // read + write
-        zk::gpu::event_destroy(e0); zk::gpu::event_destroy(e1);
-        zk::gpu::dfree(a); zk::gpu::dfree(b); zk::gpu::stream_destroy(s);
+    });
+}
+int zkaes_mem_info(uint64_t *free_bytes, uint64_t *total_bytes) {
+    return guardk([&] {
+        zk::gpu::require_device();
+        size_t f = 0, t = 0;
+        HIP_CHECK(hipMemGetInfo(&f, &t));
+        if (free_bytes) *free_bytes = f;
+        if (total_bytes) *total_bytes = t;
     });
 }
 }

@@ -5,6 +5,8 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
+#include <vector>
 #include "ec.cuh"
 #include "te28.cuh"
 
@@ -42,6 +44,45 @@ void event_record(void *ev, stream_t s);
 float event_elapsed_ms(void *start, void *stop);
 void event_destroy(void *ev);
 
+// RAII owners of the raw handles above: an exception between an allocation and its release must not leak device memory, a stream or an MSM workspace
+// (every kernel-level C entry point and the setup helpers hold their temporaries through these)
+template <class T> struct DevPtr {
+    T *p = nullptr;
+    DevPtr() = default;
+    explicit DevPtr(size_t count) : p((T *)dmalloc(count * sizeof(T))) {}
+    DevPtr(const DevPtr &) = delete; DevPtr &operator=(const DevPtr &) = delete;
+    DevPtr(DevPtr &&o) noexcept : p(o.p) { o.p = nullptr; }
+    DevPtr &operator=(DevPtr &&o) noexcept { if (this != &o) { dfree(p); p = o.p; o.p = nullptr; } return *this; }
+    ~DevPtr() { dfree(p); }
+    void alloc(size_t count) { dfree(p); p = nullptr; p = (T *)dmalloc(count * sizeof(T)); }
+    T *get() const { return p; }
+    operator T *() const { return p; }
+};
+struct StreamGuard {
+    stream_t s = nullptr;
+    StreamGuard() : s(stream_create()) {}
+    StreamGuard(const StreamGuard &) = delete; StreamGuard &operator=(const StreamGuard &) = delete;
+    ~StreamGuard() { stream_destroy(s); }
+    operator stream_t() const { return s; }
+};
+struct EventGuard {
+    void *e = nullptr;
+    EventGuard() : e(event_create()) {}
+    EventGuard(const EventGuard &) = delete; EventGuard &operator=(const EventGuard &) = delete;
+    ~EventGuard() { event_destroy(e); }
+    operator void *() const { return e; }
+};
+
+// ---- op lists (debug; zkaes_pk_op_lists): while a recording is open, every transform and every MSM the library launches is appended -- the ACTUAL lists the whole-proof
+// roofline of SURVEY.md 8(d) (bytes = W + S + T + M, T = sum 64 n_i, M = sum 128 m_j) is computed from, instead of a literal in a document.  Process-global: record with no
+// other proof in flight.  The hooks cost one relaxed atomic load when no recording is open.
+enum : int { OP_MSM_BUCKETS = 0, OP_MSM_SECOND_BASES = 1, OP_MSM_CLASS_SUM = 2 };      // Pippenger over buckets | the same prepared scalars against a second base array | class sum over a Lagrange-basis SRS
+struct OpRecord { std::vector<std::pair<uint64_t, int>> ntt /* (points, transforms sharing the launch) */, msm /* (points, kind) */; };
+void oplog_begin();
+OpRecord oplog_end();
+void oplog_ntt(uint64_t n, int count);
+void oplog_msm(uint64_t points, int kind);
+
 // ---- NTT (kernels_ntt.hip).  Tables are created lazily per (field, log n) and cached for the life of the process.
 // dst <- NTT(src zero-padded from in_len to 2^lg); dst may equal src only if in_len == 2^lg is NOT required (out of place first pass
 // reads src completely before any tile of dst is written only when dst != src; pass distinct buffers).
@@ -64,6 +105,13 @@ template <class Fr> const Fr *domain_elements(int lg);   // device table g^i, i 
 struct MsmWorkspace;
 MsmWorkspace *msm_workspace_create();
 void msm_workspace_destroy(MsmWorkspace *ws);
+struct WorkspaceGuard {
+    MsmWorkspace *ws = nullptr;
+    WorkspaceGuard() : ws(msm_workspace_create()) {}
+    WorkspaceGuard(const WorkspaceGuard &) = delete; WorkspaceGuard &operator=(const WorkspaceGuard &) = delete;
+    ~WorkspaceGuard() { msm_workspace_destroy(ws); }
+    operator MsmWorkspace *() const { return ws; }
+};
 // Bases are consumed in the reduced-radix form (Affine28, ff28.cuh): convert once with convert_bases (the SRS at key synthesis).
 template <class Curve> void convert_bases(Affine28<typename Curve::FqP> *dst, const Affine<typename Curve::Fq> *src, size_t n, stream_t s);
 template <class Curve>

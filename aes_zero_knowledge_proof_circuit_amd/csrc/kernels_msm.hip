@@ -341,7 +341,7 @@ __device__ void accumulate_fixup(const Affine28<P> *__restrict__ bases, Acc28<P>
 // the deferred degenerate additions of this kernel and of k_accumulate.  The overflow partials are folded into their buckets by the reduction when it loads them.
 // For uniformly distributed digits there are no segments and no deferred pairs: every lane exits after one load.
 template <class Law>
-__global__ void __launch_bounds__(64, 2) k_accumulate_tail(const typename Law::Base *__restrict__ bases, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ start,
+__global__ void __launch_bounds__(64) k_accumulate_tail(const typename Law::Base *__restrict__ bases, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ start,
                                                             const uint32_t *__restrict__ end, const uint32_t *__restrict__ ctrl, const uint32_t *__restrict__ ovf_bucket,
                                                             const uint32_t *__restrict__ ovf_off, uint32_t max_segments, uint32_t cap,
                                                             typename Law::Acc *__restrict__ partial, typename Law::Acc *__restrict__ buckets, uint32_t *__restrict__ deferred, uint32_t deferred_cap,
@@ -736,7 +736,7 @@ struct MsmWorkspace {
     uint32_t *deferred = nullptr, *deferred_count = nullptr;
     void *buckets = nullptr, *seg_s = nullptr, *seg_w = nullptr, *partial = nullptr, *tmp = nullptr;
     void *h_res = nullptr, *d_res = nullptr;                      // pinned host memory the last reduction kernel writes the window sums (+ flags) into, and its device address
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};      // [2 rep], [2 rep + 1]: around the k_accumulate launch of base array `rep`
 };
 constexpr size_t RES_BYTES = 192 * MAX_WSUMS + 64;
 // the accumulators and the reduction's levels, sized by the number of buckets ACCUMULATED (twice the prepared ones when one prepared state serves two base arrays at once)
@@ -750,8 +750,8 @@ static void ensure_result(MsmWorkspace &S, size_t buckets) {
 }
 static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t cap) {
     if (cap == 0) cap = BUCKET_CAP;
-    if (!S.ev0) {
-        HIP_CHECK(hipEventCreate(&S.ev0)); HIP_CHECK(hipEventCreate(&S.ev1));
+    if (!S.ev[0]) {
+        for (auto &e : S.ev) HIP_CHECK(hipEventCreate(&e));
         S.deferred = (uint32_t *)dmalloc(2 * DEFERRED_CAP * 4); S.deferred_count = (uint32_t *)dmalloc(8);
         S.ord_hist = (uint32_t *)dmalloc((size_t)ORD_BINS * ORD_MAX_BLOCKS * 4); S.ord_offs = (uint32_t *)dmalloc((size_t)ORD_BINS * ORD_MAX_BLOCKS * 4);
         S.ctrl = (uint32_t *)dmalloc(32);
@@ -788,7 +788,7 @@ void msm_workspace_destroy(MsmWorkspace *w) {
                     (void *)w->ovf_bucket, (void *)w->ovf_nseg, (void *)w->ovf_off, w->ovf_partial, (void *)w->part_hist, (void *)w->part_offs, (void *)w->dig, (void *)w->ord_hist, (void *)w->ord_offs,
                     (void *)w->ctrl, (void *)w->tickets, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->tmp}) dfree(p);
     if (w->h_res) (void)hipHostFree(w->h_res);
-    if (w->ev0) { (void)hipEventDestroy(w->ev0); (void)hipEventDestroy(w->ev1); }
+    for (auto e : w->ev) if (e) (void)hipEventDestroy(e);
     delete w;
 }
 
@@ -855,14 +855,14 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
         if constexpr (!Law::edwards) HIP_CHECK(hipMemsetAsync(S.deferred_count, 0, 8, s));
     }
 #endif
-    HIP_CHECK(hipEventRecord(S.ev0, s));
     uint32_t max_seg = (uint32_t)(pairs / cap + 1);
     for (int rep = 0; rep < nrep; rep++) {
         const typename Law::Base *src = rep ? bases2 : bases;
+        HIP_CHECK(hipEventRecord(S.ev[2 * rep], s));          // every k_accumulate launch is bracketed and booked by itself (msm_stats: launches, points, pairs, ms)
         hipLaunchKernelGGL((k_accumulate<Law>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, src, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb, cap,
                            (A *)S.buckets + rep * nb, S.deferred, DEFERRED_CAP, S.deferred_count);
         HIP_LAUNCH_CHECK();
-        if (rep == 0) HIP_CHECK(hipEventRecord(S.ev1, s));
+        HIP_CHECK(hipEventRecord(S.ev[2 * rep + 1], s));
         // oversized buckets + deferred degenerate additions (none for uniformly distributed digits: every lane exits at once)
         hipLaunchKernelGGL((k_accumulate_tail<Law>), dim3((max_seg + 63) / 64), dim3(64), 0, s, src, S.sorted_vals, S.start, S.end, S.ctrl, S.ovf_bucket, S.ovf_off, max_seg, cap,
                            (A *)S.ovf_partial + rep * S.cap_ovf, (A *)S.buckets + rep * nb, S.deferred, DEFERRED_CAP, S.deferred_count);
@@ -916,16 +916,17 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
         sync((stream_t)s);
         if (n_deferred > DEFERRED_CAP) throw GpuError("msm: more than 2^20 degenerate additions (repeated base points); refusing to return a wrong sum");
     }
-    HIP_CHECK(hipEventElapsedTime(acc_ms, S.ev0, S.ev1));
+    for (int rep = 0; rep < nrep; rep++) HIP_CHECK(hipEventElapsedTime(acc_ms + rep, S.ev[2 * rep], S.ev[2 * rep + 1]));
     (void)n_points;
     return ws;
 }
-static void add_stats(float acc_ms, size_t n, size_t pairs, std::chrono::steady_clock::time_point t_begin) {
+// one entry per k_accumulate LAUNCH: a prepared state finished against two base arrays (plain + shifted powers) is two launches over n points each
+static void add_stats(const float *acc_ms, int launches, size_t n, size_t pairs, std::chrono::steady_clock::time_point t_begin) {
     std::lock_guard<std::mutex> g(g_stats_mu);
-    g_stats.accumulate_ms += acc_ms;
-    g_stats.points += n;
-    g_stats.pairs += pairs;
-    g_stats.launches += 1;
+    for (int i = 0; i < launches; i++) g_stats.accumulate_ms += acc_ms[i];
+    g_stats.points += n * (size_t)launches;
+    g_stats.pairs += pairs * (size_t)launches;
+    g_stats.launches += (uint64_t)launches;
     g_stats.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 }
 
@@ -965,15 +966,15 @@ void convert_bases_te(Niels28<typename Curve::FqP> *dst, const Affine<typename C
     static_assert(Curve::ID == 377, "only BLS12-377's G1 has a twisted Edwards model");
     if (!n) return;
     hipStream_t s = (hipStream_t)s_;
-    uint32_t *d_bad = (uint32_t *)dmalloc(4), h_bad = 0;
+    DevPtr<uint32_t> d_bad(1);
+    uint32_t h_bad = 0;
     HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, s));
     size_t lanes = (n + 7) / 8;
-    hipLaunchKernelGGL(k_convert_bases_te, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, src, dst, n, d_bad);
+    hipLaunchKernelGGL(k_convert_bases_te, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, src, dst, n, d_bad.get());
     HIP_LAUNCH_CHECK();
     sync((stream_t)s);        // drain first (sleeps in throughput mode): the pageable device-to-host copies below wait actively inside HIP
     HIP_CHECK(hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, s));
     sync((stream_t)s);
-    dfree(d_bad);
     if (h_bad) throw GpuError("convert_bases_te: a base point has order 2 or 4 -- the Edwards path needs points of the prime-order subgroup");
 }
 template void convert_bases_te<Bls377>(Niels28<Fq377P> *, const Affine<Fq377> *, size_t, stream_t);
@@ -1026,10 +1027,12 @@ static XYZZ<typename Curve::Fq> msm_finish_impl(MsmWorkspace *ws_, const typenam
     if (S.plan_n == 0) return XYZZ<Fq>::inf();
     auto t_begin = std::chrono::steady_clock::now();
     const int c = S.plan_c, nwin = S.plan_nwin;
-    float ms = 0;
+    oplog_msm(S.plan_n, OP_MSM_BUCKETS);
+    if (bases2) oplog_msm(S.plan_n, OP_MSM_SECOND_BASES);
+    float ms[2] = {0, 0};
     if (S.plan_table) {      // `bases` = table copy 0 (+ a constant index shift): the window weights live in the copies, ONE bucket set, no Horner
-        std::vector<XYZZ<Fq>> one = run_buckets<Law>(S, bases, S.plan_pairs, c - 1, 1, S.plan_n, S.plan_cap, s, &ms, nullptr, bases2);
-        add_stats(ms, S.plan_n, S.plan_pairs, t_begin);
+        std::vector<XYZZ<Fq>> one = run_buckets<Law>(S, bases, S.plan_pairs, c - 1, 1, S.plan_n, S.plan_cap, s, ms, nullptr, bases2);
+        add_stats(ms, bases2 ? 2 : 1, S.plan_n, S.plan_pairs, t_begin);
         if (bases2) *out2 = one[1];
         return one[0];
     }
@@ -1037,8 +1040,9 @@ static XYZZ<typename Curve::Fq> msm_finish_impl(MsmWorkspace *ws_, const typenam
         *out2 = msm_finish_impl<Curve, Law>(ws_, bases2, s_);
         bases2 = nullptr;
     }
-    std::vector<XYZZ<Fq>> ws = run_buckets<Law>(S, bases, S.plan_pairs, c - 1, nwin, S.plan_n, S.plan_cap, s, &ms, nullptr, bases2);
-    if (getenv("ZKAES_MSM_DEBUG")) {
+    std::vector<XYZZ<Fq>> ws = run_buckets<Law>(S, bases, S.plan_pairs, c - 1, nwin, S.plan_n, S.plan_cap, s, ms, nullptr, bases2);
+    static const bool msm_debug = getenv("ZKAES_MSM_DEBUG") != nullptr;       // read once per process
+    if (msm_debug) {
         for (int w = 0; w < nwin; w++) {
             Affine<Fq> a = ws[w].to_affine();
             fprintf(stderr, "window %d inf=%d x0=%08x y0=%08x\n", w, (int)a.is_inf(), a.x.l[0], a.y.l[0]);
@@ -1055,7 +1059,7 @@ static XYZZ<typename Curve::Fq> msm_finish_impl(MsmWorkspace *ws_, const typenam
         total[rep] = t;
     }
     if (bases2) *out2 = total[1];
-    add_stats(ms, S.plan_n, S.plan_pairs, t_begin);
+    add_stats(ms, bases2 ? 2 : 1, S.plan_n, S.plan_pairs, t_begin);
     return total[0];
 }
 // plain + shifted powers of one degree-bounded commitment: out[0] = sum over `bases`, out[1] = sum over `bases2`, one reduction and one host wait for both
@@ -1109,8 +1113,9 @@ void msm_window_sums_device(MsmWorkspace *ws_, const Affine28<typename Curve::Fq
     if (S.plan_nwin != nwin) throw GpuError("msm_window_sums_device: window plan mismatch");
     float ms = 0;
     auto t_begin = std::chrono::steady_clock::now();
+    oplog_msm(n_local, OP_MSM_BUCKETS);
     run_buckets<WeierLaw<typename Curve::FqP>>(S, bases, S.plan_pairs, c - 1, nwin, n_local, S.plan_cap, s, &ms, dev_out);
-    add_stats(ms, n_local, S.plan_pairs, t_begin);
+    add_stats(&ms, 1, n_local, S.plan_pairs, t_begin);
 }
 template <class Fq>
 __global__ void k_fold_ranks(const XYZZ<Fq> *__restrict__ in, int world, int nwin, XYZZ<Fq> *__restrict__ out) {
@@ -1126,14 +1131,13 @@ XYZZ<typename Curve::Fq> msm_fold_window_sums_device(const XYZZ<typename Curve::
     hipStream_t s = (hipStream_t)s_;
     int c, nwin;
     msm_sharded_plan<Curve>(n_total, &c, &nwin);
-    XYZZ<Fq> *d_out = (XYZZ<Fq> *)dmalloc(sizeof(XYZZ<Fq>) * nwin);
-    hipLaunchKernelGGL((k_fold_ranks<Fq>), dim3(1), dim3(64), 0, s, dev_in, world, nwin, d_out);
+    DevPtr<XYZZ<Fq>> d_out((size_t)nwin);
+    hipLaunchKernelGGL((k_fold_ranks<Fq>), dim3(1), dim3(64), 0, s, dev_in, world, nwin, d_out.get());
     HIP_LAUNCH_CHECK();
     std::vector<XYZZ<Fq>> ws(nwin);
     sync((stream_t)s);        // drain first (sleeps in throughput mode): the pageable device-to-host copies below wait actively inside HIP
     HIP_CHECK(hipMemcpyAsync(ws.data(), d_out, sizeof(XYZZ<Fq>) * nwin, hipMemcpyDeviceToHost, s));
     sync((stream_t)s);
-    dfree(d_out);
     XYZZ<Fq> total = XYZZ<Fq>::inf();
     for (int w = nwin - 1; w >= 1; w--) {
         total.add(ws[w]);
@@ -1158,21 +1162,21 @@ void msm_table_sum_device(MsmWorkspace *ws_, const Niels28<typename Curve::FqP> 
     MsmWorkspace &S = *ws_;
     float ms = 0;
     auto t_begin = std::chrono::steady_clock::now();
+    oplog_msm(n, OP_MSM_BUCKETS);
     run_buckets<EdwardsLaw<typename Curve::FqP>>(S, tables, S.plan_pairs, S.plan_c - 1, 1, n, S.plan_cap, s, &ms, dev_out);
-    add_stats(ms, n, S.plan_pairs, t_begin);
+    add_stats(&ms, 1, n, S.plan_pairs, t_begin);
 }
 template <class Curve>
 XYZZ<typename Curve::Fq> msm_fold_points_device(const XYZZ<typename Curve::Fq> *dev_in, int world, stream_t s_) {
     using Fq = typename Curve::Fq;
     hipStream_t s = (hipStream_t)s_;
-    XYZZ<Fq> *d_out = (XYZZ<Fq> *)dmalloc(sizeof(XYZZ<Fq>));
-    hipLaunchKernelGGL((k_fold_ranks<Fq>), dim3(1), dim3(64), 0, s, dev_in, world, 1, d_out);
+    DevPtr<XYZZ<Fq>> d_out(1);
+    hipLaunchKernelGGL((k_fold_ranks<Fq>), dim3(1), dim3(64), 0, s, dev_in, world, 1, d_out.get());
     HIP_LAUNCH_CHECK();
     XYZZ<Fq> r;
     sync((stream_t)s);
     HIP_CHECK(hipMemcpyAsync(&r, d_out, sizeof r, hipMemcpyDeviceToHost, s));
     sync((stream_t)s);
-    dfree(d_out);
     return r;
 }
 
@@ -1467,7 +1471,7 @@ __global__ void __launch_bounds__(64) k_fixed_base(const Affine<Fq> *__restrict_
 
 namespace {
 template <class Curve>
-Affine<typename Curve::Fq> *upload_fixed_base_table(const Affine<typename Curve::Fq> &base, hipStream_t s) {
+DevPtr<Affine<typename Curve::Fq>> upload_fixed_base_table(const Affine<typename Curve::Fq> &base, hipStream_t s) {
     using Fq = typename Curve::Fq;
     const int NW = Curve::Fr::N * 4;
     std::vector<Affine<Fq>> table((size_t)NW * 255);
@@ -1477,7 +1481,7 @@ Affine<typename Curve::Fq> *upload_fixed_base_table(const Affine<typename Curve:
         for (int d = 1; d <= 255; d++) { table[(size_t)w * 255 + d - 1] = acc.to_affine(); acc.add(wb); }
         for (int k = 0; k < 8; k++) wb = wb.dbl();
     }
-    Affine<Fq> *d_table = (Affine<Fq> *)dmalloc(table.size() * sizeof(Affine<Fq>));
+    DevPtr<Affine<Fq>> d_table(table.size());
     HIP_CHECK(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(Affine<Fq>), hipMemcpyHostToDevice, s));
     sync((stream_t)s);
     return d_table;
@@ -1490,18 +1494,17 @@ void fixed_base_powers(Affine<typename Curve::Fq> *out, const Affine<typename Cu
     using Fr = typename Curve::Fr;
     hipStream_t s = (hipStream_t)s_;
     if (!count) return;
-    Affine<Fq> *d_table = upload_fixed_base_table<Curve>(base, s);
+    DevPtr<Affine<Fq>> d_table = upload_fixed_base_table<Curve>(base, s);
     const size_t CH = 1 << 20;
-    Fr *d_sc = (Fr *)dmalloc(CH * sizeof(Fr));
+    DevPtr<Fr> d_sc(CH);
     for (size_t off = 0; off < count; off += CH) {
         uint32_t m = (uint32_t)((count - off) < CH ? (count - off) : CH);
-        hipLaunchKernelGGL((k_power_scalars<Fr>), dim3((m + 255) / 256), dim3(256), 0, s, beta, (uint64_t)(from + off), m, d_sc);
+        hipLaunchKernelGGL((k_power_scalars<Fr>), dim3((m + 255) / 256), dim3(256), 0, s, beta, (uint64_t)(from + off), m, d_sc.get());
         HIP_LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_fixed_base<Fq, Fr>), dim3((m + 63) / 64), dim3(64), 0, s, d_table, d_sc, m, out + off);
+        hipLaunchKernelGGL((k_fixed_base<Fq, Fr>), dim3((m + 63) / 64), dim3(64), 0, s, (const Affine<Fq> *)d_table.get(), (const Fr *)d_sc.get(), m, out + off);
         HIP_LAUNCH_CHECK();
     }
     sync((stream_t)s);
-    dfree(d_table); dfree(d_sc);
 }
 // out[i] = scalars[i] * base for device-resident scalars (Lagrange-basis SRS points)
 template <class Curve>
@@ -1510,15 +1513,14 @@ void fixed_base_scalars(Affine<typename Curve::Fq> *out, const Affine<typename C
     using Fr = typename Curve::Fr;
     hipStream_t s = (hipStream_t)s_;
     if (!count) return;
-    Affine<Fq> *d_table = upload_fixed_base_table<Curve>(base, s);
+    DevPtr<Affine<Fq>> d_table = upload_fixed_base_table<Curve>(base, s);
     const size_t CH = 1 << 20;
     for (size_t off = 0; off < count; off += CH) {
         uint32_t m = (uint32_t)((count - off) < CH ? (count - off) : CH);
-        hipLaunchKernelGGL((k_fixed_base<Fq, Fr>), dim3((m + 63) / 64), dim3(64), 0, s, d_table, scalars + off, m, out + off);
+        hipLaunchKernelGGL((k_fixed_base<Fq, Fr>), dim3((m + 63) / 64), dim3(64), 0, s, (const Affine<Fq> *)d_table.get(), scalars + off, m, out + off);
         HIP_LAUNCH_CHECK();
     }
     sync((stream_t)s);
-    dfree(d_table);
 }
 
 // ---- sum of bases weighted by SMALL integers (|v| <= 2): the Lagrange-basis commitments of 0/1-valued evaluation vectors.
@@ -1623,6 +1625,7 @@ static bool class_sum_impl(MsmWorkspace *ws_, const typename Law::Base *bases, c
     memcpy(r, S.h_res, sizeof r);
     memcpy(&flags, (const char *)S.h_res + sizeof r, 4);
     if (flags) return false;          // a value outside [-2, 2] or a degenerate addition: the caller falls back to the generic MSM
+    oplog_msm(n, OP_MSM_CLASS_SUM);
     XYZZ<Fq> t = r[1].dbl();
     t.add(r[0]);
     *out = t;

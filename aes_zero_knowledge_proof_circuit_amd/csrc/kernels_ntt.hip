@@ -197,7 +197,8 @@ static void ntt_impl(const NttJob<Fr> *jobs, int count, size_t in_len, int lg, b
     for (int i = 0; i < NTT_MAX_BATCH; i++) {
         const NttJob<Fr> &j = jobs[i < count ? i : 0];
         if (j.dst == j.src) throw GpuError("ntt: dst must differ from src (first pass gathers bit-reversed)");
-        if (j.coset_c < 0 || (j.coset_c > 0 && (lg_big <= lg || j.coset_c >= (1 << (lg_big - lg))))) throw GpuError("ntt_coset: coset index out of range");
+        if (j.coset_c > 0 && (lg_big <= lg || lg_big > RootOf<Fr>::TWO_ADICITY || lg_big > 30)) throw GpuError("ntt_coset: the coset generator must come from a larger domain (lg < lg_big <= 30)");
+        if (j.coset_c < 0 || (j.coset_c > 0 && (uint32_t)j.coset_c >= (1u << (lg_big - lg)))) throw GpuError("ntt_coset: coset index out of range");
         batch.dst[i] = j.dst; batch.src[i] = j.src; batch.cs_c[i] = scale_table ? 1u : (uint32_t)j.coset_c;
         any_coset = any_coset || j.coset_c > 0;
     }
@@ -206,6 +207,7 @@ static void ntt_impl(const NttJob<Fr> *jobs, int count, size_t in_len, int lg, b
         return;
     }
     if (lg == 0) throw GpuError("ntt_coset: domain of size one");
+    oplog_ntt(n, count);
     Fr w = Tables<Fr>::gen(lg);
     const Fr *tw_std = inverse ? tables<Fr>().powers(tables<Fr>().inv, lg, w.inverse(), n / 2) : tables<Fr>().powers(tables<Fr>().fwd, lg, w, n / 2);
     const G *tw = twiddles29<Fr>(inverse ? tables<Fr>().inv29 : tables<Fr>().fwd29, lg, tw_std, n / 2);
@@ -265,7 +267,8 @@ template <class Fr>
 void ntt(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, stream_t s) { ntt_impl<Fr>(dst, src, in_len, lg, inverse, 0, 0, s); }
 template <class Fr>
 void ntt_coset(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, int coset_c, int lg_big, stream_t s) {
-    if (coset_c <= 0 || coset_c >= (1 << (lg_big - lg))) throw GpuError("ntt_coset: coset index out of range");
+    if (lg_big <= lg || lg_big > RootOf<Fr>::TWO_ADICITY || lg_big > 30) throw GpuError("ntt_coset: the coset generator must come from a larger domain (lg < lg_big <= 30)");
+    if (coset_c <= 0 || (uint32_t)coset_c >= (1u << (lg_big - lg))) throw GpuError("ntt_coset: coset index out of range");
     ntt_impl<Fr>(dst, src, in_len, lg, inverse, coset_c, lg_big, s);
 }
 
@@ -274,15 +277,16 @@ template <class Fr>
 void *coset_power_table(const Fr &g, size_t n, stream_t s_) {
     using G = Fp29<typename Fr::Params>;
     hipStream_t s = (hipStream_t)s_;
-    Fr *tmp = (Fr *)dmalloc(n * sizeof(Fr));
-    G *out = (G *)dmalloc(n * sizeof(G));
-    hipLaunchKernelGGL((k_fill_powers<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, (uint32_t)n, tmp);
+    DevPtr<Fr> tmp(n);
+    DevPtr<G> out(n);
+    hipLaunchKernelGGL((k_fill_powers<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, (uint32_t)n, tmp.get());
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_twiddles29<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const Fr *)tmp, (uint32_t)n, out);
+    hipLaunchKernelGGL((k_twiddles29<Fr>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const Fr *)tmp.get(), (uint32_t)n, out.get());
     HIP_LAUNCH_CHECK();
     sync(s_);
-    dfree(tmp);
-    return out;
+    G *r = out.p;
+    out.p = nullptr;              // ownership passes to the caller (free with dfree)
+    return r;
 }
 template <class Fr>
 void ntt_scaled(Fr *dst, const Fr *src, size_t in_len, int lg, bool inverse, const void *table, stream_t s) {

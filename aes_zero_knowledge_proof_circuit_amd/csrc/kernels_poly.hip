@@ -310,13 +310,13 @@ __global__ void k_count_nonzero(const F *__restrict__ p, size_t n, unsigned long
 }
 size_t count_nonzero(const F *p, size_t n, stream_t s_) {
     hipStream_t s = (hipStream_t)s_;
-    unsigned long long *d = (unsigned long long *)dmalloc(8), h = 0;
+    DevPtr<unsigned long long> d(1);
+    unsigned long long h = 0;
     HIP_CHECK(hipMemsetAsync(d, 0, 8, s));
-    if (n) { hipLaunchKernelGGL(k_count_nonzero, GRID(n), 0, s, p, n, d); HIP_LAUNCH_CHECK(); }
+    if (n) { hipLaunchKernelGGL(k_count_nonzero, GRID(n), 0, s, p, n, d.get()); HIP_LAUNCH_CHECK(); }
     sync((stream_t)s);        // drain first (sleeps in throughput mode): the pageable device-to-host copies below wait actively inside HIP
     HIP_CHECK(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, s));
     sync((stream_t)s);
-    dfree(d);
     return (size_t)h;
 }
 

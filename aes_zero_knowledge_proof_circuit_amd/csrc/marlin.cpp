@@ -99,6 +99,14 @@ struct Bytes {
         g1_tobytes(c.comm); u8(c.has_shifted ? 1 : 0);
         g1_tobytes(c.has_shifted ? c.shifted : G1A::inf());
     }
+    // ark-ec 0.3 GroupAffine::serialize_uncompressed: x, then y with the flags byte (only the infinity bit is ever set; zero() = (0, 1, infinity)) -- 96 bytes,
+    // what deserialize_uncompressed / deserialize_unchecked read
+    void g1_uncompressed(const G1A &p) {
+        const size_t at = b.size();
+        if (p.is_inf()) { field(Fq377::zero()); field(Fq377::one()); b[at + 95] |= 1 << 6; }
+        else { field(p.x); field(p.y); }
+    }
+    void g1(const G1A &p, bool uncompressed) { if (uncompressed) g1_uncompressed(p); else g1_compressed(p); }
     void g1_compressed(const G1A &p) {
         uint8_t buf[48] = {0};
         if (p.is_inf()) { buf[47] |= 1 << 6; put(buf, 48); return; }
@@ -230,6 +238,11 @@ void put_g2_compressed(Bytes &o, const pairing::G2Affine &p) {
     if (fq2_gt(p.y, p.y.neg())) buf[95] |= 1 << 7;
     o.put(buf, 96);
 }
+void put_g2_uncompressed(Bytes &o, const pairing::G2Affine &p) {       // x (c0, c1), y (c0, c1 with the flags byte): 192 bytes
+    const size_t at = o.b.size();
+    if (p.inf) { for (int i = 0; i < 2; i++) o.field(Fq377::zero()); o.field(Fq377::one()); o.field(Fq377::zero()); o.b[at + 191] |= 1 << 6; return; }
+    o.field(p.x.c0); o.field(p.x.c1); o.field(p.y.c0); o.field(p.y.c1);
+}
 pairing::G2Affine get_g2_compressed(Reader &r) {
     r.need(96);
     uint8_t buf[96];
@@ -308,15 +321,17 @@ void kzg_setup_points(Fr &beta, G1A &g, G1A &gamma_g, pairing::G2Affine &h) {
 //   verifier_key : marlin_pc::VerifierKey = kzg10::VerifierKey { g, gamma_g (G1 48 B each), h, beta_h (G2 compressed 96 B each); the
 //                  prepared G2 elements are not serialized }, degree_bounds_and_shift_powers Option<Vec<(usize, G1)>> (tag, u64 len,
 //                  (u64, 48 B) each), max_degree u64, supported_degree u64
-std::vector<uint8_t> serialize_vk_ark(const VerifyingKey &vk) {
+// `uncompressed`: the image serialize_uncompressed writes (G1 96 B, G2 192 B, everything else identical) -- the form deserialize_unchecked reads
+std::vector<uint8_t> serialize_vk_ark(const VerifyingKey &vk, bool uncompressed) {
     Bytes o;
+    auto g2 = [&](const pairing::G2Affine &p) { if (uncompressed) put_g2_uncompressed(o, p); else put_g2_compressed(o, p); };
     o.u64(vk.num_variables); o.u64(vk.num_constraints); o.u64(vk.num_non_zero); o.u64(vk.num_instance);
     o.u64(6);
-    for (int i = 0; i < 6; i++) { o.g1_compressed(vk.index_comms[i]); o.u8(0); }
-    o.g1_compressed(vk.g); o.g1_compressed(vk.gamma_g);
-    put_g2_compressed(o, vk.h); put_g2_compressed(o, vk.beta_h);
+    for (int i = 0; i < 6; i++) { o.g1(vk.index_comms[i], uncompressed); o.u8(0); }
+    o.g1(vk.g, uncompressed); o.g1(vk.gamma_g, uncompressed);
+    g2(vk.h); g2(vk.beta_h);
     o.u8(1); o.u64(2);
-    for (int i = 0; i < 2; i++) { o.u64(vk.degree_bounds[i]); o.g1_compressed(vk.shift_powers[i]); }
+    for (int i = 0; i < 2; i++) { o.u64(vk.degree_bounds[i]); o.g1(vk.shift_powers[i], uncompressed); }
     o.u64(vk.max_degree); o.u64(vk.supported_degree);
     return o.b;
 }
@@ -411,6 +426,144 @@ struct DevBuf {
 };
 struct KzgRand { bool hiding = false; Fr b[3]; };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The universal SRS, once per process and device (src/lib.rs:139-141: ONE generate_universal_srs(866_944, 513, 4_062_064) serves every circuit size).
+// It depends on the literals only through max_degree (and on the test_rng trapdoor, which is fixed): powers_of_g[0 ..= max_degree] on the curve's twisted Edwards
+// model, followed -- for keys that want them -- by the 12 further window-table copies 2^(offset of window j) P at multiples of `stride`.  A key's committer key is a VIEW:
+// its plain powers are the prefix [0 ..= supported_degree], its shifted powers the range [max_degree - bound_max ..= max_degree] of the same array (they are the same group
+// elements: beta^(max_degree - bound + i) g), so the 4- and 6-block keys of the bench, the 16/32-byte keys of its latency leg and every further key hold ONE table set
+// (31.4 GB for the reference's literals; round 4 built 41.9 GB per key).  Keys share it through shared_ptr; the cache holds weak references, so the memory goes back
+// to the device when the last key over that SRS is freed.
+struct UniversalSrs {
+    int device = 0;
+    size_t max_degree = 0, stride = 0;       // stride = max_degree + 1 points per copy
+    int table_c = 20;
+    size_t n_tab = 1;                        // 1 = copy 0 only (KEY_NO_TABLES, tiny circuits, or the device was short of memory)
+    Fr beta;
+    G1A g, gamma_g;
+    pairing::G2Affine h, beta_h;
+    G1A gamma_powers[3];
+    FixedBaseHost gamma_tab[3];              // host comb tables of the points multiplied by per-proof blinding scalars
+    SrsPoint *d_points = nullptr;
+    double build_s = 0;
+    bool tables() const { return n_tab > 1; }
+    uint64_t bytes() const { return (uint64_t)n_tab * stride * sizeof(SrsPoint); }
+    ~UniversalSrs() { try { gpu::set_device(device); } catch (...) {} gpu::dfree(d_points); }
+};
+// Lagrange-basis points over H (per |H| and |X|, shared the same way): L_k(beta) G for z_A, z_B; L_k(beta)/v_X(beta) G (zero on X) for w; P_j for the public-input part
+// of w; v_H(beta) G and (v_H/v_X)(beta) G for the blinding terms
+struct LagrangeSrs {
+    int device = 0;
+    size_t n = 0, m = 0;
+    SrsPoint *d_lag_h = nullptr, *d_lag_w = nullptr;
+    std::vector<G1A> lag_pj;
+    G1A lag_vh, lag_vw;
+    FixedBaseHost lag_vh_tab, lag_vw_tab;
+    ~LagrangeSrs() { try { gpu::set_device(device); } catch (...) {} gpu::dfree(d_lag_h); gpu::dfree(d_lag_w); }
+};
+namespace {
+std::mutex g_srs_mu;                          // serializes SRS construction: two keys synthesized concurrently must not both build 31 GB of tables
+std::map<std::pair<int, size_t>, std::weak_ptr<UniversalSrs>> g_srs_cache[2];      // [0] copy 0 only, [1] with window tables; key = (device, max_degree)
+std::map<std::tuple<int, size_t, size_t>, std::weak_ptr<LagrangeSrs>> g_lag_cache;  // key = (device, |H|, |X|)
+std::atomic<size_t> g_default_contexts{0};
+}  // namespace
+// proofs in flight per multi-proof call unless the key says otherwise (zkaes_pk_set_contexts): ZKAES_CONTEXTS from the environment, read ONCE, else ZKAES_DEFAULT_CONTEXTS
+size_t default_contexts() {
+    size_t v = g_default_contexts.load();
+    if (v) return v;
+    v = ZKAES_DEFAULT_CONTEXTS;
+    if (const char *e = getenv("ZKAES_CONTEXTS")) v = (size_t)std::min(64, std::max(1, atoi(e)));
+    g_default_contexts.store(v);
+    return v;
+}
+// `reserve_bytes`: what the caller will still allocate beside the tables (its prover contexts): the tables are an optimisation, not a requirement -- they are skipped
+// when the device could not hold both, instead of failing key synthesis or the first multi-proof call.
+static std::shared_ptr<UniversalSrs> acquire_srs(size_t max_degree, bool want_tables, size_t reserve_bytes, gpu::stream_t stream) {
+    std::lock_guard<std::mutex> lock(g_srs_mu);
+    const int device = gpu::current_device();
+    const auto key = std::make_pair(device, max_degree);
+    if (auto sp = g_srs_cache[1][key].lock()) return sp;                     // a table set serves every key (copy 0 is its prefix)
+    if (!want_tables) if (auto sp = g_srs_cache[0][key].lock()) return sp;
+    auto t0 = Clock::now();
+    std::shared_ptr<UniversalSrs> S(new UniversalSrs());
+    S->device = device; S->max_degree = max_degree; S->stride = max_degree + 1;
+    // KZG10::setup from ark_std::test_rng() in upstream's draw order: the trapdoor beta, then g, gamma_g (G1) and h (G2) as random curve points
+    kzg_setup_points(S->beta, S->g, S->gamma_g, S->h);
+    // c = 20: 13 signed windows instead of 15 and 2^19 buckets in ONE set (the 15 x 2^16 per-window buckets cost more to reduce).  c = 22 saves one more
+    // window but its 2^21 buckets triple the first reduction level: measured slower (profiles/r02_msm_tables.md).  The windows are balanced -- 254 = 7 x 20 + 6 x 19 bits,
+    // kernels_msm.hip TableLayout -- so no window is short and any c is safe.
+    S->table_c = 20;
+    size_t n_tab = want_tables ? (size_t)gpu::table_windows<Bls377>(S->table_c) : 1;
+    if (n_tab > 1 && (uint64_t)n_tab * S->stride >= (1ull << 30)) n_tab = 1;          // the MSM's 30-bit base index
+    if (n_tab > 1) {
+        // the copies in the reduced-radix form + two staging copies in the standard form + what the caller reserves must all fit
+        const size_t need = n_tab * S->stride * sizeof(SrsPoint) + 2 * S->stride * sizeof(G1A) + reserve_bytes + ((size_t)2 << 30);
+        if (gpu::mem_free_bytes() < need) n_tab = 1;
+    }
+    if (n_tab == 1) if (auto sp = g_srs_cache[0][key].lock()) return sp;    // (tables were wanted but do not fit: an existing plain copy serves)
+    S->n_tab = n_tab;
+    {
+        // copy j is made from copy j - 1 in a two-slot staging buffer (standard form) and converted into its place: the setup peak is the final array
+        // + two staging copies, not twice the final array
+        struct Stage { G1A *p[2] = {nullptr, nullptr}; ~Stage() { gpu::dfree(p[0]); gpu::dfree(p[1]); } } stage;
+        stage.p[0] = (G1A *)gpu::dmalloc(S->stride * sizeof(G1A));
+        if (n_tab > 1) stage.p[1] = (G1A *)gpu::dmalloc(S->stride * sizeof(G1A));
+        gpu::fixed_base_powers<Bls377>(stage.p[0], S->g, S->beta, 0, S->stride, stream);
+        S->d_points = (SrsPoint *)gpu::dmalloc(n_tab * S->stride * sizeof(SrsPoint));
+        srs_convert(S->d_points, stage.p[0], S->stride, stream);
+        for (size_t j = 1; j < n_tab; j++) {
+            gpu::table_next<Bls377>(stage.p[j & 1], stage.p[(j - 1) & 1], S->stride, S->table_c, (int)j, stream);
+            srs_convert(S->d_points + j * S->stride, stage.p[j & 1], S->stride, stream);
+        }
+        gpu::sync(stream);
+    }
+    { Fr bp = Fr::one(); for (int i = 0; i < 3; i++) { S->gamma_powers[i] = mul_affine(S->gamma_g, bp); bp = bp * S->beta; S->gamma_tab[i].build(S->gamma_powers[i]); } }
+    { uint32_t raw[8]; S->beta.to_raw(raw); S->beta_h = pairing::g2_mul_raw(S->h, raw, 8); }
+    S->build_s = ms_since(t0) / 1e3;
+    g_srs_cache[n_tab > 1 ? 1 : 0][key] = S;
+    return S;
+}
+static std::shared_ptr<LagrangeSrs> acquire_lagrange(const UniversalSrs &U, size_t n, int lg_n, size_t m, int lg_m, gpu::stream_t stream) {
+    std::lock_guard<std::mutex> lock(g_srs_mu);
+    const int device = gpu::current_device();
+    const auto key = std::make_tuple(device, n, m);
+    if (auto sp = g_lag_cache[key].lock()) return sp;
+    std::shared_ptr<LagrangeSrs> Lg(new LagrangeSrs());
+    Lg->device = device; Lg->n = n; Lg->m = m;
+    // With the (public, test_rng-derived) trapdoor the Lagrange-basis points are direct fixed-base products; a trapdoor-free universal SRS
+    // yields the same points through an inverse FFT over the group elements powers_of_g[0..|H|) (one time per |H|).
+    struct Tmp { void *p[4] = {nullptr, nullptr, nullptr, nullptr}; ~Tmp() { for (auto q : p) gpu::dfree(q); } } tmp;
+    F *d_lag = (F *)(tmp.p[0] = gpu::dmalloc(n * sizeof(F))), *d_lagw = (F *)(tmp.p[1] = gpu::dmalloc(n * sizeof(F)));
+    gpu::lagrange_scalars(d_lag, d_lagw, gpu::domain_elements<F>(lg_n), U.beta, (uint32_t)n, (uint32_t)m, stream);
+    G1A *pts = (G1A *)(tmp.p[2] = gpu::dmalloc(n * sizeof(G1A)));
+    auto to28 = [&](const F *sc, SrsPoint *&dst) {
+        gpu::fixed_base_scalars<Bls377>(pts, U.g, sc, n, stream);
+        dst = (SrsPoint *)gpu::dmalloc(n * sizeof(SrsPoint));
+        srs_convert(dst, pts, n, stream);
+        gpu::sync(stream);
+    };
+    to28(d_lag, Lg->d_lag_h);
+    to28(d_lagw, Lg->d_lag_w);
+    // P_j = sum_{k not in X} l_j(h_k) L_k(beta)/v_X(beta) G = (l_j(beta) - L_{j n/m}(beta)) / v_X(beta) G, j < |X|
+    Fr vh = eval_vanishing(n, U.beta), vx = eval_vanishing(m, U.beta), vx_inv = vx.inverse();
+    Fr cm = vx * Fr::from_u64(m).inverse(), cn = vh * Fr::from_u64(n).inverse();
+    std::vector<Fr> pj(m), den(m);
+    Fr gx = domain_gen(lg_m), e = Fr::one();
+    for (size_t j = 0; j < m; j++) { den[j] = U.beta - e; pj[j] = e; e = e * gx; }
+    { std::vector<Fr> pre(m); Fr acc = Fr::one(); for (size_t j = 0; j < m; j++) { pre[j] = acc; acc = acc * den[j]; } Fr inv = acc.inverse(); for (size_t j = m; j-- > 0;) { Fr d = den[j]; den[j] = inv * pre[j]; inv = inv * d; } }
+    for (size_t j = 0; j < m; j++) pj[j] = pj[j] * den[j] * (cm - cn) * vx_inv;
+    F *d_pj = (F *)(tmp.p[3] = gpu::dmalloc(m * sizeof(F)));
+    gpu::h2d(d_pj, pj.data(), m * sizeof(F), stream);
+    gpu::fixed_base_scalars<Bls377>(pts, U.g, d_pj, m, stream);
+    Lg->lag_pj.resize(m);
+    gpu::d2h(Lg->lag_pj.data(), pts, m * sizeof(G1A), stream);
+    Lg->lag_vh = mul_affine(U.g, vh);
+    Lg->lag_vw = mul_affine(U.g, vh * vx_inv);
+    Lg->lag_vh_tab.build(Lg->lag_vh); Lg->lag_vw_tab.build(Lg->lag_vw);
+    g_lag_cache[key] = Lg;
+    return Lg;
+}
+
 // Everything one in-flight proof needs: its own stream, MSM scratch and polynomial workspace.  Several contexts prove different
 // chunk-proofs concurrently (zkaes_encrypt_chunked): the latency-bound phases of one proof (bucket reductions, scans, host
 // transcript work) overlap with the throughput-bound kernels of the others.
@@ -459,25 +612,21 @@ class ProvingKeyImpl {
     size_t n = 0, k = 0, m = 0;       // |H|, |K|, |X|
     int lg_n = 0, lg_k = 0, lg_m = 0;
     size_t max_degree = 0, supported_degree = 0, lowest_shift = 0, bounds[2] = {0, 0};
-    Fr srs_beta;
     int device = 0;                            // the HIP device this key (SRS, index, contexts) lives on; every entry point re-selects it,
                                                // because HIP's current device is per thread and callers may arrive on fresh threads
-    G1A gamma_powers[3];
-    FixedBaseHost gamma_tab[3], lag_vh_tab, lag_vw_tab;     // host comb tables of the points multiplied by per-proof blinding scalars
-    // device SRS, reduced-radix copies (ff28.cuh) -- what k_accumulate gathers.  Copy 0 = powers_of_g[0..=supported_degree] followed by the shifted
-    // range (one index space: merged openings name bases of both); with window tables (use_tables) copies j = 1.. follow at j * srs_stride and hold
-    // 2^(table_c * j) * copy 0 (gpu.hpp msm_prepare_table).  d_shifted = d_powers + n_plain (copy 0's shifted part).
+    // The committer key is a view of the process-wide universal SRS (UniversalSrs above): d_powers = powers_of_g[0..] (this key uses the prefix up to supported_degree),
+    // the shifted powers are the same array from index `lowest_shift` (= max_degree - the larger degree bound) on -- one index space, so merged openings name bases
+    // of both; with window tables (use_tables) copies j = 1.. follow at j * srs_stride and hold 2^(offset of window j) * copy 0 (gpu.hpp msm_prepare_table).
+    std::shared_ptr<UniversalSrs> srs;
+    std::shared_ptr<LagrangeSrs> lag;
     SrsPoint *d_powers = nullptr, *d_shifted = nullptr;
-    size_t srs_stride = 0, n_plain = 0;
+    size_t srs_stride = 0;
     size_t table_min_n = 500000;    // MSMs below this many points keep the per-window buckets (their own, smaller c)
-    // Lagrange-basis SRS over H: L_k(beta) G for z_A, z_B; L_k(beta)/v_X(beta) G (zero on X) for w;
-    // P_j for the public-input part of w; v_H(beta) G and (v_H/v_X)(beta) G for the blinding terms
     bool use_lagrange = true;
-    SrsPoint *d_lag_h = nullptr, *d_lag_w = nullptr;
-    std::vector<G1A> lag_pj;
-    G1A lag_vh, lag_vw;
-    int table_c = 22;
+    int table_c = 20;
     bool use_tables = false;   // window tables for the large MSMs (on when |K| >= 2^20, memory allows and the key was not made with KEY_NO_TABLES)
+    std::atomic<size_t> n_contexts{0};          // proofs in flight per multi-proof call on this key (zkaes_pk_set_contexts); 0 = the process default
+    double setup_srs_s = 0, setup_total_s = 0;  // how long key synthesis spent building (not sharing) the SRS, and in total
     // device: circuit
     uint32_t *d_desc = nullptr, *d_sbox_in = nullptr, *d_sbox_tmpl = nullptr;
     uint32_t *d_a_rowptr = nullptr, *d_a_col = nullptr, *d_b_rowptr = nullptr, *d_b_col = nullptr;
@@ -493,7 +642,7 @@ class ProvingKeyImpl {
 
     ~ProvingKeyImpl() {
         gpu::dfree(coset_tab); gpu::dfree(coset_tab_inv);
-        gpu::dfree(d_powers); gpu::dfree(d_lag_h); gpu::dfree(d_lag_w); gpu::dfree(d_desc); gpu::dfree(d_sbox_in); gpu::dfree(d_sbox_tmpl);
+        gpu::dfree(d_desc); gpu::dfree(d_sbox_in); gpu::dfree(d_sbox_tmpl);
         gpu::dfree(d_a_rowptr); gpu::dfree(d_a_col); gpu::dfree(d_b_rowptr); gpu::dfree(d_b_col); gpu::dfree(d_a_coeff); gpu::dfree(d_b_coeff);
         gpu::dfree(d_t_heavy); gpu::dfree(d_t_colptr); gpu::dfree(d_t_seg_start); gpu::dfree(d_t_seg_end); gpu::dfree(d_t_row); gpu::dfree(d_t_mat); gpu::dfree(d_t_coeff);
         for (auto &b : ix_ev) b.release();
@@ -546,7 +695,7 @@ class ProvingKeyImpl {
         if (len == 0) return XYZZ<Fq377>::inf();
         size_t avail = shifted ? (bounds[1] + 1) : (supported_degree + 1);
         if (off + len > avail) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
-        if (table_ok(cx, len)) return gpu::msm_table<Bls377>(ln.ws, d_powers, srs_stride, (shifted ? n_plain : 0) + off, table_c, scalars, len, ln.stream);
+        if (table_ok(cx, len)) return gpu::msm_table<Bls377>(ln.ws, d_powers, srs_stride, (shifted ? lowest_shift : 0) + off, table_c, scalars, len, ln.stream);
         return gpu::msm<Bls377>(ln.ws, (shifted ? d_shifted : d_powers) + off, scalars, len, ln.stream);
     }
     struct Labeled { int idx; long bound; bool hiding; KzgRand rand, shifted_rand; Commitment comm; };
@@ -558,14 +707,14 @@ class ProvingKeyImpl {
         draw(lp.rand);
         if (lp.bound >= 0) draw(lp.shifted_rand);
     }
-    void hide(XYZZ<Fq377> &c, const KzgRand &rnd) const { if (rnd.hiding) for (int i = 0; i < 3; i++) c.add(gamma_tab[i].mul(rnd.b[i])); }
+    void hide(XYZZ<Fq377> &c, const KzgRand &rnd) const { if (rnd.hiding) for (int i = 0; i < 3; i++) c.add(srs->gamma_tab[i].mul(rnd.b[i])); }
     // commitment of w / z_A / z_B through the Lagrange-basis SRS: sum of the bases whose evaluation is non-zero (+-1, 2) + the blinding term
     // rho * V + the hiding part.  Same group element as MSM(powers, coefficients); falls back to the MSM if the class sum declines.
     bool lagrange_commit(ProverContext &cx, Lane &ln, int which, const std::vector<uint8_t> &inst, const Fr &rho, const KzgRand &rnd, G1A &out) {
         XYZZ<Fq377> c;
-        if (!gpu::class_sum<Bls377>(ln.ws, which == 0 ? d_lag_w : d_lag_h, cx.d_cls[which], n, &c, ln.stream)) return false;
-        if (which == 0) for (size_t j = 0; j < m; j++) if (inst[j]) c.madd(lag_pj[j].neg());
-        c.add((which == 0 ? lag_vw_tab : lag_vh_tab).mul(rho));
+        if (!gpu::class_sum<Bls377>(ln.ws, which == 0 ? lag->d_lag_w : lag->d_lag_h, cx.d_cls[which], n, &c, ln.stream)) return false;
+        if (which == 0) for (size_t j = 0; j < m; j++) if (inst[j]) c.madd(lag->lag_pj[j].neg());
+        c.add((which == 0 ? lag->lag_vw_tab : lag->lag_vh_tab).mul(rho));
         hide(c, rnd);
         out = c.to_affine();
         return true;
@@ -588,7 +737,7 @@ class ProvingKeyImpl {
         hide(h12[0], lp.rand);
         if (bounded) hide(h12[1], lp.shifted_rand);
         if (len) {
-            if (bounded) gpu::msm_finish2<Bls377>(ln.ws, d_powers, d_shifted + off, c12, ln.stream);       // table mode: every copy's index shifts by n_plain + off
+            if (bounded) gpu::msm_finish2<Bls377>(ln.ws, d_powers, d_shifted + off, c12, ln.stream);       // table mode: every copy's index shifts by lowest_shift + off
             else c12[0] = gpu::msm_finish<Bls377>(ln.ws, d_powers, ln.stream);
         }
         c12[0].add(h12[0]);
@@ -599,8 +748,8 @@ class ProvingKeyImpl {
     // (two steps: the digit grouping is launched and returns; the caller does its host-side share of the witness, then waits for the sum)
     void msm_opening_prepare(ProverContext &cx, Lane &ln, const F *wit, size_t wlen, const F *swit, size_t slen, size_t shift_off) {
         if (wlen > supported_degree + 1 || shift_off + slen > bounds[1] + 1) throw std::runtime_error("KZG10: polynomial degree exceeds the committer key");
-        if (table_ok(cx, wlen + slen)) gpu::msm_prepare_table<Bls377>(ln.ws, wit, wlen, 0, swit, slen, n_plain + shift_off, table_c, srs_stride, ln.stream);
-        else gpu::msm_prepare<Bls377>(ln.ws, wit, wlen, swit, slen, n_plain + shift_off, ln.stream);
+        if (table_ok(cx, wlen + slen)) gpu::msm_prepare_table<Bls377>(ln.ws, wit, wlen, 0, swit, slen, lowest_shift + shift_off, table_c, srs_stride, ln.stream);
+        else gpu::msm_prepare<Bls377>(ln.ws, wit, wlen, swit, slen, lowest_shift + shift_off, ln.stream);
     }
     XYZZ<Fq377> msm_opening_finish(Lane &ln) { return gpu::msm_finish<Bls377>(ln.ws, d_powers, ln.stream); }
     // Run the independent jobs of one prover step.  Throughput calls (several proofs in flight) and ZKAES_LANES=0 run them one after the other on lane 0;
@@ -621,11 +770,12 @@ class ProvingKeyImpl {
         for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
     }
 
-    void setup(int kind, size_t message_len, const SrsLiterals &srs, unsigned flags);
+    void setup(int kind, size_t message_len, const SrsLiterals &lits, unsigned flags);
     Proof prove(ProverContext &cx, const uint8_t *trace_or_null, const uint8_t *msg, size_t len, const uint8_t *key, const uint8_t *zk_seed, bool throughput = false);
 };
 
-void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs, unsigned flags) {
+void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &lits, unsigned flags) {
+    auto t_setup = Clock::now();
     gpu::require_device();
     device = gpu::current_device();
     message_len = message_len_;
@@ -661,95 +811,36 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
     vk.num_public_inputs = c.raw_instance - 1;
     if (vk.num_variables != vk.num_constraints) throw std::logic_error("index: matrices are not square after padding");
     // ---- universal SRS sizing + trim
-    max_degree = ahp_max_degree(srs.num_constraints, srs.num_variables, srs.num_non_zero);
+    max_degree = ahp_max_degree(lits.num_constraints, lits.num_variables, lits.num_non_zero);
     supported_degree = ahp_max_degree(vk.num_constraints, vk.num_variables, vk.num_non_zero);
     if (supported_degree > max_degree) throw std::runtime_error("IndexTooLarge: the circuit needs degree " + std::to_string(supported_degree) + " but the universal SRS supports " + std::to_string(max_degree));
     bounds[0] = std::min(n - 2, k - 2); bounds[1] = std::max(n - 2, k - 2);
     lowest_shift = max_degree - bounds[1];
-    // KZG10::setup from ark_std::test_rng() in upstream's draw order: the trapdoor beta, then g, gamma_g (G1) and h (G2) as random curve points
-    G1A g, gamma_g;
-    pairing::G2Affine srs_h;
-    kzg_setup_points(srs_beta, g, gamma_g, srs_h);
-    // window tables pay from the one-block key (|K| = 2^20: 35.5 -> 38.2 proofs/s in batch mode) upwards; tiny circuits keep per-window buckets only
-    use_tables = lg_k >= 20 && !(flags & KEY_NO_TABLES);
-    // c = 20: 13 signed windows instead of 15 and 2^19 buckets in ONE set (the 15 x 2^16 per-window buckets cost more to reduce).  c = 22 saves one more
-    // window but its 2^21 buckets triple k_reduce_l1 (1.95 ms vs 0.67 ms per MSM): measured slower (profiles/r02_msm_tables.md)
-    table_c = 20;
-    // (the windows are balanced since round 3 -- 254 = 7 x 20 + 6 x 19 bits at c = 20, kernels_msm.hip TableLayout -- so no window is short and any c is safe)
-    size_t n_tab = use_tables ? (size_t)gpu::table_windows<Bls377>(table_c) : 1;
-    // powers_of_g[0..=supported_degree] and the shifted range live in ONE reduced-radix array (shifted part right after the plain part), so
-    // an MSM may name bases of both through one index space (merged openings); table copies repeat that layout at multiples of srs_stride.
-    n_plain = supported_degree + 1;
-    const size_t n_shift = bounds[1] + 1;
-    srs_stride = n_plain + n_shift;
-    if (use_tables && (uint64_t)n_tab * srs_stride >= (1ull << 30)) { use_tables = false; }
-    if (use_tables) {
-        // the tables are an optimisation, not a requirement: skip them when the device is short of memory instead of failing key synthesis -- or the first multi-proof
-        // call, which creates the prover contexts: the copies in the reduced-radix form + two staging copies in the standard form + the workspaces of the default
-        // number of contexts a caller may still create (alloc_workspace: ~18 |H| + 6 |K| + 6 max(4 |H|, 2 |K|) field elements, plus the MSM scratch of the largest
-        // opening -- 13 windows x 16 B per pair: ~1.2 / 5 GB for the 1- / 6-block key) must all fit
+    // ---- the universal SRS: shared with every other key over the same literals on this device (built by the first one); window tables pay from the one-block key
+    // (|K| = 2^20: 35.5 -> 38.2 proofs/s in batch mode) upwards, tiny circuits keep per-window buckets only
+    {
+        const bool want_tables = lg_k >= 20 && !(flags & KEY_NO_TABLES);
+        // what this key's callers may still allocate beside the tables: the workspaces of the effective number of prover contexts (alloc_workspace: ~18 |H| + 6 |K| +
+        // 6 max(4 |H|, 2 |K|) field elements, plus the MSM scratch of the largest opening -- 13 windows x 16 B per pair: ~1.2 / 5 GB for the 1- / 6-block key)
         const size_t big = std::max(4 * n, 2 * k);
         const size_t per_context = (18 * n + 6 * k + 6 * big) * sizeof(F) + 13 * big * 16 + ((size_t)256 << 20);
-        const size_t need = n_tab * srs_stride * sizeof(SrsPoint) + 2 * srs_stride * sizeof(G1A) + ZKAES_DEFAULT_CONTEXTS * per_context + ((size_t)2 << 30);
-        if (gpu::mem_free_bytes() < need) use_tables = false;
+        auto t_srs = Clock::now();
+        srs = acquire_srs(max_degree, want_tables, default_contexts() * per_context, stream);
+        setup_srs_s = ms_since(t_srs) / 1e3;
+        use_tables = want_tables && srs->tables();
+        table_c = srs->table_c;
+        srs_stride = srs->stride;
+        d_powers = srs->d_points;
+        d_shifted = d_powers + lowest_shift;
     }
-    if (!use_tables) n_tab = 1;
-    {
-        // copy j is made from copy j - 1 in a two-slot staging buffer (standard form) and converted into its place: the setup peak is the final array
-        // + two staging copies, not twice the final array
-        G1A *stage[2] = {(G1A *)gpu::dmalloc(srs_stride * sizeof(G1A)), use_tables ? (G1A *)gpu::dmalloc(srs_stride * sizeof(G1A)) : nullptr};
-        gpu::fixed_base_powers<Bls377>(stage[0], g, srs_beta, 0, n_plain, stream);
-        gpu::fixed_base_powers<Bls377>(stage[0] + n_plain, g, srs_beta, lowest_shift, n_shift, stream);
-        d_powers = (SrsPoint *)gpu::dmalloc(n_tab * srs_stride * sizeof(SrsPoint));
-        srs_convert(d_powers, stage[0], srs_stride, stream);
-        for (size_t j = 1; j < n_tab; j++) {
-            gpu::table_next<Bls377>(stage[j & 1], stage[(j - 1) & 1], srs_stride, table_c, (int)j, stream);
-            srs_convert(d_powers + j * srs_stride, stage[j & 1], srs_stride, stream);
-        }
-        gpu::sync(stream);
-        gpu::dfree(stage[0]); gpu::dfree(stage[1]);
-        d_shifted = d_powers + n_plain;
-    }
-    if (const char *e = getenv("ZKAES_LANES")) use_lanes = atoi(e) != 0;
-    if (use_lagrange) {
-        // With the (public, test_rng-derived) trapdoor the Lagrange-basis points are direct fixed-base products; a trapdoor-free universal SRS
-        // yields the same points through an inverse FFT over the group elements powers_of_g[0..|H|) (one time per key).
-        F *d_lag = (F *)gpu::dmalloc(n * sizeof(F)), *d_lagw = (F *)gpu::dmalloc(n * sizeof(F));
-        gpu::lagrange_scalars(d_lag, d_lagw, gpu::domain_elements<F>(lg_n), srs_beta, (uint32_t)n, (uint32_t)m, stream);
-        G1A *tmp = (G1A *)gpu::dmalloc(n * sizeof(G1A));
-        auto to28 = [&](const F *sc) {
-            gpu::fixed_base_scalars<Bls377>(tmp, g, sc, n, stream);
-            SrsPoint *dst = (SrsPoint *)gpu::dmalloc(n * sizeof(SrsPoint));
-            srs_convert(dst, tmp, n, stream);
-            gpu::sync(stream);
-            return dst;
-        };
-        d_lag_h = to28(d_lag);
-        d_lag_w = to28(d_lagw);
-        // P_j = sum_{k not in X} l_j(h_k) L_k(beta)/v_X(beta) G = (l_j(beta) - L_{j n/m}(beta)) / v_X(beta) G, j < |X|
-        Fr vh = eval_vanishing(n, srs_beta), vx = eval_vanishing(m, srs_beta), vx_inv = vx.inverse();
-        Fr cm = vx * Fr::from_u64(m).inverse(), cn = vh * Fr::from_u64(n).inverse();
-        std::vector<Fr> pj(m), den(m);
-        Fr gx = domain_gen(lg_m), e = Fr::one();
-        for (size_t j = 0; j < m; j++) { den[j] = srs_beta - e; pj[j] = e; e = e * gx; }
-        { std::vector<Fr> pre(m); Fr acc = Fr::one(); for (size_t j = 0; j < m; j++) { pre[j] = acc; acc = acc * den[j]; } Fr inv = acc.inverse(); for (size_t j = m; j-- > 0;) { Fr d = den[j]; den[j] = inv * pre[j]; inv = inv * d; } }
-        for (size_t j = 0; j < m; j++) pj[j] = pj[j] * den[j] * (cm - cn) * vx_inv;
-        F *d_pj = (F *)gpu::dmalloc(m * sizeof(F));
-        gpu::h2d(d_pj, pj.data(), m * sizeof(F), stream);
-        gpu::fixed_base_scalars<Bls377>(tmp, g, d_pj, m, stream);
-        lag_pj.resize(m);
-        gpu::d2h(lag_pj.data(), tmp, m * sizeof(G1A), stream);
-        lag_vh = mul_affine(g, vh);
-        lag_vw = mul_affine(g, vh * vx_inv);
-        gpu::dfree(d_lag); gpu::dfree(d_lagw); gpu::dfree(tmp); gpu::dfree(d_pj);
-    }
-    { Fr bp = Fr::one(); for (int i = 0; i < 3; i++) { gamma_powers[i] = mul_affine(gamma_g, bp); bp = bp * srs_beta; gamma_tab[i].build(gamma_powers[i]); } }
-    if (use_lagrange) { lag_vh_tab.build(lag_vh); lag_vw_tab.build(lag_vw); }
-    vk.g = g; vk.gamma_g = gamma_g;
-    vk.h = srs_h;
-    { uint32_t raw[8]; srs_beta.to_raw(raw); vk.beta_h = pairing::g2_mul_raw(vk.h, raw, 8); }
+    static const bool lanes_default = [] { const char *e = getenv("ZKAES_LANES"); return !e || atoi(e) != 0; }();       // read once per process
+    use_lanes = lanes_default;
+    if (use_lagrange) lag = acquire_lagrange(*srs, n, lg_n, m, lg_m, stream);
+    const G1A &g = srs->g;
+    vk.g = srs->g; vk.gamma_g = srs->gamma_g;
+    vk.h = srs->h; vk.beta_h = srs->beta_h;
     vk.degree_bounds[0] = bounds[0]; vk.degree_bounds[1] = bounds[1];
-    for (int i = 0; i < 2; i++) vk.shift_powers[i] = mul_affine(g, srs_beta.pow_u64(max_degree - bounds[i]));
+    for (int i = 0; i < 2; i++) vk.shift_powers[i] = mul_affine(g, srs->beta.pow_u64(max_degree - bounds[i]));
     vk.supported_degree = supported_degree; vk.max_degree = max_degree;
     // ---- circuit tables
     {
@@ -829,6 +920,7 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &srs
     alloc_workspace(*cx0);
     ctxs.push_back(std::move(cx0));
     gpu::sync(stream);
+    setup_total_s = ms_since(t_setup) / 1e3;
 }
 
 Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const uint8_t *msg, size_t len, const uint8_t *key, const uint8_t *zk_seed, bool throughput) {
@@ -1049,11 +1141,11 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
         // (the blinding part of the witness is host work: under the device's digit grouping, not after the wait for its sum)
         XYZZ<Fq377> hw = XYZZ<Fq377>::inf();
         Fr rq[2]; host_divide_by_linear(rq, rb, beta);
-        for (int i = 0; i < 2; i++) hw.add(gamma_tab[i].mul(rq[i]));
+        for (int i = 0; i < 2; i++) hw.add(srs->gamma_tab[i].mul(rq[i]));
         Fr rv = host_eval3(rb, beta);
         Fr srb[3]; for (int i = 0; i < 3; i++) srb[i] = chp[1] * r2[1].shifted_rand.b[i];
         host_divide_by_linear(rq, srb, beta);
-        for (int i = 0; i < 2; i++) hw.add(gamma_tab[i].mul(rq[i]));
+        for (int i = 0; i < 2; i++) hw.add(srs->gamma_tab[i].mul(rq[i]));
         rv = rv + host_eval3(srb, beta);
         XYZZ<Fq377> w = msm_opening_finish(ln);
         w.add(hw);
@@ -1091,8 +1183,20 @@ const VerifyingKey &ProvingKey::vk() const { return impl->vk; }
 const Circuit &ProvingKey::circuit() const { return impl->circuit; }
 const ProverTimings &ProvingKey::last_timings() const { return impl->last_timings; }
 bool ProvingKey::tables_built(uint64_t *bytes) const {
-    if (bytes) *bytes = impl->use_tables ? (uint64_t)gpu::table_windows<Bls377>(impl->table_c) * impl->srs_stride * sizeof(SrsPoint) : 0;
+    if (bytes) *bytes = impl->use_tables ? impl->srs->bytes() : 0;        // the table set this key uses -- shared with every other key over the same universal SRS (srs_info)
     return impl->use_tables;
+}
+void ProvingKey::srs_info(uint64_t out[6], double secs[2]) const {
+    const UniversalSrs &U = *impl->srs;
+    out[0] = U.max_degree; out[1] = U.stride; out[2] = U.n_tab; out[3] = U.bytes();
+    out[4] = (uint64_t)impl->srs.use_count();                              // keys holding this SRS right now
+    out[5] = impl->lag ? 2 * (uint64_t)impl->lag->n * sizeof(SrsPoint) : 0;
+    if (secs) { secs[0] = impl->setup_srs_s; secs[1] = impl->setup_total_s; }
+}
+size_t ProvingKey::contexts() const { size_t v = impl->n_contexts.load(); return v ? v : default_contexts(); }
+void ProvingKey::set_contexts(size_t n) {
+    if (n > 64) throw std::invalid_argument("set_contexts: at most 64 prover contexts per key");
+    impl->n_contexts.store(n);                                             // 0 = back to the process default
 }
 void ProvingKey::msm_powers_partial_device(const uint8_t *scalars, size_t n_local, size_t offset, void *dev_out) {
     gpu::set_device(impl->device);
@@ -1109,6 +1213,29 @@ Proof ProvingKey::prove_aes(const uint8_t *message, size_t len, const uint8_t ke
     if (len % 16) throw std::invalid_argument("Input must be 16 bytes length when adding round key");
     if (len != impl->circuit.n_blocks * 16) throw std::invalid_argument("InstanceDoesNotMatchIndex: proving key was synthesized for " + std::to_string(impl->circuit.n_blocks * 16) + " bytes");
     return impl->prove(impl->context(0), nullptr, message, len, key, zk_seed);
+}
+// One proof with the library's op recorder open (gpu.hpp oplog_*): the transforms and MSMs it ACTUALLY launched, as JSON --
+//   {"h":..,"k":..,"x":..,"variables":..,"constraints":..,"nnz":[a,b,c],"blocks":..,"path":"throughput"|"lone","ntt":[[points, transforms in the launch],..],
+//    "msm":[[points,"buckets"|"second_bases"|"class_sum"],..]}
+// -- what bench.py computes the whole-proof roofline of SURVEY.md 8(d) from.  Process-global recorder: call with no other proof in flight.
+std::string ProvingKey::op_lists_json(const uint8_t *message, size_t len, const uint8_t key[16], bool throughput_path) {
+    if (impl->circuit.kind != CIRCUIT_AES) throw std::invalid_argument("proving key was not synthesized for the AES circuit");
+    if (len != impl->circuit.n_blocks * 16) throw std::invalid_argument("InstanceDoesNotMatchIndex: proving key was synthesized for " + std::to_string(impl->circuit.n_blocks * 16) + " bytes");
+    gpu::OpRecord rec;
+    gpu::oplog_begin();
+    try { impl->prove(impl->context(0), nullptr, message, len, key, nullptr, throughput_path); }
+    catch (...) { gpu::oplog_end(); throw; }
+    rec = gpu::oplog_end();
+    const Circuit &c = impl->circuit;
+    std::string o = "{\"h\":" + std::to_string(impl->n) + ",\"k\":" + std::to_string(impl->k) + ",\"x\":" + std::to_string(impl->m) + ",\"variables\":" + std::to_string(c.num_variables()) +
+                    ",\"constraints\":" + std::to_string(c.num_constraints) + ",\"nnz\":[" + std::to_string(c.A.nnz()) + "," + std::to_string(c.B.nnz()) + "," + std::to_string(c.C.nnz()) + "]" +
+                    ",\"blocks\":" + std::to_string(c.n_blocks) + ",\"path\":\"" + (throughput_path ? "throughput" : "lone") + "\",\"ntt\":[";
+    for (size_t i = 0; i < rec.ntt.size(); i++) o += (i ? "," : "") + std::string("[") + std::to_string(rec.ntt[i].first) + "," + std::to_string(rec.ntt[i].second) + "]";
+    o += "],\"msm\":[";
+    static const char *kinds[3] = {"buckets", "second_bases", "class_sum"};
+    for (size_t i = 0; i < rec.msm.size(); i++) o += (i ? "," : "") + std::string("[") + std::to_string(rec.msm[i].first) + ",\"" + kinds[rec.msm[i].second % 3] + "\"]";
+    o += "]}";
+    return o;
 }
 std::vector<uint8_t> ProvingKey::aes_witness(const uint8_t *message, size_t len, const uint8_t key[16]) {
     if (impl->circuit.kind != CIRCUIT_AES) throw std::invalid_argument("proving key was not synthesized for the AES circuit");
@@ -1218,14 +1345,17 @@ struct FileSink {
 };
 Fr fr_from_small(int64_t c) { return c >= 0 ? Fr::from_u64((uint64_t)c) : Fr::from_u64((uint64_t)(-c)).neg(); }
 }  // namespace
-uint64_t ProvingKey::serialize_ark_to_file(const std::string &path) const {
+// Nothing here touches a prover context: the key's index data is immutable, the powers are re-made on a private stream into a private staging buffer, so proofs on this
+// key keep running while a multi-GB image streams out.  A failure (short write, device error) removes the partial file.
+uint64_t ProvingKey::serialize_ark_to_file(const std::string &path, bool uncompressed) const {
     ProvingKeyImpl &K = *impl;
     gpu::set_device(K.device);
-    ProverContext &cx = K.context(0);
-    std::lock_guard<std::mutex> busy(cx.in_use);
-    gpu::stream_t s = cx.stream;
+    struct StreamGuard { gpu::stream_t s = nullptr; ~StreamGuard() { gpu::stream_destroy(s); } } sg;
+    sg.s = gpu::stream_create();
+    gpu::stream_t s = sg.s;
+    struct Unlink { const std::string &p; bool armed = true; ~Unlink() { if (armed) ::remove(p.c_str()); } } partial{path};
     FileSink o(path);
-    { auto v = serialize_vk_ark(K.vk); o.buf.put(v.data(), v.size()); }
+    { auto v = serialize_vk_ark(K.vk, uncompressed); o.buf.put(v.data(), v.size()); }
     o.buf.u64(6);
     for (int i = 0; i < 6; i++) { o.buf.u64(0); o.buf.u8(0); }                      // Randomness::empty(): zero blinding polynomial, no shifted_rand
     o.buf.u64(K.vk.num_variables); o.buf.u64(K.vk.num_constraints); o.buf.u64(K.vk.num_non_zero); o.buf.u64(K.vk.num_instance);
@@ -1256,25 +1386,26 @@ uint64_t ProvingKey::serialize_ark_to_file(const std::string &path) const {
         o.buf.field(Fr::from_u64(K.k)); o.buf.field(Fr::from_u64(K.k).inverse()); o.buf.field(kgen); o.buf.field(kgen.inverse()); o.buf.field(K.coset_g_inv);
     }
     // committer key: the powers in the standard affine form, re-made on the device chunk by chunk
+    const size_t CH = (size_t)1 << 20;
+    struct Chunk { G1A *d = nullptr; ~Chunk() { gpu::dfree(d); } } chunk;
+    chunk.d = (G1A *)gpu::dmalloc(CH * sizeof(G1A));
+    std::vector<G1A> h(CH);
     auto write_powers = [&](size_t from, size_t count) {
-        const size_t CH = (size_t)1 << 20;
-        G1A *d = (G1A *)gpu::dmalloc(CH * sizeof(G1A));
-        std::vector<G1A> h(CH);
         o.buf.u64(count);
         for (size_t off = 0; off < count; off += CH) {
             const size_t m_ = std::min(CH, count - off);
-            gpu::fixed_base_powers<Bls377>(d, K.vk.g, K.srs_beta, from + off, m_, s);
-            gpu::d2h(h.data(), d, m_ * sizeof(G1A), s);
-            for (size_t i = 0; i < m_; i++) { o.buf.g1_compressed(h[i]); o.maybe_flush(); }
+            gpu::fixed_base_powers<Bls377>(chunk.d, K.vk.g, K.srs->beta, from + off, m_, s);
+            gpu::d2h(h.data(), chunk.d, m_ * sizeof(G1A), s);
+            for (size_t i = 0; i < m_; i++) { o.buf.g1(h[i], uncompressed); o.maybe_flush(); }
         }
-        gpu::dfree(d);
     };
     write_powers(0, K.supported_degree + 1);
     o.buf.u8(1); write_powers(K.lowest_shift, K.bounds[1] + 1);
-    o.buf.u64(3); for (int i = 0; i < 3; i++) o.buf.g1_compressed(K.gamma_powers[i]);
+    o.buf.u64(3); for (int i = 0; i < 3; i++) o.buf.g1(K.srs->gamma_powers[i], uncompressed);
     o.buf.u8(1); o.buf.u64(2); o.buf.u64(K.bounds[0]); o.buf.u64(K.bounds[1]);
     o.buf.u64(K.max_degree);
     o.flush();
+    partial.armed = false;
     return o.n;
 }
 

@@ -50,7 +50,8 @@ struct VerifyingKey {
 // the four draws of KZG10::setup from ark_std::test_rng(): trapdoor beta, base points g, gamma_g (G1) and h (G2)
 void kzg_setup_points(Fr &beta, G1A &g, G1A &gamma_g, pairing::G2Affine &h);
 // ark-serialize 0.3 compressed layout of ark_marlin::IndexVerifierKey (what a Rust caller gets from CanonicalSerialize::serialize)
-std::vector<uint8_t> serialize_vk_ark(const VerifyingKey &vk);
+// uncompressed = the serialize_uncompressed image (G1 96 B, G2 192 B): what deserialize_unchecked reads
+std::vector<uint8_t> serialize_vk_ark(const VerifyingKey &vk, bool uncompressed = false);
 VerifyingKey deserialize_vk_ark(const uint8_t *bytes, size_t len);
 
 struct ProverTimings { double witness_ms = 0, round1_ms = 0, round2_ms = 0, round3_ms = 0, open_ms = 0, total_ms = 0; };
@@ -75,13 +76,24 @@ class ProvingKey {
     // witness generation only (kernels aes_trace + witness_expand): z = padded instance || witness, one byte per variable
     std::vector<uint8_t> aes_witness(const uint8_t *message, size_t len, const uint8_t key[16]);
     const ProverTimings &last_timings() const;
+    // one proof with the op recorder open: JSON of the transforms and MSMs the library actually launched (marlin.cpp; SURVEY.md 8d op lists)
+    std::string op_lists_json(const uint8_t *message, size_t len, const uint8_t key[16], bool throughput_path);
     // test / parity hooks: copy an intermediate of the last proof to the host. names: "z" (bytes), "z_a_evals","z_b_evals",
     // polys "w","z_a","z_b","mask_poly","t","g_1","h_1","g_2","h_2" (Montgomery Fr), index "row","col","a_val","b_val","c_val","row_col"
     std::vector<uint8_t> debug_fetch(const std::string &name) const;
     // were the fixed-base window tables of the SRS built (they are skipped under KEY_NO_TABLES or when device memory is short)?  *bytes = their size
     bool tables_built(uint64_t *bytes = nullptr) const;
-    // ark-serialize (compressed) image of the arkworks IndexProverKey this key corresponds to, streamed to `path`; returns the bytes written (marlin.cpp has the layout)
-    uint64_t serialize_ark_to_file(const std::string &path) const;
+    // the universal SRS behind this key (one per process, device and SRS literals; shared by every key over it): out = {max_degree, points per copy, copies (1 = no
+    // window tables), device bytes, keys sharing it now, bytes of the Lagrange-basis points (shared per |H|, |X|)}; secs = {seconds this key's synthesis spent BUILDING
+    // the SRS (0 when it was shared), seconds of the whole synthesis}
+    void srs_info(uint64_t out[6], double secs[2]) const;
+    // proofs in flight per multi-proof call on this key (prove_aes_chunked / _batch with n_contexts = contexts()); 0 restores the process default
+    size_t contexts() const;
+    void set_contexts(size_t n);
+    // ark-serialize image of the arkworks IndexProverKey this key corresponds to, streamed to `path`; returns the bytes written (marlin.cpp has the layout).
+    // compressed (48-byte points): what IndexProverKey::serialize writes and ::deserialize reads (square root + subgroup check per point on the Rust side);
+    // uncompressed (96-byte points): serialize_uncompressed's image, read by ::deserialize_uncompressed or -- without any check -- ::deserialize_unchecked
+    uint64_t serialize_ark_to_file(const std::string &path, bool uncompressed = false) const;
     // ONE commitment-sized MSM sharded by point range over ranks, on the prover's own path (the key's SRS on the twisted Edwards model, window tables, one bucket set):
     // sum_i scalars[i] * powers_of_g[offset + i], i < n_local (scalars: host, n_local x 32 B Montgomery Fr), left as ONE XYZZ point (192 B) in device memory at dev_out
     // -- the rank's row of the all-gather; gpu::msm_fold_points_device adds the ranks' rows.  Needs a key with tables.
@@ -94,6 +106,8 @@ class ProvingKey {
 // Without the flag the tables are built when memory allows (hipMemGetInfo) and silently skipped otherwise.
 enum : unsigned { KEY_NO_TABLES = 1u };
 std::unique_ptr<ProvingKey> synthesize_keys(int circuit_kind, size_t message_len, const SrsLiterals &srs, unsigned flags = 0);
+// process default of ProvingKey::contexts(): ZKAES_CONTEXTS from the environment (read once), else ZKAES_DEFAULT_CONTEXTS
+size_t default_contexts();
 // 32 bytes from the operating system (getrandom): the default zero-knowledge seed of the multi-proof entry points
 void os_random_seed(uint8_t out[32]);
 

@@ -2,6 +2,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <time.h>
 #include "hip_util.hpp"
 
@@ -26,6 +27,29 @@ struct HwQueueDefault {
 // the other contexts' kernels, which a one-context profile cannot show.  Release builds carry none of it.
 int knockin() { static const int v = [] { const char *e = getenv("ZKAES_KNOCKIN"); return e ? atoi(e) : 0; }(); return v; }
 #endif
+
+namespace {
+std::atomic<OpRecord *> g_oplog{nullptr};
+std::mutex g_oplog_mu;
+}  // namespace
+void oplog_begin() { std::lock_guard<std::mutex> g(g_oplog_mu); delete g_oplog.exchange(new OpRecord()); }
+OpRecord oplog_end() {
+    std::lock_guard<std::mutex> g(g_oplog_mu);
+    OpRecord *r = g_oplog.exchange(nullptr);
+    OpRecord out;
+    if (r) { out = std::move(*r); delete r; }
+    return out;
+}
+void oplog_ntt(uint64_t n, int count) {
+    if (!g_oplog.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> g(g_oplog_mu);
+    if (OpRecord *r = g_oplog.load()) r->ntt.emplace_back(n, count);
+}
+void oplog_msm(uint64_t points, int kind) {
+    if (!g_oplog.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> g(g_oplog_mu);
+    if (OpRecord *r = g_oplog.load()) r->msm.emplace_back(points, kind);
+}
 
 int device_count() {
     int n = 0;

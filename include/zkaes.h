@@ -11,8 +11,8 @@
  *   - proofs cross the boundary as bytes in the ark-serialize 0.3 compressed layout of ark_marlin::Proof
  *     (what simpleworks' (de)serialize_proof reads/writes, re-exported at src/lib.rs:52);
  *   - byte buffers returned through `uint8_t**` are owned by the library: release with zkaes_bytes_free.
- *   - a key for a plaintext of 16 bytes or more also holds fixed-base window tables of the SRS (13 copies of 192-byte records: ~10 GB for the one-block key, ~42 GB for the
- *     4- to 6-block keys; skipped when the device is short of memory or with ZKAES_KEY_NO_TABLES): multi-proof calls (zkaes_encrypt_chunked / _batch) run their
+ *   - keys for a plaintext of 16 bytes or more use fixed-base window tables of the universal SRS (13 copies of 192-byte records of powers_of_g[0 ..= max_degree]: 31.4 GB for the
+ *     reference's literals, held ONCE per process and device and shared by every key -- zkaes_pk_srs_info; skipped when the device is short of memory or with ZKAES_KEY_NO_TABLES): multi-proof calls (zkaes_encrypt_chunked / _batch) run their
  *     large MSMs (>= 500 k points) through them (13 balanced windows of 19-20 bits over ONE bucket set instead of 15 windows with their own buckets), and so does a
  *     lone zkaes_encrypt call, which additionally runs the independent commitments of each round on four MSM lanes (streams + host threads) side by side.  The
  *     SRS points are stored on BLS12-377's twisted Edwards model (7-product bucket additions): the prover's MSMs assume prime-order-subgroup bases, as KZG's are;
@@ -70,8 +70,9 @@ int zkaes_proof_roundtrip(const uint8_t *proof, size_t proof_len, uint8_t **out,
 /* as zkaes_synthesize_keys with an explicit circuit kind and universal-SRS literals (generate_universal_srs arguments) */
 int zkaes_synthesize_keys_ex(int circuit_kind, size_t plaintext_length, size_t srs_num_constraints, size_t srs_num_variables, size_t srs_num_non_zero, zkaes_pk **pk,
                              zkaes_vk **vk);
-/* the same with option flags.  ZKAES_KEY_NO_TABLES: do not build the fixed-base window tables of the SRS (saves 10-42 GB of device memory per key; multi-proof
- * calls then use 15 per-window-bucket windows instead of 13 table windows, ~9 % fewer proofs per second).  Unknown flag bits are an error. */
+/* the same with option flags.  ZKAES_KEY_NO_TABLES: this key does not use (and, if it is the first key over its SRS, does not build) the fixed-base window tables of the
+ * universal SRS (31.4 GB of device memory for the reference's literals, shared by all keys); its multi-proof calls then use 15 per-window-bucket windows instead of
+ * 13 table windows, ~9 % fewer proofs per second.  Unknown flag bits are an error. */
 #define ZKAES_KEY_NO_TABLES 1u
 int zkaes_synthesize_keys_ex2(int circuit_kind, size_t plaintext_length, size_t srs_num_constraints, size_t srs_num_variables, size_t srs_num_non_zero, unsigned flags,
                               zkaes_pk **pk, zkaes_vk **vk);
@@ -87,11 +88,16 @@ int zkaes_encrypt_seeded(const uint8_t *message, size_t message_len, const uint8
 int zkaes_encrypt_chunked(const uint8_t *message, size_t message_len, const uint8_t secret_key[16], const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len,
                           size_t *proof_lens, size_t n_chunks);
 /* n independent (message_i, secret_key_i) pairs on one key / one SRS (BASELINE config 5: many small proofs): messages = n x plaintext
- * length bytes, secret_keys = n x 16 bytes.  Up to ZKAES_CONTEXTS (environment; default ZKAES_DEFAULT_CONTEXTS, the configuration bench.py
- * measures) proofs are in flight per call, each on its own pair of HIP streams.  Randomness as zkaes_encrypt_chunked.  This entry point cannot
+ * length bytes, secret_keys = n x 16 bytes.  Up to zkaes_pk_get_contexts(pk) proofs (zkaes_pk_set_contexts; default ZKAES_DEFAULT_CONTEXTS, the configuration bench.py
+ * measures) are in flight per call, each on its own HIP stream.  Randomness as zkaes_encrypt_chunked.  This entry point cannot
  * check its buffer lengths: prefer zkaes_encrypt_batch_seeded. */
 #define ZKAES_DEFAULT_CONTEXTS 12
 int zkaes_encrypt_batch(size_t n, const uint8_t *messages, const uint8_t *secret_keys, const zkaes_pk *pk, uint8_t **proofs, size_t *proofs_len, size_t *proof_lens);
+/* Proofs in flight per multi-proof call (zkaes_encrypt_chunked* / _batch*) on THIS key: n = 1..64 prover contexts (own stream + ~0.9 / 4.7 GB of workspace each for the
+ * 1- / 6-block key, created on first use), n = 0 restores the process default -- ZKAES_DEFAULT_CONTEXTS, or the ZKAES_CONTEXTS environment variable as it stood when the
+ * library first needed it (read once; later changes of the environment are ignored).  Takes effect from the next call; calls already running keep their count. */
+int zkaes_pk_set_contexts(zkaes_pk *pk, size_t n);
+int zkaes_pk_get_contexts(const zkaes_pk *pk, size_t *n);
 /* the chunked / batch calls with explicit buffer lengths (checked: messages_len == n x plaintext length, secret_keys_len == n x 16) and a
  * caller-supplied 32-byte seed.  Proof i draws from StdRng(Blake2s(zk_seed32 || (first_proof_index + i) as u64 LE)): a caller that splits ONE job over
  * several calls or ranks under one seed passes the job-global index of the call's first proof (the *_at variants; the plain ones use 0), so that no
@@ -117,6 +123,9 @@ int zkaes_vk_deserialize(const uint8_t *bytes, size_t len, zkaes_vk **vk);
  * src/lib.rs:116 -- SURVEY.md 8f item 1.  Layout restated from the published crates (the reference holds no VK bytes to pin it). */
 int zkaes_vk_serialize_ark(const zkaes_vk *vk, uint8_t **out, size_t *out_len);
 int zkaes_vk_deserialize_ark(const uint8_t *bytes, size_t len, zkaes_vk **vk);
+/* the same key as serialize_uncompressed writes it (G1 as x || y = 96 B, G2 = 192 B, the infinity flag in the top bits of y's last byte; everything else identical;
+ * 1,431 bytes): the form `IndexVerifierKey::deserialize_uncompressed` / `::deserialize_unchecked` read -- and the index_vk prefix of the uncompressed proving-key image */
+int zkaes_vk_serialize_ark_uncompressed(const zkaes_vk *vk, uint8_t **out, size_t *out_len);
 
 /* host-only: assemble a verifying key from an index made elsewhere over the SAME universal SRS, i.e. KZG10::setup replayed from
  * ark_std::test_rng() (the reference's generate_rand(), src/lib.rs:139): info = {num_variables, num_constraints, num_non_zero,
@@ -140,9 +149,17 @@ int zkaes_circuit_matrix(int circuit_kind, size_t plaintext_length, int which, u
 int zkaes_pk_debug_fetch(const zkaes_pk *pk, const char *name, uint8_t **out, size_t *len);
 /* per-phase wall times of the last proof: witness, round1, round2, round3, open, total (ms) */
 int zkaes_pk_timings(const zkaes_pk *pk, double out[6]);
-/* accumulated MSM statistics since the last reset: bucket-accumulation kernel ms (HIP events), total MSM wall ms, points, launches,
- * (point, window) pairs */
+/* accumulated MSM statistics since the last reset, one entry per k_accumulate LAUNCH (a degree-bounded commitment = one prepared state finished against the plain and
+ * the shifted powers = two launches, each booked with its own event pair, points and pairs): bucket-accumulation kernel ms (HIP events), total MSM wall ms, points,
+ * launches, (point, window) pairs */
 int zkaes_msm_stats(double out[5], int reset);
+/* The library's ACTUAL op lists for one proof on this key ("recompute W + S + T + M from the actual op lists and print the lists"): proves `message` once with
+ * the op recorder open -- throughput_path != 0: as a multi-proof call runs a proof (window tables, one lane), 0: as a lone zkaes_encrypt does -- and returns JSON (release
+ * with zkaes_bytes_free): {"h","k","x","variables","constraints","nnz":[A,B,C],"blocks","path","ntt":[[points, transforms sharing the launch],...],
+ * "msm":[[points,"buckets"|"second_bases"|"class_sum"],...]}.  The recorder is process-global: call it with no other proof in flight. */
+int zkaes_pk_op_lists(const zkaes_pk *pk, const uint8_t *message, size_t message_len, const uint8_t secret_key[16], int throughput_path, uint8_t **json, size_t *json_len);
+/* free / total device memory of the calling thread's current device (hipMemGetInfo) */
+int zkaes_mem_info(uint64_t *free_bytes, uint64_t *total_bytes);
 
 /* ---- kernel-level entry points (parity tests + roofline measurement) -------------------------------------------- */
 /* field_id: 377 or 381 (BLS12-377 / BLS12-381 scalar field).  data: n x 32 B Montgomery limbs, host memory, transformed in place.
@@ -185,9 +202,20 @@ int zkaes_msm_fold_partials_dev(int curve_id, const void *dev_in, int world, uin
  * powers, powers_of_gamma_g, degree bounds) -- streamed to `path` (0.65 GB for a 16-byte key).  A Rust caller reads it with
  * IndexProverKey::deserialize_unchecked(BufReader::new(File::open(path)?)) and can run the reference's own CPU encrypt() on a key that was synthesized on the GPU in seconds. */
 int zkaes_pk_serialize_ark_to_file(const zkaes_pk *pk, const char *path, uint64_t *bytes_written);
+/* the same with the point encoding chosen: uncompressed = 0 as above (48-byte points; `IndexProverKey::deserialize` takes a square root and a subgroup check per point --
+ * tens of minutes for 16 M powers); uncompressed != 0: serialize_uncompressed's image (96-byte points, index_vk with 192-byte G2 elements; 1.25 GB for a 16-byte key),
+ * which `IndexProverKey::deserialize_unchecked` -- ark-serialize 0.3: deserialize_unchecked defaults to the UNCOMPRESSED layout -- reads without any per-point work.
+ * This is the image integration/rust_verify_harness/src/bin/encrypt_with_gpu_key.rs loads.  A failed write removes the partial file. */
+int zkaes_pk_serialize_ark_to_file_ex(const zkaes_pk *pk, const char *path, int uncompressed, uint64_t *bytes_written);
 /* *built = 1 when the key holds the fixed-base window tables of its SRS (they are skipped under ZKAES_KEY_NO_TABLES, or when device memory would not also hold the
  * default number of prover contexts); *table_bytes (may be NULL) = their size in device memory */
 int zkaes_pk_tables_built(const zkaes_pk *pk, int *built, uint64_t *table_bytes);
+/* The universal SRS behind the key.  src/lib.rs:139-141 builds ONE generate_universal_srs(866_944, 513, 4_062_064) for every circuit size; so does the library: per process,
+ * device and SRS literals there is one array powers_of_g[0 ..= max_degree] (+ its 12 window-table copies), built by the first key that needs it and shared by all later
+ * ones -- a key's plain and shifted powers are index ranges of it -- and released with the last key.  out = {max_degree, points per copy, copies (1 = no tables), device
+ * bytes, keys sharing it now, bytes of the Lagrange-basis points (shared per |H|, |X|)}; secs (may be NULL) = {seconds THIS key's synthesis spent building the SRS
+ * (~0 when it was shared), seconds of the whole synthesis}. */
+int zkaes_pk_srs_info(const zkaes_pk *pk, uint64_t out[6], double secs[2]);
 /* same sum through the precomputed-window layout the prover uses for the SRS (tables 2^(window offset j) P_i built on the fly here; one bucket set), on the
  * Weierstrass model with XYZZ buckets: correct for ANY curve points, both curves. */
 int zkaes_msm_table(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, int window_bits, uint8_t *out_xy, int *out_inf);

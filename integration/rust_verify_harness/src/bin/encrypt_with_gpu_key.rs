@@ -1,7 +1,9 @@
 //! usage: encrypt_with_gpu_key <pk_ark.bin> <vk_ark.bin>
 //!
-//! pk_ark.bin  zkaes_pk_serialize_ark_to_file() output for a 16-byte key (ark-serialize ark_marlin::IndexProverKey, ~0.65 GB; made on an MI355X with
-//!             `python tools/make_pk_image.py pk_ark.bin`, not committed)
+//! pk_ark.bin  zkaes_pk_serialize_ark_to_file_ex(.., uncompressed = 1) output for a 16-byte key: the serialize_uncompressed image of ark_marlin::IndexProverKey
+//!             (96-byte G1 points, ~1.25 GB; made on an MI355X with `python tools/make_pk_image.py pk_ark.bin`, not committed).  It MUST be the uncompressed image:
+//!             ark-serialize 0.3's `deserialize_unchecked` defaults to `deserialize_uncompressed`, and GroupAffine reads x || y (96 bytes) without any check there.
+//!             (The compressed image -- zkaes_pk_serialize_ark_to_file -- goes with `ProvingKey::deserialize`: a square root + subgroup check per SRS power.)
 //! vk_ark.bin  the matching verifying key (tests/golden/gpu_aes16_vk_ark.bin)
 //!
 //! Runs the REFERENCE's own CPU prover, zk_aes::encrypt (reference src/lib.rs:60-114), on a proving key that libzkaes synthesized on the GPU, and checks the proof

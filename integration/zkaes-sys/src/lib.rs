@@ -27,7 +27,10 @@ extern "C" {
                              proof_lens: *mut usize, n_chunks: usize) -> c_int;
     fn zkaes_encrypt_chunked_seeded_at(message: *const u8, message_len: usize, secret_key: *const u8, pk: *const zkaes_pk, zk_seed32: *const u8, first_proof_index: u64,
                                        proofs: *mut *mut u8, proofs_len: *mut usize, proof_lens: *mut usize, n_chunks: usize) -> c_int;
-    fn zkaes_pk_serialize_ark_to_file(pk: *const zkaes_pk, path: *const c_char, bytes_written: *mut u64) -> c_int;
+    fn zkaes_pk_serialize_ark_to_file_ex(pk: *const zkaes_pk, path: *const c_char, uncompressed: c_int, bytes_written: *mut u64) -> c_int;
+    fn zkaes_pk_set_contexts(pk: *mut zkaes_pk, n: usize) -> c_int;
+    fn zkaes_pk_get_contexts(pk: *const zkaes_pk, n: *mut usize) -> c_int;
+    fn zkaes_pk_srs_info(pk: *const zkaes_pk, out: *mut u64, secs: *mut f64) -> c_int;
     fn zkaes_pk_tables_built(pk: *const zkaes_pk, built: *mut c_int, table_bytes: *mut u64) -> c_int;
     fn zkaes_vk_serialize_ark(vk: *const zkaes_vk, out: *mut *mut u8, out_len: *mut usize) -> c_int;
     fn zkaes_vk_deserialize_ark(bytes: *const u8, len: usize, vk: *mut *mut zkaes_vk) -> c_int;
@@ -61,13 +64,32 @@ pub struct ProvingKey(Arc<PkHandle>);
 pub struct VerifyingKey(Arc<VkHandle>);
 
 impl ProvingKey {
-    /// Streams the ark-serialize image of the arkworks `IndexProverKey` this key corresponds to (0.65 GB for a 16-byte key) -- read it back with
-    /// `simpleworks::marlin::ProvingKey::deserialize_unchecked(BufReader::new(File::open(path)?))` to run the reference's CPU `encrypt()` (src/lib.rs:60) on a GPU-made key.
-    pub fn serialize_ark_to_file(&self, path: &std::path::Path) -> Result<u64> {
+    /// Streams the ark-serialize image of the arkworks `IndexProverKey` this key corresponds to, to run the reference's CPU `encrypt()` (src/lib.rs:60) on a GPU-made key.
+    /// `uncompressed = true` (1.25 GB for a 16-byte key, 96-byte points): read it back with `ProvingKey::deserialize_unchecked(BufReader::new(File::open(path)?))` --
+    /// in ark-serialize 0.3 `deserialize_unchecked` reads the UNCOMPRESSED layout and does no per-point work.  `uncompressed = false` (0.65 GB, 48-byte points) is what
+    /// `ProvingKey::serialize` writes: read it with `ProvingKey::deserialize` (a square root and a subgroup check per SRS point -- tens of minutes for a 64-byte key).
+    pub fn serialize_ark_to_file(&self, path: &std::path::Path, uncompressed: bool) -> Result<u64> {
         let c = std::ffi::CString::new(path.to_string_lossy().as_bytes()).map_err(|_| anyhow::anyhow!("path contains a NUL byte"))?;
         let mut n = 0u64;
-        if unsafe { zkaes_pk_serialize_ark_to_file((self.0).0, c.as_ptr(), &mut n) } != 0 { return Err(last_error()); }
+        if unsafe { zkaes_pk_serialize_ark_to_file_ex((self.0).0, c.as_ptr(), uncompressed as c_int, &mut n) } != 0 { return Err(last_error()); }
         Ok(n)
+    }
+    /// Proofs in flight per `encrypt_chunked` call on this key (1..=64; 0 = the process default, 12).  Replaces the ZKAES_CONTEXTS environment round-trip.
+    pub fn set_contexts(&self, n: usize) -> Result<()> {
+        if unsafe { zkaes_pk_set_contexts((self.0).0, n) } != 0 { return Err(last_error()); }
+        Ok(())
+    }
+    pub fn contexts(&self) -> Result<usize> {
+        let mut n = 0usize;
+        if unsafe { zkaes_pk_get_contexts((self.0).0, &mut n) } != 0 { return Err(last_error()); }
+        Ok(n)
+    }
+    /// The universal SRS behind the key -- ONE per process, device and SRS literals, as `generate_universal_srs` at src/lib.rs:139-141 is one for every circuit size:
+    /// (max_degree, points per copy, copies, device bytes, keys sharing it now, Lagrange-basis bytes)
+    pub fn srs_info(&self) -> Result<[u64; 6]> {
+        let mut out = [0u64; 6];
+        if unsafe { zkaes_pk_srs_info((self.0).0, out.as_mut_ptr(), std::ptr::null_mut()) } != 0 { return Err(last_error()); }
+        Ok(out)
     }
     /// (built, bytes): whether the key holds the fixed-base window tables of its SRS (skipped under KEY_NO_TABLES or when device memory is short)
     pub fn tables_built(&self) -> Result<(bool, u64)> {
@@ -99,7 +121,7 @@ pub fn synthesize_keys(plaintext_length: usize) -> Result<(ProvingKey, Verifying
 }
 
 /// Key synthesis options (include/zkaes.h ZKAES_KEY_*)
-pub const KEY_NO_TABLES: u32 = 1;   // no fixed-base window tables of the SRS: saves 10-42 GB of device memory per key, multi-proof calls run ~9 % slower
+pub const KEY_NO_TABLES: u32 = 1;   // this key does not use (or build) the window tables of the universal SRS (31.4 GB, shared by all keys); multi-proof calls run ~9 % slower
 
 /// `synthesize_keys` with options: `flags` = KEY_NO_TABLES to keep the key small (the tables are also skipped automatically when the device is short of memory)
 pub fn synthesize_keys_with(plaintext_length: usize, flags: u32) -> Result<(ProvingKey, VerifyingKey)> {

@@ -192,10 +192,10 @@ class Index:
             raise IndexError("power not held by the committer key")
         return buf.raw
 
-    def pk_serialize_ark_to_file(self, path):
-        """ark-serialize image of the IndexProverKey minus its index_vk prefix -> file; returns the size"""
-        lib().zko_api_pk_serialize.restype = C.c_uint64
-        return int(lib().zko_api_pk_serialize(self.ptr, os.fsencode(path)))
+    def pk_serialize_ark_to_file(self, path, uncompressed=False):
+        """ark-serialize image of the IndexProverKey minus its index_vk prefix -> file; returns the size (uncompressed: 96-byte points, what deserialize_unchecked reads)"""
+        lib().zko_api_pk_serialize_mode.restype = C.c_uint64
+        return int(lib().zko_api_pk_serialize_mode(self.ptr, os.fsencode(path), 1 if uncompressed else 0))
 
     def prove(self, cs, zk_seed=None):
         p = lib().zko_api_prove(self.ptr, cs.ptr, zk_seed)

@@ -119,6 +119,7 @@ int zko_api_srs_powers(const zko_index *ix, size_t from, size_t count, uint8_t *
     return 0;
 }
 uint64_t zko_api_pk_serialize(const zko_index *ix, const char *path) { return zko_pk_serialize_ark_to_file(ix, path); }
+uint64_t zko_api_pk_serialize_mode(const zko_index *ix, const char *path, int uncompressed) { return zko_pk_serialize_ark_to_file_mode(ix, path, uncompressed); }
 zko_proof *zko_api_prove(const zko_index *ix, zko_cs *cs, const uint8_t *zk_seed) { return zko_marlin_prove(ix, cs, zk_seed); }
 size_t zko_api_proof_bytes(const zko_proof *p, int curve_id, uint8_t *out, size_t cap) { return zko_proof_serialize(p, zko_curve_by_id(curve_id), out, cap); }
 size_t zko_api_proof_poly_len(const zko_proof *p, int i) { return p->polys[i].len; }

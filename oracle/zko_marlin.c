@@ -106,6 +106,17 @@ static void by_g1_compressed(bytes *o, const g1a_t *p, const zko_curve *C) {
     if (y_gt) buf[47] |= 1 << 7;
     by_put(o, buf, 48);
 }
+/* ark-ec 0.3 GroupAffine::serialize_uncompressed: x, then y with the flags byte (infinity only; zero() = (0, 1, infinity)) -- 96 bytes, what deserialize_unchecked reads */
+static void by_g1_uncompressed(bytes *o, const g1a_t *p, const zko_curve *C) {
+    uint8_t buf[96];
+    uint64_t x[6], y[6];
+    if (p->inf) { fq_t one; fq_set_one(&one, C->fq); memset(x, 0, sizeof x); fq_to_raw(y, &one, C->fq); }
+    else { fq_to_raw(x, &p->x, C->fq); fq_to_raw(y, &p->y, C->fq); }
+    for (int i = 0; i < 48; i++) { buf[i] = x[i / 8] >> (8 * (i % 8)); buf[48 + i] = y[i / 8] >> (8 * (i % 8)); }
+    if (p->inf) buf[95] |= 1 << 6;
+    by_put(o, buf, 96);
+}
+static void by_g1_mode(bytes *o, const g1a_t *p, const zko_curve *C, int uncompressed) { if (uncompressed) by_g1_uncompressed(o, p, C); else by_g1_compressed(o, p, C); }
 /* ark-serialize image of ark_marlin::IndexProverKey WITHOUT its first field (index_vk: the G2 side lives in the product), streamed to a file -- the checker for the product's
  * zkaes_pk_serialize_ark_to_file.  Layout [RECALL]: index_comm_rands (6 x empty Randomness), index (info, A, B, C as Vec<Vec<(Fr, usize)>>, six LabeledPolynomials, six
  * Evaluations in the order row, col, row_col, val_a, val_b, val_c with their Radix2 domain), committer key (powers, Some(shifted_powers), powers_of_gamma_g, Some(bounds), max_degree). */
@@ -113,7 +124,9 @@ static void fl_flush(bytes *o, FILE *f, uint64_t *total, int force) {
     if (o->n && (force || o->n > (8u << 20))) { if (fwrite(o->b, 1, o->n, f) != o->n) abort(); *total += o->n; o->n = 0; }
 }
 static void by_u32(bytes *o, uint32_t v) { uint8_t t[4]; for (int i = 0; i < 4; i++) t[i] = v >> (8 * i); by_put(o, t, 4); }
-uint64_t zko_pk_serialize_ark_to_file(const zko_index *ix, const char *path) {
+uint64_t zko_pk_serialize_ark_to_file(const zko_index *ix, const char *path) { return zko_pk_serialize_ark_to_file_mode(ix, path, 0); }
+/* uncompressed != 0: serialize_uncompressed's image (only the G1 points differ: 96 bytes each) */
+uint64_t zko_pk_serialize_ark_to_file_mode(const zko_index *ix, const char *path, int uncompressed) {
     const zko_curve *C = ix->ck.C;
     const fr_params *F = C->fr;
     FILE *f = fopen(path, "wb");
@@ -158,13 +171,13 @@ uint64_t zko_pk_serialize_ark_to_file(const zko_index *ix, const char *path) {
     }
     const zko_ck *ck = &ix->ck;
     by_u64(&o, ck->supported_degree + 1);
-    for (size_t i = 0; i <= ck->supported_degree; i++) { by_g1_compressed(&o, &ck->powers[i], C); fl_flush(&o, f, &total, 0); }
+    for (size_t i = 0; i <= ck->supported_degree; i++) { by_g1_mode(&o, &ck->powers[i], C, uncompressed); fl_flush(&o, f, &total, 0); }
     { uint8_t some = 1; by_put(&o, &some, 1); }
     const size_t nshift = ck->max_degree - ck->lowest_shift + 1;
     by_u64(&o, nshift);
-    for (size_t i = 0; i < nshift; i++) { by_g1_compressed(&o, &ck->shifted_powers[i], C); fl_flush(&o, f, &total, 0); }
+    for (size_t i = 0; i < nshift; i++) { by_g1_mode(&o, &ck->shifted_powers[i], C, uncompressed); fl_flush(&o, f, &total, 0); }
     by_u64(&o, 3);
-    for (int i = 0; i < 3; i++) by_g1_compressed(&o, &ck->gamma_powers[i], C);
+    for (int i = 0; i < 3; i++) by_g1_mode(&o, &ck->gamma_powers[i], C, uncompressed);
     { uint8_t some = 1; by_put(&o, &some, 1); }
     by_u64(&o, 2); by_u64(&o, ck->bounds[0]); by_u64(&o, ck->bounds[1]);
     by_u64(&o, ck->max_degree);

@@ -52,6 +52,8 @@ void zko_proof_free(zko_proof *p);
 size_t zko_proof_serialize(const zko_proof *p, const zko_curve *C, uint8_t *out, size_t cap);
 /* ark-serialize image of ark_marlin::IndexProverKey minus its first field (index_vk), streamed to `path`; returns the bytes written (0 = cannot open) */
 uint64_t zko_pk_serialize_ark_to_file(const zko_index *ix, const char *path);
+/* uncompressed != 0: the serialize_uncompressed image (96-byte G1 points) that deserialize_unchecked reads */
+uint64_t zko_pk_serialize_ark_to_file_mode(const zko_index *ix, const char *path, int uncompressed);
 /* IndexVerifierKey pieces the product verifier needs are serialized by the product itself; for tests: */
 void zko_commit_plain(g1a_t *out, const zko_ck *ck, const fr_t *coeffs, size_t len, size_t power_offset_in_shifted, int use_shifted);
 #endif

@@ -418,12 +418,14 @@ def test_seeded_chunked_and_batch_calls_do_not_share_randomness(zko, api, aes16)
         pk.encrypt_batch([blk], [key[:8]])
 
 
-@pytest.mark.parametrize("which", ["xor", "aes16"])
+@pytest.mark.parametrize("which", ["xor", "aes16", "xor-uncompressed", "aes16-uncompressed"])
 def test_proving_key_ark_image_equals_the_oracles(zko, api, aes16, tmp_path, which):
     """SURVEY 8 f1, third artefact: the ark-serialize image of the arkworks IndexProverKey a GPU-synthesized key corresponds to (zkaes_pk_serialize_ark_to_file) ==
     index_vk bytes (zkaes_vk_serialize_ark) followed by what the CPU oracle writes for the same circuit and SRS -- matrices, index polynomials and their evaluations,
     all powers of the committer key -- compared by size and sha256 (0.65 GB for the 16-byte key)."""
     import hashlib
+    which, _, mode = which.partition("-")
+    unc = mode == "uncompressed"       # serialize_uncompressed's image (96-byte points): what IndexProverKey::deserialize_unchecked reads (ADVICE r4)
     if which == "xor":
         pk, vk = api.synthesize_keys(0, circuit=1, srs=SMALL_SRS)
         cs, _ = zko.synth_ops("xor", 0, 0, field=377)
@@ -433,9 +435,9 @@ def test_proving_key_ark_image_equals_the_oracles(zko, api, aes16, tmp_path, whi
         cs, _ = zko.synth_aes(bytes(16), bytes(16))
         ix = zko.Index(cs)
     pg, po = str(tmp_path / "pk_gpu.bin"), str(tmp_path / "pk_oracle.bin")
-    n_gpu = pk.serialize_ark_to_file(pg)
-    n_or = ix.pk_serialize_ark_to_file(po)
-    prefix = vk.to_ark_bytes()
+    n_gpu = pk.serialize_ark_to_file(pg, uncompressed=unc)
+    n_or = ix.pk_serialize_ark_to_file(po, uncompressed=unc)
+    prefix = vk.to_ark_bytes_uncompressed() if unc else vk.to_ark_bytes()
     assert n_gpu == os.path.getsize(pg) == len(prefix) + n_or and n_or == os.path.getsize(po)
 
     def digest(path, skip=0):

@@ -256,7 +256,40 @@ def test_vk_ark_roundtrip_verifies_and_rejects_garbage(zko, api, xor_setup):
     assert api.VerifyingKey.from_ark_bytes(bytes(flipped)).verify(proof, b"") is False
 
 
-def _parse_pk_image(raw, p, expect_vk_prefix=0):
+def test_vk_ark_uncompressed_layout(zko, api, xor_setup):
+    """serialize_uncompressed's image of the IndexVerifierKey -- what deserialize_unchecked reads (ark-serialize 0.3: it defaults to the UNCOMPRESSED layout): every G1 element
+    is x || y (96 B), every G2 element x.c0 x.c1 y.c0 y.c1 (192 B), no flag bit set for finite points; scalars and lengths as in the compressed image"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import curve_math as cm
+    ix, vk = xor_setup
+    info = ix.info()
+    beta, g_or, gg_or = ix.srs_trapdoor()
+    _, g, gg, h = cm.ark_kzg10_setup_points()
+    F = cm.Fq2(cm.Q377, -5)
+    raw, comp = vk.to_ark_bytes_uncompressed(), vk.to_ark_bytes()
+    le = lambda v: int(v).to_bytes(48, "little")
+    g1 = lambda pt: le(pt[0]) + le(pt[1])
+    g2 = lambda pt: le(pt[0][0]) + le(pt[0][1]) + le(pt[1][0]) + le(pt[1][1])
+    assert raw[:40] == comp[:40]                              # index_info + the length of index_comms
+    off = 40
+    for pt in zko.pt_unpack(ix.comms()):
+        assert raw[off:off + 96] == g1(pt) and raw[off + 96] == 0
+        off += 97
+    assert raw[off:off + 96] == g1(g) and raw[off + 96:off + 192] == g1(gg)
+    off += 192
+    assert raw[off:off + 192] == g2(h) and raw[off + 192:off + 384] == g2(cm.ec2_mul(F, beta, h))
+    off += 384
+    assert raw[off] == 1 and int.from_bytes(raw[off + 1:off + 9], "little") == 2
+    off += 9
+    for b in sorted((info["h"] - 2, info["k"] - 2)):
+        assert int.from_bytes(raw[off:off + 8], "little") == b
+        assert raw[off + 8:off + 104] == g1(cm.ec_mul(pow(beta, info["max_degree"] - b, cm.R377), g, cm.Q377))
+        off += 104
+    assert raw[off:] == comp[-16:] and off + 16 == len(raw) == 759 + 10 * 48 + 2 * 96
+
+
+def _parse_pk_image(raw, p, expect_vk_prefix=0, g1_bytes=48):
     """walk the ark-serialize IndexProverKey image after its index_vk prefix; returns a dict of what it holds and checks that the file ends exactly"""
     import struct
     pos = [expect_vk_prefix]
@@ -294,10 +327,10 @@ def _parse_pk_image(raw, p, expect_vk_prefix=0):
         size_fe, size_inv, gen, gen_inv, cg_inv = fr(), fr(), fr(), fr(), fr()
         assert size_fe == k and size_fe * size_inv % p == 1 and gen * gen_inv % p == 1 and pow(gen, k, p) == 1 and pow(gen, k // 2, p) == p - 1
         out["k"] = k; out["coset_gen_inv"] = cg_inv
-    npow = u64(); pos[0] += 48 * npow
+    npow = u64(); out["powers_at"] = pos[0]; pos[0] += g1_bytes * npow
     assert u8() == 1
-    nshift = u64(); pos[0] += 48 * nshift
-    assert u64() == 3; pos[0] += 48 * 3
+    nshift = u64(); out["shifted_at"] = pos[0]; pos[0] += g1_bytes * nshift
+    assert u64() == 3; pos[0] += g1_bytes * 3
     assert u8() == 1 and u64() == 2
     out["bounds"] = [u64(), u64()]
     out["max_degree"] = u64()
@@ -322,3 +355,16 @@ def test_oracle_pk_image_of_the_xor_circuit_is_well_formed(zko, tmp_path):
     assert got["powers"] == info["supported_degree"] + 1 and got["max_degree"] == info["max_degree"]
     assert got["bounds"] == sorted([info["h"] - 2, info["k"] - 2]) and got["shifted"] == max(got["bounds"]) + 1
     assert got["coset_gen_inv"] * 22 % zko.R377 == 1            # Fr377's multiplicative generator
+    # the uncompressed image (what deserialize_unchecked reads): the same walk with 96-byte points, which are x || y of the committer key's powers
+    size_u = ix.pk_serialize_ark_to_file(path, uncompressed=True)
+    raw_u = open(path, "rb").read()
+    gu = _parse_pk_image(raw_u, zko.R377, g1_bytes=96)
+    assert size_u == len(raw_u) == size + 48 * (got["powers"] + got["shifted"] + 3)
+    assert raw_u[:gu["powers_at"]] == raw[:got["powers_at"]]                      # everything before the first point is identical
+    le = lambda v: int(v).to_bytes(48, "little")
+    pts = zko.pt_unpack(ix.srs_powers(0, 4))
+    for i, (x, y) in enumerate(pts):
+        assert raw_u[gu["powers_at"] + 96 * i:gu["powers_at"] + 96 * (i + 1)] == le(x) + le(y)
+    lowest = info["max_degree"] - max(got["bounds"])
+    (x, y), = zko.pt_unpack(ix.srs_powers(lowest, 1))
+    assert raw_u[gu["shifted_at"]:gu["shifted_at"] + 96] == le(x) + le(y)
