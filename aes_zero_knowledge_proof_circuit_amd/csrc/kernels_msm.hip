@@ -338,7 +338,7 @@ __device__ void accumulate_fixup(const Affine28<P> *__restrict__ bases, Acc28<P>
 
 // overflow segment t of list entry q (bucket k = ovf_bucket[q]) covers sorted positions [start[k] + (j+1) CAP, min(start[k] + (j+2) CAP, end[k])), j = t - ovf_off[q]
 // ONE tail launch per MSM: the overflow segments, then -- Weierstrass law only, in whichever workgroup finishes last (ticket counter deferred_count[1]) -- the replay of
-// the deferred degenerate additions of this kernel and of k_accumulate.  The overflow partials are folded into their buckets by the reduction when it loads them.
+// the deferred degenerate additions of this kernel and of k_accumulate.  The overflow partials are folded into their buckets by k_fold_overflow, launched behind this kernel.
 // For uniformly distributed digits there are no segments and no deferred pairs: every lane exits after one load.
 template <class Law>
 __global__ void __launch_bounds__(64) k_accumulate_tail(const typename Law::Base *__restrict__ bases, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ start,
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(64) k_accumulate_tail(const typename Law::Base
         key[threadIdx.x] = q;
         __syncthreads();
         // the segments of one bucket are consecutive t: the first lane of every (workgroup, bucket) run folds its run (<= 63 additions) and stores ONE
-        // partial at its own slot; load_bucket then visits one slot per workgroup the bucket's segments span, not one per segment
+        // partial at its own slot; k_fold_overflow then visits one slot per workgroup the bucket's segments span, not one per segment
         if (t < total && (threadIdx.x == 0 || key[threadIdx.x - 1] != q)) {
             for (uint32_t r = threadIdx.x + 1; r < 64 && key[r] == q; r++) PtOps<A>::add(acc, sh[r]);
             partial[t] = acc;
@@ -411,21 +411,22 @@ __global__ void __launch_bounds__(64) k_accumulate_tail(const typename Law::Base
         accumulate_fixup<P>(bases, buckets, deferred, deferred_cap, deferred_count);
     }
 }
-// bucket k with its overflow partials folded in (the reduction's load)
+// Overflow partials -> their buckets, in place, BEFORE the reduction (round 5; the reduction's loads used to fold them in, which put a call to the point addition --
+// and its register save area: 464-704 B of scratch -- into every first-level reduction kernel for a case uniform digits never reach).  One lane per entry of the overflow
+// list (ctrl[1] entries: zero for uniformly distributed digits, where every lane leaves after one load); a bucket's partials sit one per 64-segment workgroup of
+// k_accumulate_tail that its segments [a, b) span, at the run's first slot.
 template <class A>
-__device__ __forceinline__ A load_bucket(const A *__restrict__ buckets, size_t k, const uint32_t *__restrict__ ovf_slot, const uint32_t *__restrict__ ovf_off, uint32_t max_segments,
-                                         const A *__restrict__ partial, size_t period = ~(size_t)0, size_t partial_stride = 0) {
+__global__ void __launch_bounds__(64) k_fold_overflow(A *__restrict__ buckets, const uint32_t *__restrict__ ctrl, const uint32_t *__restrict__ ovf_bucket, const uint32_t *__restrict__ ovf_off,
+                                                       uint32_t max_segments, const A *__restrict__ partial) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= ctrl[1]) return;
+    uint32_t a = ovf_off[q], b = ovf_off[q + 1];
+    if (b > max_segments) b = max_segments;
+    if (a >= b) return;
+    const uint32_t k = ovf_bucket[q];
     A acc = buckets[k];
-    // (two accumulations over ONE prepared state -- plain + shifted powers: the second one's bucket sets follow the first's; same overflow list, own partials)
-    if (k >= period) { k -= period; partial += partial_stride; }
-    const uint32_t q = ovf_slot[k];
-    if (q != NO_SLOT) {
-        uint32_t a = ovf_off[q], b = ovf_off[q + 1];
-        if (b > max_segments) b = max_segments;
-        // one folded partial per 64-segment workgroup of k_accumulate_tail that the bucket's segments [a, b) span, stored at the run's first slot
-        for (uint32_t w = a / 64; w * 64 < b; w++) { uint32_t i = w * 64 > a ? w * 64 : a; if (i < b) PtOps<A>::add(acc, partial[i]); }
-    }
-    return acc;
+    for (uint32_t w = a / 64; w * 64 < b; w++) { uint32_t i = w * 64 > a ? w * 64 : a; if (i < b) PtOps<A>::add(acc, partial[i]); }
+    buckets[k] = acc;
 }
 
 // Bucket reduction  sum_j (j + 1) * B_j  per window (bucket j holds digit magnitude j + 1), in three fully parallel levels:
@@ -435,9 +436,7 @@ __device__ __forceinline__ A load_bucket(const A *__restrict__ buckets, size_t k
 // A = the accumulator type (Acc28: XYZZ on the Weierstrass model, AccTE: extended twisted Edwards); PtOps<A> is the group law.
 constexpr int RED_L1 = 8, RED_L2 = 8;
 template <class A>
-__global__ void __launch_bounds__(64) k_reduce_l1(const A *__restrict__ buckets, int c, int nwin, A *__restrict__ seg_s, A *__restrict__ seg_w,
-                                                   const uint32_t *__restrict__ ovf_slot, const uint32_t *__restrict__ ovf_off, uint32_t max_segments, const A *__restrict__ ovf_partial,
-                                                   size_t ovf_period, size_t ovf_stride) {
+__global__ void __launch_bounds__(64) k_reduce_l1(const A *__restrict__ buckets, int c, int nwin, A *__restrict__ seg_s, A *__restrict__ seg_w) {
     uint32_t segs = (1u << c) / RED_L1;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= segs * (uint32_t)nwin) return;
@@ -445,9 +444,9 @@ __global__ void __launch_bounds__(64) k_reduce_l1(const A *__restrict__ buckets,
     const size_t k0 = ((size_t)w << c) + (size_t)g * RED_L1;
     // run_d = B_7 + ... + B_d, W = sum_d run_d.  The running sum starts from the top bucket itself and the sum of the running sums lags one step behind it: 14 additions instead
     // of 16 (nothing is added to an identity), and the two additions of a step are independent of each other -- tot takes the PREVIOUS running sum while the next one forms
-    A run = load_bucket<A>(buckets, k0 + RED_L1 - 1, ovf_slot, ovf_off, max_segments, ovf_partial, ovf_period, ovf_stride), tot = run;
+    A run = buckets[k0 + RED_L1 - 1], tot = run;
     for (int d = RED_L1 - 2; d >= 0; d--) {
-        A b = load_bucket<A>(buckets, k0 + d, ovf_slot, ovf_off, max_segments, ovf_partial, ovf_period, ovf_stride);
+        A b = buckets[k0 + d];
         if (d != RED_L1 - 2) PtOps<A>::add_inline(tot, run);   // + run_{d+1}  (tot already holds run_7 when d = 6)
         PtOps<A>::add_inline(run, b);                           // run_d
     }
@@ -455,32 +454,35 @@ __global__ void __launch_bounds__(64) k_reduce_l1(const A *__restrict__ buckets,
     seg_s[t] = run;
     seg_w[t] = tot;
 }
-// The same first level for the Edwards law with LANE-INTERLEAVED segments: lane g of a set takes buckets d G + g, d < 8 (G = 2^c / 8 lanes per set), so for every d the 64
-// lanes of a wave read 64 consecutive 224-byte buckets -- one contiguous 14 KB stretch per wave and load step instead of 16-byte pieces of 64 lines 1,792 B apart (the
+// The same first level for the Edwards law with LANE-INTERLEAVED segments: segment g of a set takes buckets d G + g, d < 8 (G = 2^c / 8 segments per set), so for every d the
+// lanes of a wave read consecutive 224-byte buckets -- one contiguous stretch per wave and load step instead of 16-byte pieces of 64 lines 1,792 B apart (the
 // consecutive-bucket layout above spent ~130 of its 290 us on those loads, profiles/r04_reduce_scan.txt).  With j = d G + g:
 //     sum_j (j + 1) B_j  =  G sum_g W'_g  +  sum_g g S_g  +  sum_g S_g,      S_g = sum_d B_{d,g},   W'_g = sum_d d B_{d,g}
-// -- the same row / column decomposition of sum_g g S_g behind it (k_reduce_rc), one more plain sum and lg G doublings in k_reduce_final.  13 additions per lane.
+// -- the same row / column decomposition of sum_g g S_g behind it (k_reduce_rc), one more plain sum and lg G doublings at the end.
+// Round 5: TWO LANES PER SEGMENT.  Round 4's kernel kept both running sums of a segment in one lane (run, tot and the loaded bucket: 3 x 56 registers beside the
+// product's 56 + 56 -> 229 VGPRs and 688 B of scratch, one wave per SIMD, 13 dependent additions).  Here the even lane of a pair carries run_d = B_7 + ... + B_d and the odd
+// lane tot = run_7 + ... + run_1, one step behind: at every step the odd lane adds what the even lane held BEFORE the step (56 DPP quad_perm moves, no LDS), the even lane
+// adds the next bucket.  Both lanes execute the same seven additions -- the odd lane's first one adds run_7 to the identity, which the unified law takes in its stride --
+// so there is no divergence; a lane holds ONE accumulator and ONE operand (no scratch), the chain is 7 additions instead of 13, and twice the waves share a SIMD.
 template <class A>
-__global__ void __launch_bounds__(64) k_reduce_l1_interleaved(const A *__restrict__ buckets, int c, int nwin, A *__restrict__ seg_s, A *__restrict__ seg_w,
-                                                               const uint32_t *__restrict__ ovf_slot, const uint32_t *__restrict__ ovf_off, uint32_t max_segments, const A *__restrict__ ovf_partial,
-                                                               size_t ovf_period, size_t ovf_stride) {
+__global__ void __launch_bounds__(64) k_reduce_l1_pair(const A *__restrict__ buckets, int c, int nwin, A *__restrict__ seg_s, A *__restrict__ seg_w) {
+    using P = typename PtOps<A>::Params;
+    using G = FpMsm<P>;
     const uint32_t segs = (1u << c) / RED_L1;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= segs * (uint32_t)nwin) return;
-    const uint32_t w = t / segs, g = t % segs;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, seg = t >> 1;
+    const bool odd = t & 1;
+    if (seg >= segs * (uint32_t)nwin) return;              // (pairs never straddle the bound: both lanes of a pair leave together)
+    const uint32_t w = seg / segs, g = seg % segs;
     const size_t k0 = ((size_t)w << c) + g;
-    // run_d = B_7 + ... + B_d;  W' = run_7 + ... + run_1 (lagging one step behind the running sum, as in k_reduce_l1);  S = run_1 + B_0
-    A run = load_bucket<A>(buckets, k0 + (size_t)(RED_L1 - 1) * segs, ovf_slot, ovf_off, max_segments, ovf_partial, ovf_period, ovf_stride), tot = run;
-    for (int d = RED_L1 - 2; d >= 1; d--) {
-        A b = load_bucket<A>(buckets, k0 + (size_t)d * segs, ovf_slot, ovf_off, max_segments, ovf_partial, ovf_period, ovf_stride);
-        if (d != RED_L1 - 2) PtOps<A>::add_inline(tot, run);
-        PtOps<A>::add_inline(run, b);
+    A acc = odd ? PtOps<A>::identity() : buckets[k0 + (size_t)(RED_L1 - 1) * segs];
+    for (int d = RED_L1 - 2; d >= 0; d--) {
+        A opnd;
+        // what the partner holds now: for the odd lane that is run_{d+1}
+        opnd.x = quad_move<QP_SWAP_PAIRS, G>(acc.x); opnd.y = quad_move<QP_SWAP_PAIRS, G>(acc.y); opnd.z = quad_move<QP_SWAP_PAIRS, G>(acc.z); opnd.t = quad_move<QP_SWAP_PAIRS, G>(acc.t);
+        if (!odd) opnd = buckets[k0 + (size_t)d * segs];
+        PtOps<A>::add_inline(acc, opnd);
     }
-    PtOps<A>::add(tot, run);
-    A b0 = load_bucket<A>(buckets, k0, ovf_slot, ovf_off, max_segments, ovf_partial, ovf_period, ovf_stride);
-    PtOps<A>::add(run, b0);
-    seg_s[t] = run;
-    seg_w[t] = tot;
+    (odd ? seg_w : seg_s)[seg] = acc;                       // even: S_g = run_0;  odd: W'_g = run_7 + ... + run_1
 }
 // Two roles per group (whole 64-lane workgroups take one role, so nobody diverges): a lane's time is its NUMBER of point operations, and one lane doing both the
 // running sums (29 operations) and the scalar product (8 + up to 28) was the longest chain of the whole reduction (630 us of the 1.36 ms a bucket reduction costs
@@ -637,9 +639,11 @@ __device__ __forceinline__ void quad_weighted_small2(const QuadWeighted &p0, con
     __syncthreads();
 }
 // sum_i i E_i over M <= 256 points loaded into bufA AND bufB (M a power of two), times 2^shift: M = r1 x c1, i = r c1 + c  =>  sum_c c (column sums) + c1 sum_r r (row sums).
-// Result in bufA[0].
+// Result in bufA[0] -- unless `host_tail`: then the two halves V1 = sum_c c (column sums) and V2 = sum_r r (row sums) stay in scratch[0] and scratch[16] and the caller's
+// host side applies the weights (V1 + 2^lc V2) 2^shift: the lc + shift doublings are a serial chain one wave takes ~5 us per step for, the host 0.9 us.
+ZK_HD int quad_weighted_lc(uint32_t M) { int m = 0; while ((1u << m) < M) m++; return M <= 16 ? m : (m + 1) / 2; }
 template <class P>
-__device__ __forceinline__ void quad_weighted(uint32_t *bufA, uint32_t *bufB, uint32_t M, int shift, uint32_t *scratch, uint32_t quad, int q) {
+__device__ __forceinline__ void quad_weighted(uint32_t *bufA, uint32_t *bufB, uint32_t M, int shift, uint32_t *scratch, uint32_t quad, int q, bool host_tail) {
     int m = 0;
     while ((1u << m) < M) m++;
     const int lc = M <= 16 ? m : (m + 1) / 2;
@@ -657,6 +661,7 @@ __device__ __forceinline__ void quad_weighted(uint32_t *bufA, uint32_t *bufB, ui
     }
     // V1 = sum_c c bufA[c] (c1 points) and V2 = sum_r r bufB[r c1] (r1 points), both <= 16 points, side by side
     quad_weighted_small2<P>(QuadWeighted{bufA, 1, c1, scratch}, QuadWeighted{bufB, c1, r1, scratch + 16 * PT_WORDS}, quad, q);
+    if (host_tail) return;
     if (quad == 0) {
         FpMsm<P> v2 = quad_load<P>(scratch + 16 * PT_WORDS, q);
         for (int i = 0; i < lc; i++) v2 = te_dbl_quad<P>(v2, q);
@@ -666,11 +671,20 @@ __device__ __forceinline__ void quad_weighted(uint32_t *bufA, uint32_t *bufB, ui
     }
     __syncthreads();
 }
+// Two ways out.  dev_total != nullptr (the sharded-MSM entry points, whose sum must stay in device memory): the four workgroups of a set leave their terms in `part`,
+// the last one to finish (ticket) applies the weights, adds the four and converts to the Weierstrass XYZZ form -- a serial tail of lgG + lgC doublings on one wave.
+// dev_total == nullptr (every MSM of the prover): HOST TAIL.  The workgroups stop at the six UNWEIGHTED terms of a set,
+//     out[set][0] = sum W'   [1] = sum RS   [2], [3] = V1, V2 of the column term   [4], [5] = V1, V2 of the row term,
+// each converted to XYZZ by its own lane and written straight to host-mapped memory; reduce_host_tail() finishes
+//     2^(lgR+lgC) [0] + [1] + ([2] + 2^lc(C) [3]) + 2^lgC ([4] + 2^lc(R) [5])
+// with ~24 XYZZ doublings of 0.9 us -- where a lone GPU wave needs ~5 us per dependent point operation -- and no ticket, no fence, no second pass over `part`.
+constexpr int RF_OUT = 6;
 template <class P>
 __global__ void __launch_bounds__(RF_THREADS) k_reduce_final(const AccTE<P> *__restrict__ rc, int lgR, int lgC, AccTE<P> *__restrict__ part, uint32_t *__restrict__ tickets,
-                                                              XYZZ<Fp<P>> *__restrict__ out, XYZZ<Fp<P>> *__restrict__ out2) {
+                                                              XYZZ<Fp<P>> *__restrict__ out, XYZZ<Fp<P>> *__restrict__ dev_total) {
     __shared__ uint32_t bufA[RF_QUADS * PT_WORDS], bufB[RF_QUADS * PT_WORDS], scratch[32 * PT_WORDS];
     __shared__ uint32_t ticket;
+    const bool host_tail = dev_total == nullptr;
     const uint32_t R = 1u << lgR, C = 1u << lgC, jobs = 2 * R + C;
     const uint32_t set = blockIdx.x / 4, role = blockIdx.x % 4, quad = threadIdx.x >> 2;
     const int q = threadIdx.x & 3;
@@ -684,12 +698,19 @@ __global__ void __launch_bounds__(RF_THREADS) k_reduce_final(const AccTE<P> *__r
     __syncthreads();
     if (role == 0 || role == 3) {
         quad_tree_sum<P>(bufA, RF_QUADS, quad, q);
-        if (role == 0 && quad == 0) {                       // the W' term carries the factor G = R C
+        if (role == 0 && quad == 0 && !host_tail) {           // the W' term carries the factor G = R C
             FpMsm<P> v = quad_load<P>(bufA, q);
             for (int i = 0; i < lgR + lgC; i++) v = te_dbl_quad<P>(v, q);
             quad_store<P>(bufA, q, v);
         }
-    } else quad_weighted<P>(bufA, bufB, M, role == 2 ? lgC : 0, scratch, quad, q);       // the row term carries the factor C: applied here, beside the column term's workgroup
+    } else quad_weighted<P>(bufA, bufB, M, role == 2 ? lgC : 0, scratch, quad, q, host_tail);       // the row term carries the factor C: applied here, beside the column term's workgroup
+    if (host_tail) {
+        __syncthreads();
+        XYZZ<Fp<P>> *o = out + (size_t)set * RF_OUT;
+        if (role == 0 || role == 3) { if (threadIdx.x == 0) o[role == 0 ? 0 : 1] = te_to_std_point<P>(*reinterpret_cast<const AccTE<P> *>(bufA)); }
+        else if (threadIdx.x < 2) o[(role == 1 ? 2 : 4) + threadIdx.x] = te_to_std_point<P>(*reinterpret_cast<const AccTE<P> *>(scratch + threadIdx.x * 16 * PT_WORDS));
+        return;
+    }
     if (quad == 0) quad_store<P>(reinterpret_cast<uint32_t *>(part + (size_t)set * 4 + role), q, quad_load<P>(bufA, q));
     __threadfence();
     __syncthreads();
@@ -708,8 +729,25 @@ __global__ void __launch_bounds__(RF_THREADS) k_reduce_final(const AccTE<P> *__r
     if (threadIdx.x == 0) {
         const auto r = te_to_std_point<P>(*reinterpret_cast<const AccTE<P> *>(scratch));
         out[set] = r;
-        if (out2) out2[set] = r;
+        dev_total[set] = r;
     }
+}
+// the host's share of the Edwards reduction (k_reduce_final, host tail): the weighted sum of a set's six terms, Horner over the weights' shifts
+template <class Fq>
+static XYZZ<Fq> reduce_host_tail(const XYZZ<Fq> *o, int lgR, int lgC) {
+    auto shl = [](XYZZ<Fq> v, int k) { for (int i = 0; i < k; i++) v = v.dbl(); return v; };
+    const int lcC = quad_weighted_lc(1u << lgC), lcR = quad_weighted_lc(1u << lgR);
+    XYZZ<Fq> row = shl(o[5], lcR);                  // the row term: (V1 + 2^lc V2) 2^lgC
+    row.add(o[4]);
+    XYZZ<Fq> col = shl(o[3], lcC);
+    col.add(o[2]);
+    // 2^(lgR + lgC) [0] + 2^lgC row + col + [1]  =  2^lgC (2^lgR [0] + row) + col + [1]
+    XYZZ<Fq> t = shl(o[0], lgR);
+    t.add(row);
+    t = shl(t, lgC);
+    t.add(col);
+    t.add(o[1]);
+    return t;
 }
 
 template <class A> __global__ void k_sum_tree(const A *__restrict__ in, uint32_t total, uint32_t per, A *__restrict__ out, uint32_t in_stride, uint32_t out_stride);
@@ -738,7 +776,7 @@ struct MsmWorkspace {
     void *h_res = nullptr, *d_res = nullptr;                      // pinned host memory the last reduction kernel writes the window sums (+ flags) into, and its device address
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};      // [2 rep], [2 rep + 1]: around the k_accumulate launch of base array `rep`
 };
-constexpr size_t RES_BYTES = 192 * MAX_WSUMS + 64;
+constexpr size_t RES_BYTES = 192 * MAX_WSUMS * 6 + 64;        // six terms per set when the Edwards reduction ends on the host (k_reduce_final RF_OUT)
 // the accumulators and the reduction's levels, sized by the number of buckets ACCUMULATED (twice the prepared ones when one prepared state serves two base arrays at once)
 static void ensure_result(MsmWorkspace &S, size_t buckets) {
     if (buckets <= S.cap_result) return;
@@ -867,19 +905,21 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
         hipLaunchKernelGGL((k_accumulate_tail<Law>), dim3((max_seg + 63) / 64), dim3(64), 0, s, src, S.sorted_vals, S.start, S.end, S.ctrl, S.ovf_bucket, S.ovf_off, max_seg, cap,
                            (A *)S.ovf_partial + rep * S.cap_ovf, (A *)S.buckets + rep * nb, S.deferred, DEFERRED_CAP, S.deferred_count);
         HIP_LAUNCH_CHECK();
+        // (overflow list entries <= buckets with more than `cap` pairs <= pairs / cap)
+        hipLaunchKernelGGL((k_fold_overflow<A>), dim3((max_seg + 63) / 64), dim3(64), 0, s, (A *)S.buckets + rep * nb, S.ctrl, S.ovf_bucket, S.ovf_off, max_seg, (const A *)S.ovf_partial + rep * S.cap_ovf);
+        HIP_LAUNCH_CHECK();
     }
     XYZZ<Fq> *res = (XYZZ<Fq> *)S.d_res;
     uint32_t segs = (1u << c) / RED_L1, groups = (segs + RED_L2 - 1) / RED_L2;
+    [[maybe_unused]] int te_lgR = 0, te_lgC = 0;
 #ifdef ZKAES_MEASURE
     for (int rep = (knockin() & 2) ? 0 : 1; rep < 2; rep++)
 #endif
     {
     if constexpr (Law::edwards)
-        hipLaunchKernelGGL((k_reduce_l1_interleaved<A>), dim3((unsigned)((segs * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.buckets, c, nsets, (A *)S.seg_s, (A *)S.seg_w,
-                           S.ovf_slot, S.ovf_off, max_seg, (const A *)S.ovf_partial, nrep == 2 ? nb : ~(size_t)0, S.cap_ovf);
+        hipLaunchKernelGGL((k_reduce_l1_pair<A>), dim3((unsigned)((2 * segs * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.buckets, c, nsets, (A *)S.seg_s, (A *)S.seg_w);
     else
-        hipLaunchKernelGGL((k_reduce_l1<A>), dim3((unsigned)((segs * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.buckets, c, nsets, (A *)S.seg_s, (A *)S.seg_w,
-                           S.ovf_slot, S.ovf_off, max_seg, (const A *)S.ovf_partial, nrep == 2 ? nb : ~(size_t)0, S.cap_ovf);
+        hipLaunchKernelGGL((k_reduce_l1<A>), dim3((unsigned)((segs * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.buckets, c, nsets, (A *)S.seg_s, (A *)S.seg_w);
     HIP_LAUNCH_CHECK();
     if constexpr (Law::edwards) {
         // Edwards law: plain row / column sums of the segment sums, then four quad-cooperative workgroups per set (k_reduce_rc / k_reduce_final above)
@@ -891,6 +931,7 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
         HIP_LAUNCH_CHECK();
         hipLaunchKernelGGL((k_reduce_final<P>), dim3(4u * (unsigned)nsets), dim3(RF_THREADS), 0, s, (const A *)rc, lgR, lgC, part, S.tickets, res, dev_wsum_out);
         HIP_LAUNCH_CHECK();
+        te_lgR = lgR; te_lgC = lgC;
     } else {
     hipLaunchKernelGGL((k_reduce_l2<A>), dim3(2u * (unsigned)((groups * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.seg_s, (const A *)S.seg_w, c, nsets, (A *)S.partial);
     HIP_LAUNCH_CHECK();
@@ -910,7 +951,11 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
     std::vector<XYZZ<Fq>> ws(nsets);
     uint32_t n_deferred = 0;
     sync((stream_t)s);        // (sleeps in throughput mode) the window sums are in pinned host memory once the stream has drained: no copy launch
-    memcpy(ws.data(), S.h_res, sizeof(XYZZ<Fq>) * nsets);
+    if (Law::edwards && !dev_wsum_out) {       // host tail of the Edwards reduction: six unweighted terms per set
+        std::vector<XYZZ<Fq>> terms((size_t)nsets * RF_OUT);
+        memcpy(terms.data(), S.h_res, sizeof(XYZZ<Fq>) * terms.size());
+        for (int i = 0; i < nsets; i++) ws[i] = reduce_host_tail<Fq>(terms.data() + (size_t)i * RF_OUT, te_lgR, te_lgC);
+    } else memcpy(ws.data(), S.h_res, sizeof(XYZZ<Fq>) * nsets);
     if constexpr (!Law::edwards) {
         HIP_CHECK(hipMemcpyAsync(&n_deferred, S.deferred_count, 4, hipMemcpyDeviceToHost, s));
         sync((stream_t)s);

@@ -51,6 +51,23 @@ def bind_rank_cpus(local_rank, local_world):
     return {"local_rank": local_rank, "cpus": len(share), "first": share[0], "last": share[-1]}
 
 
+def gather_affinities(affinity, device=None):
+    """every rank's CPU share (bind_rank_cpus) on every rank, in rank order, for the bench line: [{"local_rank", "cpus", "first", "last"} | None, ...]"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [affinity]
+    a = affinity or {}
+    mine = torch.tensor([1 if affinity else 0, a.get("local_rank", -1), a.get("cpus", 0), a.get("first", -1), a.get("last", -1)], dtype=torch.int64, device=device)
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    out = []
+    for p in parts:
+        v = [int(x) for x in p.cpu()]
+        out.append({"local_rank": v[1], "cpus": v[2], "first": v[3], "last": v[4]} if v[0] else None)
+    return out
+
+
 def reduce_report(elapsed, accepted, total, negatives_ok, device=None):
     """max-over-ranks time and summed acceptance counters (no-op without an initialized process group)"""
     import torch

@@ -51,9 +51,15 @@ from aes_zero_knowledge_proof_circuit_amd import sharding  # noqa: E402
 synthetic = sharding.synthetic_bytes
 
 
-def cpu_baseline(samples_small=1, samples_chunk=1, chunk_blocks=6, budget_s=150.0):
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
+
+
+def cpu_baseline(samples_small=0, samples_chunk=3, chunk_blocks=6, budget_s=300.0):
     """The CPU oracle (oracle/, a C restatement of the same algorithm; NOT arkworks) timed on this box's host cores, SRS + index prebuilt
-    outside the timed part like the GPU side: `samples_small` one-block chunk-proofs and `samples_chunk` proofs at the bench's own chunk size."""
+    outside the timed part like the GPU side: `samples_chunk` proofs at the bench's own chunk size (the MEDIAN is the reported value; criterion reports a median-like
+    estimate of its samples too, benches/benchmark_encrypt.rs:39-49) and optionally `samples_small` one-block chunk-proofs."""
     from oracle import zko
     nthreads = int(zko.lib().zko_api_num_threads())
     out = {"unit": "blocks/s", "cores": nthreads, "kind": "port", "by_chunk": {}}
@@ -74,17 +80,16 @@ def cpu_baseline(samples_small=1, samples_chunk=1, chunk_blocks=6, budget_s=150.
             times.append(time.perf_counter() - t0)
             if time.perf_counter() - t_begin > budget_s:
                 break
-        best = min(times)
-        out["by_chunk"][str(blocks)] = {"blocks_per_s": round(blocks / best, 5), "best_s": round(best, 2), "samples_s": [round(t, 2) for t in times],
+        med, best = median(times), min(times)
+        out["by_chunk"][str(blocks)] = {"blocks_per_s": round(blocks / med, 5), "median_s": round(med, 2), "best_s": round(best, 2), "samples_s": [round(t, 2) for t in times],
                                         "index_s": round(t_index, 1), "h": int(ix.info()["h"]), "k": int(ix.info()["k"])}
         del ix
     best_chunk = max(out["by_chunk"], key=lambda b: out["by_chunk"][b]["blocks_per_s"])
     out["value"] = out["by_chunk"][best_chunk]["blocks_per_s"]
-    out["sample"] = "best of %s: %s" % (", ".join("%sx %s-block chunk-proof" % (len(v["samples_s"]), b) for b, v in out["by_chunk"].items()),
-                                        "%s-block chunk, %.1f s per proof (%d sample%s at that size; --cpu-chunk-samples N takes more, about a minute each; a 3-sample run of an "
-                                        "earlier round is kept in profiles/r03_bench_cpu_baseline_3_samples.json)" % (
-                                            best_chunk, out["by_chunk"][best_chunk]["best_s"], len(out["by_chunk"][best_chunk]["samples_s"]),
-                                            "" if len(out["by_chunk"][best_chunk]["samples_s"]) == 1 else "s"))
+    bc = out["by_chunk"][best_chunk]
+    out["sample"] = "median of %d sample%s of one %s-block chunk-proof (%s s; %.1f s median, %.1f s best)%s" % (
+        len(bc["samples_s"]), "" if len(bc["samples_s"]) == 1 else "s", best_chunk, ", ".join("%.1f" % t for t in bc["samples_s"]), bc["median_s"], bc["best_s"],
+        "".join("; %s-block chunk: %s blocks/s" % (b, v["blocks_per_s"]) for b, v in out["by_chunk"].items() if b != best_chunk))
     out["threads_effective"] = "MSM: windows x point-slices tasks (all %d threads); NTT / polynomial loops: OpenMP static; synthesis + transcript: 1 thread" % nthreads
     return out
 
@@ -106,11 +111,11 @@ def build_parser():
     ap.add_argument("--contexts", type=int, default=12, help="chunk-proofs in flight per GPU (separate HIP streams; 8, 12 and 16 measure the same, profiles/r03_knobs.txt -- 12 holds ~56 GB of workspaces)")
     ap.add_argument("--pipeline", type=int, default=2, help="timed slices in flight (1 = strictly one after the other: the chip drains at every step boundary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-chunk-samples", type=int, default=1, help="CPU-oracle samples at the bench's chunk size, ~60 s each (0 = one-block samples only; profiles/ holds a 3-sample run)")
+    ap.add_argument("--cpu-chunk-samples", type=int, default=3, help="CPU-oracle samples at the bench's chunk size, ~60 s each; the median is reported (0 = one-block samples only)")
     ap.add_argument("--serial-probe", type=int, default=2, help="chunk-proofs proven one at a time after the timed region for un-overlapped kernel durations (0 = off)")
     ap.add_argument("--alt-proofs", type=int, default=64, help="one rank, headline mode: chunk-proofs of the %d-block alt leg measured after the timed region (0 = off)" % ALT_CHUNK)
     ap.add_argument("--latency-samples", type=int, default=5, help="one rank, headline mode: lone encrypt() calls timed per message size of the latency leg (0 = off)")
-    ap.add_argument("--cpu-small-samples", type=int, default=1, help="CPU-oracle samples of a one-block chunk-proof (~17 s each + 20 s of setup)")
+    ap.add_argument("--cpu-small-samples", type=int, default=0, help="CPU-oracle samples of a one-block chunk-proof (~17 s each + 20 s of setup; off by default: the run stays under 400 s)")
     return ap
 
 
@@ -124,19 +129,18 @@ def run(args, api, dist_env=None):
     use_dist = world > 1 or "RANK" in os.environ            # under torchrun the RCCL group is created (and exercised) even for one rank
     # rehearsal hooks for a one-GPU box (not used by the driver): ZKAES_BENCH_BACKEND=gloo + ZKAES_BENCH_ONE_GPU=1 run N ranks on device 0
     backend = os.environ.get("ZKAES_BENCH_BACKEND", "nccl")
-    if os.environ.get("ZKAES_BENCH_ONE_GPU"):
-        local_rank = 0
+    device_ordinal = 0 if os.environ.get("ZKAES_BENCH_ONE_GPU") else local_rank      # (the CPU share below still goes by the true local rank)
     have_cuda = torch.cuda.is_available()
     if use_dist and not dist.is_initialized():
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            torch.cuda.set_device(device_ordinal)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_ordinal))
         else:
             dist.init_process_group(backend)
     coll_device = "cuda" if (use_dist and backend == "nccl") else None
     if api.device_count() <= 0:
         raise SystemExit("bench.py needs a HIP device: libzkaes has no CPU fallback")
-    api.set_device(local_rank)
+    api.set_device(device_ordinal)
 
     affinity = sharding.bind_rank_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if world > 1 else None
 
@@ -159,16 +163,23 @@ def run(args, api, dist_env=None):
         msg = synthetic(16 * total_blocks, 0x5EED + 1)
         keys16 = synthetic(16 * total_blocks, 0x5EED + 2) if mode == "batch" else None   # batch: one key per proof
     contexts = max(1, args.contexts)
-    os.environ["ZKAES_CONTEXTS"] = str(contexts)
     t_setup = time.perf_counter()
     chunk_bytes = 16 * chunk
     need_full = min(hi, n_full) > lo or args.warmup > 0 or args.serial_probe > 0
     need_rem = bool(rem) and hi == n_chunks and hi > lo
     pk = vk = pk_rem = vk_rem = None
+    key_setup_s = []
     if need_full:
+        tk = time.perf_counter()
         pk, vk = api.synthesize_keys(chunk_bytes)
-    if need_rem:
+        key_setup_s.append(round(time.perf_counter() - tk, 2))
+    if need_rem:                                              # (the second key over the same universal SRS: shares its powers and window tables)
+        tk = time.perf_counter()
         pk_rem, vk_rem = api.synthesize_keys(16 * rem)
+        key_setup_s.append(round(time.perf_counter() - tk, 2))
+    for k_ in (pk, pk_rem):
+        if k_ is not None and hasattr(k_, "set_contexts"):
+            k_.set_contexts(contexts)                         # proofs in flight per multi-proof call on this key (zkaes_pk_set_contexts)
     setup_s = time.perf_counter() - t_setup
     info = (pk or pk_rem).info()
 
@@ -185,7 +196,7 @@ def run(args, api, dist_env=None):
         fa, fb = a, min(b, n_full)
 
         def run_rem():
-            api.set_device(local_rank)                        # HIP's current device is per thread (libzkaes re-selects the key's device itself, too)
+            api.set_device(device_ordinal)                    # HIP's current device is per thread (libzkaes re-selects the key's device itself, too)
             out_rem.extend(pk_rem.encrypt_chunked(m[16 * chunk * n_full:16 * total_blocks], key))
         t = None
         if rem and b == n_chunks and b > a and source is None:
@@ -220,7 +231,7 @@ def run(args, api, dist_env=None):
     barrier()
     t0 = time.perf_counter()
     def timed_slice(ab):
-        api.set_device(local_rank)
+        api.set_device(device_ordinal)
         r = prove_range(*ab)
         t = pk.timings() if (pk is not None and ab[1] > ab[0]) else None      # wall times of ONE chunk-proof of the step (sampled; several are in flight concurrently)
         return r, t
@@ -236,17 +247,27 @@ def run(args, api, dist_env=None):
     barrier()
     elapsed = time.perf_counter() - t0
     stats = api.msm_stats()
+    mem_after_timed = None
+    if rank == 0 and hasattr(api, "mem_info"):
+        try:
+            f_, t_ = api.mem_info()
+            mem_after_timed = t_ - f_                           # device bytes in use right after the timed region: the SRS + this rank's keys and prover contexts
+        except Exception:
+            pass
 
     # ---- un-overlapped kernel durations: a few chunk-proofs one at a time (outside the timed region; cross-check for the rocprof one-context profile)
-    serial = None
+    serial = oplists = None
     if args.serial_probe > 0 and rank == 0 and pk is not None and mode != "batch":
-        os.environ["ZKAES_CONTEXTS"] = "1"
+        pk.set_contexts(1)
         api.msm_stats(reset=True)
         ts = time.perf_counter()
         pk.encrypt_chunked(warm_msg[:chunk_bytes * min(args.serial_probe, warm_n)], key)
         t_serial = time.perf_counter() - ts
         s1 = api.msm_stats()
-        os.environ["ZKAES_CONTEXTS"] = str(contexts)
+        pk.set_contexts(contexts)
+        # the library's ACTUAL op lists of one chunk-proof on the path the timed region uses (zkaes_pk_op_lists: one proof with the op recorder open) -- SURVEY.md 8(d)
+        if hasattr(pk, "op_lists"):
+            oplists = pk.op_lists(warm_msg[:chunk_bytes], key, throughput_path=True)
         if s1["launches"]:
             serial = {"proofs": min(args.serial_probe, warm_n), "ms_per_proof": round(1e3 * t_serial / min(args.serial_probe, warm_n), 2),
                       "avg_launch_ms": round(s1["accumulate_ms"] / s1["launches"], 4), "launches": s1["launches"],
@@ -345,9 +366,18 @@ def run(args, api, dist_env=None):
         bad = bytearray(chunk_ct(first_i, ct)); bad[1] ^= 1; bad[-1] ^= 1
         rejected_wrong = int(not api.verify_encryption(vk if first_i < n_full else vk_rem, first_p, bytes(bad)))
     elapsed, acc_sum, tot_sum, neg_sum = sharding.reduce_report(elapsed, accepted, total, rejected_wrong, device=coll_device)
+    affinity_by_rank = sharding.gather_affinities(affinity, device=coll_device) if world > 1 else None
 
     out = None
     if rank == 0:
+        srs_report = None
+        if hasattr(pk or pk_rem, "srs_info"):
+            si = (pk or pk_rem).srs_info()
+            srs_report = {"universal_srs_bytes": si["bytes"], "copies": si["copies"], "points_per_copy": si["points_per_copy"], "keys_sharing_now": si["keys_sharing"],
+                          "first_key_srs_build_s": round(si["srs_build_s"], 2), "lagrange_bytes": si["lagrange_bytes"],
+                          "note": "ONE universal SRS (powers_of_g[0..=max_degree] + 12 window-table copies) per process and device, shared by every key (src/lib.rs:139-141); "
+                                  "key_setup_s = wall seconds of synthesize_keys per key, in creation order -- the second key only indexes its circuit"}
+            srs_report["device_bytes_in_use_after_timed_region"] = mem_after_timed
         job_blocks = total_blocks * (world if mode == "headline" else 1)
         value = job_blocks / elapsed
         # roofline of the dominant kernel (MSM bucket accumulation, kernels_msm.hip k_accumulate): algorithmic bytes per launch =
@@ -370,7 +400,7 @@ def run(args, api, dist_env=None):
         achieved = (bytes_per_launch / 1e9) / (chip_ms / 1e3) if chip_ms > 0 else 0.0
         kernel_ms_per_step = launches / max(args.steps, 1) * chip_ms
         traffic = traffic_src = None
-        for name in ("r04_pmc_k_accumulate_tables.json", "r03_pmc_k_accumulate_tables.json", "r02_pmc_k_accumulate_tables.json"):
+        for name in ("r05_pmc_k_accumulate_tables.json", "r04_pmc_k_accumulate_tables.json", "r03_pmc_k_accumulate_tables.json", "r02_pmc_k_accumulate_tables.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 traffic = round(pmc["hbm_bytes_per_point_window"] * pairs_per_launch)
@@ -382,6 +412,35 @@ def run(args, api, dist_env=None):
             copy_gbs = round(api.stream_copy_bench(1 << 30, 20), 1)
         except Exception:
             copy_gbs = None
+        # ---- whole-proof algorithmic bytes: bytes = W + S + T + M from the library's ACTUAL op lists of one chunk-proof (zkaes_pk_op_lists), not a literal:
+        #   W = 16 c + 16 + 32 V (message + key in, z written once);  S = 36 (nnzA + nnzB) + 36 (nnzA + nnzB + nnzC) + 32 V + 64 N (the two SpMVs + round 2's t pass);
+        #   T = sum over transforms of 64 n_i (one read + one write);  M = sum over MSMs of 128 m_j (96 B affine base + 32 B scalar, each read once)
+        proof_roof = None
+        if oplists:
+            V, N, (na, nb_, nc) = oplists["variables"], oplists["constraints"], oplists["nnz"]
+            ntt_sizes = {}
+            for n_i, cnt in oplists["ntt"]:
+                ntt_sizes[n_i] = ntt_sizes.get(n_i, 0) + cnt
+            msm_by_kind = {}
+            for m_j, kind in oplists["msm"]:
+                msm_by_kind.setdefault(kind, []).append(m_j)
+            Wb = 16 * oplists["blocks"] + 16 + 32 * V
+            Sb = 36 * (na + nb_) + 36 * (na + nb_ + nc) + 32 * V + 64 * N
+            Tb = sum(64 * n_i * cnt for n_i, cnt in ntt_sizes.items())
+            Mb = sum(128 * m_j for ms_ in msm_by_kind.values() for m_j in ms_)
+            total_b = Wb + Sb + Tb + Mb
+            proofs_per_s = (n_chunks * (world if mode == "headline" else 1)) / elapsed
+            # (the remainder chunk-proof, if any, is counted at the full chunk's bytes: same |H|, |K|, same launches)
+            proof_roof = {"W": Wb, "S": Sb, "T": Tb, "M": Mb, "bytes": total_b, "unit": "B per %d-block chunk-proof" % oplists["blocks"],
+                          "ntt_list": {"transforms_by_size": {str(k_): v_ for k_, v_ in sorted(ntt_sizes.items())}, "launches": len(oplists["ntt"]),
+                                       "transforms": sum(ntt_sizes.values())},
+                          "msm_list": {kind: {"count": len(v_), "points": sum(v_), "sizes": sorted(v_, reverse=True)} for kind, v_ in sorted(msm_by_kind.items())},
+                          "k_accumulate_launches_per_proof": len(msm_by_kind.get("buckets", [])) + len(msm_by_kind.get("second_bases", [])),
+                          "path": oplists["path"], "h": oplists["h"], "k": oplists["k"],
+                          "proofs_per_s": round(proofs_per_s / max(world, 1), 3), "achieved_GBs": round(total_b * proofs_per_s / max(world, 1) / 1e9, 2),
+                          "frac": round(total_b * proofs_per_s / max(world, 1) / 1e9 / HBM_PEAK_GBS, 6),
+                          "source": "zkaes_pk_op_lists: one chunk-proof proven with the library's op recorder open (every ntt / msm launch appends its size); per GPU",
+                          "not_counted": "the <= 3-term hiding MSMs and blinding products (host comb tables), Fiat-Shamir, the streaming polynomial kernels between the transforms"}
         mads = MADS_PER_ADD * stats["pairs"] / 1e12
         mads_per_launch = MADS_PER_ADD * pairs_per_launch / 1e12
         workload = {
@@ -403,7 +462,7 @@ def run(args, api, dist_env=None):
                        "circuit_model": CIRCUIT_MODEL_NOTE},
             "proofs_verified": "%d/%d" % (acc_sum, tot_sum), "wrong_ciphertext_rejected": bool(neg_sum == world),
             "alt": alt, "latency_ms": latency,
-            "setup_s": round(setup_s, 2), "cpu_affinity": affinity,
+            "setup_s": round(setup_s, 2), "key_setup_s": key_setup_s, "srs": srs_report, "cpu_affinity": affinity, "cpu_affinity_by_rank": affinity_by_rank,
             "phase_ms_last_proof_avg": {k: round(v / args.steps, 2) for k, v in phase.items()},
             "roofline": {"bound": "hbm", "kernel": "k_accumulate (Pippenger bucket accumulation)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
@@ -411,7 +470,7 @@ def run(args, api, dist_env=None):
                          "avg_launch_ms": round(chip_ms, 4), "avg_launch_ms_source": chip_src, "algorithmic_bytes_per_launch": round(bytes_per_launch),
                          "launches": launches, "kernel_ms_per_step": round(kernel_ms_per_step, 1), "kernel_share_of_step": round(kernel_ms_per_step / (1e3 * elapsed / args.steps), 3) if elapsed > 0 else None,
                          "avg_launch_ms_in_situ": round(in_situ_ms, 4), "launch_overlap": round(overlap, 3),
-                         "one_context_probe": serial,
+                         "one_context_probe": serial, "proof": proof_roof,
                          "int_multiplier": {"unit": "T v_mad_u64_u32/s", "achieved": round(mads_per_launch / (chip_ms / 1e3), 2) if chip_ms > 0 else 0.0, "peak": 28.1,
                                             "frac": round(mads_per_launch / (chip_ms / 1e3) / 28.1, 4) if chip_ms > 0 else 0.0, "frac_of_wall": round(mads / elapsed / 28.1, 4),
                                             "note": "the kernel's real roof: 2649 v_mad_u64_u32 per bucket addition (7 Fq products x 378 on the curve's twisted Edwards model; round 2's XYZZ mixed add needed 3416), one addition per "
@@ -428,7 +487,7 @@ def run(args, api, dist_env=None):
         if (alt and alt["proofs_verified"] != "%d/%d" % (alt["proofs"], alt["proofs"])) or (latency and not latency["verified"]):
             out["error"] = "verification failure (alt / latency leg)"
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(samples_small=args.cpu_small_samples, samples_chunk=args.cpu_chunk_samples, chunk_blocks=chunk if chunk > 1 else 6, budget_s=150.0 + 75.0 * max(0, args.cpu_chunk_samples - 1))
+            cb = cpu_baseline(samples_small=args.cpu_small_samples, samples_chunk=args.cpu_chunk_samples, chunk_blocks=chunk if chunk > 1 else 6, budget_s=100.0 * max(1, args.cpu_chunk_samples))
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = round(value / cb["value"], 2)
         print(json.dumps(out), flush=True)

@@ -67,6 +67,18 @@ class _StubKey:
     def tables_built(self):
         return True, 0
 
+    def set_contexts(self, n):
+        self.log.append(("contexts", "key%d" % self.nbytes, n))
+
+    def srs_info(self):
+        return dict(max_degree=12582909, points_per_copy=12582910, copies=13, bytes=13 * 12582910 * 192, keys_sharing=2, lagrange_bytes=2 * 192 << 20, srs_build_s=3.0, setup_s=4.0)
+
+    def op_lists(self, message, key, throughput_path=True):
+        assert len(message) == self.nbytes
+        h, k = 1 << 20, 1 << 22
+        return {"h": h, "k": k, "x": 1024, "variables": 900000, "constraints": 900000, "nnz": [10, 20, 30], "blocks": self.nbytes // 16, "path": "throughput" if throughput_path else "lone",
+                "ntt": [[1024, 1], [h, 3], [h, 10], [k, 1]], "msm": [[h, "class_sum"], [3 * h, "buckets"], [h - 1, "buckets"], [h - 1, "second_bases"], [k - 1, "buckets"]]}
+
     @staticmethod
     def make(ct):
         import hashlib
@@ -116,6 +128,9 @@ class _StubApi:
     def stream_copy_bench(self, *a):
         raise RuntimeError("no device")
 
+    def mem_info(self):
+        return 100 << 30, 288 << 30
+
 
 def _bench_worker(rank, world, port, argv, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), ZKAES_BENCH_BACKEND="gloo")
@@ -150,6 +165,15 @@ def test_bench_strong_mode_two_ranks_gathers_and_verifies_every_proof():
     assert [e for e in timed0 if e[1] == 96][:2] == [("chunked", 96, 3), ("chunked", 96, 3)]
     log1 = out[1][1]
     assert sum(e[2] for e in log1 if e[1] == 96) - 3 == 4 and ("chunked", 64, 1) in log1      # 3 = warm-up (contexts) chunk-proofs
+    # the contexts are set per key through the C-ABI setter (no environment round-trip), dropped to 1 for the one-context probe and restored
+    assert [e[2] for e in log0 if e[0] == "contexts" and e[1] == "key96"] == [3, 1, 3] and "ZKAES_CONTEXTS" not in open(os.path.join(ROOT, "bench.py")).read()
+    # whole-proof roofline from the library's op lists (W + S + T + M), here the stub's canned lists
+    pr, h, k = res["roofline"]["proof"], 1 << 20, 1 << 22
+    assert pr["T"] == 64 * (1024 + 13 * h + k) and pr["M"] == 128 * (h + 3 * h + 2 * (h - 1) + (k - 1)) and pr["W"] == 16 * 6 + 16 + 32 * 900000
+    assert pr["S"] == 36 * 30 + 36 * 60 + 32 * 900000 + 64 * 900000 and pr["bytes"] == pr["W"] + pr["S"] + pr["T"] + pr["M"]
+    assert pr["k_accumulate_launches_per_proof"] == 4 and pr["ntt_list"]["transforms"] == 15 and pr["ntt_list"]["launches"] == 4
+    assert abs(pr["frac"] - pr["achieved_GBs"] / 8000.0) < 1e-6 and pr["msm_list"]["class_sum"]["count"] == 1
+    assert res["srs"]["copies"] == 13 and res["srs"]["keys_sharing_now"] == 2 and len(res["key_setup_s"]) == 1          # rank 0 holds the full-chunk key only
 
 
 def test_bench_batch_mode_two_ranks():
@@ -475,3 +499,32 @@ def test_srs_path_sharded_msm_through_rccl():
     for r in range(world):
         got, inf = out[r]
         assert not inf and zko.pt_unpack(got)[0] == want
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_real_prover_on_one_gpu():
+    """the N > 1 launch path with the REAL prover inside the driver's GPU suite.  `python bench.py --gpus 2` starts its two ranks itself (launch_ranks ->
+    torch.distributed.run); with ZKAES_BENCH_ONE_GPU=1 both ranks prove on device 0 and ZKAES_BENCH_BACKEND=gloo carries the collectives (RCCL needs one GPU per rank),
+    so a one-GPU box exercises everything but xGMI: bind_rank_cpus per rank, the remainder key (4 blocks) on the last rank beside its 6-block key, the chunk-range split of
+    ONE 100-block message (src/lib.rs:194 is the loop that shards), the all-gather of the proofs and rank 0 verifying all 17.  2-8 real GPUs stay unmeasured here."""
+    import subprocess
+    import time
+    env = dict(os.environ, ZKAES_BENCH_ONE_GPU="1", ZKAES_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--blocks", "100", "--steps", "2", "--warmup", "1", "--contexts", "4", "--no-cpu-baseline", "--alt-proofs", "0",
+           "--latency-samples", "0"]
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    took = time.perf_counter() - t0
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # ONE JSON line, from rank 0
+    res = json.loads(lines[0])
+    assert "error" not in res and res["n_gpus"] == 2 and res["scaling"] == "strong" and res["config"]["mode"] == "strong"
+    assert res["proofs_verified"] == "17/17" and res["wrong_ciphertext_rejected"] is True and res["config"]["proofs_total"] == 17 and res["value"] > 0
+    aff = res["cpu_affinity_by_rank"]
+    assert len(aff) == 2 and all(a and a["cpus"] >= 1 for a in aff) and [a["local_rank"] for a in aff] == [0, 1]
+    assert aff[0]["last"] < aff[1]["first"]                        # two disjoint, contiguous CPU shares
+    assert res["roofline"]["launches"] > 0 and res["roofline"]["proof"]["k_accumulate_launches_per_proof"] == 10
+    assert took < 240, took                                         # (90 s on an idle box: two key sets + 17 proofs)
