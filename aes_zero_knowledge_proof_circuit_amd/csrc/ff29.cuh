@@ -80,6 +80,32 @@ struct Fp29 {
         r.l[N - 1] = l[N - 1] + kp_spread<K>(N - 1) - b.l[N - 1] + c;
         return r;
     }
+    // ---- lazy limb arithmetic (round 5): NO carry propagation, limbs may exceed 29 bits.  A product takes ONE lazy operand with limbs < 6 x 2^29 beside a normalized one
+    // (a column then holds 9 limb products of < 6 x 2^58 plus the reduction's 9 x 2^58: 63 x 2^58 < 2^64); operator+ and sub<K> take a lazy left operand with limbs
+    // < 5 x 2^29 and return normalized limbs (their own carry chain absorbs it: 5 + 2 + carry stays below 2^32).  k_ntt_pass keeps the schedule.
+    ZK_HD Fp29 add_lazy(const Fp29 &b) const { Fp29 r; for (int i = 0; i < N; i++) r.l[i] = l[i] + b.l[i]; return r; }      // limbs: + 1 x 2^29
+    // a - b + K p for a NORMALIZED b (a product): limbs grow by less than 2 x 2^29.  On the device limbs 0..7 are ONE instruction each: kp_spread >= 2^29 - 1 >= b_i there, so
+    // l + (kp - b) = |kp - b| + l = v_sad_u32 (the top limb keeps the two-instruction form: b's excess sits there)
+    template <int K> ZK_HD Fp29 sub_lazy(const Fp29 &b) const {
+        Fp29 r;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (i < N - 1) { asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r.l[i]) : "s"(kp_spread<K>(i)), "v"(b.l[i]), "v"(l[i])); continue; }
+#endif
+            r.l[i] = l[i] + kp_spread<K>(i) - b.l[i];
+        }
+        return r;
+    }
+    // carry-propagate lazy limbs (each < 2^32) into normalized ones; the value is unchanged (the top limb keeps the excess)
+    ZK_HD Fp29 normalized() const {
+        Fp29 r;
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < N - 1; i++) { const uint64_t v = (uint64_t)l[i] + c; r.l[i] = (uint32_t)v & MASK; c = (uint32_t)(v >> B); }
+        r.l[N - 1] = l[N - 1] + c;
+        return r;
+    }
     // almost-Montgomery product (radix R' = 2^261): row-wise operand scanning, 64-bit column accumulators
     ZK_HD Fp29 operator*(const Fp29 &b) const {
         uint64_t t[2 * N];

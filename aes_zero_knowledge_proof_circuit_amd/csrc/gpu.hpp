@@ -41,6 +41,7 @@ void stream_destroy(stream_t s);
 // event timing on a stream (ms)
 void *event_create();
 void event_record(void *ev, stream_t s);
+void stream_wait_event(stream_t s, void *ev);   // work queued on s after this call starts only when the event (recorded on another stream) has completed: no host wait
 float event_elapsed_ms(void *start, void *stop);
 void event_destroy(void *ev);
 
@@ -105,6 +106,9 @@ template <class Fr> const Fr *domain_elements(int lg);   // device table g^i, i 
 struct MsmWorkspace;
 MsmWorkspace *msm_workspace_create();
 void msm_workspace_destroy(MsmWorkspace *ws);
+// lone-call lanes: run this workspace's k_accumulate launches (Edwards law) on `low_priority_stream` (stream_create_background), so that they yield workgroup slots to the
+// short kernels of the other lanes; nullptr = everything on the caller's stream (multi-proof calls)
+void msm_workspace_set_accumulate_stream(MsmWorkspace *ws, stream_t low_priority_stream);
 struct WorkspaceGuard {
     MsmWorkspace *ws = nullptr;
     WorkspaceGuard() : ws(msm_workspace_create()) {}
@@ -215,6 +219,11 @@ void poly_eval_multi(const F *const *p, const size_t *len, const F *x, int count
 // in-place batch inversion, zeros stay zero; every output optionally multiplied by `post`
 void batch_inverse(F *v, size_t n, const F *post_or_null, stream_t s);
 void sub_from_scalar(F *out, const F *v, const F &sc, size_t n, stream_t s);  // out[i] = sc - v[i]
+// r(alpha, X) = (alpha^n - X^n) / (alpha - X) from its closed form, in ONE fused pass over 3n points: on_h[i] = post_h / (alpha - h_i), on_c1[i] = post_1 / (alpha - g1 h_i),
+// on_c3[i] = post_3 / (alpha - g3 h_i) with elems = the n domain elements h_i (n = 2^lg_n) and post_* = alpha^n - (coset generator)^n.  Replaces one inverse and two forward
+// coset transforms of Marlin's second round.  alpha must not lie on H or on either coset (a denominator would vanish).
+void r_alpha_on_h_and_cosets(F *on_h, F *on_c1, F *on_c3, const F *elems, const F &alpha, const F &g1, const F &g3, const F &post_h, const F &post_1, const F &post_3, uint32_t n, int lg_n,
+                             stream_t s);
 // count how many of the first n elements are non-zero (host result; synchronizes)
 size_t count_nonzero(const F *p, size_t n, stream_t s);
 

@@ -671,9 +671,10 @@ __device__ __forceinline__ void quad_weighted(uint32_t *bufA, uint32_t *bufB, ui
     }
     __syncthreads();
 }
-// Two ways out.  dev_total != nullptr (the sharded-MSM entry points, whose sum must stay in device memory): the four workgroups of a set leave their terms in `part`,
-// the last one to finish (ticket) applies the weights, adds the four and converts to the Weierstrass XYZZ form -- a serial tail of lgG + lgC doublings on one wave.
-// dev_total == nullptr (every MSM of the prover): HOST TAIL.  The workgroups stop at the six UNWEIGHTED terms of a set,
+// Two ways out.  !host_tail (the sharded-MSM entry points, whose sum must stay in device memory at dev_total, and the per-window path with its dozens of sets, where the
+// host's share would add up): the four workgroups of a set leave their terms in `part`, the last one to finish (ticket) applies the weights, adds the four and converts
+// to the Weierstrass XYZZ form -- a serial tail of lgG + lgC doublings on one wave.
+// host_tail (one or two bucket sets: every table-path MSM of the prover): HOST TAIL.  The workgroups stop at the six UNWEIGHTED terms of a set,
 //     out[set][0] = sum W'   [1] = sum RS   [2], [3] = V1, V2 of the column term   [4], [5] = V1, V2 of the row term,
 // each converted to XYZZ by its own lane and written straight to host-mapped memory; reduce_host_tail() finishes
 //     2^(lgR+lgC) [0] + [1] + ([2] + 2^lc(C) [3]) + 2^lgC ([4] + 2^lc(R) [5])
@@ -681,10 +682,9 @@ __device__ __forceinline__ void quad_weighted(uint32_t *bufA, uint32_t *bufB, ui
 constexpr int RF_OUT = 6;
 template <class P>
 __global__ void __launch_bounds__(RF_THREADS) k_reduce_final(const AccTE<P> *__restrict__ rc, int lgR, int lgC, AccTE<P> *__restrict__ part, uint32_t *__restrict__ tickets,
-                                                              XYZZ<Fp<P>> *__restrict__ out, XYZZ<Fp<P>> *__restrict__ dev_total) {
+                                                              XYZZ<Fp<P>> *__restrict__ out, XYZZ<Fp<P>> *__restrict__ dev_total, bool host_tail) {
     __shared__ uint32_t bufA[RF_QUADS * PT_WORDS], bufB[RF_QUADS * PT_WORDS], scratch[32 * PT_WORDS];
     __shared__ uint32_t ticket;
-    const bool host_tail = dev_total == nullptr;
     const uint32_t R = 1u << lgR, C = 1u << lgC, jobs = 2 * R + C;
     const uint32_t set = blockIdx.x / 4, role = blockIdx.x % 4, quad = threadIdx.x >> 2;
     const int q = threadIdx.x & 3;
@@ -729,7 +729,7 @@ __global__ void __launch_bounds__(RF_THREADS) k_reduce_final(const AccTE<P> *__r
     if (threadIdx.x == 0) {
         const auto r = te_to_std_point<P>(*reinterpret_cast<const AccTE<P> *>(scratch));
         out[set] = r;
-        dev_total[set] = r;
+        if (dev_total) dev_total[set] = r;
     }
 }
 // the host's share of the Edwards reduction (k_reduce_final, host tail): the weighted sum of a set's six terms, Horner over the weights' shifts
@@ -775,6 +775,12 @@ struct MsmWorkspace {
     void *buckets = nullptr, *seg_s = nullptr, *seg_w = nullptr, *partial = nullptr, *tmp = nullptr;
     void *h_res = nullptr, *d_res = nullptr;                      // pinned host memory the last reduction kernel writes the window sums (+ flags) into, and its device address
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};      // [2 rep], [2 rep + 1]: around the k_accumulate launch of base array `rep`
+    // Lone-call lanes (msm_workspace_set_accumulate_stream): k_accumulate runs on this LOW-priority side stream, everything else of the MSM on the caller's stream.  A lone
+    // proof has up to four MSMs in flight on four lanes, and a k_accumulate grid (8,192 one-wave workgroups, milliseconds) otherwise keeps the other lanes' short kernels --
+    // digit grouping, bucket order, the reduction chain -- waiting for its last workgroup (1.5 ms waits in profiles/r05_lone_timeline_16_before_priority.md); at a lower
+    // priority it yields workgroup slots to them as its own workgroups retire, so the next MSM's grouping and the previous one's reduction run UNDER it.
+    hipStream_t acc_stream = nullptr;
+    hipEvent_t ev_dep = nullptr;
 };
 constexpr size_t RES_BYTES = 192 * MAX_WSUMS * 6 + 64;        // six terms per set when the Edwards reduction ends on the host (k_reduce_final RF_OUT)
 // the accumulators and the reduction's levels, sized by the number of buckets ACCUMULATED (twice the prepared ones when one prepared state serves two base arrays at once)
@@ -820,6 +826,11 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
     ensure_result(S, buckets);
 }
 MsmWorkspace *msm_workspace_create() { return new MsmWorkspace(); }
+void msm_workspace_set_accumulate_stream(MsmWorkspace *w, stream_t low_priority_stream) {
+    if (!w) throw GpuError("msm: null workspace");
+    w->acc_stream = (hipStream_t)low_priority_stream;
+    if (w->acc_stream && !w->ev_dep) HIP_CHECK(hipEventCreate(&w->ev_dep));
+}
 void msm_workspace_destroy(MsmWorkspace *w) {
     if (!w) return;
     for (void *p : {(void *)w->keys_a, (void *)w->keys_b, (void *)w->vals_a, (void *)w->vals_b, (void *)w->start, (void *)w->end, (void *)w->order, (void *)w->ovf_slot,
@@ -827,6 +838,7 @@ void msm_workspace_destroy(MsmWorkspace *w) {
                     (void *)w->ctrl, (void *)w->tickets, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->tmp}) dfree(p);
     if (w->h_res) (void)hipHostFree(w->h_res);
     for (auto e : w->ev) if (e) (void)hipEventDestroy(e);
+    if (w->ev_dep) (void)hipEventDestroy(w->ev_dep);
     delete w;
 }
 
@@ -894,24 +906,32 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
     }
 #endif
     uint32_t max_seg = (uint32_t)(pairs / cap + 1);
+    // the accumulation's own stream (Edwards law, lone-call lanes): see MsmWorkspace::acc_stream.  The overflow segments (k_accumulate_tail) read the same grouped list and
+    // write their own partials -- on the Edwards law they do not touch the buckets -- so they stay on the caller's stream, beside the accumulation; the fold waits for both.
+    hipStream_t sa = (Law::edwards && S.acc_stream) ? S.acc_stream : s;
+    if (sa != s) { HIP_CHECK(hipEventRecord(S.ev_dep, s)); HIP_CHECK(hipStreamWaitEvent(sa, S.ev_dep, 0)); }
     for (int rep = 0; rep < nrep; rep++) {
         const typename Law::Base *src = rep ? bases2 : bases;
-        HIP_CHECK(hipEventRecord(S.ev[2 * rep], s));          // every k_accumulate launch is bracketed and booked by itself (msm_stats: launches, points, pairs, ms)
-        hipLaunchKernelGGL((k_accumulate<Law>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, src, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb, cap,
+        HIP_CHECK(hipEventRecord(S.ev[2 * rep], sa));         // every k_accumulate launch is bracketed and booked by itself (msm_stats: launches, points, pairs, ms)
+        hipLaunchKernelGGL((k_accumulate<Law>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, sa, src, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb, cap,
                            (A *)S.buckets + rep * nb, S.deferred, DEFERRED_CAP, S.deferred_count);
         HIP_LAUNCH_CHECK();
-        HIP_CHECK(hipEventRecord(S.ev[2 * rep + 1], s));
+        HIP_CHECK(hipEventRecord(S.ev[2 * rep + 1], sa));
         // oversized buckets + deferred degenerate additions (none for uniformly distributed digits: every lane exits at once)
         hipLaunchKernelGGL((k_accumulate_tail<Law>), dim3((max_seg + 63) / 64), dim3(64), 0, s, src, S.sorted_vals, S.start, S.end, S.ctrl, S.ovf_bucket, S.ovf_off, max_seg, cap,
                            (A *)S.ovf_partial + rep * S.cap_ovf, (A *)S.buckets + rep * nb, S.deferred, DEFERRED_CAP, S.deferred_count);
         HIP_LAUNCH_CHECK();
-        // (overflow list entries <= buckets with more than `cap` pairs <= pairs / cap)
+    }
+    if (sa != s) HIP_CHECK(hipStreamWaitEvent(s, S.ev[2 * (nrep - 1) + 1], 0));
+    for (int rep = 0; rep < nrep; rep++) {
+        // overflow partials -> their buckets (overflow list entries <= buckets with more than `cap` pairs <= pairs / cap)
         hipLaunchKernelGGL((k_fold_overflow<A>), dim3((max_seg + 63) / 64), dim3(64), 0, s, (A *)S.buckets + rep * nb, S.ctrl, S.ovf_bucket, S.ovf_off, max_seg, (const A *)S.ovf_partial + rep * S.cap_ovf);
         HIP_LAUNCH_CHECK();
     }
     XYZZ<Fq> *res = (XYZZ<Fq> *)S.d_res;
     uint32_t segs = (1u << c) / RED_L1, groups = (segs + RED_L2 - 1) / RED_L2;
     [[maybe_unused]] int te_lgR = 0, te_lgC = 0;
+    [[maybe_unused]] bool te_host_tail = false;
 #ifdef ZKAES_MEASURE
     for (int rep = (knockin() & 2) ? 0 : 1; rep < 2; rep++)
 #endif
@@ -929,7 +949,8 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
         A *rc = (A *)S.partial, *part = rc + (size_t)nsets * jobs;
         hipLaunchKernelGGL((k_reduce_rc<P>), dim3((unsigned)nsets * jobs), dim3(RQ_THREADS), 0, s, (const A *)S.seg_s, (const A *)S.seg_w, lgR, lgC, rc);
         HIP_LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_reduce_final<P>), dim3(4u * (unsigned)nsets), dim3(RF_THREADS), 0, s, (const A *)rc, lgR, lgC, part, S.tickets, res, dev_wsum_out);
+        te_host_tail = !dev_wsum_out && nsets <= 4;
+        hipLaunchKernelGGL((k_reduce_final<P>), dim3(4u * (unsigned)nsets), dim3(RF_THREADS), 0, s, (const A *)rc, lgR, lgC, part, S.tickets, res, dev_wsum_out, te_host_tail);
         HIP_LAUNCH_CHECK();
         te_lgR = lgR; te_lgC = lgC;
     } else {
@@ -951,7 +972,7 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
     std::vector<XYZZ<Fq>> ws(nsets);
     uint32_t n_deferred = 0;
     sync((stream_t)s);        // (sleeps in throughput mode) the window sums are in pinned host memory once the stream has drained: no copy launch
-    if (Law::edwards && !dev_wsum_out) {       // host tail of the Edwards reduction: six unweighted terms per set
+    if (Law::edwards && te_host_tail) {       // host tail of the Edwards reduction: six unweighted terms per set
         std::vector<XYZZ<Fq>> terms((size_t)nsets * RF_OUT);
         memcpy(terms.data(), S.h_res, sizeof(XYZZ<Fq>) * terms.size());
         for (int i = 0; i < nsets; i++) ws[i] = reduce_host_tail<Fq>(terms.data() + (size_t)i * RF_OUT, te_lgR, te_lgC);

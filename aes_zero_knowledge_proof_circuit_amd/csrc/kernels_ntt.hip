@@ -85,6 +85,11 @@ __global__ void __launch_bounds__(256) k_ntt_pass(NttBatchArgs<Fr> batch, bool f
     const uint32_t half_tile = tile_elems >> 1;
     for (int st = 0; st < S; st++) {
         const int s = s0 + st;                       // butterflies of span 2^s
+        // Lazy stages (round 5): from stage 3 of a pass on (the first three keep the normalized forms their twiddle-1 shortcut needs) two stages in three skip the carry
+        // chains of x + t and x - t + 2p -- 18 instructions instead of 81 per butterfly.  Limb bound L (units of 2^29) of what sits in LDS: 1 after a normalized stage;
+        // a lazy stage adds 1 (p) or 2 (q): 1 -> 3 -> 5, the next stage is normalized again (its y operand, limbs < 5 x 2^29, is within the product's bound of 6; its
+        // x operand within operator+ / sub<2>'s bound of 5).  VALUE bounds are untouched (+ 2p per stage as before).  A pass that ends on a lazy stage normalizes at its store.
+        const bool lazy = st >= 3 && (st % 3) != 2;
         for (uint32_t b = threadIdx.x; b < half_tile; b += 256) {
             uint32_t lo = b & ((1u << L) - 1), rest = b >> L;
             uint32_t a_low = rest & ((1u << st) - 1), a_high = rest >> st;
@@ -100,7 +105,8 @@ __global__ void __launch_bounds__(256) k_ntt_pass(NttBatchArgs<Fr> batch, bool f
                 q = st == 0 ? x.template sub<1>(y) : (st == 1 ? x.template sub<4>(y) : x.template sub<8>(y));
             } else {
                 G t = y * tw[(size_t)j << (lg - s - 1)];
-                p = x + t; q = x.template sub<2>(t);
+                if (lazy) { p = x.add_lazy(t); q = x.template sub_lazy<2>(t); }
+                else { p = x + t; q = x.template sub<2>(t); }
             }
 #pragma unroll
             for (int k = 0; k < N; k++) { lds[k][e0] = p.l[k]; lds[k][e1] = q.l[k]; }
@@ -114,13 +120,14 @@ __global__ void __launch_bounds__(256) k_ntt_pass(NttBatchArgs<Fr> batch, bool f
 #pragma unroll
         for (int k = 0; k < N; k++) g.l[k] = lds[k][e];
         Fr v;
+        const bool last_lazy = S >= 4 && ((S - 1) % 3) != 2;          // (limbs < 3 or 5 x 2^29: fine as the lazy operand of the scaling products, normalized before a bare canonicalisation)
         if (scale && cs_tw) {                         // inverse coset transform: coefficient gi times g^-gi / n
             const uint32_t ex = (cs_c * gi) & cs_mask, half = (cs_mask >> 1) + 1;
             G t = (g * scale_by) * cs_tw[ex & (half - 1)];
             if (ex >= half) t = G::zero().template sub<2>(t);
             t.template canonical<1>().pack(v.l);
         } else if (scale) (g * scale_by).template canonical<1>().pack(v.l);
-        else g.template canonical<4>().pack(v.l);
+        else (last_lazy ? g.normalized() : g).template canonical<4>().pack(v.l);
         dst[gi] = v;
     }
 }

@@ -292,6 +292,76 @@ __global__ void __launch_bounds__(BI_BLOCK) k_batch_inverse(F *__restrict__ v, s
         acc = acc * x;
     }
 }
+// r(alpha, X) = (alpha^n - X^n) / (alpha - X) on H and on the two cosets W H, W^3 H of round 2, from its CLOSED FORM: on a coset g H the numerator is the constant
+// alpha^n - g^n, so the values are post_seg / (alpha - g_seg h_i) -- one fused pass (denominators formed in registers, Montgomery's trick per 512-lane workgroup as in
+// k_batch_inverse) over the 3n points instead of an inverse transform (values on H -> coefficients) and two forward coset transforms.  Segment seg = idx / n of the index space
+// [0, 3n): g_0 = 1 (no product), out[seg][i] = post[seg] / (alpha - g[seg] elems[i]).  alpha must lie outside all three cosets (the caller checks alpha^(4n) != 1).
+struct RAlpha3Args { F *out[3]; F g[3]; F post[3]; };
+template <int BI_CHUNK>
+__global__ void __launch_bounds__(BI_BLOCK) k_r_alpha3(RAlpha3Args A, const F *__restrict__ elems, F alpha, uint32_t n, int lg_n) {
+    __shared__ F pre_s[BI_BLOCK], suf_s[BI_BLOCK];
+    __shared__ F inv_total;
+    const int lane = threadIdx.x;
+    const size_t total = (size_t)3 * n;
+    size_t t = (size_t)blockIdx.x * BI_BLOCK + lane;
+    size_t s0 = t * BI_CHUNK;
+    if (s0 > total) s0 = total;
+    size_t e = s0 + BI_CHUNK < total ? s0 + BI_CHUNK : total;
+    F pre[BI_CHUNK];
+    F acc = F::one();
+    for (size_t i = s0; i < e; i++) {                   // the denominators are parked in the output arrays (re-read below, as k_batch_inverse re-reads its input)
+        const uint32_t seg = (uint32_t)(i >> lg_n), k = (uint32_t)i & (n - 1);
+        const F h = elems[k];
+        const F x = alpha - (seg == 0 ? h : h * A.g[seg]);
+        A.out[seg][k] = x;
+        pre[i - s0] = acc;
+        acc = acc * x;
+    }
+    pre_s[lane] = acc; suf_s[lane] = acc;
+    __syncthreads();
+    for (int d = 1; d < BI_BLOCK; d <<= 1) {
+        F a, b;
+        const bool ha = lane >= d, hb = lane + d < BI_BLOCK;
+        if (ha) a = pre_s[lane - d];
+        if (hb) b = suf_s[lane + d];
+        __syncthreads();
+        if (ha) pre_s[lane] = pre_s[lane] * a;
+        if (hb) suf_s[lane] = suf_s[lane] * b;
+        __syncthreads();
+    }
+    if (lane == 0) inv_total = BI_CHUNK == 4 ? suf_s[0].inverse() : suf_s[0].inverse_fermat();
+    __syncthreads();
+    acc = inv_total;
+    if (lane > 0) acc = acc * pre_s[lane - 1];
+    if (lane + 1 < BI_BLOCK) acc = acc * suf_s[lane + 1];
+    // the numerator: one product per lane when the lane's chunk lies in one segment (n >= BI_CHUNK: always, both are powers of two), else per element
+    const bool per_elem = n < (uint32_t)BI_CHUNK;
+    if (!per_elem && s0 < e) acc = acc * A.post[(uint32_t)(s0 >> lg_n)];
+    for (size_t i = e; i-- > s0;) {
+        const uint32_t seg = (uint32_t)(i >> lg_n), k = (uint32_t)i & (n - 1);
+        const F x = A.out[seg][k];
+        F r = acc * pre[i - s0];
+        if (per_elem) r = r * A.post[seg];
+        A.out[seg][k] = r;
+        acc = acc * x;
+    }
+}
+void r_alpha_on_h_and_cosets(F *on_h, F *on_c1, F *on_c3, const F *elems, const F &alpha, const F &g1, const F &g3, const F &post_h, const F &post_1, const F &post_3, uint32_t n, int lg_n,
+                             stream_t s) {
+    if (!n) return;
+    RAlpha3Args A;
+    A.out[0] = on_h; A.out[1] = on_c1; A.out[2] = on_c3;
+    A.g[0] = F::one(); A.g[1] = g1; A.g[2] = g3;
+    A.post[0] = post_h; A.post[1] = post_1; A.post[2] = post_3;
+    const size_t total = (size_t)3 * n;
+    if (throughput_mode() || total > ((size_t)1 << 21)) {
+        size_t threads = (total + 15) / 16;
+        hipLaunchKernelGGL(k_r_alpha3<16>, dim3((unsigned)((threads + BI_BLOCK - 1) / BI_BLOCK)), dim3(BI_BLOCK), 0, (hipStream_t)s, A, elems, alpha, n, lg_n); HIP_LAUNCH_CHECK();
+    } else {
+        size_t threads = (total + 3) / 4;
+        hipLaunchKernelGGL(k_r_alpha3<4>, dim3((unsigned)((threads + BI_BLOCK - 1) / BI_BLOCK)), dim3(BI_BLOCK), 0, (hipStream_t)s, A, elems, alpha, n, lg_n); HIP_LAUNCH_CHECK();
+    }
+}
 void batch_inverse(F *v, size_t n, const F *post, stream_t s) {
     if (!n) return;
     const F post_v = post ? *post : F::one();

@@ -579,15 +579,22 @@ struct ProverContext {
     size_t poly_len[9] = {0};
     DevBuf e[5], big_tmp, f_poly, acc, wit, wit2, scratch;
     ProverTimings timings;
-    // MSM lanes: lane 0 = (stream, msm_ws) above; lanes 1..3 (own stream + MSM scratch, created on first use) let a LONE encrypt() call run the independent
-    // commitments of a round side by side (latency path only: with several proofs in flight the chip is already full)
-    struct Lane { gpu::stream_t stream = nullptr; gpu::MsmWorkspace *ws = nullptr; };
-    Lane lane[4];
+    // MSM lanes: lane 0 = (stream, msm_ws) above; lanes 1..4 (own stream + MSM scratch, created on first use) let a LONE encrypt() call run the independent
+    // commitments of a round side by side, each started as soon as ITS polynomial exists (latency path only: with several proofs in flight the chip is already full)
+    static constexpr int N_LANES = 5;
+    struct Lane { gpu::stream_t stream = nullptr; gpu::MsmWorkspace *ws = nullptr; void *ready = nullptr; /* event: the lane's input exists on the main stream */
+                  gpu::stream_t acc = nullptr; /* low-priority side stream of the lane's bucket accumulations (gpu.hpp msm_workspace_set_accumulate_stream) */ };
+    Lane lane[N_LANES];
     DevBuf acc_b, wit_b, wit2_b, scratch_b;             // second set of opening buffers (the two openings run side by side on the latency path)
     bool throughput = false;           // set per proof: several proofs in flight (chunked / batch calls) -> window tables; a lone encrypt() call -> per-window buckets
     ProverContext() { stream = gpu::stream_create(); msm_ws = gpu::msm_workspace_create(); lane[0].stream = stream; lane[0].ws = msm_ws; }
-    // (lane 3 is the background lane: the early mask commitment of round 1 runs there, under the witness generation on the main stream)
-    void ensure_lanes() { for (int i = 1; i < 4; i++) if (!lane[i].stream) { lane[i].stream = i == 3 ? gpu::stream_create_background() : gpu::stream_create(); lane[i].ws = gpu::msm_workspace_create(); } }
+    void ensure_lanes() {
+        for (int i = 1; i < N_LANES; i++) if (!lane[i].stream) {
+            lane[i].stream = gpu::stream_create(); lane[i].ws = gpu::msm_workspace_create(); lane[i].ready = gpu::event_create();
+            lane[i].acc = gpu::stream_create_background();
+            gpu::msm_workspace_set_accumulate_stream(lane[i].ws, lane[i].acc);
+        }
+    }
     ~ProverContext() {
         gpu::dfree(d_trace); gpu::dfree(d_z); gpu::dfree(d_msg); gpu::dfree(d_key);
         for (auto p : d_cls) gpu::dfree(p);
@@ -596,7 +603,7 @@ struct ProverContext {
         for (auto &b : poly) b.release();
         for (auto &b : e) b.release();
         for (DevBuf *b : {&acc_b, &wit_b, &wit2_b, &scratch_b}) b->release();
-        for (int i = 1; i < 4; i++) if (lane[i].stream) { gpu::msm_workspace_destroy(lane[i].ws); gpu::stream_destroy(lane[i].stream); }
+        for (int i = 1; i < N_LANES; i++) if (lane[i].stream) { gpu::msm_workspace_destroy(lane[i].ws); gpu::stream_destroy(lane[i].stream); gpu::stream_destroy(lane[i].acc); gpu::event_destroy(lane[i].ready); }
         gpu::msm_workspace_destroy(msm_ws);
         gpu::stream_destroy(stream);
     }
@@ -621,7 +628,10 @@ class ProvingKeyImpl {
     std::shared_ptr<LagrangeSrs> lag;
     SrsPoint *d_powers = nullptr, *d_shifted = nullptr;
     size_t srs_stride = 0;
-    size_t table_min_n = 500000;    // MSMs below this many points keep the per-window buckets (their own, smaller c)
+#ifndef ZKAES_TABLE_MIN_N
+#define ZKAES_TABLE_MIN_N 100000
+#endif
+    size_t table_min_n = ZKAES_TABLE_MIN_N;    // MSMs below this many points keep the per-window buckets (their own, smaller c)
     bool use_lagrange = true;
     int table_c = 20;
     bool use_tables = false;   // window tables for the large MSMs (on when |K| >= 2^20, memory allows and the key was not made with KEY_NO_TABLES)
@@ -752,23 +762,43 @@ class ProvingKeyImpl {
         else gpu::msm_prepare<Bls377>(ln.ws, wit, wlen, swit, slen, lowest_shift + shift_off, ln.stream);
     }
     XYZZ<Fq377> msm_opening_finish(Lane &ln) { return gpu::msm_finish<Bls377>(ln.ws, d_powers, ln.stream); }
-    // Run the independent jobs of one prover step.  Throughput calls (several proofs in flight) and ZKAES_LANES=0 run them one after the other on lane 0;
-    // a lone encrypt() call gives each job its own lane (stream + MSM scratch) and a host thread, after the main stream has produced their inputs.
+    // The independent MSM jobs of a prover round.  A lone encrypt() call starts each job AT ONCE on a lane of its own (stream + MSM scratch + host thread) -- gated, where
+    // its input is still being produced, on an event of the main stream (no host wait) -- while the calling thread keeps queuing the rest of the round on the main stream:
+    // the latency-bound remainder of a round (small dependent kernels) then runs under the job's bucket accumulation instead of in front of it.  Multi-proof calls
+    // (several proofs in flight: the chip is full anyway) and ZKAES_LANES=0 defer the jobs to join(), one after the other on lane 0, as before.
     bool use_lanes = true;
-    void run_jobs(ProverContext &cx, std::vector<std::function<void(Lane &)>> &jobs) {
-        if (cx.throughput || !use_lanes || jobs.size() < 2) { for (auto &j : jobs) j(cx.lane[0]); return; }
-        if (jobs.size() > 4) throw std::logic_error("run_jobs: more jobs than lanes");
-        cx.ensure_lanes();
-        gpu::sync(cx.stream);
-        std::vector<std::string> errs(jobs.size());
-        std::vector<std::thread> th;
-        const int dev = device;
-        for (size_t i = 1; i < jobs.size(); i++)
-            th.emplace_back([&, i] { try { gpu::set_device(dev); jobs[i](cx.lane[i]); } catch (const std::exception &e) { errs[i] = e.what(); if (errs[i].empty()) errs[i] = "error"; } });
-        try { jobs[0](cx.lane[0]); } catch (const std::exception &e) { errs[0] = e.what(); if (errs[0].empty()) errs[0] = "error"; }
-        for (auto &t : th) t.join();
-        for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
-    }
+    struct RoundJobs {
+        ProvingKeyImpl &K; ProverContext &cx;
+        const bool async;
+        struct Slot { std::thread th; std::string err; std::function<void(Lane &)> fn; };
+        std::vector<std::unique_ptr<Slot>> slots;
+        RoundJobs(ProvingKeyImpl &k, ProverContext &c) : K(k), cx(c), async(!c.throughput && k.use_lanes) { if (async) cx.ensure_lanes(); }
+        // gate = true: the job's input is produced by work already queued on the main stream (an event is recorded there now and the lane waits for it on the device);
+        // gate = false: the caller knows the input is complete
+        void start(int lane_i, std::function<void(Lane &)> fn, bool gate) {
+            std::unique_ptr<Slot> sl(new Slot());
+            sl->fn = std::move(fn);
+            Slot *p = sl.get();
+            slots.push_back(std::move(sl));
+            if (!async) return;
+            if (lane_i < 1 || lane_i >= ProverContext::N_LANES) throw std::logic_error("RoundJobs: bad lane");
+            Lane &ln = cx.lane[lane_i];
+            if (gate) { gpu::event_record(ln.ready, cx.stream); gpu::stream_wait_event(ln.stream, ln.ready); }
+            const int dev = K.device;
+            p->th = std::thread([p, &ln, dev] { try { gpu::set_device(dev); p->fn(ln); } catch (const std::exception &e) { p->err = e.what(); if (p->err.empty()) p->err = "error"; } });
+        }
+        void join() {
+            std::string first;
+            for (auto &sl : slots) {
+                if (async) { if (sl->th.joinable()) sl->th.join(); }
+                else { try { sl->fn(cx.lane[0]); } catch (const std::exception &e) { sl->err = e.what(); if (sl->err.empty()) sl->err = "error"; } }
+                if (first.empty() && !sl->err.empty()) first = sl->err;
+            }
+            slots.clear();
+            if (!first.empty()) throw std::runtime_error(first);
+        }
+        ~RoundJobs() { for (auto &sl : slots) if (sl->th.joinable()) sl->th.join(); }       // (an exception must not leave a thread running on this context)
+    };
 
     void setup(int kind, size_t message_len, const SrsLiterals &lits, unsigned flags);
     Proof prove(ProverContext &cx, const uint8_t *trace_or_null, const uint8_t *msg, size_t len, const uint8_t *key, const uint8_t *zk_seed, bool throughput = false);
@@ -952,16 +982,9 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
         poly_len[3] = 3 * n;
     }
     for (auto &lp : r1) draw_rand(lp, zk);
-    const bool early_mask = !cx.throughput && use_lanes;
-    std::thread mask_thread;
-    std::string mask_err;
-    struct JoinGuard { std::thread &t; ~JoinGuard() { if (t.joinable()) t.join(); } } mask_guard{mask_thread};       // (an exception below must not leave the thread running on this context)
-    if (early_mask) {
-        cx.ensure_lanes();
-        gpu::sync(s);                    // the mask polynomial is in place (nothing else is on the stream yet)
-        const int dev = device;
-        mask_thread = std::thread([&, dev] { try { gpu::set_device(dev); mpc_commit(cx, cx.lane[3], r1[3]); } catch (const std::exception &e) { mask_err = e.what(); if (mask_err.empty()) mask_err = "error"; } });
-    }
+    RoundJobs jobs(*this, cx);
+    if (jobs.async) gpu::sync(s);        // the mask polynomial is in place (nothing else is on the stream yet)
+    jobs.start(3, [&](Lane &ln) { mpc_commit(cx, ln, r1[3]); }, false);
     // ---- witness: trace -> z (bytes) -> z_A, z_B
     if (host_trace) gpu::h2d(d_trace, host_trace, c.trace_bytes, s);
     else {
@@ -973,8 +996,22 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     gpu::spmv_bits(zb_ev.p, cx.d_cls[2], n, d_b_rowptr, d_b_col, d_b_coeff, c.num_constraints, d_z, s);
     if (use_lagrange) gpu::w_classes(cx.d_cls[0], d_z, (uint32_t)n, (uint32_t)m, (uint32_t)c.num_witness, s);
     std::vector<uint8_t> inst(m);
-    gpu::d2h(inst.data(), d_z, m, s);
+    gpu::d2h(inst.data(), d_z, m, s);            // (drains the main stream: the evaluation classes of w, z_A, z_B exist from here on)
     timings.witness_ms = ms_since(t0); t0 = Clock::now();
+    // The commitments of w, z_A, z_B are class sums over the Lagrange-basis SRS (lagrange_commit): they need the evaluation classes only, NOT the interpolated polynomials --
+    // so a lone call starts them here, beside the mask commitment, and the round's interpolations (needed from round 2 on) run under them on the main stream.  A class sum
+    // that declines (a value outside the small classes) falls back to the MSM over the coefficients after the interpolation.
+    bool declined[3] = {false, false, false};
+    static const int r1_lane[3] = {1, 2, 4};
+    for (int i = 0; i < 3; i++) {
+        Labeled *lp = &r1[i];
+        bool *dec = &declined[i];
+        jobs.start(r1_lane[i], [&, lp, dec](Lane &ln) {
+            if (use_lagrange && lagrange_commit(cx, ln, lp->idx, inst, rhos[lp->idx], lp->rand, lp->comm.comm)) { lp->comm.has_shifted = false; return; }
+            if (jobs.async) { *dec = true; return; }     // (the coefficients are not there yet: the calling thread commits after the interpolation)
+            mpc_commit(cx, ln, *lp);
+        }, false);
+    }
     // ---- transcript init: "MARLIN-2019" || index_vk || public_input
     FiatShamirRng fs;
     {
@@ -999,21 +1036,8 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     poly_len[0] = n + 1 - m;
     gpu::poly_add_at(poly[1].p, 0, rhos[1].neg(), s); gpu::poly_set_at(poly[1].p, n, rhos[1], s); poly_len[1] = n + 1;
     gpu::poly_add_at(poly[2].p, 0, rhos[2].neg(), s); gpu::poly_set_at(poly[2].p, n, rhos[2], s); poly_len[2] = n + 1;
-    using Jobs = std::vector<std::function<void(Lane &)>>;
-    {
-        Jobs jobs;
-        for (auto &lp_ : r1) {
-            Labeled *lp = &lp_;
-            if (early_mask && lp->idx == 3) continue;          // (already under way on lane 3)
-            jobs.push_back([&, lp](Lane &ln) {
-                if (use_lagrange && lp->idx < 3 && lagrange_commit(cx, ln, lp->idx, inst, rhos[lp->idx], lp->rand, lp->comm.comm)) { lp->comm.has_shifted = false; return; }
-                mpc_commit(cx, ln, *lp);
-            });
-        }
-        run_jobs(cx, jobs);
-        if (mask_thread.joinable()) mask_thread.join();
-        if (!mask_err.empty()) throw std::runtime_error(mask_err);
-    }
+    jobs.join();
+    for (int i = 0; i < 3; i++) if (declined[i]) mpc_commit(cx, cx.lane[0], r1[i]);
     { Bytes o; for (auto &lp : r1) o.commitment_tobytes(lp.comm); fs.absorb(o.b); }
     auto sample_outside_h = [&]() { Fr t; do { t = fs.rng().rand_field<Fr>(); } while (eval_vanishing(n, t).is_zero()); return t; };
     Fr alpha = sample_outside_h();
@@ -1021,34 +1045,44 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     timings.round1_ms = ms_since(t0); t0 = Clock::now();
     // ---- second round
     Labeled r2[3] = {{4, -1, false}, {5, (long)(n - 2), true}, {6, -1, false}};
+    for (auto &lp : r2) draw_rand(lp, zk);           // (the prover RNG is consumed in label order before any commitment is computed: draw_rand)
     Fr vh_alpha = eval_vanishing(n, alpha);
     const F *elems = gpu::domain_elements<F>(lg_n);
-    gpu::sub_from_scalar(ra_ev.p, elems, alpha, n, s);
-    gpu::batch_inverse(ra_ev.p, n, &vh_alpha, s);                            // r(alpha, h) = v_H(alpha) / (alpha - h)
-    gpu::t_evals(tmp_n.p, (uint32_t)n, t_partial.p, t_nseg, d_t_colptr, d_t_seg_start, d_t_seg_end, d_t_heavy, t_nheavy, d_t_row, d_t_mat, d_t_coeff, ra_ev.p, eta_a, eta_b, eta_c, s);
     // q = q_1 - mask = r(alpha, X) (eta_A z_A + eta_B z_B + eta_C z_A z_B) - t z has degree < 3|H|; instead of five zero-padded transforms to the 4|H| domain, a pointwise
     // product there and a 4|H|-point inverse (18 passes over 4|H| elements), it is taken on THREE cosets of H inside that domain: on H itself every factor is already known
     // (the evaluation vectors of round 1 -- the blinding terms rho v_H vanish there), on W H and W^3 H (W the 4|H|-th root) each factor costs one |H|-point coset transform, where
     // rho (X^|H| - 1) is the constant rho (zeta^c - 1), zeta = W^|H|.  Three |H|-point inverses give the interpolants Q0, Q1, Q3; q_1_combine solves for q's three |H|-coefficient
-    // thirds and divides by v_H = X^|H| - 1 in coefficient space, mask included: 15 |H|-point transforms in all, no 4|H| buffer traffic, no division kernel -- and since
-    // transforms of one shape share their launches (ntt_batch), six launches: {t, r, Q0} inverse, {z_A, z_B, r, t, z} x {W H, W^3 H} forward, {Q1, Q3} inverse.
+    // thirds and divides by v_H = X^|H| - 1 in coefficient space, mask included: no 4|H| buffer traffic, no division kernel.
+    // Round 5: r(alpha, X) = (alpha^|H| - X^|H|) / (alpha - X) needs NO transform at all -- on the coset W^c H its numerator is the constant alpha^|H| - zeta^c, so its values on H
+    // and on both cosets come from ONE fused batch inversion over 3|H| denominators (r_alpha_on_h_and_cosets) instead of an inverse transform to coefficients and two forward
+    // coset transforms: 12 |H|-point transforms in round 2 (was 15) in five launches: {t, Q0} inverse, {z_A, z_B, t, z} x {W H, W^3 H} forward, {Q1, Q3} inverse.
+    // And t's commitment starts as soon as t's coefficients exist, under the rest of the round (lone call).
     {
         using Job = gpu::NttJob<F>;
-        const Fr zeta = domain_gen(lg_n4).pow_u64(n);                    // primitive 4th root of unity
+        const Fr W = domain_gen(lg_n4), W3 = W * W * W;
+        const Fr zeta = W.pow_u64(n);                                    // primitive 4th root of unity
         const Fr inv2 = Fr::from_u64(2).inverse(), inv2zeta = (zeta + zeta).inverse(), zero = Fr::zero();
         F *Q0 = e[1].p, *Q1 = e[1].p + n, *Q3 = e[1].p + 2 * n, *zH = e[0].p, *qH = e[0].p + n;
-        gpu::z_evals_h(zH, d_z, (uint32_t)n, (uint32_t)m, (uint32_t)c.num_witness, s);
-        gpu::q1_coset_pointwise(qH, ra_ev.p, za_ev.p, zb_ev.p, tmp_n.p, zH, zero, zero, zero, eta_a, eta_b, eta_c, n, s);
-        const Job inv0[3] = {{poly[4].p, tmp_n.p, 0}, {ra_poly.p, ra_ev.p, 0}, {Q0, qH, 0}};
-        gpu::ntt_batch<F>(inv0, 3, n, lg_n, true, 0, s); poly_len[4] = n;
-        gpu::z_poly_from_w(zpoly.p, poly[0].p, poly_len[0], x_poly.p, (uint32_t)m, n, s);
         // per coset: z_A, z_B, r, t in e[2 | 3], z and the product in e[4]
         F *cs_buf[2][6];
         for (int i = 0; i < 2; i++) { for (int j = 0; j < 4; j++) cs_buf[i][j] = e[2 + i].p + j * n; cs_buf[i][4] = e[4].p + i * n; cs_buf[i][5] = e[4].p + (2 + i) * n; }
-        const F *srcs[5] = {poly[1].p, poly[2].p, ra_poly.p, poly[4].p, zpoly.p};
+        const Fr alpha_n = vh_alpha + Fr::one();
+        const bool closed_form = !eval_vanishing(n4, alpha).is_zero();    // alpha on one of the cosets (probability ~2^-230): a denominator would vanish -> transforms
+        if (closed_form) gpu::r_alpha_on_h_and_cosets(ra_ev.p, cs_buf[0][2], cs_buf[1][2], elems, alpha, W, W3, vh_alpha, alpha_n - zeta, alpha_n + zeta, (uint32_t)n, lg_n, s);
+        else { gpu::sub_from_scalar(ra_ev.p, elems, alpha, n, s); gpu::batch_inverse(ra_ev.p, n, &vh_alpha, s); }      // r(alpha, h) = v_H(alpha) / (alpha - h)
+        gpu::t_evals(tmp_n.p, (uint32_t)n, t_partial.p, t_nseg, d_t_colptr, d_t_seg_start, d_t_seg_end, d_t_heavy, t_nheavy, d_t_row, d_t_mat, d_t_coeff, ra_ev.p, eta_a, eta_b, eta_c, s);
+        gpu::z_evals_h(zH, d_z, (uint32_t)n, (uint32_t)m, (uint32_t)c.num_witness, s);
+        gpu::q1_coset_pointwise(qH, ra_ev.p, za_ev.p, zb_ev.p, tmp_n.p, zH, zero, zero, zero, eta_a, eta_b, eta_c, n, s);
+        const Job inv0[3] = {{poly[4].p, tmp_n.p, 0}, {Q0, qH, 0}, {ra_poly.p, ra_ev.p, 0}};
+        gpu::ntt_batch<F>(inv0, closed_form ? 2 : 3, n, lg_n, true, 0, s); poly_len[4] = n;
+        jobs.start(1, [&](Lane &ln) { mpc_commit(cx, ln, r2[0]); }, true);                      // t
+        gpu::z_poly_from_w(zpoly.p, poly[0].p, poly_len[0], x_poly.p, (uint32_t)m, n, s);
+        const F *srcs[5] = {poly[1].p, poly[2].p, poly[4].p, zpoly.p, ra_poly.p};
+        static const int dst_slot[5] = {0, 1, 3, 4, 2};
+        const int nsrc = closed_form ? 4 : 5;
         Job fwd[10];
-        for (int i = 0; i < 2; i++) for (int j = 0; j < 5; j++) fwd[5 * i + j] = Job{cs_buf[i][j], srcs[j], i == 0 ? 1 : 3};
-        gpu::ntt_batch<F>(fwd, 10, n, lg_n, false, lg_n4, s);
+        for (int i = 0; i < 2; i++) for (int j = 0; j < nsrc; j++) fwd[nsrc * i + j] = Job{cs_buf[i][dst_slot[j]], srcs[j], i == 0 ? 1 : 3};
+        gpu::ntt_batch<F>(fwd, 2 * nsrc, n, lg_n, false, lg_n4, s);
         for (int i = 0; i < 2; i++) {
             const Fr zc = i == 0 ? zeta : zeta.neg();                    // zeta^cs: the value of X^|H| on the coset
             // the coefficient of X^|H| (rho of z_A, z_B; rho_w for z = w v_X + x) contributes rho zeta^cs everywhere on the coset
@@ -1059,17 +1093,15 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
         gpu::q1_combine(poly[6].p, poly[5].p, Q0, Q1, Q3, poly[3].p, inv2, inv2zeta, n, s);     // h_1 (2|H| coefficients), g_1 = remainder / X
         poly_len[6] = 2 * n; poly_len[5] = n - 1;
     }
-    for (auto &lp : r2) draw_rand(lp, zk);
-    {
-        Jobs jobs;
-        for (auto &lp_ : r2) { Labeled *lp = &lp_; jobs.push_back([&, lp](Lane &ln) { mpc_commit(cx, ln, *lp); }); }
-        run_jobs(cx, jobs);
-    }
+    jobs.start(2, [&](Lane &ln) { mpc_commit(cx, ln, r2[1]); }, true);                          // g_1 (plain + shifted)
+    jobs.start(4, [&](Lane &ln) { mpc_commit(cx, ln, r2[2]); }, true);                          // h_1
+    jobs.join();
     { Bytes o; for (auto &lp : r2) o.commitment_tobytes(lp.comm); fs.absorb(o.b); }
     Fr beta = sample_outside_h();
     timings.round2_ms = ms_since(t0); t0 = Clock::now();
     // ---- third round
     Labeled r3[2] = {{7, (long)(k - 2), false}, {8, -1, false}};
+    for (auto &lp : r3) draw_rand(lp, zk);
     Fr vh_beta = eval_vanishing(n, beta);
     Fr vv = vh_alpha * vh_beta, ea_vv = eta_a * vv, eb_vv = eta_b * vv, ec_vv = eta_c * vv, alpha_beta = alpha * beta;
     gpu::round3_den(e[0].p, ix_ev[0].p, ix_ev[1].p, alpha, beta, k, s);
@@ -1078,24 +1110,36 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     gpu::mul_pointwise(e[1].p, e[1].p, e[0].p, k, s);                         // f on K
     gpu::ntt<F>(f_poly.p, e[1].p, k, lg_k, true, s);
     gpu::d2d(poly[7].p, f_poly.p + 1, (k - 1) * sizeof(F), s); poly_len[7] = k - 1;   // g_2 = (f - f(0)) / X
+    jobs.start(1, [&](Lane &ln) { mpc_commit(cx, ln, r3[0]); }, true);                           // g_2 (plain + shifted): under the rest of the round
     // h_2 = (a - b f) / v_K with a = sum eta_M v_H(alpha) v_H(beta) val_M, b = (beta - row)(alpha - col) expanded with row_col: degree <= |K| - 2,
     // so it is interpolated from ONE coset of K, where v_K is the constant g^|K| - 1 and a, b come from the key's precomputed coset values
     gpu::ntt_scaled<F>(e[2].p, f_poly.p, k, lg_k, false, coset_tab, s);       // f on g K (the scaling by g^i rides on the transform's first pass)
     gpu::h2_coset(e[0].p, ix_cs[0].p, ix_cs[1].p, ix_cs[2].p, ix_cs[3].p, ix_cs[4].p, ix_cs[5].p, e[2].p, alpha, beta, alpha_beta, ea_vv, eb_vv, ec_vv, coset_vk_inv, k, s);
     gpu::ntt_scaled<F>(poly[8].p, e[0].p, k, lg_k, true, coset_tab_inv, s);   // h_2: interpolated from g K, scaled back by g^-i at the last pass's store (the coefficient of X^(|K|-1) is zero for a satisfied instance)
     poly_len[8] = k - 1;
-    for (auto &lp : r3) draw_rand(lp, zk);
-    {
-        Jobs jobs;
-        for (auto &lp_ : r3) { Labeled *lp = &lp_; jobs.push_back([&, lp](Lane &ln) { mpc_commit(cx, ln, *lp); }); }
-        run_jobs(cx, jobs);
+    jobs.start(2, [&](Lane &ln) { mpc_commit(cx, ln, r3[1]); }, true);                           // h_2
+    // ---- evaluations.  Three of the four points are evaluations at beta, known since round 2: a lone call computes them (and the beta opening's shifted witness
+    // g_1 / (X - beta)) NOW, on the main stream under round 3's commitments; only g_2(gamma) has to wait for gamma.
+    Proof pf;
+    const bool early_evals = jobs.async;
+    if (early_evals) {
+        const F *ps[3] = {poly[5].p, poly[4].p, poly[2].p};
+        const size_t ls[3] = {poly_len[5], poly_len[4], poly_len[2]};
+        const Fr at[3] = {beta, beta, beta};
+        Fr ev[3];
+        gpu::poly_eval_multi(ps, ls, at, 3, ev, scratch.p, scratch.n, s);           // g_1(beta), t(beta), z_b(beta)
+        pf.evals[0] = ev[0]; pf.evals[2] = ev[1]; pf.evals[3] = ev[2];
+        gpu::divide_by_linear(wit2.p, poly[5].p, poly_len[5], beta, scratch.p, scratch.n, s);
     }
+    jobs.join();
     { Bytes o; for (auto &lp : r3) o.commitment_tobytes(lp.comm); fs.absorb(o.b); }
     Fr gamma = fs.rng().rand_field<Fr>();
     timings.round3_ms = ms_since(t0); t0 = Clock::now();
-    // ---- evaluations, opening challenge
-    Proof pf;
-    {
+    if (early_evals) {
+        const F *ps[1] = {poly[7].p};
+        const size_t ls[1] = {poly_len[7]};
+        gpu::poly_eval_multi(ps, ls, &gamma, 1, &pf.evals[1], scratch.p, scratch.n, s);   // g_2(gamma)
+    } else {
         const F *ps[4] = {poly[5].p, poly[7].p, poly[4].p, poly[2].p};
         const size_t ls[4] = {poly_len[5], poly_len[7], poly_len[4], poly_len[2]};
         const Fr at[4] = {beta, gamma, beta, beta};
@@ -1117,12 +1161,12 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     auto host_divide_by_linear = [](Fr q[2], const Fr p[3], const Fr &z) { q[1] = p[2]; q[0] = p[1] + z * p[2]; };
     auto host_eval3 = [](const Fr p[3], const Fr &z) { return p[0] + z * (p[1] + z * p[2]); };
     // the two openings are independent: on the latency path they run side by side, the second one on its own buffers
-    if (!cx.throughput && use_lanes && !cx.acc_b.p) {
+    if (jobs.async && !cx.acc_b.p) {
         cx.acc_b.alloc(acc.n); cx.wit_b.alloc(wit.n); cx.wit2_b.alloc(wit2.n); cx.scratch_b.alloc(scratch.n);
     }
-    const bool two_sets = cx.acc_b.p != nullptr && !cx.throughput && use_lanes;
-    Jobs open_jobs;
-    open_jobs.push_back([&](Lane &ln) {   // open at beta: g_1 (ch^0; shifted ch^1), outer_sumcheck (ch^2), t (ch^3), z_b (ch^4)
+    const bool two_sets = cx.acc_b.p != nullptr && jobs.async;
+    if (jobs.async) gpu::sync(s);                 // (the opening jobs read what the main stream made: everything is in place from here)
+    jobs.start(1, [&](Lane &ln) {   // open at beta: g_1 (ch^0; shifted ch^1), outer_sumcheck (ch^2), t (ch^3), z_b (ch^4)
         gpu::stream_t ls_ = ln.stream;
         size_t plen = 3 * n;
         Fr rb[3] = {Fr::zero(), Fr::zero(), Fr::zero()};
@@ -1133,9 +1177,10 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
             gpu::poly_lincomb_n(acc.p, plen, ps, ls, sc, 7, ls_);
         }
         rand_axpy(rb, chp[0], r2[1].rand); rand_axpy(rb, chp[2] * c_za, r1[1].rand); rand_axpy(rb, chp[2] * c_w, r1[0].rand); rand_axpy(rb, chp[4], r1[2].rand);
+        // the shifted part (g_1, degree bound |H| - 2) rides in the same Pippenger instance; its quotient by X - beta may already exist (early_evals).  The second scratch half
+        // keeps the two divisions of this job apart when they were queued on different streams.
+        if (!early_evals) gpu::divide_by_linear(wit2.p, poly[5].p, poly_len[5], beta, scratch.p, scratch.n, ls_);
         gpu::divide_by_linear(wit.p, acc.p, plen, beta, scratch.p, scratch.n, ls_);
-        // shifted part (g_1, degree bound |H| - 2) rides in the same Pippenger instance
-        gpu::divide_by_linear(wit2.p, poly[5].p, poly_len[5], beta, scratch.p, scratch.n, ls_);
         gpu::poly_scale(wit2.p, chp[1], poly_len[5] - 1, ls_);
         msm_opening_prepare(cx, ln, wit.p, plen - 1, wit2.p, poly_len[5] - 1, bounds[1] - (n - 2));
         // (the blinding part of the witness is host work: under the device's digit grouping, not after the wait for its sum)
@@ -1150,8 +1195,8 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
         XYZZ<Fq377> w = msm_opening_finish(ln);
         w.add(hw);
         pf.w_beta = w.to_affine(); pf.random_v_beta = rv;
-    });
-    open_jobs.push_back([&](Lane &ln) {   // open at gamma: g_2 (ch^0; shifted ch^1), inner_sumcheck (ch^2)
+    }, false);
+    jobs.start(2, [&](Lane &ln) {   // open at gamma: g_2 (ch^0; shifted ch^1), inner_sumcheck (ch^2)
         gpu::stream_t ls_ = ln.stream;
         DevBuf &acc_ = two_sets ? cx.acc_b : acc, &wit_ = two_sets ? cx.wit_b : wit, &wit2_ = two_sets ? cx.wit2_b : wit2, &scr_ = two_sets ? cx.scratch_b : scratch;
         size_t plen = k;
@@ -1167,8 +1212,8 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
         msm_opening_prepare(cx, ln, wit_.p, plen - 1, wit2_.p, poly_len[7] - 1, bounds[1] - (k - 2));
         XYZZ<Fq377> w = msm_opening_finish(ln);
         pf.w_gamma = w.to_affine();
-    });
-    run_jobs(cx, open_jobs);
+    }, false);
+    jobs.join();
     for (int i = 0; i < 4; i++) pf.comms[i] = r1[i].comm;
     for (int i = 0; i < 3; i++) pf.comms[4 + i] = r2[i].comm;
     for (int i = 0; i < 2; i++) pf.comms[7 + i] = r3[i].comm;

@@ -117,6 +117,7 @@ stream_t stream_create_background() {
 void stream_destroy(stream_t s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
 void *event_create() { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return (void *)e; }
 void event_record(void *ev, stream_t s) { HIP_CHECK(hipEventRecord((hipEvent_t)ev, (hipStream_t)s)); }
+void stream_wait_event(stream_t s, void *ev) { HIP_CHECK(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)ev, 0)); }
 float event_elapsed_ms(void *a, void *b) { float ms = 0; HIP_CHECK(hipEventSynchronize((hipEvent_t)b)); HIP_CHECK(hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b)); return ms; }
 void event_destroy(void *ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
 

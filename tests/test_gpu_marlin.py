@@ -506,7 +506,7 @@ def test_one_universal_srs_serves_every_key(zko, api, aes16, aes96, vectors):
 
 def test_contexts_setter_and_op_lists(api, aes96):
     """zkaes_pk_set_contexts / zkaes_pk_op_lists / zkaes_msm_stats: the per-key setter bounds the proofs in flight; the op recorder returns the transforms and MSMs one
-    6-block chunk-proof actually launches -- 19 |H|-point transforms + 3 over |K| + 2 over |X|, 10 k_accumulate launches (8 prepared MSMs, two of them against a
+    6-block chunk-proof actually launches -- 16 |H|-point transforms (19 before round 5's closed form for r(alpha, X)) + 3 over |K| + 1 over |X|, 10 k_accumulate launches (8 prepared MSMs, two of them against a
     second base array) + 3 class sums -- and the MSM statistics book every one of those launches (VERDICT r4 weak #2: the plain + shifted pair was booked once)."""
     pk, vk = aes96
     assert pk.contexts() == 12
@@ -523,7 +523,8 @@ def test_contexts_setter_and_op_lists(api, aes96):
     by_size = {}
     for n, cnt in ops["ntt"]:
         by_size[n] = by_size.get(n, 0) + cnt
-    assert by_size == {1024: 1, h: 20, k: 3}, by_size          # x-hat interpolation (|X|) + its evaluation on H; rounds 1-2: 3 + 3 + 10 + 2 + (x on H) = 19 + 1; round 3: f, f on gK, h_2
+    # |X|: x-hat's interpolation; |H|: x-hat on H (1) + round 1 (3) + round 2 (2 + 8 + 2: r(alpha, X) comes from its closed form, no transform) = 16; |K|: f, f on g K, h_2
+    assert by_size == {1024: 1, h: 16, k: 3}, by_size
     kinds = [kd for _, kd in ops["msm"]]
     assert kinds.count("class_sum") == 3 and kinds.count("buckets") == 8 and kinds.count("second_bases") == 2
     sizes = sorted(n for n, kd in ops["msm"] if kd == "buckets")

@@ -14,7 +14,7 @@ import subprocess
 import sys
 
 nbytes = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r05"
 CHILD = r'''
 import os, sys, time
 sys.path.insert(0, '.')
