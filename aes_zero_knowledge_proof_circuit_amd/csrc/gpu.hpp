@@ -106,9 +106,6 @@ template <class Fr> const Fr *domain_elements(int lg);   // device table g^i, i 
 struct MsmWorkspace;
 MsmWorkspace *msm_workspace_create();
 void msm_workspace_destroy(MsmWorkspace *ws);
-// lone-call lanes: run this workspace's k_accumulate launches (Edwards law) on `low_priority_stream` (stream_create_background), so that they yield workgroup slots to the
-// short kernels of the other lanes; nullptr = everything on the caller's stream (multi-proof calls)
-void msm_workspace_set_accumulate_stream(MsmWorkspace *ws, stream_t low_priority_stream);
 struct WorkspaceGuard {
     MsmWorkspace *ws = nullptr;
     WorkspaceGuard() : ws(msm_workspace_create()) {}

@@ -775,12 +775,6 @@ struct MsmWorkspace {
     void *buckets = nullptr, *seg_s = nullptr, *seg_w = nullptr, *partial = nullptr, *tmp = nullptr;
     void *h_res = nullptr, *d_res = nullptr;                      // pinned host memory the last reduction kernel writes the window sums (+ flags) into, and its device address
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};      // [2 rep], [2 rep + 1]: around the k_accumulate launch of base array `rep`
-    // Lone-call lanes (msm_workspace_set_accumulate_stream): k_accumulate runs on this LOW-priority side stream, everything else of the MSM on the caller's stream.  A lone
-    // proof has up to four MSMs in flight on four lanes, and a k_accumulate grid (8,192 one-wave workgroups, milliseconds) otherwise keeps the other lanes' short kernels --
-    // digit grouping, bucket order, the reduction chain -- waiting for its last workgroup (1.5 ms waits in profiles/r05_lone_timeline_16_before_priority.md); at a lower
-    // priority it yields workgroup slots to them as its own workgroups retire, so the next MSM's grouping and the previous one's reduction run UNDER it.
-    hipStream_t acc_stream = nullptr;
-    hipEvent_t ev_dep = nullptr;
 };
 constexpr size_t RES_BYTES = 192 * MAX_WSUMS * 6 + 64;        // six terms per set when the Edwards reduction ends on the host (k_reduce_final RF_OUT)
 // the accumulators and the reduction's levels, sized by the number of buckets ACCUMULATED (twice the prepared ones when one prepared state serves two base arrays at once)
@@ -826,11 +820,6 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
     ensure_result(S, buckets);
 }
 MsmWorkspace *msm_workspace_create() { return new MsmWorkspace(); }
-void msm_workspace_set_accumulate_stream(MsmWorkspace *w, stream_t low_priority_stream) {
-    if (!w) throw GpuError("msm: null workspace");
-    w->acc_stream = (hipStream_t)low_priority_stream;
-    if (w->acc_stream && !w->ev_dep) HIP_CHECK(hipEventCreate(&w->ev_dep));
-}
 void msm_workspace_destroy(MsmWorkspace *w) {
     if (!w) return;
     for (void *p : {(void *)w->keys_a, (void *)w->keys_b, (void *)w->vals_a, (void *)w->vals_b, (void *)w->start, (void *)w->end, (void *)w->order, (void *)w->ovf_slot,
@@ -838,7 +827,6 @@ void msm_workspace_destroy(MsmWorkspace *w) {
                     (void *)w->ctrl, (void *)w->tickets, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->tmp}) dfree(p);
     if (w->h_res) (void)hipHostFree(w->h_res);
     for (auto e : w->ev) if (e) (void)hipEventDestroy(e);
-    if (w->ev_dep) (void)hipEventDestroy(w->ev_dep);
     delete w;
 }
 
@@ -906,23 +894,20 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
     }
 #endif
     uint32_t max_seg = (uint32_t)(pairs / cap + 1);
-    // the accumulation's own stream (Edwards law, lone-call lanes): see MsmWorkspace::acc_stream.  The overflow segments (k_accumulate_tail) read the same grouped list and
-    // write their own partials -- on the Edwards law they do not touch the buckets -- so they stay on the caller's stream, beside the accumulation; the fold waits for both.
-    hipStream_t sa = (Law::edwards && S.acc_stream) ? S.acc_stream : s;
-    if (sa != s) { HIP_CHECK(hipEventRecord(S.ev_dep, s)); HIP_CHECK(hipStreamWaitEvent(sa, S.ev_dep, 0)); }
+    // (A side stream of its own for k_accumulate -- at lower priority than, or beside higher-priority streams for, the short kernels of a lone proof's other lanes -- was
+    // measured in round 5 and dropped: the 64-byte lone call went from 74 to 105 ms, profiles/r05_lone_latency.md.)
     for (int rep = 0; rep < nrep; rep++) {
         const typename Law::Base *src = rep ? bases2 : bases;
-        HIP_CHECK(hipEventRecord(S.ev[2 * rep], sa));         // every k_accumulate launch is bracketed and booked by itself (msm_stats: launches, points, pairs, ms)
-        hipLaunchKernelGGL((k_accumulate<Law>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, sa, src, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb, cap,
+        HIP_CHECK(hipEventRecord(S.ev[2 * rep], s));          // every k_accumulate launch is bracketed and booked by itself (msm_stats: launches, points, pairs, ms)
+        hipLaunchKernelGGL((k_accumulate<Law>), dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, src, S.sorted_vals, S.start, S.end, S.order, (uint32_t)nb, cap,
                            (A *)S.buckets + rep * nb, S.deferred, DEFERRED_CAP, S.deferred_count);
         HIP_LAUNCH_CHECK();
-        HIP_CHECK(hipEventRecord(S.ev[2 * rep + 1], sa));
+        HIP_CHECK(hipEventRecord(S.ev[2 * rep + 1], s));
         // oversized buckets + deferred degenerate additions (none for uniformly distributed digits: every lane exits at once)
         hipLaunchKernelGGL((k_accumulate_tail<Law>), dim3((max_seg + 63) / 64), dim3(64), 0, s, src, S.sorted_vals, S.start, S.end, S.ctrl, S.ovf_bucket, S.ovf_off, max_seg, cap,
                            (A *)S.ovf_partial + rep * S.cap_ovf, (A *)S.buckets + rep * nb, S.deferred, DEFERRED_CAP, S.deferred_count);
         HIP_LAUNCH_CHECK();
     }
-    if (sa != s) HIP_CHECK(hipStreamWaitEvent(s, S.ev[2 * (nrep - 1) + 1], 0));
     for (int rep = 0; rep < nrep; rep++) {
         // overflow partials -> their buckets (overflow list entries <= buckets with more than `cap` pairs <= pairs / cap)
         hipLaunchKernelGGL((k_fold_overflow<A>), dim3((max_seg + 63) / 64), dim3(64), 0, s, (A *)S.buckets + rep * nb, S.ctrl, S.ovf_bucket, S.ovf_off, max_seg, (const A *)S.ovf_partial + rep * S.cap_ovf);

@@ -582,17 +582,15 @@ struct ProverContext {
     // MSM lanes: lane 0 = (stream, msm_ws) above; lanes 1..4 (own stream + MSM scratch, created on first use) let a LONE encrypt() call run the independent
     // commitments of a round side by side, each started as soon as ITS polynomial exists (latency path only: with several proofs in flight the chip is already full)
     static constexpr int N_LANES = 5;
-    struct Lane { gpu::stream_t stream = nullptr; gpu::MsmWorkspace *ws = nullptr; void *ready = nullptr; /* event: the lane's input exists on the main stream */
-                  gpu::stream_t acc = nullptr; /* low-priority side stream of the lane's bucket accumulations (gpu.hpp msm_workspace_set_accumulate_stream) */ };
+    struct Lane { gpu::stream_t stream = nullptr; gpu::MsmWorkspace *ws = nullptr; void *ready = nullptr; /* event: the lane's input exists on the main stream */ };
+    // (lane 3 is the background lane: the early mask commitment of round 1 runs there, under the witness generation on the main stream)
     Lane lane[N_LANES];
     DevBuf acc_b, wit_b, wit2_b, scratch_b;             // second set of opening buffers (the two openings run side by side on the latency path)
     bool throughput = false;           // set per proof: several proofs in flight (chunked / batch calls) -> window tables; a lone encrypt() call -> per-window buckets
     ProverContext() { stream = gpu::stream_create(); msm_ws = gpu::msm_workspace_create(); lane[0].stream = stream; lane[0].ws = msm_ws; }
     void ensure_lanes() {
         for (int i = 1; i < N_LANES; i++) if (!lane[i].stream) {
-            lane[i].stream = gpu::stream_create(); lane[i].ws = gpu::msm_workspace_create(); lane[i].ready = gpu::event_create();
-            lane[i].acc = gpu::stream_create_background();
-            gpu::msm_workspace_set_accumulate_stream(lane[i].ws, lane[i].acc);
+            lane[i].stream = i == 3 ? gpu::stream_create_background() : gpu::stream_create(); lane[i].ws = gpu::msm_workspace_create(); lane[i].ready = gpu::event_create();
         }
     }
     ~ProverContext() {
@@ -603,7 +601,7 @@ struct ProverContext {
         for (auto &b : poly) b.release();
         for (auto &b : e) b.release();
         for (DevBuf *b : {&acc_b, &wit_b, &wit2_b, &scratch_b}) b->release();
-        for (int i = 1; i < N_LANES; i++) if (lane[i].stream) { gpu::msm_workspace_destroy(lane[i].ws); gpu::stream_destroy(lane[i].stream); gpu::stream_destroy(lane[i].acc); gpu::event_destroy(lane[i].ready); }
+        for (int i = 1; i < N_LANES; i++) if (lane[i].stream) { gpu::msm_workspace_destroy(lane[i].ws); gpu::stream_destroy(lane[i].stream); gpu::event_destroy(lane[i].ready); }
         gpu::msm_workspace_destroy(msm_ws);
         gpu::stream_destroy(stream);
     }
