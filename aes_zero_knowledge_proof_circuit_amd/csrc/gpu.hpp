@@ -198,11 +198,9 @@ using F = Fr377;
 
 void poly_set_at(F *p, size_t idx, const F &val, stream_t s);                 // p[idx] = val
 void poly_add_at(F *p, size_t idx, const F &val, stream_t s);                 // p[idx] += val
-void poly_axpy(F *acc, const F *p, const F &sc, size_t n, stream_t s);        // acc[i] += sc * p[i]
 void poly_scale(F *p, const F &sc, size_t n, stream_t s);                     // p[i] *= sc
 // out[i] = sum_j scalars[j] * polys[j][i] for i < n, each polynomial contributing only below its own length (1..8 terms)
 void poly_lincomb_n(F *out, size_t n, const F *const *polys, const size_t *lens, const F *scalars, int count, stream_t s);
-void poly_lincomb3(F *out, const F *a, const F *b, const F *c, const F &sa, const F &sb, const F &sc, size_t n, stream_t s);
 // q = p / (X^m - 1) (len - m coefficients), rem = remainder (m coefficients); requires len > m
 void divide_by_vanishing(F *q, F *rem, const F *p, size_t len, size_t m, stream_t s, F *scratch = nullptr, size_t scratch_len = 0);
 // q = p / (X - z) (len - 1 coefficients, remainder dropped); scratch >= divide_by_linear_scratch(len) elements (block values and carries of the blocked recurrence)
@@ -215,14 +213,14 @@ size_t poly_eval_scratch(size_t len);
 void poly_eval_multi(const F *const *p, const size_t *len, const F *x, int count, F *out, F *scratch, size_t scratch_elems, stream_t s);
 // in-place batch inversion, zeros stay zero; every output optionally multiplied by `post`
 void batch_inverse(F *v, size_t n, const F *post_or_null, stream_t s);
-void sub_from_scalar(F *out, const F *v, const F &sc, size_t n, stream_t s);  // out[i] = sc - v[i]
-// r(alpha, X) = (alpha^n - X^n) / (alpha - X) from its closed form, in ONE fused pass over 3n points: on_h[i] = post_h / (alpha - h_i), on_c1[i] = post_1 / (alpha - g1 h_i),
-// on_c3[i] = post_3 / (alpha - g3 h_i) with elems = the n domain elements h_i (n = 2^lg_n) and post_* = alpha^n - (coset generator)^n.  Replaces one inverse and two forward
-// coset transforms of Marlin's second round.  alpha must not lie on H or on either coset (a denominator would vanish).
-void r_alpha_on_h_and_cosets(F *on_h, F *on_c1, F *on_c3, const F *elems, const F &alpha, const F &g1, const F &g3, const F &post_h, const F &post_1, const F &post_3, uint32_t n, int lg_n,
-                             stream_t s);
-// count how many of the first n elements are non-zero (host result; synchronizes)
-size_t count_nonzero(const F *p, size_t n, stream_t s);
+// r(a, X) = (a^n - X^n) / (a - X) (Marlin's u_H(a, X)) on `ncosets` <= 3 cosets g[c] H of the size-n domain H (elems = its n elements, n = 2^lg_n):
+// out[c][i] = r(a, g[c] h_i) = prod_{k < lg_n} (a^(2^k) + (g[c] h_i)^(2^k)) -- a product tree, two products per node, NO inversion and no transform.  With g = 1 this is
+// v_H(a) / (a - h_i).  scratch: >= vanishing_quotient_scratch(lg_n, ncosets) field elements.
+size_t vanishing_quotient_scratch(int lg_n, int ncosets);
+void vanishing_quotient_evals(F *const *out, const F *g, int ncosets, const F &a, const F *elems, uint32_t n, int lg_n, F *scratch, size_t scratch_elems, stream_t s);
+// round 3: out[kappa] = (ea va + eb vb + ec vc)[kappa] rb[ci[kappa]] ra[ri[kappa]] with ra[i] = v_H(alpha) / (alpha - h_i), rb[i] = v_H(beta) / (beta - h_i): the values of f on K
+void f_evals_from_tables(F *out, const F *va, const F *vb, const F *vc, const F &ea, const F &eb, const F &ec, const F *ra, const F *rb, const uint32_t *ri, const uint32_t *ci, size_t k,
+                         stream_t s);
 
 // ---- witness generation + sparse products
 void upload_sbox(const uint8_t table[256]);
@@ -254,8 +252,6 @@ void t_evals(F *out, uint32_t n, F *partial, uint32_t nseg, const uint32_t *col_
 uint64_t chacha_field_stream(F *out, size_t count, const uint32_t key[8], int rounds, uint64_t word_pos, void *scratch, size_t scratch_bytes, stream_t s);
 // mask-polynomial fix-up of ark-marlin: p[0] -= p[0] + p[n] + p[2n]
 void mask_fixup(F *p, size_t n, stream_t s);
-// e_ra[i] = e_ra[i] * (eta_a za + eta_b zb + eta_c za zb)[i] - t[i] * z[i]
-void q1_pointwise(F *e_ra, const F *e_za, const F *e_zb, const F *e_t, const F *e_z, const F &eta_a, const F &eta_b, const F &eta_c, size_t n, stream_t s);
 // Round 2 on cosets of H (marlin.cpp second round): out[i] = r[i] (eta_a A + eta_b B + eta_c A B) - t[i] Z with A = za[i] + ca, B = zb[i] + cb, Z = z[i] + cz (the constants are
 // the blinding terms rho (X^|H| - 1), constant on a coset); z_evals_h = the full assignment on H as field elements; q1_combine turns the interpolants Q0 (on H), Q1, Q3 (on the
 // cosets W H, W^3 H) of q_1 - mask into h_1 (2n coefficients) and g_1 (n - 1), adding the mask's own quotient and remainder by X^n - 1.
@@ -263,9 +259,6 @@ void q1_coset_pointwise(F *out, const F *r, const F *za, const F *zb, const F *t
                         size_t n, stream_t s);
 void z_evals_h(F *out, const uint8_t *z, uint32_t n, uint32_t m, uint32_t num_witness, stream_t s);
 void q1_combine(F *h1, F *g1, const F *q0, const F *q1, const F *q3, const F *mask, const F &inv2, const F &inv2zeta, size_t n, stream_t s);
-void round3_den(F *den, const F *row, const F *col, const F &alpha, const F &beta, size_t k, stream_t s);     // (beta - row)(alpha - col)
-void mul_pointwise(F *out, const F *a, const F *b, size_t n, stream_t s);                                       // out = a * b
-void mul_sub(F *acc, const F *b, const F *f, size_t n, stream_t s);
 // out[j] = in[j] * g^j for j < n (in zero-padded beyond in_len): coefficients of p(g X)
 void coset_scale(F *out, const F *in, const F &g, size_t in_len, size_t n, stream_t s);
 // round 3 on one coset of K: out = ((ea va + eb vb + ec vc) - (alpha beta - alpha row - beta col + row_col) f) * vinv, all arrays = values on the coset

@@ -17,11 +17,6 @@ __global__ void k_set_at(F *p, size_t idx, F val, bool add) { if (threadIdx.x ==
 void poly_set_at(F *p, size_t idx, const F &val, stream_t s) { hipLaunchKernelGGL(k_set_at, dim3(1), dim3(64), 0, (hipStream_t)s, p, idx, val, false); HIP_LAUNCH_CHECK(); }
 void poly_add_at(F *p, size_t idx, const F &val, stream_t s) { hipLaunchKernelGGL(k_set_at, dim3(1), dim3(64), 0, (hipStream_t)s, p, idx, val, true); HIP_LAUNCH_CHECK(); }
 
-__global__ void k_axpy(F *__restrict__ acc, const F *__restrict__ p, F sc, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) acc[i] = acc[i] + sc * p[i];
-}
-void poly_axpy(F *acc, const F *p, const F &sc, size_t n, stream_t s) { if (!n) return; hipLaunchKernelGGL(k_axpy, GRID(n), 0, (hipStream_t)s, acc, p, sc, n); HIP_LAUNCH_CHECK(); }
 __global__ void k_scale(F *p, F sc, size_t n) { size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = p[i] * sc; }
 void poly_scale(F *p, const F &sc, size_t n, stream_t s) { if (!n) return; hipLaunchKernelGGL(k_scale, GRID(n), 0, (hipStream_t)s, p, sc, n); HIP_LAUNCH_CHECK(); }
 // ---- linear combinations and the pointwise kernels of rounds 2 / 3 on the NTT's reduced-radix field (ff29.cuh): data is only re-limbed (x R stays x R), scalars travel as
@@ -30,16 +25,6 @@ void poly_scale(F *p, const F &sc, size_t n, stream_t s) { if (!n) return; hipLa
 using G29 = Fp29<Fr377P>;
 __device__ __forceinline__ G29 ld29(const F &x) { return G29::split(x.l); }
 __device__ __forceinline__ F st29(const G29 &g) { F r; g.template canonical<1>().pack(r.l); return r; }        // values < 4 p
-__global__ void k_lincomb3(F *__restrict__ out, const F *__restrict__ a, const F *__restrict__ b, const F *__restrict__ c, G29 sa, G29 sb, G29 sc, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const G29 v[3] = {ld29(a[i]), ld29(b[i]), ld29(c[i])}, w[3] = {sa, sb, sc};
-    out[i] = st29(G29::dot<3>(v, w));
-}
-void poly_lincomb3(F *out, const F *a, const F *b, const F *c, const F &sa, const F &sb, const F &sc, size_t n, stream_t s) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_lincomb3, GRID(n), 0, (hipStream_t)s, out, a, b, c, G29::twiddle_from_std(sa), G29::twiddle_from_std(sb), G29::twiddle_from_std(sc), n); HIP_LAUNCH_CHECK();
-}
 // out[i] = sum_j sc[j] * p[j][i] over the (up to 8) polynomials long enough to have a coefficient i: the opening combinations in ONE pass, two dot products of four terms
 struct LincombArgs { const F *p[8]; size_t len[8]; G29 sc[8]; int count; };
 __global__ void k_lincomb_n(F *__restrict__ out, LincombArgs a, size_t n) {
@@ -60,8 +45,6 @@ void poly_lincomb_n(F *out, size_t n, const F *const *polys, const size_t *lens,
     for (int j = 0; j < 8; j++) { a.p[j] = j < count ? polys[j] : nullptr; a.len[j] = j < count ? lens[j] : 0; a.sc[j] = j < count ? G29::twiddle_from_std(scalars[j]) : G29::zero(); }
     hipLaunchKernelGGL(k_lincomb_n, GRID(n), 0, (hipStream_t)s, out, a, n); HIP_LAUNCH_CHECK();
 }
-__global__ void k_sub_from_scalar(F *__restrict__ out, const F *__restrict__ v, F sc, size_t n) { size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = sc - v[i]; }
-void sub_from_scalar(F *out, const F *v, const F &sc, size_t n, stream_t s) { if (!n) return; hipLaunchKernelGGL(k_sub_from_scalar, GRID(n), 0, (hipStream_t)s, out, v, sc, n); HIP_LAUNCH_CHECK(); }
 
 // ---- p / (X^m - 1): residue class j: q_i = p_{i+m} + q_{i+m}; rem_j = p_j + q_j
 __global__ void k_div_vanishing(F *__restrict__ q, F *__restrict__ rem, const F *__restrict__ p, size_t len, size_t m) {
@@ -292,75 +275,105 @@ __global__ void __launch_bounds__(BI_BLOCK) k_batch_inverse(F *__restrict__ v, s
         acc = acc * x;
     }
 }
-// r(alpha, X) = (alpha^n - X^n) / (alpha - X) on H and on the two cosets W H, W^3 H of round 2, from its CLOSED FORM: on a coset g H the numerator is the constant
-// alpha^n - g^n, so the values are post_seg / (alpha - g_seg h_i) -- one fused pass (denominators formed in registers, Montgomery's trick per 512-lane workgroup as in
-// k_batch_inverse) over the 3n points instead of an inverse transform (values on H -> coefficients) and two forward coset transforms.  Segment seg = idx / n of the index space
-// [0, 3n): g_0 = 1 (no product), out[seg][i] = post[seg] / (alpha - g[seg] elems[i]).  alpha must lie outside all three cosets (the caller checks alpha^(4n) != 1).
-struct RAlpha3Args { F *out[3]; F g[3]; F post[3]; };
-template <int BI_CHUNK>
-__global__ void __launch_bounds__(BI_BLOCK) k_r_alpha3(RAlpha3Args A, const F *__restrict__ elems, F alpha, uint32_t n, int lg_n) {
-    __shared__ F pre_s[BI_BLOCK], suf_s[BI_BLOCK];
-    __shared__ F inv_total;
-    const int lane = threadIdx.x;
-    const size_t total = (size_t)3 * n;
-    size_t t = (size_t)blockIdx.x * BI_BLOCK + lane;
-    size_t s0 = t * BI_CHUNK;
-    if (s0 > total) s0 = total;
-    size_t e = s0 + BI_CHUNK < total ? s0 + BI_CHUNK : total;
-    F pre[BI_CHUNK];
-    F acc = F::one();
-    for (size_t i = s0; i < e; i++) {                   // the denominators are parked in the output arrays (re-read below, as k_batch_inverse re-reads its input)
-        const uint32_t seg = (uint32_t)(i >> lg_n), k = (uint32_t)i & (n - 1);
-        const F h = elems[k];
-        const F x = alpha - (seg == 0 ? h : h * A.g[seg]);
-        A.out[seg][k] = x;
-        pre[i - s0] = acc;
-        acc = acc * x;
-    }
-    pre_s[lane] = acc; suf_s[lane] = acc;
+// r(a, X) = (a^n - X^n) / (a - X) -- Marlin's u_H(a, X) -- on cosets g H of the size-n domain H, with NO inversion and no transform: over a field
+//      (a^n - y^n) / (a - y)  =  prod_{k < lg n} (a^(2^k) + y^(2^k)),
+// and the factors are shared along a binary tree: T_k[j] = prod_{k' >= k} (a^(2^k') + Y_k'[j]) with Y_k[j] = (g h_j)^(2^k) = g^(2^k) elems[j 2^k] only depends on
+// j mod n / 2^k, so T_k[j] = (a^(2^k) + Y_k[j]) T_(k+1)[j mod n / 2^(k+1)], T_(lg n) = 1, and T_0[i] = r(a, g h_i): two products per tree node, 2n nodes, depth lg n, every
+// node of a level independent.  Replaces (round 5) the batch inversions of the prover's rounds 2 and 3 -- v_H(alpha) / (alpha - h) on H and on round 2's two cosets, and
+// 1 / ((beta - row)(alpha - col)) on K, which is a product of two such tables' entries -- and with them a ~300 us single-lane inversion chain per call of a lone proof.
+// k_vq_top runs levels lg n .. lg n - 10 of every coset in one workgroup each (<= 1024 nodes, LDS); k_vq_expand takes one node of level k_hi per workgroup down to level
+// k_lo >= k_hi - 10 (its descendants are the indices j + m (n >> k_hi)).  tables (device, uploaded per call): a^(2^k) then, per coset, g^(2^k), k < lg n.
+constexpr int VQ_MAX_COSETS = 3, VQ_STEP = 10;
+struct VqArgs { F *out[VQ_MAX_COSETS]; const F *tab; const F *elems; uint32_t n; int lg_n; bool unit_g[VQ_MAX_COSETS]; };
+__device__ __forceinline__ F vq_factor(const VqArgs &A, int c, int k, uint32_t j) {       // a^(2^k) + (g_c h_j)^(2^k)
+    const F e = A.elems[(size_t)j << k];
+    return A.tab[k] + (A.unit_g[c] ? e : e * A.tab[(size_t)(c + 1) * A.lg_n + k]);
+}
+__global__ void __launch_bounds__(1024) k_vq_top(VqArgs A, F *__restrict__ mid) {
+    __shared__ F buf[2][1 << VQ_STEP];
+    const int c = blockIdx.x, L = A.lg_n, k_stop = L > VQ_STEP ? L - VQ_STEP : 0;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) buf[0][0] = F::one();
     __syncthreads();
-    for (int d = 1; d < BI_BLOCK; d <<= 1) {
-        F a, b;
-        const bool ha = lane >= d, hb = lane + d < BI_BLOCK;
-        if (ha) a = pre_s[lane - d];
-        if (hb) b = suf_s[lane + d];
+    int cur = 0;
+    for (int k = L - 1; k >= k_stop; k--) {
+        const uint32_t s = A.n >> k;                       // nodes of level k
+        if (t < s) buf[cur ^ 1][t] = vq_factor(A, c, k, t) * buf[cur][t & ((s >> 1) - 1)];
         __syncthreads();
-        if (ha) pre_s[lane] = pre_s[lane] * a;
-        if (hb) suf_s[lane] = suf_s[lane] * b;
-        __syncthreads();
+        cur ^= 1;
     }
-    if (lane == 0) inv_total = BI_CHUNK == 4 ? suf_s[0].inverse() : suf_s[0].inverse_fermat();
+    const uint32_t s = A.n >> k_stop;
+    F *dst = k_stop == 0 ? A.out[c] : mid + (size_t)c * (1u << VQ_STEP);
+    if (t < s) dst[t] = buf[cur][t];
+}
+// src: level k_hi of every coset (n >> k_hi nodes each, coset-major); dst: level k_lo likewise, or the cosets' out arrays when k_lo == 0
+__global__ void __launch_bounds__(256) k_vq_expand(VqArgs A, const F *__restrict__ src, F *__restrict__ dst, int k_hi, int k_lo) {
+    __shared__ F buf[2][1 << VQ_STEP];
+    const uint32_t s_hi = A.n >> k_hi;
+    const int c = blockIdx.x / s_hi;
+    const uint32_t j = blockIdx.x % s_hi, t = threadIdx.x;
+    if (t == 0) buf[0][0] = src[(size_t)c * s_hi + j];
     __syncthreads();
-    acc = inv_total;
-    if (lane > 0) acc = acc * pre_s[lane - 1];
-    if (lane + 1 < BI_BLOCK) acc = acc * suf_s[lane + 1];
-    // the numerator: one product per lane when the lane's chunk lies in one segment (n >= BI_CHUNK: always, both are powers of two), else per element
-    const bool per_elem = n < (uint32_t)BI_CHUNK;
-    if (!per_elem && s0 < e) acc = acc * A.post[(uint32_t)(s0 >> lg_n)];
-    for (size_t i = e; i-- > s0;) {
-        const uint32_t seg = (uint32_t)(i >> lg_n), k = (uint32_t)i & (n - 1);
-        const F x = A.out[seg][k];
-        F r = acc * pre[i - s0];
-        if (per_elem) r = r * A.post[seg];
-        A.out[seg][k] = r;
-        acc = acc * x;
+    int cur = 0;
+    for (int k = k_hi - 1; k >= k_lo; k--) {
+        const uint32_t cnt = 1u << (k_hi - k);             // this node's descendants at level k: local m <-> global j + m s_hi; parent: local m mod cnt / 2
+        for (uint32_t m = t; m < cnt; m += 256) buf[cur ^ 1][m] = vq_factor(A, c, k, j + m * s_hi) * buf[cur][m & ((cnt >> 1) - 1)];
+        __syncthreads();
+        cur ^= 1;
+    }
+    const uint32_t cnt = 1u << (k_hi - k_lo);
+    F *o = k_lo == 0 ? A.out[c] : dst + (size_t)c * (A.n >> k_lo);
+    for (uint32_t m = t; m < cnt; m += 256) o[j + (size_t)m * s_hi] = buf[cur][m];
+}
+size_t vanishing_quotient_scratch(int lg_n, int ncosets) {          // field elements of `scratch` vanishing_quotient_evals needs
+    size_t tab = (size_t)(ncosets + 1) * (lg_n > 0 ? lg_n : 1), mids = 0;
+    for (int k = lg_n - VQ_STEP; k > 0; k -= VQ_STEP) mids += (size_t)ncosets << (lg_n - k);
+    return tab + mids + 8;
+}
+void vanishing_quotient_evals(F *const *out, const F *g, int ncosets, const F &a, const F *elems, uint32_t n, int lg_n, F *scratch, size_t scratch_elems, stream_t s_) {
+    hipStream_t s = (hipStream_t)s_;
+    if (ncosets < 1 || ncosets > VQ_MAX_COSETS) throw GpuError("vanishing_quotient_evals: 1..3 cosets");
+    if (n == 0 || n != (1u << lg_n)) throw GpuError("vanishing_quotient_evals: n must be 2^lg_n");
+    if (vanishing_quotient_scratch(lg_n, ncosets) > scratch_elems) throw GpuError("vanishing_quotient_evals: scratch too small");
+    if (lg_n == 0) { for (int c = 0; c < ncosets; c++) { F one = F::one(); h2d(out[c], &one, sizeof(F), s_); } return; }
+    // host: the power chains a^(2^k), g_c^(2^k)
+    std::vector<F> tab((size_t)(ncosets + 1) * lg_n);
+    F v = a;
+    for (int k = 0; k < lg_n; k++) { tab[k] = v; v = v.sqr(); }
+    VqArgs A;
+    for (int c = 0; c < VQ_MAX_COSETS; c++) { A.out[c] = c < ncosets ? out[c] : nullptr; A.unit_g[c] = true; }
+    for (int c = 0; c < ncosets; c++) {
+        A.unit_g[c] = g[c] == F::one();
+        v = g[c];
+        for (int k = 0; k < lg_n; k++) { tab[(size_t)(c + 1) * lg_n + k] = v; v = v.sqr(); }
+    }
+    h2d(scratch, tab.data(), tab.size() * sizeof(F), s_);
+    A.tab = scratch; A.elems = elems; A.n = n; A.lg_n = lg_n;
+    F *mid = scratch + tab.size();
+    hipLaunchKernelGGL(k_vq_top, dim3(ncosets), dim3(1024), 0, s, A, mid); HIP_LAUNCH_CHECK();
+    for (int k_hi = lg_n - VQ_STEP; k_hi > 0; ) {
+        const int k_lo = k_hi > VQ_STEP ? k_hi - VQ_STEP : 0;
+        F *dst = mid + ((size_t)ncosets << (lg_n - k_hi));
+        hipLaunchKernelGGL(k_vq_expand, dim3((unsigned)((size_t)ncosets * (n >> k_hi))), dim3(256), 0, s, A, (const F *)mid, dst, k_hi, k_lo); HIP_LAUNCH_CHECK();
+        mid = dst; k_hi = k_lo;
     }
 }
-void r_alpha_on_h_and_cosets(F *on_h, F *on_c1, F *on_c3, const F *elems, const F &alpha, const F &g1, const F &g3, const F &post_h, const F &post_1, const F &post_3, uint32_t n, int lg_n,
-                             stream_t s) {
-    if (!n) return;
-    RAlpha3Args A;
-    A.out[0] = on_h; A.out[1] = on_c1; A.out[2] = on_c3;
-    A.g[0] = F::one(); A.g[1] = g1; A.g[2] = g3;
-    A.post[0] = post_h; A.post[1] = post_1; A.post[2] = post_3;
-    const size_t total = (size_t)3 * n;
-    if (throughput_mode() || total > ((size_t)1 << 21)) {
-        size_t threads = (total + 15) / 16;
-        hipLaunchKernelGGL(k_r_alpha3<16>, dim3((unsigned)((threads + BI_BLOCK - 1) / BI_BLOCK)), dim3(BI_BLOCK), 0, (hipStream_t)s, A, elems, alpha, n, lg_n); HIP_LAUNCH_CHECK();
-    } else {
-        size_t threads = (total + 3) / 4;
-        hipLaunchKernelGGL(k_r_alpha3<4>, dim3((unsigned)((threads + BI_BLOCK - 1) / BI_BLOCK)), dim3(BI_BLOCK), 0, (hipStream_t)s, A, elems, alpha, n, lg_n); HIP_LAUNCH_CHECK();
-    }
+// round 3 of Marlin: f(kappa) = v_H(alpha) v_H(beta) (eta_a val_a + eta_b val_b + eta_c val_c)(kappa) / ((beta - row(kappa)) (alpha - col(kappa))) on K, where row(kappa) and col(kappa)
+// are ELEMENTS OF H (the indexer's "row" holds elems[ci], "col" elems[ri]): with ra[i] = v_H(alpha) / (alpha - h_i) and rb[i] = v_H(beta) / (beta - h_i) (vanishing_quotient_evals)
+// the quotient is rb[ci[kappa]] ra[ri[kappa]] -- two gathers and two products instead of a batch inversion over K.  Entries past the index's non-zeros carry (0, 0) and zero values.
+__global__ void k_f_from_tables(F *__restrict__ out, const F *__restrict__ va, const F *__restrict__ vb, const F *__restrict__ vc, G29 ea, G29 eb, G29 ec, const F *__restrict__ ra,
+                                const F *__restrict__ rb, const uint32_t *__restrict__ ri, const uint32_t *__restrict__ ci, size_t k) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const G29 v[3] = {ld29(va[i]), ld29(vb[i]), ld29(vc[i])}, w[3] = {ea, eb, ec};       // (scalars in twiddle form: one Montgomery reduction for the three terms)
+    const F num = st29(G29::dot<3>(v, w));
+    out[i] = num.is_zero() ? num : num * (rb[ci[i]] * ra[ri[i]]);
+}
+void f_evals_from_tables(F *out, const F *va, const F *vb, const F *vc, const F &ea, const F &eb, const F &ec, const F *ra, const F *rb, const uint32_t *ri, const uint32_t *ci, size_t k,
+                         stream_t s) {
+    if (!k) return;
+    hipLaunchKernelGGL(k_f_from_tables, GRID(k), 0, (hipStream_t)s, out, va, vb, vc, G29::twiddle_from_std(ea), G29::twiddle_from_std(eb), G29::twiddle_from_std(ec), ra, rb, ri, ci, k);
+    HIP_LAUNCH_CHECK();
 }
 void batch_inverse(F *v, size_t n, const F *post, stream_t s) {
     if (!n) return;
@@ -374,33 +387,7 @@ void batch_inverse(F *v, size_t n, const F *post, stream_t s) {
     }
 }
 
-__global__ void k_count_nonzero(const F *__restrict__ p, size_t n, unsigned long long *out) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && !p[i].is_zero()) atomicAdd(out, 1ull);
-}
-size_t count_nonzero(const F *p, size_t n, stream_t s_) {
-    hipStream_t s = (hipStream_t)s_;
-    DevPtr<unsigned long long> d(1);
-    unsigned long long h = 0;
-    HIP_CHECK(hipMemsetAsync(d, 0, 8, s));
-    if (n) { hipLaunchKernelGGL(k_count_nonzero, GRID(n), 0, s, p, n, d.get()); HIP_LAUNCH_CHECK(); }
-    sync((stream_t)s);        // drain first (sleeps in throughput mode): the pageable device-to-host copies below wait actively inside HIP
-    HIP_CHECK(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, s));
-    sync((stream_t)s);
-    return (size_t)h;
-}
-
 // ---- round 2 / 3 pointwise kernels
-__global__ void k_q1(F *__restrict__ e_ra, const F *__restrict__ za, const F *__restrict__ zb, const F *__restrict__ t, const F *__restrict__ z, F ea, F eb, F ec, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    F a = za[i], b = zb[i];
-    F sum = ec * (a * b) + ea * a + eb * b;
-    e_ra[i] = e_ra[i] * sum - t[i] * z[i];
-}
-void q1_pointwise(F *e_ra, const F *e_za, const F *e_zb, const F *e_t, const F *e_z, const F &ea, const F &eb, const F &ec, size_t n, stream_t s) {
-    hipLaunchKernelGGL(k_q1, GRID(n), 0, (hipStream_t)s, e_ra, e_za, e_zb, e_t, e_z, ea, eb, ec, n); HIP_LAUNCH_CHECK();
-}
 __global__ void k_q1_coset(F *__restrict__ out, const F *__restrict__ r, const F *__restrict__ za, const F *__restrict__ zb, const F *__restrict__ t, const F *__restrict__ z,
                            F ca, F cb, F cz, G29 ea, G29 eb, G29 ec, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -446,15 +433,6 @@ __global__ void k_q1_combine(F *__restrict__ h1, F *__restrict__ g1, const F *__
 void q1_combine(F *h1, F *g1, const F *q0, const F *q1, const F *q3, const F *mask, const F &inv2, const F &inv2zeta, size_t n, stream_t s) {
     hipLaunchKernelGGL(k_q1_combine, GRID(n), 0, (hipStream_t)s, h1, g1, q0, q1, q3, mask, inv2, inv2zeta, n); HIP_LAUNCH_CHECK();
 }
-__global__ void k_r3_den(F *__restrict__ den, const F *__restrict__ row, const F *__restrict__ col, F alpha, F beta, size_t k) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < k) den[i] = (beta - row[i]) * (alpha - col[i]);
-}
-void round3_den(F *den, const F *row, const F *col, const F &alpha, const F &beta, size_t k, stream_t s) { hipLaunchKernelGGL(k_r3_den, GRID(k), 0, (hipStream_t)s, den, row, col, alpha, beta, k); HIP_LAUNCH_CHECK(); }
-__global__ void k_mul(F *__restrict__ out, const F *__restrict__ a, const F *__restrict__ b, size_t n) { size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = a[i] * b[i]; }
-void mul_pointwise(F *out, const F *a, const F *b, size_t n, stream_t s) { if (!n) return; hipLaunchKernelGGL(k_mul, GRID(n), 0, (hipStream_t)s, out, a, b, n); HIP_LAUNCH_CHECK(); }
-__global__ void k_mul_sub(F *__restrict__ acc, const F *__restrict__ b, const F *__restrict__ f, size_t n) { size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) acc[i] = acc[i] - b[i] * f[i]; }
-void mul_sub(F *acc, const F *b, const F *f, size_t n, stream_t s) { if (!n) return; hipLaunchKernelGGL(k_mul_sub, GRID(n), 0, (hipStream_t)s, acc, b, f, n); HIP_LAUNCH_CHECK(); }
 // ---- coset tools for round 3: h_2 = (a - b f) / v_K has degree <= |K| - 2, so its |K| values on ONE coset g K determine it and there
 // v_K(g w^i) = g^|K| - 1 is a non-zero constant: no 2|K|-point transforms, no division by the vanishing polynomial.
 // out[j] = in[j] * g^j  (coefficients of p(g X)); 16 consecutive coefficients per lane, one pow per lane

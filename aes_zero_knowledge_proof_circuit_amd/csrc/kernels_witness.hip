@@ -152,19 +152,25 @@ __global__ void k_w_classes(int8_t *__restrict__ out, const uint8_t *__restrict_
 void w_classes(int8_t *out, const uint8_t *z, uint32_t n, uint32_t m, uint32_t num_witness, stream_t s) {
     hipLaunchKernelGGL(k_w_classes, GRID(n), 0, (hipStream_t)s, out, z, n, m, num_witness); HIP_LAUNCH_CHECK();
 }
-__global__ void k_lagrange_finish(F *__restrict__ lag, F *__restrict__ lag_w, const F *__restrict__ elems, uint32_t n, uint32_t m, F vx_inv) {
+__global__ void k_lagrange_finish(F *__restrict__ lag, F *__restrict__ lag_w, const F *__restrict__ elems, uint32_t n, uint32_t m, F vx_inv, F n_inv) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    F v = lag[k] * elems[k];            // lag[k] arrives as (beta^n - 1) / (n (beta - g^k))
+    F v = lag[k] * (elems[k] * n_inv);  // lag[k] arrives as (beta^n - 1) / (beta - g^k)
     lag[k] = v;
     lag_w[k] = (k % (n / m) == 0) ? F::zero() : v * vx_inv;
 }
 void lagrange_scalars(F *lag, F *lag_w, const F *elems, const F &beta, uint32_t n, uint32_t m, stream_t s) {
-    F c = (beta.pow_u64(n) - F::one()) * F::from_u64(n).inverse();
+    int lg_n = 0;
+    while ((1u << lg_n) < n) lg_n++;
     F vx_inv = (beta.pow_u64(m) - F::one()).inverse();
-    sub_from_scalar(lag, elems, beta, n, s);
-    batch_inverse(lag, n, &c, s);
-    hipLaunchKernelGGL(k_lagrange_finish, GRID(n), 0, (hipStream_t)s, lag, lag_w, elems, n, m, vx_inv); HIP_LAUNCH_CHECK();
+    // (beta^n - 1) / (beta - g^k) = r(beta, g^k): the product tree of kernels_poly.hip (no batch inversion)
+    const size_t need = vanishing_quotient_scratch(lg_n, 1);
+    DevPtr<F> scratch(need);
+    F *outs[1] = {lag};
+    const F one = F::one();
+    vanishing_quotient_evals(outs, &one, 1, beta, elems, n, lg_n, scratch, need, s);
+    hipLaunchKernelGGL(k_lagrange_finish, GRID(n), 0, (hipStream_t)s, lag, lag_w, elems, n, m, vx_inv, F::from_u64(n).inverse()); HIP_LAUNCH_CHECK();
+    sync(s);                            // (the scratch is released on return)
 }
 
 __global__ void k_w_evals(F *__restrict__ out, const uint8_t *__restrict__ z, const F *__restrict__ x_evals, uint32_t n, uint32_t m, uint32_t num_witness) {

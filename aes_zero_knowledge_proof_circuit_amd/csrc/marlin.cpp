@@ -642,6 +642,7 @@ class ProvingKeyImpl {
     uint32_t *d_t_colptr = nullptr, *d_t_seg_start = nullptr, *d_t_seg_end = nullptr, *d_t_row = nullptr; uint8_t *d_t_mat = nullptr; int64_t *d_t_coeff = nullptr;
     uint32_t t_nseg = 0, t_nheavy = 0;
     uint32_t *d_t_heavy = nullptr;
+    uint32_t *d_ix_ci = nullptr, *d_ix_ri = nullptr;     // per entry of K: the indices into H of its "row" / "col" domain elements (zero past the joint matrix's non-zeros): round 3 gathers through them
     // device: index polynomials (evaluations on K and coefficients); order row col a_val b_val c_val row_col
     DevBuf ix_ev[6], ix_co[6], ix_cs[6];       // index polynomials: values on K, coefficients, values on the coset g K (round 3)
     Fr coset_g, coset_g_inv, coset_vk_inv;     // g = the field's multiplicative generator, 1 / (g^|K| - 1)
@@ -652,6 +653,7 @@ class ProvingKeyImpl {
         gpu::dfree(coset_tab); gpu::dfree(coset_tab_inv);
         gpu::dfree(d_desc); gpu::dfree(d_sbox_in); gpu::dfree(d_sbox_tmpl);
         gpu::dfree(d_a_rowptr); gpu::dfree(d_a_col); gpu::dfree(d_b_rowptr); gpu::dfree(d_b_col); gpu::dfree(d_a_coeff); gpu::dfree(d_b_coeff);
+        gpu::dfree(d_ix_ci); gpu::dfree(d_ix_ri);
         gpu::dfree(d_t_heavy); gpu::dfree(d_t_colptr); gpu::dfree(d_t_seg_start); gpu::dfree(d_t_seg_end); gpu::dfree(d_t_row); gpu::dfree(d_t_mat); gpu::dfree(d_t_coeff);
         for (auto &b : ix_ev) b.release();
         for (auto &b : ix_co) b.release();
@@ -919,14 +921,16 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &lit
     // ---- index polynomials on the GPU
     for (int i = 0; i < 6; i++) { ix_ev[i].alloc(k); ix_co[i].alloc(k); }
     {
-        uint32_t *d_ci = upload(j_ci.empty() ? std::vector<uint32_t>{0} : j_ci, stream), *d_ri = upload(j_ri.empty() ? std::vector<uint32_t>{0} : j_ri, stream);
+        j_ci.resize(k, 0u); j_ri.resize(k, 0u);           // (entries past the non-zeros: elems[0], as index_evals pads row / col)
+        uint32_t *d_ci = upload(j_ci, stream), *d_ri = upload(j_ri, stream);
         int64_t *d_ja = upload(j_a.empty() ? std::vector<int64_t>{0} : j_a, stream), *d_jb = upload(j_b.empty() ? std::vector<int64_t>{0} : j_b, stream), *d_jc = upload(j_c.empty() ? std::vector<int64_t>{0} : j_c, stream);
         const F *elems = gpu::domain_elements<F>(lg_n);
         // order: 0 row, 1 col, 2 a_val, 3 b_val, 4 c_val, 5 row_col ; ix_co[0] doubles as the batch-inverse scratch
         gpu::index_evals(ix_ev[0].p, ix_ev[1].p, ix_ev[5].p, ix_ev[2].p, ix_ev[3].p, ix_ev[4].p, ix_co[0].p, d_ci, d_ri, d_ja, d_jb, d_jc, nnz, k, elems, (uint32_t)n, stream);
         for (int i = 0; i < 6; i++) gpu::ntt<F>(ix_co[i].p, ix_ev[i].p, k, lg_k, true, stream);
         gpu::sync(stream);
-        gpu::dfree(d_ci); gpu::dfree(d_ri); gpu::dfree(d_ja); gpu::dfree(d_jb); gpu::dfree(d_jc);
+        d_ix_ci = d_ci; d_ix_ri = d_ri;
+        gpu::dfree(d_ja); gpu::dfree(d_jb); gpu::dfree(d_jc);
     }
     for (int i = 0; i < 6; i++) vk.index_comms[i] = msm_powers(*cx0, cx0->lane[0], false, 0, ix_co[i].p, k).to_affine();
     {   // values of the index polynomials on the coset g K, once per key: round 3 then needs no transform for a(X) and b(X)
@@ -1051,9 +1055,9 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     // (the evaluation vectors of round 1 -- the blinding terms rho v_H vanish there), on W H and W^3 H (W the 4|H|-th root) each factor costs one |H|-point coset transform, where
     // rho (X^|H| - 1) is the constant rho (zeta^c - 1), zeta = W^|H|.  Three |H|-point inverses give the interpolants Q0, Q1, Q3; q_1_combine solves for q's three |H|-coefficient
     // thirds and divides by v_H = X^|H| - 1 in coefficient space, mask included: no 4|H| buffer traffic, no division kernel.
-    // Round 5: r(alpha, X) = (alpha^|H| - X^|H|) / (alpha - X) needs NO transform at all -- on the coset W^c H its numerator is the constant alpha^|H| - zeta^c, so its values on H
-    // and on both cosets come from ONE fused batch inversion over 3|H| denominators (r_alpha_on_h_and_cosets) instead of an inverse transform to coefficients and two forward
-    // coset transforms: 12 |H|-point transforms in round 2 (was 15) in five launches: {t, Q0} inverse, {z_A, z_B, t, z} x {W H, W^3 H} forward, {Q1, Q3} inverse.
+    // Round 5: r(alpha, X) = (alpha^|H| - X^|H|) / (alpha - X) = prod_k (alpha^(2^k) + X^(2^k)) needs NO transform and NO inversion: its values on H and on both cosets are a
+    // product tree (vanishing_quotient_evals: two products per node) instead of a batch inversion, an inverse transform to coefficients and two forward coset transforms:
+    // 12 |H|-point transforms in round 2 (was 15) in five launches: {t, Q0} inverse, {z_A, z_B, t, z} x {W H, W^3 H} forward, {Q1, Q3} inverse.
     // And t's commitment starts as soon as t's coefficients exist, under the rest of the round (lone call).
     {
         using Job = gpu::NttJob<F>;
@@ -1064,23 +1068,23 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
         // per coset: z_A, z_B, r, t in e[2 | 3], z and the product in e[4]
         F *cs_buf[2][6];
         for (int i = 0; i < 2; i++) { for (int j = 0; j < 4; j++) cs_buf[i][j] = e[2 + i].p + j * n; cs_buf[i][4] = e[4].p + i * n; cs_buf[i][5] = e[4].p + (2 + i) * n; }
-        const Fr alpha_n = vh_alpha + Fr::one();
-        const bool closed_form = !eval_vanishing(n4, alpha).is_zero();    // alpha on one of the cosets (probability ~2^-230): a denominator would vanish -> transforms
-        if (closed_form) gpu::r_alpha_on_h_and_cosets(ra_ev.p, cs_buf[0][2], cs_buf[1][2], elems, alpha, W, W3, vh_alpha, alpha_n - zeta, alpha_n + zeta, (uint32_t)n, lg_n, s);
-        else { gpu::sub_from_scalar(ra_ev.p, elems, alpha, n, s); gpu::batch_inverse(ra_ev.p, n, &vh_alpha, s); }      // r(alpha, h) = v_H(alpha) / (alpha - h)
+        {   // r(alpha, .) on H (= v_H(alpha) / (alpha - h): alpha lies outside H) and on W H, W^3 H; e[4] (free until the forward transforms) is the tree's scratch
+            F *outs[3] = {ra_ev.p, cs_buf[0][2], cs_buf[1][2]};
+            const Fr gs[3] = {Fr::one(), W, W3};
+            gpu::vanishing_quotient_evals(outs, gs, 3, alpha, elems, (uint32_t)n, lg_n, e[4].p, e[4].n, s);
+        }
         gpu::t_evals(tmp_n.p, (uint32_t)n, t_partial.p, t_nseg, d_t_colptr, d_t_seg_start, d_t_seg_end, d_t_heavy, t_nheavy, d_t_row, d_t_mat, d_t_coeff, ra_ev.p, eta_a, eta_b, eta_c, s);
         gpu::z_evals_h(zH, d_z, (uint32_t)n, (uint32_t)m, (uint32_t)c.num_witness, s);
         gpu::q1_coset_pointwise(qH, ra_ev.p, za_ev.p, zb_ev.p, tmp_n.p, zH, zero, zero, zero, eta_a, eta_b, eta_c, n, s);
-        const Job inv0[3] = {{poly[4].p, tmp_n.p, 0}, {Q0, qH, 0}, {ra_poly.p, ra_ev.p, 0}};
-        gpu::ntt_batch<F>(inv0, closed_form ? 2 : 3, n, lg_n, true, 0, s); poly_len[4] = n;
+        const Job inv0[2] = {{poly[4].p, tmp_n.p, 0}, {Q0, qH, 0}};
+        gpu::ntt_batch<F>(inv0, 2, n, lg_n, true, 0, s); poly_len[4] = n;
         jobs.start(1, [&](Lane &ln) { mpc_commit(cx, ln, r2[0]); }, true);                      // t
         gpu::z_poly_from_w(zpoly.p, poly[0].p, poly_len[0], x_poly.p, (uint32_t)m, n, s);
-        const F *srcs[5] = {poly[1].p, poly[2].p, poly[4].p, zpoly.p, ra_poly.p};
-        static const int dst_slot[5] = {0, 1, 3, 4, 2};
-        const int nsrc = closed_form ? 4 : 5;
-        Job fwd[10];
-        for (int i = 0; i < 2; i++) for (int j = 0; j < nsrc; j++) fwd[nsrc * i + j] = Job{cs_buf[i][dst_slot[j]], srcs[j], i == 0 ? 1 : 3};
-        gpu::ntt_batch<F>(fwd, 2 * nsrc, n, lg_n, false, lg_n4, s);
+        const F *srcs[4] = {poly[1].p, poly[2].p, poly[4].p, zpoly.p};
+        static const int dst_slot[4] = {0, 1, 3, 4};
+        Job fwd[8];
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 4; j++) fwd[4 * i + j] = Job{cs_buf[i][dst_slot[j]], srcs[j], i == 0 ? 1 : 3};
+        gpu::ntt_batch<F>(fwd, 8, n, lg_n, false, lg_n4, s);
         for (int i = 0; i < 2; i++) {
             const Fr zc = i == 0 ? zeta : zeta.neg();                    // zeta^cs: the value of X^|H| on the coset
             // the coefficient of X^|H| (rho of z_A, z_B; rho_w for z = w v_X + x) contributes rho zeta^cs everywhere on the coset
@@ -1102,10 +1106,13 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     for (auto &lp : r3) draw_rand(lp, zk);
     Fr vh_beta = eval_vanishing(n, beta);
     Fr vv = vh_alpha * vh_beta, ea_vv = eta_a * vv, eb_vv = eta_b * vv, ec_vv = eta_c * vv, alpha_beta = alpha * beta;
-    gpu::round3_den(e[0].p, ix_ev[0].p, ix_ev[1].p, alpha, beta, k, s);
-    gpu::batch_inverse(e[0].p, k, nullptr, s);
-    gpu::poly_lincomb3(e[1].p, ix_ev[2].p, ix_ev[3].p, ix_ev[4].p, ea_vv, eb_vv, ec_vv, k, s);
-    gpu::mul_pointwise(e[1].p, e[1].p, e[0].p, k, s);                         // f on K
+    {   // f on K.  Its denominator (beta - row)(alpha - col) runs over pairs of ELEMENTS OF H, so 1 / den is a product of two entries of the tables v_H(alpha) / (alpha - h)
+        // (round 2's, still in ra_ev) and v_H(beta) / (beta - h) (one more product tree over H): two gathers instead of a batch inversion over K -- v_H(alpha) v_H(beta) included
+        F *outs[1] = {ra_poly.p};
+        const Fr one = Fr::one();
+        gpu::vanishing_quotient_evals(outs, &one, 1, beta, elems, (uint32_t)n, lg_n, e[0].p, e[0].n, s);
+        gpu::f_evals_from_tables(e[1].p, ix_ev[2].p, ix_ev[3].p, ix_ev[4].p, eta_a, eta_b, eta_c, ra_ev.p, ra_poly.p, d_ix_ri, d_ix_ci, k, s);
+    }
     gpu::ntt<F>(f_poly.p, e[1].p, k, lg_k, true, s);
     gpu::d2d(poly[7].p, f_poly.p + 1, (k - 1) * sizeof(F), s); poly_len[7] = k - 1;   // g_2 = (f - f(0)) / X
     jobs.start(1, [&](Lane &ln) { mpc_commit(cx, ln, r3[0]); }, true);                           // g_2 (plain + shifted): under the rest of the round
