@@ -89,7 +89,9 @@ __global__ void __launch_bounds__(256) k_ntt_pass(NttBatchArgs<Fr> batch, bool f
         // chains of x + t and x - t + 2p -- 18 instructions instead of 81 per butterfly.  Limb bound L (units of 2^29) of what sits in LDS: 1 after a normalized stage;
         // a lazy stage adds 1 (p) or 2 (q): 1 -> 3 -> 5, the next stage is normalized again (its y operand, limbs < 5 x 2^29, is within the product's bound of 6; its
         // x operand within operator+ / sub<2>'s bound of 5).  VALUE bounds are untouched (+ 2p per stage as before).  A pass that ends on a lazy stage normalizes at its store.
-        const bool lazy = st >= 3 && (st % 3) != 2;
+        // Later passes (s0 > 0) start from canonical values too and their twiddle-1 butterflies are one in 2^s0: they take the product like everybody else and the
+        // schedule starts at their first stage (lazy, lazy, normalized, ...).
+        const bool lazy = (s0 > 0 || st >= 3) && (st % 3) != 2;
         for (uint32_t b = threadIdx.x; b < half_tile; b += 256) {
             uint32_t lo = b & ((1u << L) - 1), rest = b >> L;
             uint32_t a_low = rest & ((1u << st) - 1), a_high = rest >> st;
@@ -100,7 +102,7 @@ __global__ void __launch_bounds__(256) k_ntt_pass(NttBatchArgs<Fr> batch, bool f
 #pragma unroll
             for (int k = 0; k < N; k++) { x.l[k] = lds[k][e0]; y.l[k] = lds[k][e1]; }
             G p, q;
-            if (j == 0 && st < 3) {                  // twiddle 1 while the values are still small: no product
+            if (s0 == 0 && j == 0 && st < 3) {       // first pass, twiddle 1 while the values are still small: no product
                 p = x + y;
                 q = st == 0 ? x.template sub<1>(y) : (st == 1 ? x.template sub<4>(y) : x.template sub<8>(y));
             } else {
@@ -120,7 +122,7 @@ __global__ void __launch_bounds__(256) k_ntt_pass(NttBatchArgs<Fr> batch, bool f
 #pragma unroll
         for (int k = 0; k < N; k++) g.l[k] = lds[k][e];
         Fr v;
-        const bool last_lazy = S >= 4 && ((S - 1) % 3) != 2;          // (limbs < 3 or 5 x 2^29: fine as the lazy operand of the scaling products, normalized before a bare canonicalisation)
+        const bool last_lazy = (s0 > 0 || S >= 4) && ((S - 1) % 3) != 2;          // (limbs < 3 or 5 x 2^29: fine as the lazy operand of the scaling products, normalized before a bare canonicalisation)
         if (scale && cs_tw) {                         // inverse coset transform: coefficient gi times g^-gi / n
             const uint32_t ex = (cs_c * gi) & cs_mask, half = (cs_mask >> 1) + 1;
             G t = (g * scale_by) * cs_tw[ex & (half - 1)];

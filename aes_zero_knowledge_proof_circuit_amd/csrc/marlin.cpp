@@ -586,6 +586,7 @@ struct ProverContext {
     // (lane 3 is the background lane: the early mask commitment of round 1 runs there, under the witness generation on the main stream)
     Lane lane[N_LANES];
     DevBuf acc_b, wit_b, wit2_b, scratch_b;             // second set of opening buffers (the two openings run side by side on the latency path)
+    DevBuf scratch_c; void *ev_aux = nullptr;           // ... and the calling thread divides g_2 by (X - gamma) on the main stream beside them: its own division scratch + the event the gamma opening waits for
     bool throughput = false;           // set per proof: several proofs in flight (chunked / batch calls) -> window tables; a lone encrypt() call -> per-window buckets
     ProverContext() { stream = gpu::stream_create(); msm_ws = gpu::msm_workspace_create(); lane[0].stream = stream; lane[0].ws = msm_ws; }
     void ensure_lanes() {
@@ -600,7 +601,8 @@ struct ProverContext {
         for (DevBuf *b : {&za_ev, &zb_ev, &x_poly, &x_tmp, &x_evals, &tmp_n, &ra_ev, &ra_poly, &zpoly, &t_partial, &big_tmp, &f_poly, &acc, &wit, &wit2, &scratch}) b->release();
         for (auto &b : poly) b.release();
         for (auto &b : e) b.release();
-        for (DevBuf *b : {&acc_b, &wit_b, &wit2_b, &scratch_b}) b->release();
+        for (DevBuf *b : {&acc_b, &wit_b, &wit2_b, &scratch_b, &scratch_c}) b->release();
+        gpu::event_destroy(ev_aux);
         for (int i = 1; i < N_LANES; i++) if (lane[i].stream) { gpu::msm_workspace_destroy(lane[i].ws); gpu::stream_destroy(lane[i].stream); gpu::event_destroy(lane[i].ready); }
         gpu::msm_workspace_destroy(msm_ws);
         gpu::stream_destroy(stream);
@@ -1168,7 +1170,9 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
     // the two openings are independent: on the latency path they run side by side, the second one on its own buffers
     if (jobs.async && !cx.acc_b.p) {
         cx.acc_b.alloc(acc.n); cx.wit_b.alloc(wit.n); cx.wit2_b.alloc(wit2.n); cx.scratch_b.alloc(scratch.n);
+        cx.scratch_c.alloc(gpu::divide_by_linear_scratch(std::max(n, k) + 1)); cx.ev_aux = gpu::event_create();
     }
+    std::atomic<bool> g2_quotient_queued{false};
     const bool two_sets = cx.acc_b.p != nullptr && jobs.async;
     if (jobs.async) gpu::sync(s);                 // (the opening jobs read what the main stream made: everything is in place from here)
     jobs.start(1, [&](Lane &ln) {   // open at beta: g_1 (ch^0; shifted ch^1), outer_sumcheck (ch^2), t (ch^3), z_b (ch^4)
@@ -1212,12 +1216,25 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
             gpu::poly_lincomb_n(acc_.p, plen, ps, ls, sc, 8, ls_);
         }
         gpu::divide_by_linear(wit_.p, acc_.p, plen, gamma, scr_.p, scr_.n, ls_);
-        gpu::divide_by_linear(wit2_.p, poly[7].p, poly_len[7], gamma, scr_.p, scr_.n, ls_);
-        gpu::poly_scale(wit2_.p, chp[1], poly_len[7] - 1, ls_);
+        if (jobs.async) {        // the shifted part g_2 / (X - gamma) is being made on the main stream by the calling thread, beside this division (two chains of a dozen short launches)
+            while (!g2_quotient_queued.load(std::memory_order_acquire)) std::this_thread::yield();
+            gpu::stream_wait_event(ls_, cx.ev_aux);
+        } else {
+            gpu::divide_by_linear(wit2_.p, poly[7].p, poly_len[7], gamma, scr_.p, scr_.n, ls_);
+            gpu::poly_scale(wit2_.p, chp[1], poly_len[7] - 1, ls_);
+        }
         msm_opening_prepare(cx, ln, wit_.p, plen - 1, wit2_.p, poly_len[7] - 1, bounds[1] - (k - 2));
         XYZZ<Fq377> w = msm_opening_finish(ln);
         pf.w_gamma = w.to_affine();
     }, false);
+    if (jobs.async) {
+        try {
+            gpu::divide_by_linear(cx.wit2_b.p, poly[7].p, poly_len[7], gamma, cx.scratch_c.p, cx.scratch_c.n, s);
+            gpu::poly_scale(cx.wit2_b.p, chp[1], poly_len[7] - 1, s);
+            gpu::event_record(cx.ev_aux, s);
+        } catch (...) { g2_quotient_queued.store(true, std::memory_order_release); throw; }      // (never leave the gamma job spinning)
+        g2_quotient_queued.store(true, std::memory_order_release);
+    }
     jobs.join();
     for (int i = 0; i < 4; i++) pf.comms[i] = r1[i].comm;
     for (int i = 0; i < 3; i++) pf.comms[4 + i] = r2[i].comm;
