@@ -2,15 +2,16 @@
 //
 // Replaces ark-ec 0.3.0 VariableBaseMSM::multi_scalar_mul (one rayon task per window, Cargo.lock:118) behind
 // KZG10::commit / open (ark-poly-commit 0.3.0) -- SURVEY.md §8 a17.  GPU shape:
-//   1. k_digits      : scalars Montgomery -> canonical, split into c-bit window digits, emit (window|digit, index) pairs
-//   2. grouping      : table mode: a two-level bucket partition written for this layout and for instruction count (k_part_*); per-window mode and small instances:
-//                      one stable rocPRIM radix sort on the bucket bits over all windows at once
-//   3. k_bounds      : bucket [start, end) ranges in the sorted pair list (empty buckets filled in on the way: nothing is memset)
-//      k_order_*     : visiting order of the buckets by descending size (counting sort, deterministic) + the list of oversized buckets
-//   4. k_accumulate  : ONE LANE PER BUCKET, XYZZ accumulator, mixed adds of affine bases gathered through the sorted
-//                      index list -- the dominant kernel (integer-ALU bound: ~10 Fq products of 12x12 v_mad_u64_u32 each per add)
-//   5. k_reduce_*    : running-sum reduction in 64-bucket segments, then an LDS tree per window
-//   6. host          : Horner over the <= 32 window sums (c doublings each)
+//   1. digits + grouping : table mode (the prover's SRS path: 13 balanced signed windows over ONE bucket set, the window weights live in 12 table copies): a two-level
+//                      bucket partition written for this layout and for instruction count (k_part_hist / k_part_scatter / k_part_fine) leaves the (point, window) pairs
+//                      bucket-contiguous and the bucket ranges; per-window mode and small instances: k_digits + one stable rocPRIM radix sort + k_bounds
+//   2. k_order_*     : visiting order of the buckets by descending size (counting sort, deterministic) + the list of oversized buckets
+//   3. k_accumulate  : ONE LANE PER BUCKET, the dominant kernel (integer-ALU bound).  EdwardsLaw (BLS12-377 SRS paths): extended twisted Edwards accumulator, 7-product
+//                      unified additions of gathered 192-byte Niels28 records (te28.cuh); WeierLaw (arbitrary points, BLS12-381): XYZZ accumulator, 10-product mixed
+//                      additions with the P = +-Q case deferred.  k_accumulate_tail: overflow segments of oversized buckets; k_fold_overflow folds them into their buckets
+//   4. reduction     : Edwards: k_reduce_l1_pair (8-bucket lane-interleaved segments, two lanes per segment) -> k_reduce_rc (row / column sums on DPP quads) ->
+//                      k_reduce_final (six unweighted terms per set) -> the weighted tail on the host; Weierstrass: k_reduce_l1 / l2 -> k_sum_tree -> k_reduce_window
+//   5. host          : table mode: nothing (one bucket set); per-window mode: Horner over the <= 37 window sums (c doublings each)
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>

@@ -154,8 +154,9 @@ def test_msm_2_16_matches_oracle(zko, api):
 @pytest.mark.parametrize("n,c", [(1, 8), (33, 5), (1000, 11), (1 << 12, 13), ((1 << 13) + 3, 20), ((1 << 14) + 77, 18), (5000, 16)])
 def test_msm_precomputed_window_tables_match_oracle(zko, api, cid, srs, n, c):
     """the prover's SRS path: tables 2^(offset of window j) P_i over balanced windows (254 or 256 bits spread evenly: widths c and c - 1), one shared
-    bucket set (kernels_msm.hip msm_table, TableLayout); pairs grouped by digits + rocPRIM radix sort.  srs = zkaes_msm_table_srs, the twisted Edwards
-    law the prover runs over its SRS (oracle points are multiples of the generator: in the prime-order subgroup); otherwise the generic XYZZ entry."""
+    bucket set (kernels_msm.hip msm_table, TableLayout).  These sizes stay below the two-level partition's threshold (2^16 pairs): digits (k_digits_table) + one stable
+    rocPRIM radix sort on the bucket bits + k_bounds.  srs = zkaes_msm_table_srs, the twisted Edwards law the prover runs over its SRS (oracle points are multiples of
+    the generator: in the prime-order subgroup); otherwise the generic XYZZ entry."""
     bases = oracle_points(zko, cid, n, 3 * n + c)
     scalars = bytearray(rand_fr_mont(n, zko.FR[cid], 5 * n + c))
     if n >= 33:
@@ -172,10 +173,10 @@ def test_msm_precomputed_window_tables_match_oracle(zko, api, cid, srs, n, c):
 
 @pytest.mark.parametrize("srs", [True, False])
 @pytest.mark.parametrize("n,c", [((1 << 14) + 5, 20), (9000, 18), (6000, 17), (9000, 15)])
-def test_msm_table_presplit_digits_agree_with_oracle(zko, api, srs, n, c):
-    """from 2^16 (point, window) pairs and more than 16 bucket bits the digit kernels split the pairs stably on the low bucket bits (k_split_hist /
-    k_split_scatter) and the radix sort covers 16 bits in two passes; c = 15 (14 bucket bits) takes digits + one full-width sort.  Both must match the oracle,
-    incl. the scalars 0 (every digit zero: SKIP entries), 1 and r - 1, and empty buckets (k_bounds fills their ranges in: nothing is memset)."""
+def test_msm_table_partition_and_sort_paths_agree_with_oracle(zko, api, srs, n, c):
+    """from 2^16 (point, window) pairs on, window plans with 10..19 bucket bits and at most 16 windows go through the two-level partition (k_part_hist: digits + coarse-bin
+    counts, one scan, k_part_scatter, k_part_fine: in-LDS sort of a coarse bin on (fine bucket, window) + the bucket ranges); c = 15 (14 bucket bits, 17 windows) stays on
+    digits + one stable radix sort + k_bounds.  Both must match the oracle, incl. the scalars 0 (every digit zero: no pairs emitted), 1 and r - 1, and empty buckets."""
     bases = oracle_points(zko, 377, n, 13 * n + c)
     scalars = bytearray(rand_fr_mont(n, zko.FR[377], 17 * n + c))
     scalars[0:32] = bytes(32)
