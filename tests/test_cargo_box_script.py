@@ -63,9 +63,9 @@ def test_check_on_cargo_box_dry_run(tmp_path):
     env = dict(os.environ, ZKAES_CARGO_BOX_DRY_RUN="1", PYTHON=sys.executable)
     r = subprocess.run(["bash", script, str(tmp_path)], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("CONFIRMED") == 2
+    assert r.stdout.count("CONFIRMED") == 2 and "headline `value` of bench.py applies" in r.stdout
     # the reference's literal-sized circuit (a fake with more rows) must make the script fail and say where
     (tmp_path / "steps_64.log").write_text(fake_log(sc.steps(64, cv.Variant(shift="wit_eq", rot="wit_eq"))))
     r = subprocess.run(["bash", script, str(tmp_path)], capture_output=True, text=True, env=env)
-    assert r.returncode == 1 and "steps_64" in r.stdout and "differ" in r.stdout
+    assert r.returncode == 1 and "steps_64" in r.stdout and "differ" in r.stdout and "read `alt`" in r.stdout
     assert "FIRST DIVERGENCE" in (tmp_path / "steps_64.diff").read_text()
