@@ -1322,7 +1322,7 @@ std::vector<uint8_t> ProvingKey::aes_witness(const uint8_t *message, size_t len,
 // zero-knowledge randomness of proof i of a chunked / batch call: the caller's seed is domain-separated per proof, Blake2s(seed || (offset + i) as u64 LE),
 // so no two proofs share rho, the KZG hiding coefficients or the mask polynomial -- across calls and ranks too when they pass job-global offsets.
 // seed == nullptr keeps the reference's behaviour (every encrypt() call draws from ark_std::test_rng(), src/lib.rs:65): bit-parity mode for tests,
-// NOT zero-knowledge across proofs; the C ABI only reaches it with ZKAES_PARITY_RNG=1 or the explicit *_seeded(NULL) calls.
+// NOT zero-knowledge across proofs; the C ABI only reaches it through the explicit *_seeded(NULL) calls (no environment override).
 void os_random_seed(uint8_t out[32]) {
     size_t got = 0;
     while (got < 32) {
