@@ -34,9 +34,11 @@ __global__ void k_twiddles29(const Fr *__restrict__ tw, uint32_t n, Fp29<typenam
 //
 // Butterflies run on the reduced-radix form (ff29.cuh): data is only re-limbed (8 x 32 -> 9 x 29 bits, still x R), the twiddles come from a
 // table of w R' so one 162-multiply product gives t = y w (< 1.5 p); x + t and x - t + 2 p are carry-light limb additions that let the values
-// grow -- bounded statically: every pass starts from canonical inputs (< p); in its first three stages the butterflies with twiddle 1 skip the
+// grow -- bounded statically: the first pass starts from canonical inputs (< p); in its first three stages the butterflies with twiddle 1 skip the
 // product (y is still small: bounds 1, 3, 7 p -> K = 1, 4, 8 in x - y + K p), from then on every y is multiplied, so the bound grows by 2 p per
-// stage: < 29 p after ten stages, far below R' = 2^261 >= 64 p.  The store peels 16 p, 8 p, ..., p and re-packs canonical 8 x 32-bit words.
+// stage: < 29 p after ten stages, far below R' = 2^261 >= 64 p.  Later passes start from values < 2 p (what the previous pass's store leaves) and multiply
+// every y: < 22 p after ten stages.  The store takes v - q p with q estimated from the top limb ([0, 2 p), < 2^256: round 5 -- canonical<4>'s five
+// compare-and-subtract rounds were ~335 of the ~2,000 instructions an element costs per pass) and only a transform's last pass finishes to [0, p).
 // Coset transforms (ntt_coset): the points are g w^i with g = W^c, W a primitive root of a LARGER power-of-two domain of size cs_mask + 1 -- the cosets of H inside the
 // 4|H| domain the prover's round 2 evaluates on.  Forward: coefficient k is scaled by g^k while pass 1 gathers it (one more product per element, from the larger
 // domain's twiddle table: W^e for e < half, -W^(e - half) above); inverse: coefficient k is scaled by g^-k (and 1/n) at the last pass's store.
@@ -47,7 +49,7 @@ template <class Fr> struct NttBatchArgs { Fr *dst[NTT_MAX_BATCH]; const Fr *src[
 template <class Fr, int TILE_LG>
 __global__ void __launch_bounds__(256) k_ntt_pass(NttBatchArgs<Fr> batch, bool from_dst, uint32_t in_len, int lg, int s0, int S, int L,
                                                    const Fp29<typename Fr::Params> *__restrict__ tw, bool bitrev_load, bool scale, Fp29<typename Fr::Params> scale_by,
-                                                   const Fp29<typename Fr::Params> *__restrict__ cs_tw_all, uint32_t cs_mask) {
+                                                   const Fp29<typename Fr::Params> *__restrict__ cs_tw_all, uint32_t cs_mask, bool final_pass) {
     using G = Fp29<typename Fr::Params>;
     Fr *dst = batch.dst[blockIdx.y];
     const Fr *src = from_dst ? (const Fr *)dst : batch.src[blockIdx.y];
@@ -129,7 +131,10 @@ __global__ void __launch_bounds__(256) k_ntt_pass(NttBatchArgs<Fr> batch, bool f
             if (ex >= half) t = G::zero().template sub<2>(t);
             t.template canonical<1>().pack(v.l);
         } else if (scale) (g * scale_by).template canonical<1>().pack(v.l);
-        else (last_lazy ? g.normalized() : g).template canonical<4>().pack(v.l);
+        else {                                        // < 32 p -> [0, 2 p) by a quotient estimate from the top limb (ff29.cuh): that fits the 8 x 32-bit words a later pass
+            const G r = (last_lazy ? g.normalized() : g).reduce_by_top_limb();   // re-limbs (its stage bounds start from 2 p); only the transform's LAST pass pays the round to [0, p)
+            (final_pass ? r.template canonical<0>() : r).pack(v.l);
+        }
         dst[gi] = v;
     }
 }
@@ -245,7 +250,7 @@ static void ntt_impl(const NttJob<Fr> *jobs, int count, size_t in_len, int lg, b
     {
         bool last = remaining == 0;
         hipLaunchKernelGGL((k_ntt_pass<Fr, 10>), dim3(n >> S1, count), dim3(256), 0, s, batch, false, (uint32_t)in_len, lg, 0, S1, 0, tw, true, inverse && last, n_inv,
-                           (!inverse || last) ? cs_tw : (const G *)nullptr, cs_mask);
+                           (!inverse || last) ? cs_tw : (const G *)nullptr, cs_mask, last);
         HIP_LAUNCH_CHECK();
         s0 = S1;
     }
@@ -257,7 +262,7 @@ static void ntt_impl(const NttJob<Fr> *jobs, int count, size_t in_len, int lg, b
         if (L < 2) L = 2;
         bool last = remaining == S;
         hipLaunchKernelGGL((k_ntt_pass<Fr, 10>), dim3(n >> (S + L), count), dim3(256), 0, s, batch, true, n, lg, s0, S, L, tw, false, inverse && last, n_inv,
-                           (inverse && last) ? cs_tw : (const G *)nullptr, cs_mask);
+                           (inverse && last) ? cs_tw : (const G *)nullptr, cs_mask, last);
         HIP_LAUNCH_CHECK();
         s0 += S;
         remaining -= S;

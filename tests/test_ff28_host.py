@@ -151,6 +151,16 @@ template <class P> int run(const char *name) {
         bad += !(x.template to_std_relimb<4>() == xs);
         bad += !(y.template to_std_relimb<4>() == ys);
         bad += !((x * W).template to_std_relimb<1>() == xs * b);
+        // the NTT's stores (round 5): quotient estimate from the top limb -> [0, 2 p), fits the 8 x 32-bit words between passes; one more round gives the canonical value
+        {
+            G rx = x.reduce_by_top_limb(), ry = y.reduce_by_top_limb();
+            bad += (rx.l[8] >> 24) != 0 || (ry.l[8] >> 24) != 0;                       // < 2^256
+            for (int i = 0; i < 8; i++) bad += rx.l[i] > G::MASK || ry.l[i] > G::MASK;
+            bad += !(rx.template to_std_relimb<0>() == xs);
+            bad += !(ry.template to_std_relimb<0>() == ys);
+            uint32_t w8[8]; rx.pack(w8);
+            bad += !(G::split(w8).template to_std_relimb<0>() == xs);                  // survives the trip through memory
+        }
         // dot products with one reduction (the polynomial kernels' linear combinations): data x scalar-in-twiddle-form terms, lazy operands (< 2 p, < 4 p), and
         // data x data through the five-bit shift: mul(shl5(a R), b R) = a b R
         {
@@ -165,6 +175,28 @@ template <class P> int run(const char *name) {
             bad += !((A.shl5() * B).template to_std_relimb<1>() == a * b);
             G s5[2] = {A.shl5(), (C + C).shl5()}, dd[2] = {B, G::zero().template sub<2>(D2 + D2)};
             bad += !(G::template dot<2>(s5, dd).template to_std_relimb<1>() == a * b - (c + c) * (d2 + d2));
+        }
+    }
+    // edges of the estimate: K p - 1, K p, K p + 1 for every K <= 32 (a ten-stage pass holds values below 32 p); the expected residues as raw integers
+    {
+        G pp, one = G::zero();
+        for (int i = 0; i < 9; i++) pp.l[i] = G::mod29(i);
+        one.l[0] = 1;
+        F r0 = F::zero(), r1 = F::zero(), rm = F::zero();
+        r1.l[0] = 1;
+        for (int i = 0; i < 8; i++) rm.l[i] = P::mod(i);
+        rm.l[0] -= 1;                                                  // p is odd
+        G v = G::zero();
+        for (int K = 0; K <= 32; K++) {
+            for (int d = -1; d <= 1; d++) {
+                if ((K == 0 && d < 0) || (K == 32 && d >= 0)) continue;
+                G u = d < 0 ? v.template sub<0>(one) : (d > 0 ? v + one : v);
+                G r = u.reduce_by_top_limb();
+                bad += (r.l[8] >> 24) != 0;
+                F got; r.template canonical<0>().pack(got.l);
+                bad += !(got == (d < 0 ? rm : (d > 0 ? r1 : r0)));
+            }
+            v = v + pp;
         }
     }
     printf("%s %d\n", name, bad);
