@@ -1277,7 +1277,7 @@ constexpr int PART_MAXW = 1 << PART_WBITS;                                      
 constexpr int PART_STAGE = PART_TILE * PART_MAXW;                                         // staged pairs per tile (LDS: 8 B each = 128 KB)
 constexpr uint32_t PART_NBIN_MAX = 1024;                                                  // coarse bins (bucket bits <= 19, i.e. c_hi <= 20)
 constexpr uint32_t PART_GRID = 512, PART_NONE = 0xffffffffu;
-constexpr int PART_FINE_THREADS = 1024, PART_FINE_UNROLL = 4;     // the last pass is latency-bound (load -> LDS atomic -> scattered store): many lanes per bin, several loads in flight per lane
+constexpr int PART_FINE_THREADS = 1024, PART_FINE_UNROLL = 8;     // the last pass is latency-bound (load -> LDS atomic -> LDS store): many lanes per bin, several loads in flight per lane
 
 // signed window digits of one scalar: d[w] = (|digit| - 1) | neg << 31, PART_NONE for a zero digit or w >= nwin
 template <class Fr>
@@ -1392,10 +1392,16 @@ __global__ void __launch_bounds__(PART_THREADS) k_part_scatter(const uint32_t *_
         __syncthreads();
     }
 }
-// one workgroup per coarse bin
+// one workgroup per coarse bin.  Round 5: the values reach their final place THROUGH LDS.  The direct form (out_val[lo + rank] = val from every lane) wrote 4 scattered
+// bytes per pair into a region far larger than the L2s hold together; the lines left the chip partly filled: WRITE_SIZE 1.83 GB for 218 MB of values at 2^22 points,
+// 1.08 ms per launch and the longest stretch a lone call's MSM waits for (profiles/r05_pmc_partition.md).  Now a sweep ranks the pairs of a KEY RANGE whose runs fit
+// the staging array (30,720 values), drops them at their final relative position in LDS and streams the range out in order (full lines); a bin of 2^22 / 2^23 points
+// takes two / four sweeps, each re-reading the bin's keys and values (6 bytes per pair, coalesced).  A single key with more pairs than the stage (skewed scalars) keeps
+// the direct form for that key alone.
+constexpr uint32_t PART_FINE_STAGE = 30720;
 __global__ void __launch_bounds__(PART_FINE_THREADS) k_part_fine(const uint32_t *__restrict__ offs, uint32_t grid_a, const uint32_t *__restrict__ in_val, const uint16_t *__restrict__ in_key,
                                                                  uint32_t *__restrict__ out_val, uint32_t *__restrict__ start, uint32_t *__restrict__ end) {
-    __shared__ uint32_t cur[PART_KEYS], wave_sums[PART_FINE_THREADS / 64], total;
+    __shared__ uint32_t cur[PART_KEYS], stage[PART_FINE_STAGE], wave_sums[PART_FINE_THREADS / 64], total, split_key;
     const uint32_t bin = blockIdx.x, t = threadIdx.x;
     const uint32_t lo = offs[(size_t)bin * grid_a], hi = offs[(size_t)(bin + 1) * grid_a];
     for (uint32_t f = t; f < PART_KEYS; f += PART_FINE_THREADS) cur[f] = 0;
@@ -1415,16 +1421,40 @@ __global__ void __launch_bounds__(PART_FINE_THREADS) k_part_fine(const uint32_t 
         end[k] = lo + (f + 1 < PART_FINE ? cur[(f + 1) << PART_WBITS] : total);
     }
     __syncthreads();
-    for (uint32_t e0 = lo + t; e0 < hi; e0 += PART_FINE_THREADS * PART_FINE_UNROLL) {
-        uint32_t key[PART_FINE_UNROLL], val[PART_FINE_UNROLL];
-#pragma unroll
-        for (int u = 0; u < PART_FINE_UNROLL; u++) {
-            const uint32_t e = e0 + u * PART_FINE_THREADS;
-            key[u] = PART_NONE;
-            if (e < hi) { key[u] = in_key[e]; val[u] = in_val[e]; }
+    const uint32_t tot = total;
+    uint32_t k_lo = 0, base = 0;                   // keys below k_lo are done (their cursors have run to the next key's start); `base` = where key k_lo's run begins
+    while (base < tot) {                           // (uniform over the workgroup)
+        // keys [k_lo, k_hi): the longest range whose runs end within base + STAGE.  The run that holds position base + STAGE belongs to exactly one key >= k_lo.
+        const uint32_t lim = base + PART_FINE_STAGE;
+        if (tot <= lim) { if (t == 0) split_key = PART_KEYS; }
+        else for (uint32_t f = k_lo + t; f < PART_KEYS; f += PART_FINE_THREADS) {
+            const uint32_t e_f = f + 1 < PART_KEYS ? cur[f + 1] : tot;
+            if (cur[f] <= lim && e_f > lim) split_key = f;
         }
+        __syncthreads();
+        uint32_t k_hi = split_key;
+        const bool direct = k_hi == k_lo;          // one key alone overflows the stage
+        if (direct) k_hi = k_lo + 1;
+        const uint32_t stop = k_hi < PART_KEYS ? cur[k_hi] : tot;      // (key k_hi's cursor is not touched by this sweep)
+        __syncthreads();
+        for (uint32_t e0 = lo + t; e0 < hi; e0 += PART_FINE_THREADS * PART_FINE_UNROLL) {
+            uint32_t key[PART_FINE_UNROLL], val[PART_FINE_UNROLL];
 #pragma unroll
-        for (int u = 0; u < PART_FINE_UNROLL; u++) if (key[u] != PART_NONE) out_val[lo + atomicAdd(&cur[key[u]], 1u)] = val[u];
+            for (int u = 0; u < PART_FINE_UNROLL; u++) {          // (keys and values in one round of loads: a sweep's latency is what a lone call waits for, the re-read is coalesced)
+                const uint32_t e = e0 + u * PART_FINE_THREADS;
+                key[u] = PART_NONE;
+                if (e < hi) { key[u] = in_key[e]; val[u] = in_val[e]; }
+            }
+#pragma unroll
+            for (int u = 0; u < PART_FINE_UNROLL; u++) if (key[u] >= k_lo && key[u] < k_hi) {
+                const uint32_t pos = atomicAdd(&cur[key[u]], 1u);
+                if (direct) out_val[lo + pos] = val[u]; else stage[pos - base] = val[u];
+            }
+        }
+        __syncthreads();
+        if (!direct) for (uint32_t i = t; i < stop - base; i += PART_FINE_THREADS) out_val[lo + base + i] = stage[i];
+        __syncthreads();
+        base = stop; k_lo = k_hi;
     }
 }
 // digits + grouping of the table path; leaves S.sorted_vals / S.start / S.end as prepare_buckets would (bucket-contiguous, by window inside a bucket, zero digits absent)
