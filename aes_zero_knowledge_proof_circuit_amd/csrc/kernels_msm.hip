@@ -234,10 +234,26 @@ __global__ void __launch_bounds__(ORD_BINS) k_order_scan(const uint32_t *__restr
         }
         return part[t] - v;
     };
+    // (a lone call waits for this one workgroup: the loads of a lane are independent, so they go out eight at a time instead of one latency each)
     uint32_t sum = 0;
-    for (uint32_t i = 0; i < nblk; i++) sum += hist[(size_t)i * ORD_BINS + t];
+    uint32_t i0 = 0;
+    for (; i0 + 8 <= nblk; i0 += 8) {
+        uint32_t c[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) c[u] = hist[(size_t)(i0 + u) * ORD_BINS + t];
+#pragma unroll
+        for (int u = 0; u < 8; u++) sum += c[u];
+    }
+    for (; i0 < nblk; i0++) sum += hist[(size_t)i0 * ORD_BINS + t];
     uint32_t run = block_exclusive(sum);
-    for (uint32_t i = 0; i < nblk; i++) { const uint32_t c = hist[(size_t)i * ORD_BINS + t]; offs[(size_t)i * ORD_BINS + t] = run; run += c; }
+    for (i0 = 0; i0 + 8 <= nblk; i0 += 8) {
+        uint32_t c[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) c[u] = hist[(size_t)(i0 + u) * ORD_BINS + t];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { offs[(size_t)(i0 + u) * ORD_BINS + t] = run; run += c[u]; }
+    }
+    for (; i0 < nblk; i0++) { const uint32_t c = hist[(size_t)i0 * ORD_BINS + t]; offs[(size_t)i0 * ORD_BINS + t] = run; run += c; }
     uint32_t n = ctrl[0];
     if (n > ovf_cap) n = ovf_cap;
     uint32_t base = 0;
