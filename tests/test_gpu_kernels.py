@@ -219,11 +219,38 @@ def test_msm_table_skewed_scalars_fold_overflow_runs_across_workgroups(zko, api,
     assert not inf and not ref_inf and got == ref.raw
 
 
-def test_msm_full_size_independent_paths_agree(api):
-    """BASELINE-size MSM (2^20 points = |H| of a 6-block proof; the oracle would need minutes): per-window buckets on the Weierstrass model (XYZZ, the
-    generic path), the same buckets on the twisted Edwards model (the prover's lone-call SRS path), and the precomputed-table single-bucket-set path
-    (Edwards, 13 balanced windows) are different algorithms, group laws and table copies -- their sums must be identical."""
-    n = 1 << 20
+@pytest.mark.parametrize("srs", [True, False])
+@pytest.mark.parametrize("kind,n,c", [("one", 70_000, 16), ("half", 120_000, 16), ("few", 90_000, 17)])
+def test_msm_table_partition_stages_key_ranges_and_writes_oversized_keys_directly(zko, api, srs, kind, n, c):
+    """k_part_fine (round 5) places a coarse bin's values through a 30,720-value LDS stage, one sweep per key range that fits; a single (bucket, window) key with more
+    pairs than the stage is written directly.  "one": every scalar equal -> each window's pairs sit on ONE key of 70,000 (direct mode, nothing staged);
+    "half": half the scalars equal, half random -> the heavy keys go direct between staged ranges of the same bin (the sweep's key range restarts after them);
+    "few": five distinct scalars -> keys of 18,000 pairs: two of them do not fit one stage together, so a bin takes several staged sweeps."""
+    bases = oracle_points(zko, 377, n, 31 * n + c)
+    rnd = rand_fr_mont(n, zko.FR[377], 7 * n + c)
+    vals = [int.from_bytes(np.random.RandomState(4100 + i).bytes(31), "little") for i in range(5)]
+    if kind == "one":
+        scalars = zko.fr_pack([vals[0]] * n)
+    elif kind == "few":
+        scalars = zko.fr_pack([vals[i % 5] for i in range(n)])
+    else:
+        heavy = zko.fr_pack([vals[1]])
+        scalars = bytearray(rnd)
+        for i in range(0, n, 2):
+            scalars[32 * i:32 * i + 32] = heavy
+        scalars = bytes(scalars)
+    ref = C.create_string_buffer(96)
+    ref_inf = zko.lib().zko_api_msm(377, bases, scalars, C.c_size_t(n), ref)
+    got, inf = api.msm_table(377, bases, scalars, c, srs=srs)
+    assert not inf and not ref_inf and got == ref.raw
+
+
+@pytest.mark.parametrize("n", [1 << 20, 3 << 20])
+def test_msm_full_size_independent_paths_agree(api, n):
+    """BASELINE-size MSMs (2^20 points = |H| of a 6-block proof, 3 x 2^20 = its mask polynomial; the oracle would need minutes): per-window buckets on the Weierstrass
+    model (XYZZ, the generic path), the same buckets on the twisted Edwards model (the prover's lone-call SRS path), and the precomputed-table single-bucket-set path
+    (Edwards, 13 balanced windows) are different algorithms, group laws and table copies -- their sums must be identical.  At 3 x 2^20 points a coarse bin of the
+    table path's partition holds ~40,000 pairs: k_part_fine stages it in two sweeps."""
     _, _, p_classic = api.msm_bench_synth(n, 0, 1, want_point=True)
     _, _, p_edwards = api.msm_bench_synth(n, -1, 1, want_point=True)
     _, _, p_table17 = api.msm_bench_synth(n, 17, 1, want_point=True)
