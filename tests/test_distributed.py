@@ -22,6 +22,21 @@ def _free_port():
     return p
 
 
+def _spawn(fn, first, rest, nprocs):
+    """mp.spawn(fn, args=(first, <rendezvous port>) + rest): the port comes from _free_port(), which can lose a race for it (another process binds it between the probe
+    and the store's listen, or the previous test's sockets linger); a rendezvous failure is retried once on a fresh port -- anything else is raised as it is."""
+    for attempt in range(2):
+        port = _free_port()
+        try:
+            mp.spawn(fn, args=(first, port) + tuple(rest), nprocs=nprocs, join=True)
+            return
+        except Exception as e:      # noqa: BLE001
+            msg = str(e)
+            if attempt == 0 and any(k in msg for k in ("Address already in use", "EADDRINUSE", "Connection refused", "Connection reset", "timed out", "TCPStore", "connect()")):
+                continue
+            raise
+
+
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -42,7 +57,7 @@ def test_two_rank_report_reduction():
     world, port = 2, _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    _spawn(_worker, world, (out, ), world)
     r0, r1 = out[0], out[1]
     assert r0[0] == r1[0] == 2.0                      # max over ranks
     assert (r0[1], r0[2], r0[3]) == (6, 6, 2)          # 3 chunk-proofs per rank, both negatives rejected
@@ -148,7 +163,7 @@ def _bench_worker(rank, world, port, argv, out):
 def _run_bench(argv, world=2):
     port = _free_port()
     out = mp.Manager().dict()
-    mp.spawn(_bench_worker, args=(world, port, argv, out), nprocs=world, join=True)
+    _spawn(_bench_worker, world, (argv, out, ), world)
     return out
 
 
@@ -279,7 +294,7 @@ def _gather_worker(rank, world, port, out):
 def test_gather_proofs_uneven_shares():
     port = _free_port()
     out = mp.Manager().dict()
-    mp.spawn(_gather_worker, args=(2, port, out), nprocs=2, join=True)
+    _spawn(_gather_worker, 2, (out, ), 2)
     assert out[0] == out[1] == [b"\x07" * 855, b"\x07" * 854, b"\x07" * 853]
 
 
@@ -330,7 +345,7 @@ def test_point_range_sharded_msm_two_ranks(cid, n):
     """per-rank partials come from the oracle here (no GPU); the exchange + zkaes_g1_sum fold is the product code under test"""
     world, port = 2, _free_port()
     out = mp.Manager().dict()
-    mp.spawn(_msm_worker, args=(world, port, cid, n, False, out), nprocs=world, join=True)
+    _spawn(_msm_worker, world, (cid, n, False, out, ), world)
     bases, scalars = _msm_inputs(cid, n, 4000 + n)
     ref = _oracle_msm(cid)(bases, scalars)
     assert out[0] == out[1] == ref
@@ -357,7 +372,7 @@ def test_point_range_sharded_msm_two_gpu_processes():
     """both ranks run the HIP Pippenger on their slice through the C ABI (sharing GPU 0 on a one-GPU box), then all-gather + fold"""
     world, port, cid, n = 2, _free_port(), 377, 5000
     out = mp.Manager().dict()
-    mp.spawn(_msm_worker, args=(world, port, cid, n, True, out), nprocs=world, join=True)
+    _spawn(_msm_worker, world, (cid, n, True, out, ), world)
     bases, scalars = _msm_inputs(cid, n, 4000 + n)
     assert out[0] == out[1] == _oracle_msm(cid)(bases, scalars)
 
@@ -383,7 +398,7 @@ def test_point_range_sharded_msm_device_resident_exchange_rccl(cid, n):
     One rank here (a one-GPU box; RCCL refuses two ranks on one device) -- the collective and both C-ABI calls still run."""
     port = _free_port()
     out = mp.Manager().dict()
-    mp.spawn(_msm_device_worker, args=(1, port, cid, n, out), nprocs=1, join=True)
+    _spawn(_msm_device_worker, 1, (cid, n, out, ), 1)
     bases, scalars = _msm_inputs(cid, n, 4000 + n)
     assert out[0] == _oracle_msm(cid)(bases, scalars)
 
@@ -395,7 +410,7 @@ def test_point_range_sharded_msm_device_resident_exchange_two_gpus():
         pytest.skip("needs two GPUs")
     cid, n, port = 377, 5000, _free_port()
     out = mp.Manager().dict()
-    mp.spawn(_msm_device_worker, args=(2, port, cid, n, out), nprocs=2, join=True)
+    _spawn(_msm_device_worker, 2, (cid, n, out, ), 2)
     bases, scalars = _msm_inputs(cid, n, 4000 + n)
     assert out[0] == out[1] == _oracle_msm(cid)(bases, scalars)
 
@@ -494,7 +509,7 @@ def test_srs_path_sharded_msm_through_rccl():
     world = 2 if torch.cuda.device_count() >= 2 else 1
     n, off, port = 500_500, 7, _free_port()
     out = mp.Manager().dict()
-    mp.spawn(_srs_msm_device_worker, args=(world, port, n, off, out), nprocs=world, join=True)
+    _spawn(_srs_msm_device_worker, world, (n, off, out, ), world)
     _, want = _srs_msm_case(n, off, 12)
     for r in range(world):
         got, inf = out[r]
