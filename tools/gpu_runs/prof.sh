@@ -1,9 +1,9 @@
 #!/bin/bash
 # rocprofv3 kernel statistics of bench.py on the GPU box, summarized into gpurun_out/<tag>/ (copy what should be judged into profiles/).
-#   gpurun -- 'bash tools/gpu_runs/prof.sh r04 serial'     one prover context: un-overlapped kernel durations, launches per proof (21 proofs)
-#   gpurun -- 'bash tools/gpu_runs/prof.sh r04 driver'     the driver's own command (saturated: in-situ durations)
+#   gpurun -- 'bash tools/gpu_runs/prof.sh r05 serial'     one prover context: un-overlapped kernel durations, launches per proof (21 proofs)
+#   gpurun -- 'bash tools/gpu_runs/prof.sh r05 driver'     the driver's own command (saturated: in-situ durations)
 # Counters (--pmc) are collected separately: tools/pmc_accumulate.py.  Round 1-3 ran ~35 one-off scripts from this directory; they are in the git history.
-TAG=${1:-r04}; MODE=${2:-serial}
+TAG=${1:-r05}; MODE=${2:-serial}
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 O=gpurun_out/${TAG}_prof_${MODE}; mkdir -p $O
 if [ "$MODE" = serial ]; then ARGS="--blocks 120 --steps 2 --warmup 1 --contexts 1 --pipeline 1 --serial-probe 0 --no-cpu-baseline --alt-proofs 0 --latency-samples 0"
