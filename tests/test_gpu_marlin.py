@@ -270,6 +270,38 @@ def test_aes96_matches_the_committed_oracle_fixture(api, aes96):
     assert api.verify_encryption(vk, bytes.fromhex(fx["proof"]), bytes.fromhex(fx["ciphertext"])) is True
 
 
+def test_aes64_reference_test_message_matches_the_committed_oracle_fixture(api):
+    """The reference's OWN 64-byte case (tests/integration_tests.rs:340-371: its message, its key, accept with its ciphertext, reject with its altered one) at the byte level:
+    tests/golden/oracle_aes64.json holds what the CPU oracle produced for it (make_oracle_aes96.py 64) -- witness, the nine prover polynomials and the proof bytes must be
+    identical on the GPU, through the lone and the multi-proof path.  This is also the 4-block key of the bench's `alt` leg (|H| = 2^20, |K| = 2^22)."""
+    import hashlib
+    import json
+    path = os.path.join(GOLD, "oracle_aes64.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/oracle_aes64.json not generated yet (python tests/golden/make_oracle_aes96.py 64)")
+    fx = json.load(open(path))
+    vec = json.load(open(os.path.join(GOLD, "reference_vectors.json")))
+    msg, key = bytes.fromhex(fx["message"]), bytes.fromhex(fx["key"])
+    assert msg == bytes(vec["plaintext_64"]) and key == bytes(vec["key"]) and bytes.fromhex(fx["ciphertext"]) == bytes(vec["ciphertext_64"])
+    pk, vk = api.synthesize_keys(64)
+    info = pk.info()
+    assert (info["h"], info["k"]) == (fx["index"]["h"], fx["index"]["k"]) == (1 << 20, 1 << 22)
+    assert (info["constraints"], info["joint_nnz"]) == (fx["index"]["num_constraints"], fx["index"]["num_non_zero"])
+    z = pk.witness(msg, key)
+    assert len(z) == fx["witness_len"] and hashlib.sha256(z).hexdigest() == fx["witness_sha256"]
+    proof = api.encrypt(msg, key, pk)
+    for name, want in fx["poly_sha256"].items():
+        got = pk.debug_fetch(name)
+        assert len(got) // 32 == fx["poly_len"][name], name
+        assert hashlib.sha256(got).hexdigest() == want, name
+    assert proof.hex() == fx["proof"] and hashlib.sha256(proof).hexdigest() == fx["proof_sha256"]
+    assert api.verify_encryption(vk, proof, bytes(vec["ciphertext_64"])) is True
+    assert api.verify_encryption(vk, proof, bytes(vec["wrong_ciphertext_64"])) is False
+    two = pk.encrypt_chunked(msg + msg, key, zk_seed=api.PARITY)
+    assert two[0] == proof and two[1] == proof
+    assert api.verify_encryption(vk, bytes.fromhex(fx["proof"]), bytes(vec["ciphertext_64"])) is True      # the oracle's own bytes through the product verifier
+
+
 def _verify_all(api, jobs):
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 4)) as ex:     # ctypes releases the GIL inside the verifier
