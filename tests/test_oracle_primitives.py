@@ -63,6 +63,24 @@ def test_aes_fips197_every_round(zko, vectors):
     assert list(zko.aes_encrypt(bytes(vectors["plaintext_64"]), key)) == vectors["ciphertext_64"]
 
 
+def test_committed_oracle_fixtures_are_about_the_inputs_they_claim(zko, vectors):
+    """tests/golden/oracle_aes64.json is the oracle's proof of the reference's OWN 64-byte test case (tests/integration_tests.rs:340-371): its message, key and ciphertext are the
+    reference's numbers, the ciphertext is what the byte-level AES gives, and the proof is the 855 / 859-byte MarlinProof whose hash the file states (the -m gpu suite compares the GPU's
+    bytes with it); the same consistency for the 6-block bench fixture."""
+    import json
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    fx = json.load(open(os.path.join(gold, "oracle_aes64.json")))
+    assert bytes.fromhex(fx["message"]) == bytes(vectors["plaintext_64"]) and bytes.fromhex(fx["key"]) == bytes(vectors["key"])
+    assert bytes.fromhex(fx["ciphertext"]) == bytes(vectors["ciphertext_64"]) == zko.aes_encrypt(bytes(vectors["plaintext_64"]), bytes(vectors["key"]))
+    assert fx["blocks"] == 4 and fx["index"]["h"] == 1 << 20 and fx["index"]["k"] == 1 << 22
+    for name in ("oracle_aes64.json", "oracle_aes96.json"):
+        f = json.load(open(os.path.join(gold, name)))
+        proof = bytes.fromhex(f["proof"])
+        assert hashlib.sha256(proof).hexdigest() == f["proof_sha256"] and len(proof) in (855, 859)
+        assert bytes.fromhex(f["ciphertext"]) == zko.aes_encrypt(bytes.fromhex(f["message"]), bytes.fromhex(f["key"]))
+        assert set(f["poly_sha256"]) == set(zko.POLY_NAMES)
+
+
 def test_sbox_equals_reference_lookup_table(zko, vectors):
     L = zko.lib()
     assert [L.zko_aes_substitute_byte(C.c_uint8(i)) for i in range(256)] == vectors["lookup_table"]
