@@ -9,6 +9,9 @@
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <future>
+#include <deque>
+#include <condition_variable>
 #include <thread>
 #include <functional>
 #include <stdexcept>
@@ -567,6 +570,25 @@ static std::shared_ptr<LagrangeSrs> acquire_lagrange(const UniversalSrs &U, size
 // Everything one in-flight proof needs: its own stream, MSM scratch and polynomial workspace.  Several contexts prove different
 // chunk-proofs concurrently (zkaes_encrypt_chunked): the latency-bound phases of one proof (bucket reductions, scans, host
 // transcript work) overlap with the throughput-bound kernels of the others.
+// One persistent host thread per MSM lane of a lone call (created with the lane): a job is handed over through a condition variable instead of a std::thread per job --
+// the spawn (~50-100 us before the job's first launch) sat on the critical path at the head of every round.
+struct LaneWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    bool stop = false;
+    LaneWorker() { th = std::thread([this] { run(); }); }
+    ~LaneWorker() { { std::lock_guard<std::mutex> g(mu); stop = true; } cv.notify_one(); if (th.joinable()) th.join(); }
+    void run() {
+        for (;;) {
+            std::function<void()> t;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || !q.empty(); }); if (q.empty()) return; t = std::move(q.front()); q.pop_front(); }
+            t();
+        }
+    }
+    void submit(std::function<void()> f) { { std::lock_guard<std::mutex> g(mu); q.push_back(std::move(f)); } cv.notify_one(); }
+};
 struct ProverContext {
     std::mutex in_use;                                // one proof at a time per context: concurrent callers of one key queue up here
     gpu::stream_t stream = nullptr;
@@ -582,7 +604,7 @@ struct ProverContext {
     // MSM lanes: lane 0 = (stream, msm_ws) above; lanes 1..4 (own stream + MSM scratch, created on first use) let a LONE encrypt() call run the independent
     // commitments of a round side by side, each started as soon as ITS polynomial exists (latency path only: with several proofs in flight the chip is already full)
     static constexpr int N_LANES = 5;
-    struct Lane { gpu::stream_t stream = nullptr; gpu::MsmWorkspace *ws = nullptr; void *ready = nullptr; /* event: the lane's input exists on the main stream */ };
+    struct Lane { gpu::stream_t stream = nullptr; gpu::MsmWorkspace *ws = nullptr; void *ready = nullptr; /* event: the lane's input exists on the main stream */ std::unique_ptr<LaneWorker> worker; };
     // (lane 3 is the background lane: the early mask commitment of round 1 runs there, under the witness generation on the main stream)
     Lane lane[N_LANES];
     DevBuf acc_b, wit_b, wit2_b, scratch_b;             // second set of opening buffers (the two openings run side by side on the latency path)
@@ -592,6 +614,7 @@ struct ProverContext {
     void ensure_lanes() {
         for (int i = 1; i < N_LANES; i++) if (!lane[i].stream) {
             lane[i].stream = i == 3 ? gpu::stream_create_background() : gpu::stream_create(); lane[i].ws = gpu::msm_workspace_create(); lane[i].ready = gpu::event_create();
+            lane[i].worker.reset(new LaneWorker());
         }
     }
     ~ProverContext() {
@@ -603,6 +626,7 @@ struct ProverContext {
         for (auto &b : e) b.release();
         for (DevBuf *b : {&acc_b, &wit_b, &wit2_b, &scratch_b, &scratch_c}) b->release();
         gpu::event_destroy(ev_aux);
+        for (int i = 1; i < N_LANES; i++) lane[i].worker.reset();        // (joins the lane threads before their streams go)
         for (int i = 1; i < N_LANES; i++) if (lane[i].stream) { gpu::msm_workspace_destroy(lane[i].ws); gpu::stream_destroy(lane[i].stream); gpu::event_destroy(lane[i].ready); }
         gpu::msm_workspace_destroy(msm_ws);
         gpu::stream_destroy(stream);
@@ -772,7 +796,7 @@ class ProvingKeyImpl {
     struct RoundJobs {
         ProvingKeyImpl &K; ProverContext &cx;
         const bool async;
-        struct Slot { std::thread th; std::string err; std::function<void(Lane &)> fn; };
+        struct Slot { std::string err; std::function<void(Lane &)> fn; std::promise<void> done; std::future<void> fut; bool queued = false; };
         std::vector<std::unique_ptr<Slot>> slots;
         RoundJobs(ProvingKeyImpl &k, ProverContext &c) : K(k), cx(c), async(!c.throughput && k.use_lanes) { if (async) cx.ensure_lanes(); }
         // gate = true: the job's input is produced by work already queued on the main stream (an event is recorded there now and the lane waits for it on the device);
@@ -787,19 +811,23 @@ class ProvingKeyImpl {
             Lane &ln = cx.lane[lane_i];
             if (gate) { gpu::event_record(ln.ready, cx.stream); gpu::stream_wait_event(ln.stream, ln.ready); }
             const int dev = K.device;
-            p->th = std::thread([p, &ln, dev] { try { gpu::set_device(dev); p->fn(ln); } catch (const std::exception &e) { p->err = e.what(); if (p->err.empty()) p->err = "error"; } });
+            p->fut = p->done.get_future(); p->queued = true;
+            ln.worker->submit([p, &ln, dev] {
+                try { gpu::set_device(dev); p->fn(ln); } catch (const std::exception &e) { p->err = e.what(); if (p->err.empty()) p->err = "error"; } catch (...) { p->err = "error"; }
+                p->done.set_value();
+            });
         }
         void join() {
             std::string first;
             for (auto &sl : slots) {
-                if (async) { if (sl->th.joinable()) sl->th.join(); }
+                if (async) { if (sl->queued) { sl->fut.wait(); sl->queued = false; } }
                 else { try { sl->fn(cx.lane[0]); } catch (const std::exception &e) { sl->err = e.what(); if (sl->err.empty()) sl->err = "error"; } }
                 if (first.empty() && !sl->err.empty()) first = sl->err;
             }
             slots.clear();
             if (!first.empty()) throw std::runtime_error(first);
         }
-        ~RoundJobs() { for (auto &sl : slots) if (sl->th.joinable()) sl->th.join(); }       // (an exception must not leave a thread running on this context)
+        ~RoundJobs() { for (auto &sl : slots) if (sl->queued) sl->fut.wait(); }       // (an exception must not leave a job running on this context)
     };
 
     void setup(int kind, size_t message_len, const SrsLiterals &lits, unsigned flags);
