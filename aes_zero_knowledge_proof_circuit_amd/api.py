@@ -404,6 +404,14 @@ def msm_bench_synth(n, window_bits=0, reps=3, want_point=False):
     return (t.value, a.value, out.raw) if want_point else (t.value, a.value)
 
 
+def int_rate_bench(seconds=0.5):
+    """zkaes_int_rate_bench: per-box calibration of the integer roof (include/zkaes.h)"""
+    out = (C.c_double * 8)()
+    _check(lib().zkaes_int_rate_bench(C.c_double(seconds), out))
+    return {"fq_products_per_s": out[0], "fq_stream_sclk_mhz": out[1], "mad_per_s": 378.0 * out[0], "hot_loop_l2_additions_per_s": out[2], "hot_loop_l2_sclk_mhz": out[3],
+            "hot_loop_cycles_per_addition_per_wave": out[4], "rounds": int(out[5])}
+
+
 def stream_copy_bench(nbytes=1 << 30, reps=20):
     """Measured HBM stream-copy rate (read + write GB/s) of a plain 16 B/lane copy kernel -- printed beside the nominal peak."""
     g = C.c_double()

@@ -15,8 +15,9 @@ OUT = os.path.join(HERE, "libzkaes.so")
 OBJ = os.path.join(CSRC, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_SOURCES = ["runtime.hip", "kernels_ntt.hip", "kernels_msm.hip", "kernels_poly.hip", "kernels_witness.hip", "capi_kernels.hip"]
-CXX_SOURCES = ["circuit.cpp", "marlin.cpp", "capi.cpp"]
-HEADERS = ["ff.cuh", "ff28.cuh", "ff29.cuh", "ec.cuh", "ec28.cuh", "te28.cuh", "gpu.hpp", "hip_util.hpp", "consts32.h", "trace_layout.h", "circuit.hpp", "marlin.hpp", "pairing.hpp", "transcript.hpp",
+CXX_SOURCES = ["circuit.cpp", "marlin.cpp", "marlin_codec.cpp", "capi.cpp", "capi_host.cpp"]
+HOST_ONLY_SOURCES = ["circuit.cpp", "marlin_codec.cpp", "capi_host.cpp"]      # no device code path: also built under sanitizers + libFuzzer (build_host_fuzz)
+HEADERS = ["ff.cuh", "ff28.cuh", "ff29.cuh", "ec.cuh", "ec28.cuh", "te28.cuh", "gpu.hpp", "hip_util.hpp", "consts32.h", "trace_layout.h", "circuit.hpp", "marlin.hpp", "marlin_host.hpp", "capi_common.hpp", "pairing.hpp", "transcript.hpp",
            os.path.join("..", "..", "include", "zkaes.h")]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-I", CSRC, "-Wno-unused-result"]
 if os.environ.get("ZK_EXTRA_DEFINES"):      # e.g. "-DZKAES_MEASURE" (knock-in hooks of the measurement builds) for A/B builds on the GPU box

@@ -1,47 +1,14 @@
-// csrc/capi.cpp -- the extern "C" boundary declared in include/zkaes.h
-#include "../../include/zkaes.h"
+// csrc/capi.cpp -- the entry points of include/zkaes.h that need a GPU: key synthesis, the prover, key-handle queries (host-only ones: capi_host.cpp)
+#include "capi_common.hpp"
 #include <algorithm>
-#include <cstdlib>
-#include <cstring>
-#include <exception>
-#include <string>
-#include <vector>
 #include "gpu.hpp"
-#include "marlin.hpp"
 
-struct zkaes_pk { std::unique_ptr<zk::ProvingKey> pk; };
-struct zkaes_vk { zk::VerifyingKey vk; };
-
-namespace {
-thread_local std::string g_err;
-template <class Fn> int guard(Fn &&fn) {
-    try { g_err.clear(); fn(); return 0; }
-    catch (const std::exception &e) { g_err = e.what(); return 1; }
-    catch (...) { g_err = "unknown error"; return 1; }
-}
-uint8_t *give(const std::vector<uint8_t> &v) { uint8_t *p = (uint8_t *)malloc(v.size() ? v.size() : 1); memcpy(p, v.data(), v.size()); return p; }
-void fill_info(const zk::Circuit &c, uint64_t out[12]) {
-    out[0] = c.raw_constraints; out[1] = c.raw_instance; out[2] = c.raw_witness;
-    out[3] = c.A.nnz(); out[4] = c.B.nnz(); out[5] = c.C.nnz();
-    out[6] = c.num_constraints; out[7] = c.num_instance; out[8] = c.num_witness; out[9] = 0; out[10] = 0; out[11] = 0;
-}
-zk::Circuit compile(int kind, size_t len) { return kind == ZKAES_CIRCUIT_AES ? zk::compile_aes_circuit(len) : zk::compile_ops_circuit(kind); }
-size_t next_pow2(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
-
-// ---- VK transport (private layout v1)
-struct W { std::vector<uint8_t> b; void put(const void *p, size_t n) { const uint8_t *q = (const uint8_t *)p; b.insert(b.end(), q, q + n); } template <class T> void pod(const T &v) { put(&v, sizeof v); } };
-struct R { const uint8_t *p; size_t n, off = 0; template <class T> void pod(T &v) { if (off + sizeof v > n) throw std::runtime_error("vk_deserialize: truncated"); memcpy(&v, p + off, sizeof v); off += sizeof v; } };
-}  // namespace
-namespace zk { void capi_set_error(const std::string &m) { g_err = m; } }
+using zk::capi::guard; using zk::capi::give; using zk::capi::fill_info; using zk::capi::next_pow2;
 
 extern "C" {
 
-const char *zkaes_last_error(void) { return g_err.c_str(); }
-void zkaes_bytes_free(uint8_t *p) { free(p); }
 void zkaes_pk_free(zkaes_pk *pk) { delete pk; }
-void zkaes_vk_free(zkaes_vk *vk) { delete vk; }
 int zkaes_device_count(void) { return zk::gpu::device_count(); }
-int zkaes_set_device(int ordinal);   // defined in runtime glue below
 
 int zkaes_synthesize_keys_ex2(int kind, size_t len, size_t nc, size_t nv, size_t nnz, unsigned flags, zkaes_pk **pk, zkaes_vk **vk) {
     return guard([&] {
@@ -128,90 +95,6 @@ int zkaes_prove_ops(const zkaes_pk *pk, uint32_t x, uint32_t y, const uint8_t *s
         *proof = give(b); *proof_len = b.size();
     });
 }
-int zkaes_verify(const zkaes_vk *vk, const uint8_t *proof, size_t proof_len, const uint8_t *bits, size_t n_bits, int *accepted) {
-    return guard([&] {
-        if (!vk || !proof || !accepted) throw std::invalid_argument("null argument");
-        zk::Proof p = zk::deserialize_proof(proof, proof_len);
-        std::vector<zk::Fr> pub(n_bits);
-        for (size_t i = 0; i < n_bits; i++) pub[i] = bits[i] ? zk::Fr::one() : zk::Fr::zero();
-        *accepted = zk::verify(vk->vk, pub, p) ? 1 : 0;
-    });
-}
-int zkaes_verify_encryption(const zkaes_vk *vk, const uint8_t *proof, size_t proof_len, const uint8_t *ct, size_t ct_len, int *accepted) {
-    return guard([&] {
-        if (!vk || !proof || !accepted) throw std::invalid_argument("null argument");
-        zk::Proof p = zk::deserialize_proof(proof, proof_len);
-        *accepted = zk::verify(vk->vk, zk::ciphertext_to_public_input(ct, ct_len), p) ? 1 : 0;
-    });
-}
-int zkaes_proof_roundtrip(const uint8_t *proof, size_t proof_len, uint8_t **out, size_t *out_len) {
-    return guard([&] { auto b = zk::serialize_proof(zk::deserialize_proof(proof, proof_len)); *out = give(b); *out_len = b.size(); });
-}
-int zkaes_vk_serialize(const zkaes_vk *vk, uint8_t **out, size_t *out_len) {
-    return guard([&] {
-        W w;
-        uint32_t magic = 0x314b565au;   // "ZVK1"
-        w.pod(magic);
-        static_assert(std::is_trivially_copyable<zk::VerifyingKey>::value, "VerifyingKey must be POD for the v1 transport");
-        w.pod(vk->vk);
-        *out = give(w.b); *out_len = w.b.size();
-    });
-}
-int zkaes_vk_serialize_ark(const zkaes_vk *vk, uint8_t **out, size_t *out_len) {
-    return guard([&] {
-        if (!vk || !out || !out_len) throw std::invalid_argument("null argument");
-        auto b = zk::serialize_vk_ark(vk->vk);
-        *out = give(b); *out_len = b.size();
-    });
-}
-int zkaes_vk_serialize_ark_uncompressed(const zkaes_vk *vk, uint8_t **out, size_t *out_len) {
-    return guard([&] {
-        if (!vk || !out || !out_len) throw std::invalid_argument("null argument");
-        auto b = zk::serialize_vk_ark(vk->vk, true);
-        *out = give(b); *out_len = b.size();
-    });
-}
-int zkaes_vk_deserialize_ark(const uint8_t *bytes, size_t len, zkaes_vk **vk) {
-    return guard([&] {
-        if (!bytes || !vk) throw std::invalid_argument("null argument");
-        *vk = new zkaes_vk{zk::deserialize_vk_ark(bytes, len)};
-    });
-}
-int zkaes_vk_deserialize(const uint8_t *bytes, size_t len, zkaes_vk **vk) {
-    return guard([&] {
-        R r{bytes, len};
-        uint32_t magic; r.pod(magic);
-        if (magic != 0x314b565au) throw std::runtime_error("vk_deserialize: bad magic");
-        zkaes_vk *v = new zkaes_vk();
-        try { r.pod(v->vk); } catch (...) { delete v; throw; }
-        if (r.off != len) { delete v; throw std::runtime_error("vk_deserialize: trailing bytes"); }
-        *vk = v;
-    });
-}
-int zkaes_vk_from_trapdoor(const uint64_t info[7], const uint8_t *index_comms, const uint8_t *beta_b, zkaes_vk **vk) {
-    return guard([&] {
-        if (!info || !index_comms || !beta_b || !vk) throw std::invalid_argument("null argument");
-        zk::Fr beta_in, beta;
-        memcpy(beta_in.l, beta_b, 32);
-        zk::G1A g, gamma_g;
-        zk::pairing::G2Affine h;
-        zk::kzg_setup_points(beta, g, gamma_g, h);                   // this library's own replay of KZG10::setup's draws from test_rng
-        if (!(beta == beta_in)) throw std::invalid_argument("vk_from_trapdoor: beta is not the first Fr draw of ark_std::test_rng()");
-        zkaes_vk *v = new zkaes_vk();
-        zk::VerifyingKey &k = v->vk;
-        k.num_variables = info[0]; k.num_constraints = info[1]; k.num_non_zero = info[2]; k.num_instance = info[3];
-        k.num_public_inputs = info[4]; k.max_degree = info[5]; k.supported_degree = info[6];
-        for (int i = 0; i < 6; i++) { memcpy(k.index_comms[i].x.l, index_comms + 96 * i, 48); memcpy(k.index_comms[i].y.l, index_comms + 96 * i + 48, 48); }
-        auto mulg = [&](const zk::Fr &s) { return zk::mul_fr(zk::XYZZ<zk::Fq377>::from_affine(g), s).to_affine(); };
-        k.g = g; k.gamma_g = gamma_g; k.h = h;
-        uint32_t raw[8]; beta.to_raw(raw);
-        k.beta_h = zk::pairing::g2_mul_raw(k.h, raw, 8);
-        size_t n = next_pow2(k.num_constraints), kk = next_pow2(k.num_non_zero);
-        k.degree_bounds[0] = std::min(n - 2, kk - 2); k.degree_bounds[1] = std::max(n - 2, kk - 2);
-        for (int i = 0; i < 2; i++) k.shift_powers[i] = mulg(beta.pow_u64(k.max_degree - k.degree_bounds[i]));
-        *vk = v;
-    });
-}
 int zkaes_pk_info(const zkaes_pk *pk, uint64_t out[12]) {
     return guard([&] {
         fill_info(pk->pk->circuit(), out);
@@ -262,18 +145,6 @@ int zkaes_pk_msm_partial_dev(const zkaes_pk *pk, const uint8_t *scalars, size_t 
         if (!pk || (!scalars && n_local)) throw std::invalid_argument("null argument");
         if (!dev_out || dev_out_bytes < 192) throw std::invalid_argument("zkaes_pk_msm_partial_dev: device buffer too small for the partial sum (192 bytes)");
         pk->pk->msm_powers_partial_device(scalars, n_local, offset, dev_out);
-    });
-}
-int zkaes_circuit_info(int kind, size_t len, uint64_t out[12]) { return guard([&] { fill_info(compile(kind, len), out); }); }
-int zkaes_circuit_matrix(int kind, size_t len, int which, uint64_t *n_rows, uint64_t *nnz, uint32_t *rowptr, uint32_t *col, int64_t *coeff) {
-    return guard([&] {
-        zk::Circuit c = compile(kind, len);
-        const zk::CsrMatrix &m = which == 0 ? c.A : which == 1 ? c.B : c.C;
-        if (n_rows) *n_rows = m.rows();
-        if (nnz) *nnz = m.nnz();
-        if (rowptr) memcpy(rowptr, m.rowptr.data(), m.rowptr.size() * 4);
-        if (col) memcpy(col, m.col.data(), m.col.size() * 4);
-        if (coeff) memcpy(coeff, m.coeff.data(), m.coeff.size() * 8);
     });
 }
 int zkaes_pk_debug_fetch(const zkaes_pk *pk, const char *name, uint8_t **out, size_t *len) {

@@ -5,6 +5,9 @@
 #include <vector>
 #include "hip_util.hpp"
 #include "marlin.hpp"
+#include "te28.cuh"
+#include <algorithm>
+#include <chrono>
 
 // stream-copy probe for the measured HBM peak bench.py prints next to the nominal 8 TB/s: 4 x 16 B per lane, all four loads
 // issued before the first store, non-temporal both ways
@@ -22,7 +25,51 @@ __global__ void __launch_bounds__(256) k_stream_copy(uint4 *__restrict__ dst_, c
     }
 }
 
-struct zkaes_pk { std::unique_ptr<zk::ProvingKey> pk; };
+
+// ---- per-box calibration of the integer roof (zkaes_int_rate_bench; bench.py prints it as roofline.int_multiplier.calibration).  Two probes, both bracketed per wave by
+// s_memtime (shader-clock counter) and s_memrealtime (100 MHz): the isolated Fq377 reduced-radix product stream at four waves per SIMD -- what round 3's tools/ubench/rates.hip
+// measured once on one box and every later bench line quoted -- and k_accumulate<EdwardsLaw>'s own loop (te_madd_hot) at the production launch shape over a table that stays
+// in L2: the rate the hot kernel would run at on THIS box if its gathers were free.  Stamps: {shader cycles, real-time ticks} of lane 0 of every wave.
+struct CalStamp { uint64_t cyc, rt; };
+__global__ void __launch_bounds__(64) k_cal_fqmul(CalStamp *st, zk::FpMsm<zk::Fq377P> *sink, zk::FpMsm<zk::Fq377P> a, int iters) {
+    using G = zk::FpMsm<zk::Fq377P>;
+    const uint64_t bias = G::hot_loop_bias();
+    G x = a, y = a;
+    x.l[0] += threadIdx.x & 0xff;
+    const uint64_t r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; i++) { x = G::mul_biased(x, y, bias); y = G::mul_biased(y, x, bias); }
+    const uint64_t c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { st[blockIdx.x].cyc = c1 - c0; st[blockIdx.x].rt = r1 - r0; }
+    sink[blockIdx.x * 64 + threadIdx.x] = x + y;
+}
+__global__ void __launch_bounds__(64, 2) k_cal_hot_loop(CalStamp *st, zk::AccTE<zk::Fq377P> *sink, const zk::Niels28<zk::Fq377P> *__restrict__ tab, uint32_t mask, int iters) {
+    using P = zk::Fq377P;
+    const uint64_t bias = zk::FpMsm<P>::hot_loop_bias();
+    uint32_t t = blockIdx.x * 64 + threadIdx.x, x = t * 2654435761u + 12345u;
+    zk::AccTE<P> acc = zk::te_identity<P>();
+    zk::Niels28<P> pt = zk::niels_load_signed<P>(tab + (x & mask), false);
+    const uint64_t r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; i++) {
+        const uint32_t cur = x;
+        x = x * 1664525u + 1013904223u;
+        zk::te_madd_hot<P>(acc, pt, cur >> 31, tab + ((x >> 8) & mask), x >> 31, bias);
+    }
+    const uint64_t c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { st[blockIdx.x].cyc = c1 - c0; st[blockIdx.x].rt = r1 - r0; }
+    sink[t] = acc;
+}
+__global__ void k_cal_fill(zk::Niels28<zk::Fq377P> *tab, uint32_t n) {       // arbitrary limbs < 2^28 stand in for curve points: the arithmetic is data-independent
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t x = i * 2654435761u + 99u;
+    zk::Niels28<zk::Fq377P> r;
+    for (int k = 0; k < 14; k++) { x = x * 1664525u + 1013904223u; r.ymx.l[k] = x >> 4; x = x * 1664525u + 1013904223u; r.ypx.l[k] = x >> 4; x = x * 1664525u + 1013904223u; r.td.l[k] = x >> 4; }
+    r.ymx.l[13] &= 0xffff; r.ypx.l[13] &= 0xffff; r.td.l[13] &= 0xffff;
+    for (int k = 0; k < 6; k++) r.pad[k] = 0;
+    tab[i] = r;
+}
+
+#include "capi_common.hpp"
 extern "C" const char *zkaes_last_error(void);
 namespace zk { void capi_set_error(const std::string &); }
 
@@ -283,6 +330,51 @@ int zkaes_stream_copy_bench(size_t bytes, int reps, double *gb_per_s) {
         zk::gpu::event_record(e1, s);
         float ms = zk::gpu::event_elapsed_ms(e0, e1);
         *gb_per_s = 2.0 * (double)(n16 * 16) * reps / 1e9 / (ms / 1e3);   // read + write
+    });
+}
+int zkaes_int_rate_bench(double seconds, double out[8]) {
+    return guardk([&] {
+        if (!out || !(seconds > 0.0) || seconds > 30.0) throw std::invalid_argument("zkaes_int_rate_bench: 0 < seconds <= 30, out != NULL");
+        zk::gpu::require_device();
+        using P = zk::Fq377P; using G = zk::FpMsm<P>;
+        StreamGuard s;
+        hipStream_t hs = (hipStream_t)s.s;
+        const int GRID_A = 4096, ITERS_A = 300, GRID_B = 8192, ITERS_B = 83;      // A: 4 waves per SIMD, 600 products per lane; B: k_accumulate's launch shape for 2^19 buckets of ~83 points
+        const uint32_t NREC = 4096;                                                // 768 KB of records: L2-resident
+        DevPtr<CalStamp> st(GRID_B);
+        DevPtr<G> sink_a((size_t)GRID_A * 64);
+        DevPtr<zk::AccTE<P>> sink_b((size_t)GRID_B * 64);
+        DevPtr<zk::Niels28<P>> tab(NREC);
+        k_cal_fill<<<NREC / 256, 256, 0, hs>>>(tab, NREC);
+        G ga; for (int k = 0; k < 14; k++) ga.l[k] = 0x0123457u + 977u * k;
+        std::vector<double> rate_a, mhz_a, rate_b, mhz_b, cyc_b;
+        std::vector<CalStamp> h(GRID_B);
+        auto median = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+        auto stamps = [&](int grid, double per_wave_units, double *mhz, double *cyc_per_unit) {
+            zk::gpu::d2h(h.data(), st, (size_t)grid * sizeof(CalStamp), s);
+            std::vector<double> m(grid), c(grid);
+            for (int i = 0; i < grid; i++) { m[i] = (double)h[i].cyc / ((double)h[i].rt / 1e8) / 1e6; c[i] = (double)h[i].cyc / per_wave_units; }
+            *mhz = median(m); *cyc_per_unit = median(c);
+        };
+        EventGuard e0, e1;
+        const auto t_begin = std::chrono::steady_clock::now();
+        int rounds = 0;
+        // warm-up launches are part of the loop: the first rounds run while the clocks settle and the median discards them
+        while (rounds < 3 || std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() < seconds) {
+            double mhz, cyc;
+            zk::gpu::event_record(e0, s);
+            k_cal_fqmul<<<GRID_A, 64, 0, hs>>>(st, sink_a, ga, ITERS_A);
+            zk::gpu::event_record(e1, s);
+            stamps(GRID_A, 2.0 * ITERS_A, &mhz, &cyc);
+            rate_a.push_back(2.0 * ITERS_A * 64.0 * GRID_A / (zk::gpu::event_elapsed_ms(e0, e1) * 1e-3)); mhz_a.push_back(mhz);
+            zk::gpu::event_record(e0, s);
+            k_cal_hot_loop<<<GRID_B, 64, 0, hs>>>(st, sink_b, tab, NREC - 1, ITERS_B);
+            zk::gpu::event_record(e1, s);
+            stamps(GRID_B, (double)ITERS_B, &mhz, &cyc);
+            rate_b.push_back((double)ITERS_B * 64.0 * GRID_B / (zk::gpu::event_elapsed_ms(e0, e1) * 1e-3)); mhz_b.push_back(mhz); cyc_b.push_back(cyc);
+            rounds++;
+        }
+        out[0] = median(rate_a); out[1] = median(mhz_a); out[2] = median(rate_b); out[3] = median(mhz_b); out[4] = median(cyc_b); out[5] = (double)rounds; out[6] = 0; out[7] = 0;
     });
 }
 int zkaes_mem_info(uint64_t *free_bytes, uint64_t *total_bytes) {

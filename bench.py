@@ -47,6 +47,7 @@ ALT_CHUNK = 4            # blocks per chunk-proof that fit |H| = 2^20 at the den
 LATENCY_BYTES = (16, 32, 64)   # the reference's own criterion shape: ONE encrypt() per message size (benches/benchmark.rs:8-10, benches/benchmark_encrypt.rs:39-49)
 
 from aes_zero_knowledge_proof_circuit_amd import sharding  # noqa: E402
+from tools import gpu_telemetry  # noqa: E402   (shader clock / socket power / temperature sampled beside the timed region: what the box was doing)
 
 synthetic = sharding.synthetic_bytes
 
@@ -115,6 +116,7 @@ def build_parser():
     ap.add_argument("--serial-probe", type=int, default=2, help="chunk-proofs proven one at a time after the timed region for un-overlapped kernel durations (0 = off)")
     ap.add_argument("--alt-proofs", type=int, default=64, help="one rank, headline mode: chunk-proofs of the %d-block alt leg measured after the timed region (0 = off)" % ALT_CHUNK)
     ap.add_argument("--latency-samples", type=int, default=5, help="one rank, headline mode: lone encrypt() calls timed per message size of the latency leg (0 = off)")
+    ap.add_argument("--calibrate-s", type=float, default=0.5, help="seconds of the per-box integer-rate calibration before and after the timed region (0 = off)")
     ap.add_argument("--cpu-small-samples", type=int, default=0, help="CPU-oracle samples of a one-block chunk-proof (~17 s each + 20 s of setup; off by default: the run stays under 400 s)")
     return ap
 
@@ -212,6 +214,15 @@ def run(args, api, dist_env=None):
             t.join()
         return out_full + out_rem
 
+    # ---- per-box calibration of the integer roof (the same kernel read 5.02 ... 5.54 ms per launch on five boxes): the isolated Fq product stream and the hot
+    # loop over an L2-resident table, ~0.5 s, before anything is timed; repeated right after the timed region (a warm chip clocks lower)
+    calibration = None
+    if rank == 0 and args.calibrate_s > 0 and hasattr(api, "int_rate_bench"):
+        try:
+            calibration = {"before": api.int_rate_bench(args.calibrate_s)}
+        except Exception as e:                                      # noqa: BLE001 -- the bench line says so instead of dying on a diagnostic
+            calibration = {"error": str(e)[:200]}
+
     # ---- warm-up on a separate short message: `contexts` chunk-proofs per step (allocates every context's workspace outside the timed region)
     warm_n = min(contexts, max(1, n_full))
     warm_msg = synthetic(chunk_bytes * warm_n, 0x5EED + 7777 + rank)
@@ -228,7 +239,10 @@ def run(args, api, dist_env=None):
     api.msm_stats(reset=True)
     phase = dict(witness_ms=0.0, round1_ms=0.0, round2_ms=0.0, round3_ms=0.0, open_ms=0.0, total_ms=0.0)
     proofs = []
+    telemetry = gpu_telemetry.Sampler(device_ordinal, 0.5) if rank == 0 else None
     barrier()
+    if telemetry:
+        telemetry.__enter__()
     t0 = time.perf_counter()
     def timed_slice(ab):
         api.set_device(device_ordinal)
@@ -246,7 +260,14 @@ def run(args, api, dist_env=None):
         gathered = sharding.gather_proofs(proofs, device=coll_device)    # the job's one exchange: ~855 B per chunk-proof to every rank
     barrier()
     elapsed = time.perf_counter() - t0
+    if telemetry:
+        telemetry.__exit__(None, None, None)
     stats = api.msm_stats()
+    if calibration is not None and "before" in calibration:
+        try:
+            calibration["after"] = api.int_rate_bench(args.calibrate_s)
+        except Exception as e:                                      # noqa: BLE001
+            calibration["after_error"] = str(e)[:200]
     mem_after_timed = None
     if rank == 0 and hasattr(api, "mem_info"):
         try:
@@ -273,7 +294,7 @@ def run(args, api, dist_env=None):
                       "avg_launch_ms": round(s1["accumulate_ms"] / s1["launches"], 4), "launches": s1["launches"],
                       "algorithmic_bytes_per_launch": round(128.0 * s1["points"] / s1["launches"]), "pairs_per_launch": round(s1["pairs"] / s1["launches"]),
                       "achieved_GBs": round(128.0 * s1["points"] / 1e9 / (s1["accumulate_ms"] / 1e3), 2),
-                      "int_multiplier_frac": round(MADS_PER_ADD * s1["pairs"] / 1e12 / (s1["accumulate_ms"] / 1e3) / 28.1, 4)}
+                      "int_multiplier_frac_vs_round3_reference_peak": round(MADS_PER_ADD * s1["pairs"] / 1e12 / (s1["accumulate_ms"] / 1e3) / 28.1, 4)}
 
     from oracle import zko   # checker only: byte-level AES for the expected ciphertext
     pool = ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 4))        # ctypes releases the GIL inside zkaes_verify_encryption
@@ -400,11 +421,12 @@ def run(args, api, dist_env=None):
         achieved = (bytes_per_launch / 1e9) / (chip_ms / 1e3) if chip_ms > 0 else 0.0
         kernel_ms_per_step = launches / max(args.steps, 1) * chip_ms
         traffic = traffic_src = None
-        for name in ("r05_pmc_k_accumulate_tables.json", "r04_pmc_k_accumulate_tables.json", "r03_pmc_k_accumulate_tables.json", "r02_pmc_k_accumulate_tables.json"):
+        for name in ("r06_pmc_k_accumulate_tables.json", "r05_pmc_k_accumulate_tables.json", "r04_pmc_k_accumulate_tables.json", "r03_pmc_k_accumulate_tables.json", "r02_pmc_k_accumulate_tables.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 traffic = round(pmc["hbm_bytes_per_point_window"] * pairs_per_launch)
-                traffic_src = "separate PMC run of the isolated kernel (profiles/%s: rocprofv3 --pmc bytes per (point, window) gather), scaled by this run's pairs per launch -- not counters of this run" % name
+                traffic_src = ("separate PMC run of the isolated kernel (profiles/%s, measured at commit %s: rocprofv3 --pmc bytes per (point, window) gather), scaled by this run's pairs per launch -- "
+                               "not counters of this run" % (name, pmc.get("measured_at_commit", "unrecorded (rounds 2-5 did not stamp their PMC files)")))
                 break
             except Exception:
                 pass
@@ -443,6 +465,21 @@ def run(args, api, dist_env=None):
                           "not_counted": "the <= 3-term hiding MSMs and blinding products (host comb tables), Fiat-Shamir, the streaming polynomial kernels between the transforms"}
         mads = MADS_PER_ADD * stats["pairs"] / 1e12
         mads_per_launch = MADS_PER_ADD * pairs_per_launch / 1e12
+        # the integer roof, calibrated on THIS box (zkaes_int_rate_bench right after the timed region, chip warm; `before` = cold, ahead of the warm-up)
+        PEAK_REF = 28.1          # T v_mad_u64_u32/s: round 3's measurement on one box (tools/ubench/rates.hip), what rounds 3-5 divided by
+        cal = (calibration or {}).get("after") or (calibration or {}).get("before")
+        peak_box = round(cal["mad_per_s"] / 1e12, 2) if cal else None
+        peak = peak_box or PEAK_REF
+        mad_rate = mads_per_launch / (chip_ms / 1e3) if chip_ms > 0 else 0.0
+        add_rate = pairs_per_launch / (chip_ms / 1e3) if chip_ms > 0 else 0.0
+        hot_loop = None
+        if cal:
+            hot_loop = {"additions_per_s": round(add_rate / 1e9, 3), "additions_per_s_gathers_from_L2_this_box": round(cal["hot_loop_l2_additions_per_s"] / 1e9, 3), "unit": "G bucket additions/s",
+                        "frac": round(add_rate / cal["hot_loop_l2_additions_per_s"], 4), "shader_cycles_per_addition_per_simd": round(cal["hot_loop_cycles_per_addition_per_wave"] / 3.0),
+                        "sclk_mhz_of_the_l2_resident_loop": round(cal["hot_loop_l2_sclk_mhz"]),
+                        "note": "k_accumulate's own loop (te_madd_hot, same launch shape) over a table that stays in L2, timed on this box after the timed region: what the kernel would do if its gathers were free. "
+                                "The loop costs the same ~13,380 shader cycles per addition per SIMD either way (3,349 VALU instructions x 4 cycles = 13,396: the SIMD issues back to back at three waves, "
+                                "profiles/r06_accumulate_4waves.md); the gap to frac 1.0 is shader clock the chip gives back while ~1.9 TB/s of random 192-byte gathers are live, plus uneven bucket sizes"}
         workload = {
             "headline": "%d-block (%d B) ECB message per GPU as %d chunk-proofs of %d block(s)%s, sliced over the %d timed steps" % (total_blocks, 16 * total_blocks, n_full, chunk, (" + 1 of %d" % rem) if rem else "", args.steps),
             "strong": "ONE %d-block (%d B) ECB message%s as %d chunk-proofs of %d block(s)%s, chunk ranges sharded over %d rank(s), proofs all-gathered, rank 0 verifies all" % (
@@ -464,6 +501,7 @@ def run(args, api, dist_env=None):
             "alt": alt, "latency_ms": latency,
             "setup_s": round(setup_s, 2), "key_setup_s": key_setup_s, "srs": srs_report, "cpu_affinity": affinity, "cpu_affinity_by_rank": affinity_by_rank,
             "phase_ms_last_proof_avg": {k: round(v / args.steps, 2) for k, v in phase.items()},
+            "telemetry": dict(telemetry.summary(), window="the timed region, sampled from a side thread (tools/gpu_telemetry.py)") if telemetry else None,
             "roofline": {"bound": "hbm", "kernel": "k_accumulate (Pippenger bucket accumulation)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "peak_measured_stream_copy": copy_gbs,
@@ -471,11 +509,12 @@ def run(args, api, dist_env=None):
                          "launches": launches, "kernel_ms_per_step": round(kernel_ms_per_step, 1), "kernel_share_of_step": round(kernel_ms_per_step / (1e3 * elapsed / args.steps), 3) if elapsed > 0 else None,
                          "avg_launch_ms_in_situ": round(in_situ_ms, 4), "launch_overlap": round(overlap, 3),
                          "one_context_probe": serial, "proof": proof_roof,
-                         "int_multiplier": {"unit": "T v_mad_u64_u32/s", "achieved": round(mads_per_launch / (chip_ms / 1e3), 2) if chip_ms > 0 else 0.0, "peak": 28.1,
-                                            "frac": round(mads_per_launch / (chip_ms / 1e3) / 28.1, 4) if chip_ms > 0 else 0.0, "frac_of_wall": round(mads / elapsed / 28.1, 4),
+                         "int_multiplier": {"unit": "T v_mad_u64_u32/s", "achieved": round(mad_rate, 2), "peak": peak, "peak_this_box": peak_box, "peak_reference_round3_box": PEAK_REF,
+                                            "frac": round(mad_rate / peak, 4), "frac_vs_round3_reference_peak": round(mad_rate / PEAK_REF, 4), "frac_of_wall": round(mads / elapsed / peak, 4),
+                                            "calibration": calibration, "hot_loop": hot_loop,
                                             "note": "the kernel's real roof: 2649 v_mad_u64_u32 per bucket addition (7 Fq products x 378 on the curve's twisted Edwards model; round 2's XYZZ mixed add needed 3416), one addition per "
-                                                    "(point, window) pair; peak = rate of the same Fq product stream in isolation (tools/ubench/rates.hip: 74.4 G products/s x 378). frac uses the same chip time "
-                                                    "per launch as roofline.frac; frac_of_wall = all multiplies of the timed region / whole timed region."},
+                                                    "(point, window) pair; peak = rate of the same Fq product stream in isolation MEASURED ON THIS BOX in this run (zkaes_int_rate_bench, four waves per SIMD; rounds 3-5 divided by one "
+                                                    "box's 28.1). frac uses the same chip time per launch as roofline.frac; frac_of_wall = all multiplies of the timed region / whole timed region."},
                          "note": "integer-ALU bound (7 Fq limb products with their Montgomery reductions = 2649 v_mad_u64_u32 per bucket addition); HBM fraction of O(1%) is the expected regime (BASELINE.md §3); traffic is ~23x the "
                                  "algorithmic bytes by construction: every one of the 13 windows gathers its own 192-byte (64-byte aligned) precomputed copy of the base + a 4-byte index (2,548 B per point against 128 B), "
                                  "~1.7 TB/s, not the limiter"},

@@ -115,7 +115,8 @@ int zkaes_encrypt_batch_seeded_at(size_t n, const uint8_t *messages, size_t mess
 int zkaes_prove_ops(const zkaes_pk *pk, uint32_t x, uint32_t y, const uint8_t *zk_seed32, uint8_t **proof, size_t *proof_len);
 /* generic verify: public_input_bits = instance assignment without the leading One, one byte (0/1) per variable */
 int zkaes_verify(const zkaes_vk *vk, const uint8_t *proof, size_t proof_len, const uint8_t *public_input_bits, size_t n_bits, int *accepted);
-/* verifying-key transport, library-private layout (versioned POD image; fastest, same-build only) */
+/* verifying-key transport, library-private layout v2 ("ZVK2", the unpadded public-input count, then the ark-serialize compressed image below): validated like the ark
+ * path (canonical field elements, curve and prime-order-subgroup membership, index-info bounds) -- safe on untrusted bytes */
 int zkaes_vk_serialize(const zkaes_vk *vk, uint8_t **out, size_t *out_len);
 int zkaes_vk_deserialize(const uint8_t *bytes, size_t len, zkaes_vk **vk);
 /* verifying-key transport in the ark-serialize 0.3 compressed layout of ark_marlin::IndexVerifierKey<Fr, MarlinKZG10<Bls12_377, _>>
@@ -233,6 +234,12 @@ int zkaes_msm_bench_synth(size_t n, int window_bits, int reps, double *ms_total,
 /* stream-copy probe: copies `bytes` device-to-device `reps` times with a plain 16 B/lane kernel and returns read+write GB/s -- the measured
  * HBM peak bench.py prints beside the nominal 8 TB/s (SURVEY.md 8d "measure achievable with a stream-copy kernel and report both") */
 int zkaes_stream_copy_bench(size_t bytes, int reps, double *gb_per_s);
+/* per-box calibration of the hot kernel's integer roof (measurement only; ~`seconds` of GPU time, 0 < seconds <= 30).  out[0] = Fq377 reduced-radix Montgomery products per
+ * second of the isolated product stream at four waves per SIMD (x 378 = v_mad_u64_u32 per second: the "peak" of roofline.int_multiplier), out[1] = the shader clock it ran at
+ * in MHz (s_memtime ticks per second of s_memrealtime, median over waves and launches); out[2] = bucket additions per second of k_accumulate<EdwardsLaw>'s own loop at the
+ * production launch shape over an L2-resident table (the kernel with its gathers made free), out[3] = its shader clock, out[4] = its shader cycles per addition per wave
+ * (three waves share a SIMD); out[5] = rounds measured.  Medians over the rounds. */
+int zkaes_int_rate_bench(double seconds, double out[8]);
 /* AES witness only: fills z (padded instance + witness, one byte per variable) for a message under the key's circuit */
 int zkaes_aes_witness(const zkaes_pk *pk, const uint8_t *message, size_t message_len, const uint8_t secret_key[16], uint8_t *z, size_t z_cap, size_t *z_len);
 
