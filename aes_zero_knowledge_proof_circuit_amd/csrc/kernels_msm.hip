@@ -10,7 +10,7 @@
 //                      unified additions of gathered 192-byte Niels28 records (te28.cuh); WeierLaw (arbitrary points, BLS12-381): XYZZ accumulator, 10-product mixed
 //                      additions with the P = +-Q case deferred.  k_accumulate_tail: overflow segments of oversized buckets; k_fold_overflow folds them into their buckets
 //   4. reduction     : Edwards: k_reduce_l1_pair (8-bucket lane-interleaved segments, two lanes per segment) -> k_reduce_rc (row / column sums on DPP quads) ->
-//                      k_reduce_final (six unweighted terms per set) -> the weighted tail on the host; Weierstrass: k_reduce_l1 / l2 -> k_sum_tree -> k_reduce_window
+//                      k_reduce_terms (six unweighted terms per set) -> the weighted tail on the host (or k_reduce_combine); Weierstrass: k_reduce_l1 / l2 -> k_sum_tree -> k_reduce_window
 //   5. host          : table mode: nothing (one bucket set); per-window mode: Horner over the <= 37 window sums (c doublings each)
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -571,12 +571,11 @@ __global__ void __launch_bounds__(256) k_reduce_window(const A *__restrict__ par
 // With g = r C + c (G = R C segments, both powers of two):  sum_g g S_g = sum_c c CS_c + C sum_r r RS_r, where CS_c (column sums) and RS_r (row sums) are PLAIN sums -- trees, no running
 // sums, no scalar products on thousands of lanes (k_reduce_l2's second role did a 16-bit double-and-add per 64 buckets).
 //   k_reduce_rc    : one 64-quad workgroup per plain sum: the R row sums of W (their total is sum_g W_g), the R row sums RS_r and the C column sums CS_c of S
-//   k_reduce_final : four workgroups per set (G x the total of the W' sums; sum_c c CS_c; sum_r r RS_r -- an index-weighted sum of <= 256 points is split 16 x 16 once more,
-//                    then taken bit plane by bit plane; the row term is scaled by C where it is made; the total of the row sums), the last one to finish (ticket) adds the
-//                    four and converts to the Weierstrass XYZZ form.
+//   k_reduce_terms : six small workgroups per set, one per unweighted term (the total of the W' sums; the total of the row sums; V1, V2 of sum_c c CS_c; V1, V2 of
+//                    sum_r r RS_r -- an index-weighted sum of <= 256 points is split 16 x 16 once more, then taken bit plane by bit plane); the weights are applied by the
+//                    host (reduce_host_tail) or by k_reduce_combine
 // Depth of the whole reduction: 16 sequential additions in k_reduce_l1, then ~40 quad operations of 2-3 product-times each, instead of ~70 whole additions.
 constexpr int RQ_THREADS = 256, RQ_QUADS = RQ_THREADS / 4;          // k_reduce_rc
-constexpr int RF_THREADS = 1024, RF_QUADS = RF_THREADS / 4;         // k_reduce_final: up to 256 points per weighted sum
 constexpr int PT_WORDS = 4 * FpMsm<Fq377P>::N;                      // one extended point: 4 coordinates x 14 limbs (224 B: sizeof(AccTE))
 template <class P> __device__ __forceinline__ FpMsm<P> quad_load(const uint32_t *pt, int q) {
     FpMsm<P> r;
@@ -615,141 +614,109 @@ __global__ void __launch_bounds__(RQ_THREADS) k_reduce_rc(const AccTE<P> *__rest
     quad_tree_sum<P>(pt, RQ_QUADS, quad, q);
     if (quad == 0) quad_store<P>(reinterpret_cast<uint32_t *>(out + (size_t)set * jobs + job), q, quad_load<P>(pt, q));
 }
-// index-weighted sums  sum_i i E_i  of n <= 16 points E_i = pt[i * stride] (n a power of two), TWO of them side by side (problem 0 on quads [0, 16), problem 1 on quads
-// [RF_QUADS / 2, RF_QUADS / 2 + 16)), bit plane by bit plane: plane b = the sum of the points whose index has bit b set (n / 2 points: a tree), then Horner over the planes.
-// Planes and their trees live in the problem's `scratch` (>= 16 points); result in scratch[0].  All lanes call it (uniform barriers); ends with a barrier.
-struct QuadWeighted { const uint32_t *pt; uint32_t stride, n; uint32_t *scratch; };
-template <class P>
-__device__ __forceinline__ void quad_weighted_small2(const QuadWeighted &p0, const QuadWeighted &p1, uint32_t quad, int q) {
-    const bool second = quad >= RF_QUADS / 2;
-    const QuadWeighted &pr = second ? p1 : p0;
-    const uint32_t lq = second ? quad - RF_QUADS / 2 : quad, n = pr.n, nmax = p0.n > p1.n ? p0.n : p1.n;
-    int lg = 0;
-    while ((1u << lg) < n) lg++;
-    const uint32_t half = n >> 1;                      // points per plane; plane b occupies scratch[b * 4 .. b * 4 + half / 2) after the first level (half <= 8)
-    // first level: quad (b, j) adds the plane's points 2j and 2j + 1 (or copies the single point when half == 1)
-    if (lg > 0) {
-        const uint32_t per = half > 1 ? half >> 1 : 1, b = lq / per, j = lq % per;
-        if (b < (uint32_t)lg) {
-            auto member = [&](uint32_t i) { const uint32_t lo = i & ((1u << b) - 1), hi = i >> b; return (hi << (b + 1)) | (1u << b) | lo; };      // i-th index with bit b set
-            FpMsm<P> v = quad_load<P>(pr.pt + (size_t)member(half > 1 ? 2 * j : 0) * pr.stride * PT_WORDS, q);
-            if (half > 1) v = te_add_quad<P>(v, quad_load<P>(pr.pt + (size_t)member(2 * j + 1) * pr.stride * PT_WORDS, q), q);
-            quad_store<P>(pr.scratch + (b * 4 + j) * PT_WORDS, q, v);
-        }
-    }
-    __syncthreads();
-    for (uint32_t cmax = nmax >> 2, cnt = half >> 1; cmax > 1; cmax >>= 1, cnt >>= 1) {       // remaining tree levels of all planes side by side (trip count of the larger problem)
-        if (cnt > 1) {
-            const uint32_t h2 = cnt >> 1, b = lq / h2, j = lq % h2;
-            if (b < (uint32_t)lg) quad_store<P>(pr.scratch + (b * 4 + j) * PT_WORDS, q, te_add_quad<P>(quad_load<P>(pr.scratch + (b * 4 + j) * PT_WORDS, q), quad_load<P>(pr.scratch + (b * 4 + j + h2) * PT_WORDS, q), q));
-        }
-        __syncthreads();
-    }
-    if (lq == 0) {                                                 // Horner: ((p_top 2 + p_next) 2 + ...) + p_0; a single point has weight 0
-        FpMsm<P> acc = te_identity_quad<P>(q);
-        if (lg > 0) {
-            acc = quad_load<P>(pr.scratch + (size_t)(lg - 1) * 4 * PT_WORDS, q);
-            for (int b = lg - 2; b >= 0; b--) acc = te_add_quad<P>(te_dbl_quad<P>(acc, q), quad_load<P>(pr.scratch + (size_t)b * 4 * PT_WORDS, q), q);
-        }
-        quad_store<P>(pr.scratch, q, acc);
-    }
-    __syncthreads();
-}
-// sum_i i E_i over M <= 256 points loaded into bufA AND bufB (M a power of two), times 2^shift: M = r1 x c1, i = r c1 + c  =>  sum_c c (column sums) + c1 sum_r r (row sums).
-// Result in bufA[0] -- unless `host_tail`: then the two halves V1 = sum_c c (column sums) and V2 = sum_r r (row sums) stay in scratch[0] and scratch[16] and the caller's
-// host side applies the weights (V1 + 2^lc V2) 2^shift: the lc + shift doublings are a serial chain one wave takes ~5 us per step for, the host 0.9 us.
+// ---- k_reduce_terms: the last level of the Edwards reduction, SIX small workgroups per bucket set -- one per term of
+//     set sum = 2^(lgR+lgC) [0] + [1] + ([2] + 2^lc(C) [3]) + 2^lgC ([4] + 2^lc(R) [5])
+//   [0] = sum of the R row sums of W'      [1] = sum of the R row sums RS_r of S
+//   [2], [3] = V1, V2 of the column term sum_c c CS_c      [4], [5] = V1, V2 of the row term sum_r r RS_r
+// where an index-weighted sum over M <= 256 points P_i is split once more, i = r c1 + c (c1 = 2^lc columns, r1 = M / c1 rows):
+//     sum_i i P_i = V1 + c1 V2,   V1 = sum_c c (sum_r P[r c1 + c]),   V2 = sum_r r (sum_c P[r c1 + c])
+// and a weighted sum over <= 16 group sums is taken bit plane by bit plane (plane b = the sum of the groups whose index has bit b set; Horner over the planes).
+// Round 5's k_reduce_final did the same arithmetic in FOUR 1024-lane workgroups per set with every quad operation inlined where it was used: 90,456 instructions (0.7 MB of
+// straight-line code against a 64 KB instruction cache), 128 registers + 392 B of scratch, and a workgroup that needs a whole empty CU (16 waves x 128 registers) -- 174 us alone,
+// 620 us behind another lane's accumulation grid.  Here every point operation of a workgroup goes through ONE of two te_add_quad call sites (a doubling is
+// the unified addition of a point to itself): a gather loop from global memory and a step loop over LDS slots whose (destination, operand, operand) triples are plain index
+// arithmetic.  256 lanes (64 quads), ~6 k instructions, no scratch, 21 KB of LDS: it fits beside two accumulation waves per SIMD.
+// The weights are applied by the host (reduce_host_tail: ~24 XYZZ doublings of 0.9 us) when the terms go to host-mapped memory, or by k_reduce_combine below when the sum has to
+// stay on the device (sharded MSM entry points) or there are dozens of sets (per-window buckets).
 ZK_HD int quad_weighted_lc(uint32_t M) { int m = 0; while ((1u << m) < M) m++; return M <= 16 ? m : (m + 1) / 2; }
-template <class P>
-__device__ __forceinline__ void quad_weighted(uint32_t *bufA, uint32_t *bufB, uint32_t M, int shift, uint32_t *scratch, uint32_t quad, int q, bool host_tail) {
-    int m = 0;
-    while ((1u << m) < M) m++;
-    const int lc = M <= 16 ? m : (m + 1) / 2;
-    const uint32_t c1 = 1u << lc, r1 = M >> lc;
-    // column sums in bufA (tree over the rows) and row sums in bufB (tree inside every row), side by side: quads [0, M / 2) and [RF_QUADS / 2, RF_QUADS / 2 + M / 2)
-    for (uint32_t lvl = 0;; lvl++) {
-        const uint32_t hr = (r1 >> 1) >> lvl, hc = r1 > 1 ? (c1 >> 1) >> lvl : 0;          // halves of the two trees at this level (0 once a tree is done; one row: no row sums)
-        if (hr == 0 && hc == 0) break;
-        if (quad < hr * c1) quad_store<P>(bufA + quad * PT_WORDS, q, te_add_quad<P>(quad_load<P>(bufA + quad * PT_WORDS, q), quad_load<P>(bufA + (quad + hr * c1) * PT_WORDS, q), q));
-        else if (quad >= RF_QUADS / 2 && quad - RF_QUADS / 2 < hc * r1) {
-            const uint32_t k = quad - RF_QUADS / 2, r = k / hc, c = k % hc, at = r * c1 + c;
-            quad_store<P>(bufB + at * PT_WORDS, q, te_add_quad<P>(quad_load<P>(bufB + at * PT_WORDS, q), quad_load<P>(bufB + (at + hc) * PT_WORDS, q), q));
-        }
-        __syncthreads();
-    }
-    // V1 = sum_c c bufA[c] (c1 points) and V2 = sum_r r bufB[r c1] (r1 points), both <= 16 points, side by side
-    quad_weighted_small2<P>(QuadWeighted{bufA, 1, c1, scratch}, QuadWeighted{bufB, c1, r1, scratch + 16 * PT_WORDS}, quad, q);
-    if (host_tail) return;
-    if (quad == 0) {
-        FpMsm<P> v2 = quad_load<P>(scratch + 16 * PT_WORDS, q);
-        for (int i = 0; i < lc; i++) v2 = te_dbl_quad<P>(v2, q);
-        FpMsm<P> v = te_add_quad<P>(quad_load<P>(scratch, q), v2, q);
-        for (int i = 0; i < shift; i++) v = te_dbl_quad<P>(v, q);
-        quad_store<P>(bufA, q, v);
-    }
-    __syncthreads();
-}
-// Two ways out.  !host_tail (the sharded-MSM entry points, whose sum must stay in device memory at dev_total, and the per-window path with its dozens of sets, where the
-// host's share would add up): the four workgroups of a set leave their terms in `part`, the last one to finish (ticket) applies the weights, adds the four and converts
-// to the Weierstrass XYZZ form -- a serial tail of lgG + lgC doublings on one wave.
-// host_tail (one or two bucket sets: every table-path MSM of the prover): HOST TAIL.  The workgroups stop at the six UNWEIGHTED terms of a set,
-//     out[set][0] = sum W'   [1] = sum RS   [2], [3] = V1, V2 of the column term   [4], [5] = V1, V2 of the row term,
-// each converted to XYZZ by its own lane and written straight to host-mapped memory; reduce_host_tail() finishes
-//     2^(lgR+lgC) [0] + [1] + ([2] + 2^lc(C) [3]) + 2^lgC ([4] + 2^lc(R) [5])
-// with ~24 XYZZ doublings of 0.9 us -- where a lone GPU wave needs ~5 us per dependent point operation -- and no ticket, no fence, no second pass over `part`.
 constexpr int RF_OUT = 6;
+constexpr int RT_THREADS = 256, RT_QUADS = RT_THREADS / 4;
+constexpr int RT_PLANES = RT_QUADS, RT_IDENT = RT_QUADS + 32, RT_SLOTS = RT_IDENT + 1;      // LDS slots: 64 partials | 4 planes x 8 | the identity
+__device__ __forceinline__ uint32_t rt_plane_member(uint32_t b, uint32_t i) {                 // i-th index of [0, 16) with bit b set
+    const uint32_t lo = i & ((1u << b) - 1), hi = i >> b;
+    return (hi << (b + 1)) | (1u << b) | lo;
+}
 template <class P>
-__global__ void __launch_bounds__(RF_THREADS) k_reduce_final(const AccTE<P> *__restrict__ rc, int lgR, int lgC, AccTE<P> *__restrict__ part, uint32_t *__restrict__ tickets,
-                                                              XYZZ<Fp<P>> *__restrict__ out, XYZZ<Fp<P>> *__restrict__ dev_total, bool host_tail) {
-    __shared__ uint32_t bufA[RF_QUADS * PT_WORDS], bufB[RF_QUADS * PT_WORDS], scratch[32 * PT_WORDS];
-    __shared__ uint32_t ticket;
+__global__ void __launch_bounds__(RT_THREADS) k_reduce_terms(const AccTE<P> *__restrict__ rc, int lgR, int lgC, AccTE<P> *__restrict__ part, XYZZ<Fp<P>> *__restrict__ out, bool to_host) {
+    __shared__ uint32_t pt[RT_SLOTS * PT_WORDS];
     const uint32_t R = 1u << lgR, C = 1u << lgC, jobs = 2 * R + C;
-    const uint32_t set = blockIdx.x / 4, role = blockIdx.x % 4, quad = threadIdx.x >> 2;
+    const uint32_t set = blockIdx.x / RF_OUT, term = blockIdx.x % RF_OUT, quad = threadIdx.x >> 2;
     const int q = threadIdx.x & 3;
-    const AccTE<P> *src = rc + (size_t)set * jobs + (role == 0 ? 0 : (role == 1 ? 2 * R : R));        // W' row sums | column sums of S | row sums of S (roles 2 and 3)
-    const uint32_t M = role == 1 ? C : R;
-    {
-        FpMsm<P> v = quad < M ? quad_load<P>(reinterpret_cast<const uint32_t *>(src + quad), q) : te_identity_quad<P>(q);
-        quad_store<P>(bufA + quad * PT_WORDS, q, v);
-        if (role == 1 || role == 2) quad_store<P>(bufB + quad * PT_WORDS, q, v);
+    const bool plain = term < 2, second = term & 1;                                           // weighted terms: V1 (even) or V2 (odd) of their point list
+    const AccTE<P> *src = rc + (size_t)set * jobs + (term == 0 ? 0 : (term == 2 || term == 3) ? 2 * R : R);
+    const uint32_t M = (term == 2 || term == 3) ? C : R;
+    // ---- gather: every quad sums its share of the source points (<= 4 of them) into its slot
+    uint32_t first = 0, stride = 0, count = 0;
+    if (plain) { first = quad; stride = RT_QUADS; count = quad < M ? (M - quad + RT_QUADS - 1) / RT_QUADS : 0; }
+    else {
+        const int lc = quad_weighted_lc(M);
+        const uint32_t c1 = 1u << lc, r1 = M >> lc, G = second ? r1 : c1, S = second ? c1 : r1, g = quad >> 2, p = quad & 3;      // group g, member share p of 4
+        if (g < G && p < S) { count = (S - p + 3) / 4; first = second ? g * c1 + p : p * c1 + g; stride = second ? 4 : 4 * c1; }
     }
+    FpMsm<P> acc = te_identity_quad<P>(q);
+    for (uint32_t i = 0; i < count; i++) acc = te_add_quad<P>(acc, quad_load<P>(reinterpret_cast<const uint32_t *>(src + first + (size_t)i * stride), q), q);
+    quad_store<P>(pt + quad * PT_WORDS, q, acc);
+    if (quad == 0) quad_store<P>(pt + RT_IDENT * PT_WORDS, q, te_identity_quad<P>(q));
     __syncthreads();
-    if (role == 0 || role == 3) {
-        quad_tree_sum<P>(bufA, RF_QUADS, quad, q);
-        if (role == 0 && quad == 0 && !host_tail) {           // the W' term carries the factor G = R C
-            FpMsm<P> v = quad_load<P>(bufA, q);
-            for (int i = 0; i < lgR + lgC; i++) v = te_dbl_quad<P>(v, q);
-            quad_store<P>(bufA, q, v);
-        }
-    } else quad_weighted<P>(bufA, bufB, M, role == 2 ? lgC : 0, scratch, quad, q, host_tail);       // the row term carries the factor C: applied here, beside the column term's workgroup
-    if (host_tail) {
+    // ---- steps over the LDS slots
+    const int nsteps = plain ? 6 : 11;
+    for (int step = 0; step < nsteps; step++) {
+        bool active = false;
+        uint32_t dst = 0, a = 0, b = 0;
+        if (plain) { const uint32_t half = (RT_QUADS / 2) >> step; active = quad < half; dst = a = quad; b = quad + half; }
+        else if (step == 0) { active = (quad & 3) < 2; dst = a = quad; b = quad + 2; }                         // group sums: shares 0 + 2, 1 + 3
+        else if (step == 1) { active = (quad & 3) == 0; dst = a = quad; b = quad + 1; }                        // ... group g's sum is slot 4 g
+        else if (step == 2) { active = quad < 16; const uint32_t pl = quad >> 2, j = quad & 3; dst = RT_PLANES + 8 * pl + j; a = 4 * rt_plane_member(pl, 2 * j); b = 4 * rt_plane_member(pl, 2 * j + 1); }
+        else if (step == 3) { active = quad < 8; const uint32_t pl = quad >> 1, j = quad & 1; dst = a = RT_PLANES + 8 * pl + j; b = a + 2; }
+        else if (step == 4) { active = quad < 4; dst = a = RT_PLANES + 8 * quad; b = a + 1; }
+        else { active = quad == 0; dst = a = RT_PLANES + 24; const int h = step - 5; b = (h & 1) ? RT_PLANES + 8 * (2 - h / 2) : a; }      // Horner from plane 3 down: double, add plane 2, double, add plane 1, ...
+        if (active) quad_store<P>(pt + dst * PT_WORDS, q, te_add_quad<P>(quad_load<P>(pt + a * PT_WORDS, q), quad_load<P>(pt + b * PT_WORDS, q), q));
         __syncthreads();
-        XYZZ<Fp<P>> *o = out + (size_t)set * RF_OUT;
-        if (role == 0 || role == 3) { if (threadIdx.x == 0) o[role == 0 ? 0 : 1] = te_to_std_point<P>(*reinterpret_cast<const AccTE<P> *>(bufA)); }
-        else if (threadIdx.x < 2) o[(role == 1 ? 2 : 4) + threadIdx.x] = te_to_std_point<P>(*reinterpret_cast<const AccTE<P> *>(scratch + threadIdx.x * 16 * PT_WORDS));
-        return;
     }
-    if (quad == 0) quad_store<P>(reinterpret_cast<uint32_t *>(part + (size_t)set * 4 + role), q, quad_load<P>(bufA, q));
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) ticket = atomicAdd(&tickets[set], 1u);
-    __syncthreads();
-    if (ticket != 3) return;
-    __threadfence();
-    if (threadIdx.x == 0) tickets[set] = 0;                         // re-armed for the next MSM of this workspace
-    if (quad == 0) {                                                // G sum W' + sum_c c CS_c + C sum_r r RS_r + sum_r RS_r
-        const AccTE<P> *pp = part + (size_t)set * 4;
-        FpMsm<P> t = quad_load<P>(reinterpret_cast<const uint32_t *>(pp + 0), q), u1 = quad_load<P>(reinterpret_cast<const uint32_t *>(pp + 1), q),
-                 u2 = quad_load<P>(reinterpret_cast<const uint32_t *>(pp + 2), q), st = quad_load<P>(reinterpret_cast<const uint32_t *>(pp + 3), q);
-        quad_store<P>(scratch, q, te_add_quad<P>(te_add_quad<P>(t, st, q), te_add_quad<P>(u1, u2, q), q));
-    }
-    __syncthreads();
+    const uint32_t *res = pt + (plain ? 0 : RT_PLANES + 24) * PT_WORDS;
+    if (to_host) { if (threadIdx.x == 0) out[(size_t)set * RF_OUT + term] = te_to_std_point<P>(*reinterpret_cast<const AccTE<P> *>(res)); }
+    else if (quad == 0) quad_store<P>(reinterpret_cast<uint32_t *>(part + (size_t)set * RF_OUT + term), q, quad_load<P>(res, q));
+}
+// the weights of the six terms applied on the device (what reduce_host_tail does on the host): one quad per set runs a short program of unified additions over six LDS slots
+// -- 2^k X as k self-additions -- and converts the sum to the Weierstrass XYZZ form.  Rare paths only: ~30 dependent quad operations (~0.1 ms).
+template <class P>
+__global__ void __launch_bounds__(64) k_reduce_combine(const AccTE<P> *__restrict__ part, int lgR, int lgC, XYZZ<Fp<P>> *__restrict__ out, XYZZ<Fp<P>> *__restrict__ dev_total) {
+    __shared__ uint32_t pt[RF_OUT * PT_WORDS];
+    __shared__ uint8_t prog[64][3];
+    __shared__ int nprog;
+    const uint32_t set = blockIdx.x, quad = threadIdx.x >> 2;
+    const int q = threadIdx.x & 3;
+    if (quad < RF_OUT) quad_store<P>(pt + quad * PT_WORDS, q, quad_load<P>(reinterpret_cast<const uint32_t *>(part + (size_t)set * RF_OUT + quad), q));
     if (threadIdx.x == 0) {
-        const auto r = te_to_std_point<P>(*reinterpret_cast<const AccTE<P> *>(scratch));
+        int n = 0;
+        auto op = [&](int d, int a, int b) { prog[n][0] = (uint8_t)d; prog[n][1] = (uint8_t)a; prog[n][2] = (uint8_t)b; n++; };
+        const int lcC = quad_weighted_lc(1u << lgC), lcR = quad_weighted_lc(1u << lgR);
+        for (int i = 0; i < lcR; i++) op(5, 5, 5);
+        op(5, 5, 4);                                     // row = 2^lcR [5] + [4]
+        for (int i = 0; i < lcC; i++) op(3, 3, 3);
+        op(3, 3, 2);                                     // col = 2^lcC [3] + [2]
+        for (int i = 0; i < lgR; i++) op(0, 0, 0);
+        op(0, 0, 5);                                     // 2^lgR [0] + row
+        for (int i = 0; i < lgC; i++) op(0, 0, 0);
+        op(0, 0, 3); op(0, 0, 1);                        // ... 2^lgC (.) + col + [1]
+        nprog = n;
+    }
+    __syncthreads();
+    const int n = nprog;
+    for (int i = 0; i < n; i++) {
+        // (every quad of the wave runs the same program on the same slots; quad 0 stores)
+        const FpMsm<P> v = te_add_quad<P>(quad_load<P>(pt + prog[i][1] * PT_WORDS, q), quad_load<P>(pt + prog[i][2] * PT_WORDS, q), q);
+        __syncthreads();
+        if (quad == 0) quad_store<P>(pt + prog[i][0] * PT_WORDS, q, v);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const auto r = te_to_std_point<P>(*reinterpret_cast<const AccTE<P> *>(pt));
         out[set] = r;
         if (dev_total) dev_total[set] = r;
     }
 }
-// the host's share of the Edwards reduction (k_reduce_final, host tail): the weighted sum of a set's six terms, Horner over the weights' shifts
+// the host's share of the Edwards reduction (k_reduce_terms with to_host): the weighted sum of a set's six terms, Horner over the weights' shifts
 template <class Fq>
 static XYZZ<Fq> reduce_host_tail(const XYZZ<Fq> *o, int lgR, int lgC) {
     auto shl = [](XYZZ<Fq> v, int k) { for (int i = 0; i < k; i++) v = v.dbl(); return v; };
@@ -784,7 +751,6 @@ struct MsmWorkspace {
     uint32_t *dig = nullptr; size_t cap_dig = 0;                                   // two-level partition: 16 digit words per scalar
     uint32_t *ord_hist = nullptr, *ord_offs = nullptr;            // ORD_BINS x ORD_MAX_BLOCKS counts and their scan
     uint32_t *ctrl = nullptr;                                     // 8 control words (see k_order_hist); armed at zero between MSMs
-    uint32_t *tickets = nullptr;                                  // k_reduce_final's per-set workgroup tickets (re-armed by the kernel itself)
     bool ctrl_dirty = false;                                      // an exception left the order pass half done: re-arm ctrl before the next one
     size_t plan_n = 0, plan_pairs = 0; int plan_c = 0, plan_nwin = 0;     // state between msm_prepare and msm_finish
     bool plan_table = false; uint32_t plan_cap = BUCKET_CAP;
@@ -793,7 +759,7 @@ struct MsmWorkspace {
     void *h_res = nullptr, *d_res = nullptr;                      // pinned host memory the last reduction kernel writes the window sums (+ flags) into, and its device address
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};      // [2 rep], [2 rep + 1]: around the k_accumulate launch of base array `rep`
 };
-constexpr size_t RES_BYTES = 192 * MAX_WSUMS * 6 + 64;        // six terms per set when the Edwards reduction ends on the host (k_reduce_final RF_OUT)
+constexpr size_t RES_BYTES = 192 * MAX_WSUMS * 6 + 64;        // six terms per set when the Edwards reduction ends on the host (k_reduce_terms RF_OUT)
 // the accumulators and the reduction's levels, sized by the number of buckets ACCUMULATED (twice the prepared ones when one prepared state serves two base arrays at once)
 static void ensure_result(MsmWorkspace &S, size_t buckets) {
     if (buckets <= S.cap_result) return;
@@ -811,8 +777,6 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
         S.ord_hist = (uint32_t *)dmalloc((size_t)ORD_BINS * ORD_MAX_BLOCKS * 4); S.ord_offs = (uint32_t *)dmalloc((size_t)ORD_BINS * ORD_MAX_BLOCKS * 4);
         S.ctrl = (uint32_t *)dmalloc(32);
         HIP_CHECK(hipMemset(S.ctrl, 0, 32));
-        S.tickets = (uint32_t *)dmalloc(MAX_WSUMS * 4);
-        HIP_CHECK(hipMemset(S.tickets, 0, MAX_WSUMS * 4));
         HIP_CHECK(hipHostMalloc(&S.h_res, RES_BYTES, hipHostMallocMapped));
         HIP_CHECK(hipHostGetDevicePointer(&S.d_res, S.h_res, 0));
     }
@@ -841,7 +805,7 @@ void msm_workspace_destroy(MsmWorkspace *w) {
     if (!w) return;
     for (void *p : {(void *)w->keys_a, (void *)w->keys_b, (void *)w->vals_a, (void *)w->vals_b, (void *)w->start, (void *)w->end, (void *)w->order, (void *)w->ovf_slot,
                     (void *)w->ovf_bucket, (void *)w->ovf_nseg, (void *)w->ovf_off, w->ovf_partial, (void *)w->part_hist, (void *)w->part_offs, (void *)w->dig, (void *)w->ord_hist, (void *)w->ord_offs,
-                    (void *)w->ctrl, (void *)w->tickets, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->tmp}) dfree(p);
+                    (void *)w->ctrl, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->tmp}) dfree(p);
     if (w->h_res) (void)hipHostFree(w->h_res);
     for (auto e : w->ev) if (e) (void)hipEventDestroy(e);
     delete w;
@@ -944,7 +908,7 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
         hipLaunchKernelGGL((k_reduce_l1<A>), dim3((unsigned)((segs * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.buckets, c, nsets, (A *)S.seg_s, (A *)S.seg_w);
     HIP_LAUNCH_CHECK();
     if constexpr (Law::edwards) {
-        // Edwards law: plain row / column sums of the segment sums, then four quad-cooperative workgroups per set (k_reduce_rc / k_reduce_final above)
+        // Edwards law: plain row / column sums of the segment sums, then six small quad-cooperative workgroups per set (k_reduce_rc / k_reduce_terms above)
         const int lgG = c - 3 > 0 ? c - 3 : 0, lgC = (lgG + 1) / 2, lgR = lgG - lgC;
         if (lgC > 8) throw GpuError("msm: more than 2^19 buckets per set");
         const unsigned jobs = 2u * (1u << lgR) + (1u << lgC);
@@ -952,8 +916,12 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
         hipLaunchKernelGGL((k_reduce_rc<P>), dim3((unsigned)nsets * jobs), dim3(RQ_THREADS), 0, s, (const A *)S.seg_s, (const A *)S.seg_w, lgR, lgC, rc);
         HIP_LAUNCH_CHECK();
         te_host_tail = !dev_wsum_out && nsets <= 4;
-        hipLaunchKernelGGL((k_reduce_final<P>), dim3(4u * (unsigned)nsets), dim3(RF_THREADS), 0, s, (const A *)rc, lgR, lgC, part, S.tickets, res, dev_wsum_out, te_host_tail);
+        hipLaunchKernelGGL((k_reduce_terms<P>), dim3((unsigned)(RF_OUT * nsets)), dim3(RT_THREADS), 0, s, (const A *)rc, lgR, lgC, part, res, te_host_tail);
         HIP_LAUNCH_CHECK();
+        if (!te_host_tail) {
+            hipLaunchKernelGGL((k_reduce_combine<P>), dim3((unsigned)nsets), dim3(64), 0, s, (const A *)part, lgR, lgC, res, dev_wsum_out);
+            HIP_LAUNCH_CHECK();
+        }
         te_lgR = lgR; te_lgC = lgC;
     } else {
     hipLaunchKernelGGL((k_reduce_l2<A>), dim3(2u * (unsigned)((groups * nsets + 63) / 64)), dim3(64), 0, s, (const A *)S.seg_s, (const A *)S.seg_w, c, nsets, (A *)S.partial);
@@ -1634,18 +1602,20 @@ __global__ void __launch_bounds__(64, 2) k_class_partials(const typename Law::Ba
     if (s0 >= n) return;
     uint32_t e = s0 + CLS_CHUNK < n ? s0 + CLS_CHUNK : n;
     if constexpr (Law::edwards) {
-        AccTE<P> a1 = te_identity<P>(), a2 = a1;
-        for (uint32_t i = s0; i < e; i++) {
-            int v = vals[i];
-            if (v == 0) continue;
-            Niels28<P> p = bases[i];
-            if (v < 0) { p = niels_neg<P>(p); v = -v; }
-            if (v == 1) te_madd<P>(a1, p);
-            else if (v == 2) te_madd<P>(a2, p);
-            else atomicOr(flags, 2u);
+        // ONE accumulator and ONE te_madd call site: the chunk is walked once per class (round 5 kept both classes' accumulators live around two inlined additions:
+        // 256 registers + 164 B of scratch).  The second walk costs 16 byte loads when -- as almost always -- no value of the chunk is +-2.
+#pragma unroll 1
+        for (int cls = 1; cls <= 2; cls++) {
+            AccTE<P> a = te_identity<P>();
+            for (uint32_t i = s0; i < e; i++) {
+                const int v = vals[i], m = v < 0 ? -v : v;
+                if (m != cls) { if (m > 2 && cls == 1) atomicOr(flags, 2u); continue; }
+                Niels28<P> p = bases[i];
+                if (v < 0) p = niels_neg<P>(p);
+                te_madd<P>(a, p);
+            }
+            (cls == 1 ? part1 : part2)[t] = a;
         }
-        part1[t] = a1;
-        part2[t] = a2;
         return;
     } else
     {
@@ -1689,9 +1659,25 @@ __global__ void __launch_bounds__(256) k_sum_tree(const A *__restrict__ in, uint
     }
     if (t == 0) out[b] = sh[0];
 }
+// the same on the Edwards law with four lanes per point operation (te28.cuh te_add_quad: 91 registers, no scratch, no call): 64 quads gather their shares, then a tree in LDS.
+// k_sum_tree's full-lane additions go through a function call -- 229 registers + 464 B of stack -- and took 451 us per launch in a lone 16-byte call, twice per class sum.
+template <class P>
+__global__ void __launch_bounds__(RQ_THREADS) k_quad_sum(const AccTE<P> *__restrict__ in, uint32_t total, uint32_t per, AccTE<P> *__restrict__ out, uint32_t in_stride, uint32_t out_stride) {
+    __shared__ uint32_t pt[RQ_QUADS * PT_WORDS];
+    in += (size_t)blockIdx.y * in_stride; out += (size_t)blockIdx.y * out_stride;
+    const uint32_t b = blockIdx.x, quad = threadIdx.x >> 2;
+    const int q = threadIdx.x & 3;
+    const uint32_t lo = b * per, hi = lo + per < total ? lo + per : total;
+    FpMsm<P> acc = te_identity_quad<P>(q);
+    for (uint32_t i = lo + quad; i < hi; i += RQ_QUADS) acc = te_add_quad<P>(acc, quad_load<P>(reinterpret_cast<const uint32_t *>(in + i), q), q);
+    quad_store<P>(pt + quad * PT_WORDS, q, acc);
+    __syncthreads();
+    quad_tree_sum<P>(pt, RQ_QUADS, quad, q);
+    if (quad == 0) quad_store<P>(reinterpret_cast<uint32_t *>(out + b), q, quad_load<P>(pt, q));
+}
 // the two class sums in the library-wide form + the flag word, straight into the workspace's pinned host result; re-arms the flag word
 template <class A>
-__global__ void k_class_result(const A *__restrict__ in, uint32_t *__restrict__ flags, XYZZ<Fp<typename PtOps<A>::Params>> *__restrict__ out) {
+__global__ void __launch_bounds__(64) k_class_result(const A *__restrict__ in, uint32_t *__restrict__ flags, XYZZ<Fp<typename PtOps<A>::Params>> *__restrict__ out) {
     uint32_t i = threadIdx.x;
     if (i < 2) out[i] = PtOps<A>::to_std(in[i]);
     if (i == 2) { *reinterpret_cast<uint32_t *>(out + 2) = *flags; *flags = 0; }
@@ -1714,8 +1700,13 @@ static bool class_sum_impl(MsmWorkspace *ws_, const typename Law::Base *bases, c
     hipLaunchKernelGGL((k_class_partials<Law>), dim3((chunks + 63) / 64), dim3(64), 0, s, bases, vals, (uint32_t)n, p1, p2, S.ctrl + 3);
     HIP_LAUNCH_CHECK();
     (void)p2; (void)m2;          // (class 2's arrays follow class 1's at the strides below)
-    hipLaunchKernelGGL((k_sum_tree<A>), dim3(mid, 2), dim3(256), 0, s, (const A *)p1, chunks, 256u, m1, chunks, mid); HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_sum_tree<A>), dim3(1, 2), dim3(256), 0, s, (const A *)m1, mid, mid, fin, mid, 1u); HIP_LAUNCH_CHECK();
+    if constexpr (Law::edwards) {
+        hipLaunchKernelGGL((k_quad_sum<typename Law::Params>), dim3(mid, 2), dim3(RQ_THREADS), 0, s, (const A *)p1, chunks, 256u, m1, chunks, mid); HIP_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_quad_sum<typename Law::Params>), dim3(1, 2), dim3(RQ_THREADS), 0, s, (const A *)m1, mid, mid, fin, mid, 1u); HIP_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL((k_sum_tree<A>), dim3(mid, 2), dim3(256), 0, s, (const A *)p1, chunks, 256u, m1, chunks, mid); HIP_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_sum_tree<A>), dim3(1, 2), dim3(256), 0, s, (const A *)m1, mid, mid, fin, mid, 1u); HIP_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL((k_class_result<A>), dim3(1), dim3(64), 0, s, (const A *)fin, S.ctrl + 3, (XYZZ<Fq> *)S.d_res); HIP_LAUNCH_CHECK();
     XYZZ<Fq> r[2];
     uint32_t flags = 0;

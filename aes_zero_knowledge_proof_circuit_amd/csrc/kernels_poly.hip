@@ -117,14 +117,38 @@ __global__ void k_divlin_local(F *__restrict__ q, const F *__restrict__ p, size_
     }
     v[t] = l;
 }
-// one workgroup: the whole recurrence for a short sequence (the top of the recursion)
-__global__ void k_divlin_base(F *__restrict__ q, const F *__restrict__ p, size_t len, F z) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// one workgroup: the WHOLE division of a short sequence (len <= DL_TOP = 256 blocks of DL_B), the top of the recursion.  Lane t runs the recurrence inside block t, the 256
+// block values are combined by a suffix scan in LDS -- S_t = sum_{t' >= t} V_t' Y^(t' - t), Y = z^DL_B: eight doubling steps S_t += Y^(2^k) S_(t + 2^k) -- and every lane
+// adds its carry C_t = S_(t+1) times z^(block end - 1 - i) to its own coefficients.  Round 5 recursed down to 16 coefficients: three more levels of k_divlin_local /
+// k_divlin_apply launches and a single-lane base case per division, ~40 tiny launches in front of the openings of a lone proof.  Exact field
+// arithmetic: bit-identical to the recurrence.
+constexpr int DL_TOP_THREADS = 256;
+constexpr size_t DL_TOP = (size_t)DL_TOP_THREADS * DL_B;
+__global__ void __launch_bounds__(DL_TOP_THREADS) k_divlin_top(F *__restrict__ q, const F *__restrict__ p, size_t len, F z) {
+    __shared__ F sh[DL_TOP_THREADS];
+    const uint32_t t = threadIdx.x;
+    const size_t s0 = (size_t)t * DL_B, e = s0 + DL_B < len ? s0 + DL_B : len;
     F l = F::zero();
-    for (size_t i = len; i-- > 0;) {
-        if (i + 1 < len) q[i] = l;
-        l = p[i] + z * l;
+    if (s0 < len) {
+        for (size_t i = e; i-- > s0;) {
+            if (i + 1 < len) q[i] = l;                  // (q has len - 1 entries)
+            l = p[i] + z * l;
+        }
     }
+    sh[t] = l;                                          // V_t (zero for blocks beyond the sequence)
+    __syncthreads();
+    F y = z.pow_u64(DL_B);
+    for (int k = 1; k < DL_TOP_THREADS; k <<= 1) {
+        const F other = t + k < DL_TOP_THREADS ? sh[t + k] : F::zero();
+        __syncthreads();
+        sh[t] = sh[t] + y * other;
+        __syncthreads();
+        y = y.sqr();
+    }
+    if (s0 >= len || e >= len) return;                  // the top block misses nothing
+    const F c = sh[t + 1];                              // (t + 1 < DL_TOP_THREADS: a block below the top one)
+    F w = F::one();
+    for (size_t i = e; i-- > s0;) { q[i] = q[i] + w * c; w = w * z; }
 }
 // q_i += z^(end of i's block - 1 - i) * carry[block of i]     (carry has nblocks - 1 entries: the top block misses nothing)
 __global__ void __launch_bounds__(256) k_divlin_apply(F *__restrict__ q, size_t qlen, const F *__restrict__ zp_table, const F *__restrict__ carry, size_t nblocks) {
@@ -145,7 +169,7 @@ size_t divide_by_linear_scratch(size_t len) {       // in field elements: block 
 }
 static void divlin_rec(F *q, const F *p, size_t len, const F &z, F *scratch, hipStream_t s) {
     if (len < 2) return;
-    if (len <= DL_B) { hipLaunchKernelGGL(k_divlin_base, dim3(1), dim3(64), 0, s, q, p, len, z); HIP_LAUNCH_CHECK(); return; }
+    if (len <= DL_TOP) { hipLaunchKernelGGL(k_divlin_top, dim3(1), dim3(DL_TOP_THREADS), 0, s, q, p, len, z); HIP_LAUNCH_CHECK(); return; }
     const size_t nblocks = (len + DL_B - 1) / DL_B;
     F *v = scratch, *carry = scratch + nblocks + 1, *zp = carry + nblocks + 1;
     hipLaunchKernelGGL(k_divlin_local, GRID(nblocks), 0, s, q, p, len, z, v, zp); HIP_LAUNCH_CHECK();
