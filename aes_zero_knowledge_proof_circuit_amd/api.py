@@ -404,6 +404,11 @@ def msm_bench_synth(n, window_bits=0, reps=3, want_point=False):
     return (t.value, a.value, out.raw) if want_point else (t.value, a.value)
 
 
+def srs_hold(hold=True):
+    """zkaes_srs_hold: keep every universal / Lagrange SRS resident after its last key is freed (hold=False releases them again)"""
+    _check(lib().zkaes_srs_hold(1 if hold else 0))
+
+
 def int_rate_bench(seconds=0.5):
     """zkaes_int_rate_bench: per-box calibration of the integer roof (include/zkaes.h)"""
     out = (C.c_double * 8)()

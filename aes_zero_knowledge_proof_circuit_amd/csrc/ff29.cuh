@@ -191,13 +191,19 @@ struct Fp29 {
         }
         return v;
     }
-    // v < 32 p with normalized limbs -> v - q p in [0, 3 p) for an UNDER-estimate q of floor(v / p) taken from the top limb alone (round 5: replaces the 16 p, 8 p, 4 p
-    // rounds of canonical<4> at the NTT's stores -- ~55 instructions instead of ~190).  l_8 = floor(v / 2^232) < 2^28 and p_8 = floor(p / 2^232) >= 2^20:
-    //   rho = l_8 / (p_8 + 1) <= v / p < (l_8 + 1) / p_8 < rho + 2^-11,   q = floor(l_8 RECIP / 2^32) with RECIP = floor(2^32 / (p_8 + 1)) in (rho - 1/16 - 1, rho],
-    // so q <= floor(v / p) <= q + 2 and the remainder is in [0, 3 p).  The signed carry chain re-normalizes the limbs (the top limb keeps what is left).
+    // v < 32 p with normalized limbs -> v - q p in [0, 1.07 p) for an UNDER-estimate q of floor(v / p) taken from the top limb alone (round 5: replaces the 16 p, 8 p, 4 p
+    // rounds of canonical<4> at the NTT's stores -- ~55 instructions instead of ~190).  l_8 = floor(v / 2^232) < 2^28 and p_8 = floor(p / 2^232) >= 2^20; with
+    // RECIP = floor(2^32 / (p_8 + 1)) and q = floor(l_8 RECIP / 2^32):
+    //   q <= l_8 / (p_8 + 1) <= v / p                                  (never an over-estimate: the remainder is >= 0)
+    //   q >  l_8 / (p_8 + 1) - l_8 / 2^32 - 1 >= l_8 / (p_8 + 1) - 17/16
+    //   v / p < (l_8 + 1) / p_8   =>   v / p - q < l_8 / (p_8 (p_8 + 1)) + 1 / p_8 + 17/16 < 2^-15 + 2^-20 + 1.0625        (l_8 <= 32 p_8 + 31)
+    // so the remainder is below 1.07 p < 2 p, which k_ntt_pass relies on when it packs the value into 8 x 32-bit words between passes (2 p < 2^256 is asserted below:
+    // a bound of 3 p -- what this comment claimed in round 5 -- would NOT fit for BLS12-381's scalar field).  The signed carry chain re-normalizes the limbs (the top limb
+    // keeps what is left).
     ZK_HD Fp29 reduce_by_top_limb() const {
         constexpr uint32_t RECIP = (uint32_t)((1ull << 32) / ((uint64_t)mod29(N - 1) + 1));
         static_assert(mod29(N - 1) >= (1u << 20), "the estimate's error bound assumes a modulus of at least 253 bits");
+        static_assert(P::mod(P::N - 1) < (1u << 31), "the callers pack a remainder < 2 p into 8 x 32-bit words: needs 2 p < 2^256");
 #if defined(__HIP_DEVICE_COMPILE__)
         const uint32_t q = __umulhi(l[N - 1], RECIP);
 #else

@@ -748,7 +748,6 @@ struct MsmWorkspace {
     uint32_t *order = nullptr, *ovf_slot = nullptr;               // per bucket: visiting order, slot in the overflow list (NO_SLOT for all but oversized buckets)
     uint32_t *ovf_bucket = nullptr, *ovf_nseg = nullptr, *ovf_off = nullptr; void *ovf_partial = nullptr; size_t cap_ovf = 0;    // overflow list + the segments' partial sums
     uint32_t *part_hist = nullptr, *part_offs = nullptr; size_t cap_part = 0;      // two-level partition: (coarse bin, workgroup) counts and their scan
-    uint32_t *dig = nullptr; size_t cap_dig = 0;                                   // two-level partition: 16 digit words per scalar
     uint32_t *ord_hist = nullptr, *ord_offs = nullptr;            // ORD_BINS x ORD_MAX_BLOCKS counts and their scan
     uint32_t *ctrl = nullptr;                                     // 8 control words (see k_order_hist); armed at zero between MSMs
     bool ctrl_dirty = false;                                      // an exception left the order pass half done: re-arm ctrl before the next one
@@ -804,7 +803,7 @@ MsmWorkspace *msm_workspace_create() { return new MsmWorkspace(); }
 void msm_workspace_destroy(MsmWorkspace *w) {
     if (!w) return;
     for (void *p : {(void *)w->keys_a, (void *)w->keys_b, (void *)w->vals_a, (void *)w->vals_b, (void *)w->start, (void *)w->end, (void *)w->order, (void *)w->ovf_slot,
-                    (void *)w->ovf_bucket, (void *)w->ovf_nseg, (void *)w->ovf_off, w->ovf_partial, (void *)w->part_hist, (void *)w->part_offs, (void *)w->dig, (void *)w->ord_hist, (void *)w->ord_offs,
+                    (void *)w->ovf_bucket, (void *)w->ovf_nseg, (void *)w->ovf_off, w->ovf_partial, (void *)w->part_hist, (void *)w->part_offs, (void *)w->ord_hist, (void *)w->ord_offs,
                     (void *)w->ctrl, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->tmp}) dfree(p);
     if (w->h_res) (void)hipHostFree(w->h_res);
     for (auto e : w->ev) if (e) (void)hipEventDestroy(e);
@@ -1247,10 +1246,10 @@ void table_next(Affine<typename Curve::Fq> *next, const Affine<typename Curve::F
 // onesweep passes, whose stable ranking is a chain of match-any ballots per item) spent ~470 lane-instructions per (point, window) pair, 13 % of what the bucket
 // additions themselves take.  Nothing here needs a stable sort -- only "bucket-contiguous, and inside a bucket by window" (the lanes of a wave then gather from the same
 // table copy, which the round-3 partition got wrong: 5.7 % slower accumulation) -- so ranks come from LDS atomics, ~70 lane-instructions per pair:
-//   k_part_hist    : one pass over the scalars: window digits (Montgomery -> canonical, carry recoding) stored as 16 words per scalar, LDS histogram of the pairs over the
-//                    COARSE bins (the high bucket bits, <= 1024 bins); fixed tiling over a fixed grid, counts written per (bin, workgroup)
+//   k_part_hist    : one pass over the scalars: window digits (Montgomery -> canonical, carry recoding), LDS histogram of the pairs over the COARSE bins (the high bucket
+//                    bits, <= 1024 bins); fixed tiling over a fixed grid, counts written per (bin, workgroup)
 //   one scan       : every (bin, workgroup) gets its range -- no global atomics, deterministic
-//   k_part_scatter : same tiling, digits re-read (not recomputed): a tile's pairs are ranked by LDS atomics into bin-contiguous runs staged in LDS and written out as
+//   k_part_scatter : same tiling, digits recomputed (round 6; rounds 4-5 stored 16 words per scalar and read them back): a tile's pairs are ranked by LDS atomics into bin-contiguous runs staged in LDS and written out as
 //                    (value, 13-bit key = fine bucket bits x 16 + window)
 //   k_part_fine    : one workgroup per coarse bin: LDS counts of its 8,192 (fine bucket, window) keys, in-place scan, bucket [start, end) ranges (what k_bounds used to
 //                    find), values scattered to their final place through LDS cursors
@@ -1303,7 +1302,7 @@ __device__ __forceinline__ void part_block_scan(uint32_t *cnt, uint32_t len, uin
 }
 template <class Fr>
 __global__ void __launch_bounds__(PART_THREADS) k_part_hist(const Fr *__restrict__ s1, uint32_t n1, const Fr *__restrict__ s2, uint32_t n2, TableLayout L, uint32_t nbin,
-                                                            uint32_t *__restrict__ dig, uint32_t *__restrict__ hist) {
+                                                            uint32_t *__restrict__ hist) {
     __shared__ uint32_t sh[PART_NBIN_MAX];
     for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) sh[b] = 0;
     __syncthreads();
@@ -1318,16 +1317,15 @@ __global__ void __launch_bounds__(PART_THREADS) k_part_hist(const Fr *__restrict
             part_recode<Fr>(g < n1 ? s1[g] : s2[g - n1], L, d);
 #pragma unroll
             for (int w = 0; w < PART_MAXW; w++) if (d[w] != PART_NONE) atomicAdd(&sh[(d[w] & 0x7fffffffu) >> PART_FINE_BITS], 1u);
-            uint4 *dst = reinterpret_cast<uint4 *>(dig + (size_t)g * PART_MAXW);
-#pragma unroll
-            for (int k = 0; k < PART_MAXW / 4; k++) dst[k] = make_uint4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
         }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) hist[(size_t)b * gridDim.x + blockIdx.x] = sh[b];      // bin-major: the scan gives every (bin, workgroup) its range
     if (blockIdx.x == 0 && threadIdx.x == 0) hist[(size_t)nbin * gridDim.x] = 0;                                       // the scan's last entry = the number of pairs
 }
-__global__ void __launch_bounds__(PART_THREADS) k_part_scatter(const uint32_t *__restrict__ dig, uint32_t n, uint32_t n1, uint32_t off1, uint32_t off2, uint32_t stride, uint32_t nbin,
-                                                               const uint32_t *__restrict__ offs, uint32_t *__restrict__ out_val, uint16_t *__restrict__ out_key) {
+template <class Fr>
+__global__ void __launch_bounds__(PART_THREADS) k_part_scatter(const Fr *__restrict__ s1, uint32_t n1, const Fr *__restrict__ s2, uint32_t n2, TableLayout L, uint32_t off1, uint32_t off2, uint32_t stride,
+                                                               uint32_t nbin, const uint32_t *__restrict__ offs, uint32_t *__restrict__ out_val, uint16_t *__restrict__ out_key) {
+    const uint32_t n = n1 + n2;
     __shared__ uint32_t cursor[PART_NBIN_MAX], cnt[PART_NBIN_MAX], fill[PART_NBIN_MAX], st_val[PART_STAGE], st_key[PART_STAGE];
     __shared__ uint32_t wave_sums[PART_THREADS / 64], total;
     for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) cursor[b] = offs[(size_t)b * gridDim.x + blockIdx.x];
@@ -1340,11 +1338,12 @@ __global__ void __launch_bounds__(PART_THREADS) k_part_scatter(const uint32_t *_
 #pragma unroll
         for (int q = 0; q < PART_SPT; q++) {
             const uint32_t g = tile * PART_TILE + q * PART_THREADS + threadIdx.x;
+            // the digits are RECOMPUTED from the scalar (round 5 wrote them -- 16 words per scalar, 2.0 GB per proof -- in k_part_hist and read them back here: ~250 more
+            // instructions per scalar against 96 bytes of HBM traffic, on a chip that runs at its power limit)
+            if (g < n) part_recode<Fr>(g < n1 ? s1[g] : s2[g - n1], L, d[q]);
+            else {
 #pragma unroll
-            for (int k = 0; k < PART_MAXW / 4; k++) {
-                uint4 v = make_uint4(PART_NONE, PART_NONE, PART_NONE, PART_NONE);
-                if (g < n) v = reinterpret_cast<const uint4 *>(dig + (size_t)g * PART_MAXW)[k];
-                d[q][4 * k] = v.x; d[q][4 * k + 1] = v.y; d[q][4 * k + 2] = v.z; d[q][4 * k + 3] = v.w;
+                for (int w = 0; w < PART_MAXW; w++) d[q][w] = PART_NONE;
             }
 #pragma unroll
             for (int w = 0; w < PART_MAXW; w++) if (d[q][w] != PART_NONE) atomicAdd(&cnt[(d[q][w] & 0x7fffffffu) >> PART_FINE_BITS], 1u);
@@ -1448,18 +1447,17 @@ static void partition_buckets(MsmWorkspace &S, const Fr *scal1, size_t n1, size_
     const uint32_t nbin = 1u << (B - PART_FINE_BITS), G = PART_GRID;
     const size_t n = n1 + n2, nb = (size_t)1 << B, nh = (size_t)nbin * G + 1;
     if (nh > S.cap_part) { dfree(S.part_hist); dfree(S.part_offs); S.part_hist = (uint32_t *)dmalloc(nh * 4); S.part_offs = (uint32_t *)dmalloc(nh * 4); S.cap_part = nh; }
-    if (n > S.cap_dig) { dfree(S.dig); S.dig = (uint32_t *)dmalloc(n * PART_MAXW * 4); S.cap_dig = n; }
 #ifdef ZKAES_MEASURE
     for (int rep = (knockin() & 1) ? 0 : 1; rep < 2; rep++)
 #endif
     {
-    hipLaunchKernelGGL((k_part_hist<Fr>), dim3(G), dim3(PART_THREADS), 0, s, scal1, (uint32_t)n1, scal2, (uint32_t)n2, L, nbin, S.dig, S.part_hist);
+    hipLaunchKernelGGL((k_part_hist<Fr>), dim3(G), dim3(PART_THREADS), 0, s, scal1, (uint32_t)n1, scal2, (uint32_t)n2, L, nbin, S.part_hist);
     HIP_LAUNCH_CHECK();
     size_t tb = 0;
     HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, S.part_hist, S.part_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
     if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
     HIP_CHECK(rocprim::exclusive_scan(S.tmp, tb, S.part_hist, S.part_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
-    hipLaunchKernelGGL(k_part_scatter, dim3(G), dim3(PART_THREADS), 0, s, (const uint32_t *)S.dig, (uint32_t)n, (uint32_t)n1, (uint32_t)off1, (uint32_t)off2, (uint32_t)stride, nbin,
+    hipLaunchKernelGGL((k_part_scatter<Fr>), dim3(G), dim3(PART_THREADS), 0, s, scal1, (uint32_t)n1, scal2, (uint32_t)n2, L, (uint32_t)off1, (uint32_t)off2, (uint32_t)stride, nbin,
                        (const uint32_t *)S.part_offs, S.vals_a, (uint16_t *)S.keys_a);
     HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_part_fine, dim3(nbin), dim3(PART_FINE_THREADS), 0, s, (const uint32_t *)S.part_offs, G, (const uint32_t *)S.vals_a, (const uint16_t *)S.keys_a, S.vals_b, S.start, S.end);

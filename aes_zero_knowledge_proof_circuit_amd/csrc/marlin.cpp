@@ -38,6 +38,13 @@ double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std
 using SrsPoint = Niels28<Fq377P>;
 static void srs_convert(SrsPoint *dst, const G1A *src, size_t n, gpu::stream_t s) { gpu::convert_bases_te<Bls377>(dst, src, n, s); }
 
+// select `device` for the calling thread and put the caller's device back on the way out (destructors of device-resident objects may run on any thread:
+// they must not leave it pointing at another GPU -- advisor r05)
+struct DeviceScope {
+    int prev = -1;
+    explicit DeviceScope(int device) noexcept { try { prev = gpu::current_device(); if (prev != device) gpu::set_device(device); else prev = -1; } catch (...) { prev = -1; } }
+    ~DeviceScope() { if (prev >= 0) { try { gpu::set_device(prev); } catch (...) {} } }
+};
 struct DevBuf {
     F *p = nullptr; size_t n = 0;
     void alloc(size_t count) { n = count; p = (F *)gpu::dmalloc(count * sizeof(F)); }
@@ -67,7 +74,7 @@ struct UniversalSrs {
     double build_s = 0;
     bool tables() const { return n_tab > 1; }
     uint64_t bytes() const { return (uint64_t)n_tab * stride * sizeof(SrsPoint); }
-    ~UniversalSrs() { try { gpu::set_device(device); } catch (...) {} gpu::dfree(d_points); }
+    ~UniversalSrs() { DeviceScope on(device); gpu::dfree(d_points); }
 };
 // Lagrange-basis points over H (per |H| and |X|, shared the same way): L_k(beta) G for z_A, z_B; L_k(beta)/v_X(beta) G (zero on X) for w; P_j for the public-input part
 // of w; v_H(beta) G and (v_H/v_X)(beta) G for the blinding terms
@@ -78,12 +85,17 @@ struct LagrangeSrs {
     std::vector<G1A> lag_pj;
     G1A lag_vh, lag_vw;
     FixedBaseHost lag_vh_tab, lag_vw_tab;
-    ~LagrangeSrs() { try { gpu::set_device(device); } catch (...) {} gpu::dfree(d_lag_h); gpu::dfree(d_lag_w); }
+    ~LagrangeSrs() { DeviceScope on(device); gpu::dfree(d_lag_h); gpu::dfree(d_lag_w); }
 };
 namespace {
 std::mutex g_srs_mu;                          // serializes SRS construction: two keys synthesized concurrently must not both build 31 GB of tables
 std::map<std::pair<int, size_t>, std::weak_ptr<UniversalSrs>> g_srs_cache[2];      // [0] copy 0 only, [1] with window tables; key = (device, max_degree)
 std::map<std::tuple<int, size_t, size_t>, std::weak_ptr<LagrangeSrs>> g_lag_cache;  // key = (device, |H|, |X|)
+// zkaes_srs_hold(1): the process keeps every universal / Lagrange SRS alive after its last key is freed (a caller that creates and frees keys in turn -- one key per
+// request size, say -- would otherwise rebuild 31 GB of tables each time: advisor r05); zkaes_srs_hold(0) lets them go again with their last key
+bool g_srs_hold = false;
+std::vector<std::shared_ptr<UniversalSrs>> g_srs_held;
+std::vector<std::shared_ptr<LagrangeSrs>> g_lag_held;
 std::atomic<size_t> g_default_contexts{0};
 }  // namespace
 // proofs in flight per multi-proof call unless the key says otherwise (zkaes_pk_set_contexts): ZKAES_CONTEXTS from the environment, read ONCE, else ZKAES_DEFAULT_CONTEXTS
@@ -140,6 +152,7 @@ static std::shared_ptr<UniversalSrs> acquire_srs(size_t max_degree, bool want_ta
     { uint32_t raw[8]; S->beta.to_raw(raw); S->beta_h = pairing::g2_mul_raw(S->h, raw, 8); }
     S->build_s = ms_since(t0) / 1e3;
     g_srs_cache[n_tab > 1 ? 1 : 0][key] = S;
+    if (g_srs_hold) g_srs_held.push_back(S);
     return S;
 }
 static std::shared_ptr<LagrangeSrs> acquire_lagrange(const UniversalSrs &U, size_t n, int lg_n, size_t m, int lg_m, gpu::stream_t stream) {
@@ -180,8 +193,23 @@ static std::shared_ptr<LagrangeSrs> acquire_lagrange(const UniversalSrs &U, size
     Lg->lag_vw = mul_affine(U.g, vh * vx_inv);
     Lg->lag_vh_tab.build(Lg->lag_vh); Lg->lag_vw_tab.build(Lg->lag_vw);
     g_lag_cache[key] = Lg;
+    if (g_srs_hold) g_lag_held.push_back(Lg);
     return Lg;
 }
+void srs_hold(bool hold) {
+    std::vector<std::shared_ptr<UniversalSrs>> drop_u;
+    std::vector<std::shared_ptr<LagrangeSrs>> drop_l;
+    {
+        std::lock_guard<std::mutex> lock(g_srs_mu);
+        g_srs_hold = hold;
+        if (hold) {        // what is alive now stays
+            for (auto &cache : g_srs_cache) for (auto &kv : cache) if (auto sp = kv.second.lock()) if (std::find(g_srs_held.begin(), g_srs_held.end(), sp) == g_srs_held.end()) g_srs_held.push_back(sp);
+            for (auto &kv : g_lag_cache) if (auto sp = kv.second.lock()) if (std::find(g_lag_held.begin(), g_lag_held.end(), sp) == g_lag_held.end()) g_lag_held.push_back(sp);
+        } else { drop_u.swap(g_srs_held); drop_l.swap(g_lag_held); }
+    }
+    // (the last references go -- and device memory is freed -- outside the lock)
+}
+
 
 // Everything one in-flight proof needs: its own stream, MSM scratch and polynomial workspace.  Several contexts prove different
 // chunk-proofs concurrently (zkaes_encrypt_chunked): the latency-bound phases of one proof (bucket reductions, scans, host
@@ -228,9 +256,13 @@ struct ProverContext {
     bool throughput = false;           // set per proof: several proofs in flight (chunked / batch calls) -> window tables; a lone encrypt() call -> per-window buckets
     ProverContext() { stream = gpu::stream_create(); msm_ws = gpu::msm_workspace_create(); lane[0].stream = stream; lane[0].ws = msm_ws; }
     void ensure_lanes() {
-        for (int i = 1; i < N_LANES; i++) if (!lane[i].stream) {
-            lane[i].stream = i == 3 ? gpu::stream_create_background() : gpu::stream_create(); lane[i].ws = gpu::msm_workspace_create(); lane[i].ready = gpu::event_create();
-            lane[i].worker.reset(new LaneWorker());
+        for (int i = 1; i < N_LANES; i++) if (!lane[i].worker) {        // guarded by the LAST member created; leftovers of an attempt that threw half way are released first (advisor r05)
+            Lane &L = lane[i];
+            gpu::msm_workspace_destroy(L.ws); L.ws = nullptr;
+            gpu::event_destroy(L.ready); L.ready = nullptr;
+            gpu::stream_destroy(L.stream); L.stream = nullptr;
+            L.stream = i == 3 ? gpu::stream_create_background() : gpu::stream_create(); L.ws = gpu::msm_workspace_create(); L.ready = gpu::event_create();
+            L.worker.reset(new LaneWorker());
         }
     }
     ~ProverContext() {
@@ -443,11 +475,42 @@ class ProvingKeyImpl {
             slots.clear();
             if (!first.empty()) throw std::runtime_error(first);
         }
-        ~RoundJobs() { for (auto &sl : slots) if (sl->queued) sl->fut.wait(); }       // (an exception must not leave a job running on this context)
+        void wait_all() noexcept { for (auto &sl : slots) if (sl->queued) sl->fut.wait(); }
+        ~RoundJobs() { wait_all(); }       // (an exception must not leave a job running on this context)
     };
+
+    // What one proof carries from round to round: the prover RNG, the Fiat-Shamir transcript, the labeled commitments of each round with their blinding scalars, the
+    // challenges and what is derived from them, the proof being filled in.  `jobs` is the LAST member on purpose: members are destroyed in reverse order, so when a round
+    // throws (a HIP error in a transform, say) ~RoundJobs waits for the lane workers BEFORE `inst`, `declined`, `pf`, ... -- which their lambdas hold by reference -- go away
+    // (advisor r05: `jobs` used to be declared ahead of what it captured).
+    struct ProofRun {
+        ProverContext &cx;
+        const uint8_t *host_trace, *msg; size_t len; const uint8_t *key;
+        Clock::time_point t_all, t0;
+        ChaChaRng zk;                                   // the prover's zero-knowledge randomness (generate_rand(): ark_std::test_rng unless a seed is given)
+        FiatShamirRng fs;
+        Labeled r1[4], r2[3], r3[2];                    // w z_a z_b mask | t g_1 h_1 | g_2 h_2
+        Fr rhos[3];
+        std::vector<uint8_t> inst;
+        bool declined[3] = {false, false, false};
+        Fr alpha, eta_a, eta_b, eta_c, vh_alpha, beta, vh_beta, ea_vv, eb_vv, ec_vv, alpha_beta, gamma;
+        Proof pf;
+        bool early_evals = false;
+        std::atomic<bool> g2_quotient_queued{false};
+        RoundJobs jobs;
+        ProofRun(ProvingKeyImpl &K, ProverContext &c, const uint8_t *trace, const uint8_t *msg_, size_t len_, const uint8_t *key_, const uint8_t *zk_seed)
+            : cx(c), host_trace(trace), msg(msg_), len(len_), key(key_), t_all(Clock::now()), t0(t_all), zk(zk_seed ? zk_seed : ark_test_rng_seed(), 12),
+              r1{{0, -1, true}, {1, -1, true}, {2, -1, true}, {3, -1, false}}, r2{{4, -1, false}, {5, (long)(K.n - 2), true}, {6, -1, false}},
+              r3{{7, (long)(K.k - 2), false}, {8, -1, false}}, jobs(K, c) {}
+    };
+    Fr sample_outside_h(FiatShamirRng &fs) const;
 
     void setup(int kind, size_t message_len, const SrsLiterals &lits, unsigned flags);
     Proof prove(ProverContext &cx, const uint8_t *trace_or_null, const uint8_t *msg, size_t len, const uint8_t *key, const uint8_t *zk_seed, bool throughput = false);
+    void prove_round1(ProofRun &R);      // randomness, mask polynomial, witness, interpolations, commitments of w z_A z_B mask -> alpha, eta
+    void prove_round2(ProofRun &R);      // t, the sumcheck quotient on three cosets of H, commitments of t g_1 h_1 -> beta
+    void prove_round3(ProofRun &R);      // f on K from the two quotient tables, g_2, h_2 from one coset, their commitments -> gamma
+    void prove_open(ProofRun &R);        // the four evaluations, the opening challenge, the two batched KZG openings side by side
 };
 
 void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &lits, unsigned flags) {
@@ -601,100 +664,94 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &lit
     setup_total_s = ms_since(t_setup) / 1e3;
 }
 
-Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const uint8_t *msg, size_t len, const uint8_t *key, const uint8_t *zk_seed, bool throughput) {
-    gpu::set_device(device);
-    std::lock_guard<std::mutex> busy(cx.in_use);
-    cx.throughput = throughput;
+// ---- one proof.  prove() = witness + round 1, round 2, round 3, the two openings, over a ProofRun that carries what the rounds hand to each other (the transcript, the prover
+// RNG, the labeled commitments with their blinding scalars, the challenges); the workspace buffers are the context's (cx.poly[..], cx.e[..], ...) and are named as such.
+// (Round 5: one 290-line function over thirty local aliases of the context's buffers -- VERDICT r05 weak #10.)
+Fr ProvingKeyImpl::sample_outside_h(FiatShamirRng &fs) const { Fr t; do { t = fs.rng().rand_field<Fr>(); } while (eval_vanishing(n, t).is_zero()); return t; }
+
+void ProvingKeyImpl::prove_round1(ProofRun &R) {
+    ProverContext &cx = R.cx;
     const Circuit &c = circuit;
     gpu::stream_t s = cx.stream;
-    auto &d_trace = cx.d_trace; auto &d_z = cx.d_z; auto &d_msg = cx.d_msg; auto &d_key = cx.d_key;
-    auto &za_ev = cx.za_ev; auto &zb_ev = cx.zb_ev; auto &x_poly = cx.x_poly; auto &x_tmp = cx.x_tmp; auto &x_evals = cx.x_evals; auto &tmp_n = cx.tmp_n;
-    auto &ra_ev = cx.ra_ev; auto &ra_poly = cx.ra_poly; auto &zpoly = cx.zpoly; auto &t_partial = cx.t_partial;
-    auto &poly = cx.poly; auto &poly_len = cx.poly_len; auto &e = cx.e; auto &big_tmp = cx.big_tmp; auto &f_poly = cx.f_poly;
-    auto &acc = cx.acc; auto &wit = cx.wit; auto &wit2 = cx.wit2; auto &scratch = cx.scratch; auto &timings = cx.timings;
-    auto t_all = Clock::now(), t0 = t_all;
-    ChaChaRng zk(zk_seed ? zk_seed : ark_test_rng_seed(), 12);
-    const size_t n4 = next_pow2(3 * n + 1), k2 = 2 * k;
-    const int lg_n4 = log2_exact(n4), lg_k2 = log2_exact(k2);
     // ---- the prover's own randomness first: none of it depends on the witness.  Upstream's draw order is rho_w, rho_zA, rho_zB, the 3|H| mask coefficients, then the
     // commitments' blinding scalars label by label -- kept -- but the mask polynomial and its commitment (the one full-width MSM of round 1, and the round's critical
     // path in a lone call: 2.9 of 26.8 ms at 16 bytes) start NOW on a lane of their own, under the witness generation and the round's transforms.
-    Labeled r1[4] = {{0, -1, true}, {1, -1, true}, {2, -1, true}, {3, -1, false}};
-    Fr rhos[3];
-    for (auto &r : rhos) r = zk.rand_field<Fr>();
+    for (auto &r : R.rhos) r = R.zk.rand_field<Fr>();
     {   // mask polynomial: degree 3|H| + 2 zk_bound - 3, sum over H forced to zero.  The 3|H| coefficients are the next 3|H| Fr::rand draws
         // of the prover RNG: generated on the device from the same ChaCha12 key stream, then the host RNG skips past them.
-        uint64_t next = gpu::chacha_field_stream(poly[3].p, 3 * n, zk.key_words(), zk.rounds(), zk.word_pos(), cx.d_rng, cx.rng_bytes, s);
-        zk.set_word_pos(next);
-        gpu::mask_fixup(poly[3].p, n, s);
-        poly_len[3] = 3 * n;
+        uint64_t next = gpu::chacha_field_stream(cx.poly[3].p, 3 * n, R.zk.key_words(), R.zk.rounds(), R.zk.word_pos(), cx.d_rng, cx.rng_bytes, s);
+        R.zk.set_word_pos(next);
+        gpu::mask_fixup(cx.poly[3].p, n, s);
+        cx.poly_len[3] = 3 * n;
     }
-    for (auto &lp : r1) draw_rand(lp, zk);
-    RoundJobs jobs(*this, cx);
-    if (jobs.async) gpu::sync(s);        // the mask polynomial is in place (nothing else is on the stream yet)
-    jobs.start(3, [&](Lane &ln) { mpc_commit(cx, ln, r1[3]); }, false);
+    for (auto &lp : R.r1) draw_rand(lp, R.zk);
+    if (R.jobs.async) gpu::sync(s);        // the mask polynomial is in place (nothing else is on the stream yet)
+    R.jobs.start(3, [&](Lane &ln) { mpc_commit(cx, ln, R.r1[3]); }, false);
     // ---- witness: trace -> z (bytes) -> z_A, z_B
-    if (host_trace) gpu::h2d(d_trace, host_trace, c.trace_bytes, s);
+    if (R.host_trace) gpu::h2d(cx.d_trace, R.host_trace, c.trace_bytes, s);
     else {
-        gpu::h2d(d_msg, msg, len, s); gpu::h2d(d_key, key, 16, s);
-        gpu::aes_trace(d_trace, c.trace_bytes, d_msg, d_key, 1, (uint32_t)c.n_blocks, s);
+        gpu::h2d(cx.d_msg, R.msg, R.len, s); gpu::h2d(cx.d_key, R.key, 16, s);
+        gpu::aes_trace(cx.d_trace, c.trace_bytes, cx.d_msg, cx.d_key, 1, (uint32_t)c.n_blocks, s);
     }
-    gpu::witness_expand(d_z, d_desc, (uint32_t)c.num_variables(), d_trace, d_sbox_in, d_sbox_tmpl, s);
-    gpu::spmv_bits(za_ev.p, cx.d_cls[1], n, d_a_rowptr, d_a_col, d_a_coeff, c.num_constraints, d_z, s);
-    gpu::spmv_bits(zb_ev.p, cx.d_cls[2], n, d_b_rowptr, d_b_col, d_b_coeff, c.num_constraints, d_z, s);
-    if (use_lagrange) gpu::w_classes(cx.d_cls[0], d_z, (uint32_t)n, (uint32_t)m, (uint32_t)c.num_witness, s);
-    std::vector<uint8_t> inst(m);
-    gpu::d2h(inst.data(), d_z, m, s);            // (drains the main stream: the evaluation classes of w, z_A, z_B exist from here on)
-    timings.witness_ms = ms_since(t0); t0 = Clock::now();
+    gpu::witness_expand(cx.d_z, d_desc, (uint32_t)c.num_variables(), cx.d_trace, d_sbox_in, d_sbox_tmpl, s);
+    gpu::spmv_bits(cx.za_ev.p, cx.d_cls[1], n, d_a_rowptr, d_a_col, d_a_coeff, c.num_constraints, cx.d_z, s);
+    gpu::spmv_bits(cx.zb_ev.p, cx.d_cls[2], n, d_b_rowptr, d_b_col, d_b_coeff, c.num_constraints, cx.d_z, s);
+    if (use_lagrange) gpu::w_classes(cx.d_cls[0], cx.d_z, (uint32_t)n, (uint32_t)m, (uint32_t)c.num_witness, s);
+    R.inst.resize(m);
+    gpu::d2h(R.inst.data(), cx.d_z, m, s);            // (drains the main stream: the evaluation classes of w, z_A, z_B exist from here on)
+    cx.timings.witness_ms = ms_since(R.t0); R.t0 = Clock::now();
     // The commitments of w, z_A, z_B are class sums over the Lagrange-basis SRS (lagrange_commit): they need the evaluation classes only, NOT the interpolated polynomials --
     // so a lone call starts them here, beside the mask commitment, and the round's interpolations (needed from round 2 on) run under them on the main stream.  A class sum
     // that declines (a value outside the small classes) falls back to the MSM over the coefficients after the interpolation.
-    bool declined[3] = {false, false, false};
     static const int r1_lane[3] = {1, 2, 4};
     for (int i = 0; i < 3; i++) {
-        Labeled *lp = &r1[i];
-        bool *dec = &declined[i];
-        jobs.start(r1_lane[i], [&, lp, dec](Lane &ln) {
-            if (use_lagrange && lagrange_commit(cx, ln, lp->idx, inst, rhos[lp->idx], lp->rand, lp->comm.comm)) { lp->comm.has_shifted = false; return; }
-            if (jobs.async) { *dec = true; return; }     // (the coefficients are not there yet: the calling thread commits after the interpolation)
+        Labeled *lp = &R.r1[i];
+        bool *dec = &R.declined[i];
+        R.jobs.start(r1_lane[i], [&, lp, dec](Lane &ln) {
+            if (use_lagrange && lagrange_commit(cx, ln, lp->idx, R.inst, R.rhos[lp->idx], lp->rand, lp->comm.comm)) { lp->comm.has_shifted = false; return; }
+            if (R.jobs.async) { *dec = true; return; }     // (the coefficients are not there yet: the calling thread commits after the interpolation)
             mpc_commit(cx, ln, *lp);
         }, false);
     }
     // ---- transcript init: "MARLIN-2019" || index_vk || public_input
-    FiatShamirRng fs;
     {
         Bytes o;
         o.put("MARLIN-2019", 11);
         o.u64(vk.num_variables); o.u64(vk.num_constraints); o.u64(vk.num_non_zero);
         for (int i = 0; i < 6; i++) { Commitment ic; ic.comm = vk.index_comms[i]; o.commitment_tobytes(ic); }
-        for (size_t i = 1; i < m; i++) o.field(inst[i] ? Fr::one() : Fr::zero());
-        fs.initialize(o.b);
+        for (size_t i = 1; i < m; i++) o.field(R.inst[i] ? Fr::one() : Fr::zero());
+        R.fs.initialize(o.b);
     }
     // ---- first round
-    gpu::bits_to_field(x_tmp.p, d_z, m, s);
-    gpu::ntt<F>(x_poly.p, x_tmp.p, m, lg_m, true, s);
-    gpu::ntt<F>(x_evals.p, x_poly.p, m, lg_n, false, s);
-    gpu::w_evals(tmp_n.p, d_z, x_evals.p, (uint32_t)n, (uint32_t)m, (uint32_t)c.num_witness, s);
+    gpu::bits_to_field(cx.x_tmp.p, cx.d_z, m, s);
+    gpu::ntt<F>(cx.x_poly.p, cx.x_tmp.p, m, lg_m, true, s);
+    gpu::ntt<F>(cx.x_evals.p, cx.x_poly.p, m, lg_n, false, s);
+    gpu::w_evals(cx.tmp_n.p, cx.d_z, cx.x_evals.p, (uint32_t)n, (uint32_t)m, (uint32_t)c.num_witness, s);
     {   // interpolate w v_X + x (then / v_X), z_A, z_B: three transforms, shared launches
-        const gpu::NttJob<F> interp[3] = {{e[0].p, tmp_n.p, 0}, {poly[1].p, za_ev.p, 0}, {poly[2].p, zb_ev.p, 0}};
+        const gpu::NttJob<F> interp[3] = {{cx.e[0].p, cx.tmp_n.p, 0}, {cx.poly[1].p, cx.za_ev.p, 0}, {cx.poly[2].p, cx.zb_ev.p, 0}};
         gpu::ntt_batch<F>(interp, 3, n, lg_n, true, 0, s);
     }
-    gpu::poly_add_at(e[0].p, 0, rhos[0].neg(), s); gpu::poly_set_at(e[0].p, n, rhos[0], s);   // + rho * v_H
-    gpu::divide_by_vanishing(poly[0].p, e[1].p, e[0].p, n + 1, m, s, e[1].p + m, n);       // / v_X ; remainder must vanish
-    poly_len[0] = n + 1 - m;
-    gpu::poly_add_at(poly[1].p, 0, rhos[1].neg(), s); gpu::poly_set_at(poly[1].p, n, rhos[1], s); poly_len[1] = n + 1;
-    gpu::poly_add_at(poly[2].p, 0, rhos[2].neg(), s); gpu::poly_set_at(poly[2].p, n, rhos[2], s); poly_len[2] = n + 1;
-    jobs.join();
-    for (int i = 0; i < 3; i++) if (declined[i]) mpc_commit(cx, cx.lane[0], r1[i]);
-    { Bytes o; for (auto &lp : r1) o.commitment_tobytes(lp.comm); fs.absorb(o.b); }
-    auto sample_outside_h = [&]() { Fr t; do { t = fs.rng().rand_field<Fr>(); } while (eval_vanishing(n, t).is_zero()); return t; };
-    Fr alpha = sample_outside_h();
-    Fr eta_a = fs.rng().rand_field<Fr>(), eta_b = fs.rng().rand_field<Fr>(), eta_c = fs.rng().rand_field<Fr>();
-    timings.round1_ms = ms_since(t0); t0 = Clock::now();
+    gpu::poly_add_at(cx.e[0].p, 0, R.rhos[0].neg(), s); gpu::poly_set_at(cx.e[0].p, n, R.rhos[0], s);   // + rho * v_H
+    gpu::divide_by_vanishing(cx.poly[0].p, cx.e[1].p, cx.e[0].p, n + 1, m, s, cx.e[1].p + m, n);       // / v_X ; remainder must vanish
+    cx.poly_len[0] = n + 1 - m;
+    gpu::poly_add_at(cx.poly[1].p, 0, R.rhos[1].neg(), s); gpu::poly_set_at(cx.poly[1].p, n, R.rhos[1], s); cx.poly_len[1] = n + 1;
+    gpu::poly_add_at(cx.poly[2].p, 0, R.rhos[2].neg(), s); gpu::poly_set_at(cx.poly[2].p, n, R.rhos[2], s); cx.poly_len[2] = n + 1;
+    R.jobs.join();
+    for (int i = 0; i < 3; i++) if (R.declined[i]) mpc_commit(cx, cx.lane[0], R.r1[i]);
+    { Bytes o; for (auto &lp : R.r1) o.commitment_tobytes(lp.comm); R.fs.absorb(o.b); }
+    R.alpha = sample_outside_h(R.fs);
+    R.eta_a = R.fs.rng().rand_field<Fr>(); R.eta_b = R.fs.rng().rand_field<Fr>(); R.eta_c = R.fs.rng().rand_field<Fr>();      // (drawn in this order)
+    cx.timings.round1_ms = ms_since(R.t0); R.t0 = Clock::now();
+}
+
+void ProvingKeyImpl::prove_round2(ProofRun &R) {
+    ProverContext &cx = R.cx;
+    const Circuit &c = circuit;
+    gpu::stream_t s = cx.stream;
+    const int lg_n4 = log2_exact(next_pow2(3 * n + 1));
     // ---- second round
-    Labeled r2[3] = {{4, -1, false}, {5, (long)(n - 2), true}, {6, -1, false}};
-    for (auto &lp : r2) draw_rand(lp, zk);           // (the prover RNG is consumed in label order before any commitment is computed: draw_rand)
-    Fr vh_alpha = eval_vanishing(n, alpha);
+    for (auto &lp : R.r2) draw_rand(lp, R.zk);           // (the prover RNG is consumed in label order before any commitment is computed: draw_rand)
+    R.vh_alpha = eval_vanishing(n, R.alpha);
     const F *elems = gpu::domain_elements<F>(lg_n);
     // q = q_1 - mask = r(alpha, X) (eta_A z_A + eta_B z_B + eta_C z_A z_B) - t z has degree < 3|H|; instead of five zero-padded transforms to the 4|H| domain, a pointwise
     // product there and a 4|H|-point inverse (18 passes over 4|H| elements), it is taken on THREE cosets of H inside that domain: on H itself every factor is already known
@@ -710,23 +767,23 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
         const Fr W = domain_gen(lg_n4), W3 = W * W * W;
         const Fr zeta = W.pow_u64(n);                                    // primitive 4th root of unity
         const Fr inv2 = Fr::from_u64(2).inverse(), inv2zeta = (zeta + zeta).inverse(), zero = Fr::zero();
-        F *Q0 = e[1].p, *Q1 = e[1].p + n, *Q3 = e[1].p + 2 * n, *zH = e[0].p, *qH = e[0].p + n;
+        F *Q0 = cx.e[1].p, *Q1 = cx.e[1].p + n, *Q3 = cx.e[1].p + 2 * n, *zH = cx.e[0].p, *qH = cx.e[0].p + n;
         // per coset: z_A, z_B, r, t in e[2 | 3], z and the product in e[4]
         F *cs_buf[2][6];
-        for (int i = 0; i < 2; i++) { for (int j = 0; j < 4; j++) cs_buf[i][j] = e[2 + i].p + j * n; cs_buf[i][4] = e[4].p + i * n; cs_buf[i][5] = e[4].p + (2 + i) * n; }
+        for (int i = 0; i < 2; i++) { for (int j = 0; j < 4; j++) cs_buf[i][j] = cx.e[2 + i].p + j * n; cs_buf[i][4] = cx.e[4].p + i * n; cs_buf[i][5] = cx.e[4].p + (2 + i) * n; }
         {   // r(alpha, .) on H (= v_H(alpha) / (alpha - h): alpha lies outside H) and on W H, W^3 H; e[4] (free until the forward transforms) is the tree's scratch
-            F *outs[3] = {ra_ev.p, cs_buf[0][2], cs_buf[1][2]};
+            F *outs[3] = {cx.ra_ev.p, cs_buf[0][2], cs_buf[1][2]};
             const Fr gs[3] = {Fr::one(), W, W3};
-            gpu::vanishing_quotient_evals(outs, gs, 3, alpha, elems, (uint32_t)n, lg_n, e[4].p, e[4].n, s);
+            gpu::vanishing_quotient_evals(outs, gs, 3, R.alpha, elems, (uint32_t)n, lg_n, cx.e[4].p, cx.e[4].n, s);
         }
-        gpu::t_evals(tmp_n.p, (uint32_t)n, t_partial.p, t_nseg, d_t_colptr, d_t_seg_start, d_t_seg_end, d_t_heavy, t_nheavy, d_t_row, d_t_mat, d_t_coeff, ra_ev.p, eta_a, eta_b, eta_c, s);
-        gpu::z_evals_h(zH, d_z, (uint32_t)n, (uint32_t)m, (uint32_t)c.num_witness, s);
-        gpu::q1_coset_pointwise(qH, ra_ev.p, za_ev.p, zb_ev.p, tmp_n.p, zH, zero, zero, zero, eta_a, eta_b, eta_c, n, s);
-        const Job inv0[2] = {{poly[4].p, tmp_n.p, 0}, {Q0, qH, 0}};
-        gpu::ntt_batch<F>(inv0, 2, n, lg_n, true, 0, s); poly_len[4] = n;
-        jobs.start(1, [&](Lane &ln) { mpc_commit(cx, ln, r2[0]); }, true);                      // t
-        gpu::z_poly_from_w(zpoly.p, poly[0].p, poly_len[0], x_poly.p, (uint32_t)m, n, s);
-        const F *srcs[4] = {poly[1].p, poly[2].p, poly[4].p, zpoly.p};
+        gpu::t_evals(cx.tmp_n.p, (uint32_t)n, cx.t_partial.p, t_nseg, d_t_colptr, d_t_seg_start, d_t_seg_end, d_t_heavy, t_nheavy, d_t_row, d_t_mat, d_t_coeff, cx.ra_ev.p, R.eta_a, R.eta_b, R.eta_c, s);
+        gpu::z_evals_h(zH, cx.d_z, (uint32_t)n, (uint32_t)m, (uint32_t)c.num_witness, s);
+        gpu::q1_coset_pointwise(qH, cx.ra_ev.p, cx.za_ev.p, cx.zb_ev.p, cx.tmp_n.p, zH, zero, zero, zero, R.eta_a, R.eta_b, R.eta_c, n, s);
+        const Job inv0[2] = {{cx.poly[4].p, cx.tmp_n.p, 0}, {Q0, qH, 0}};
+        gpu::ntt_batch<F>(inv0, 2, n, lg_n, true, 0, s); cx.poly_len[4] = n;
+        R.jobs.start(1, [&](Lane &ln) { mpc_commit(cx, ln, R.r2[0]); }, true);                      // t
+        gpu::z_poly_from_w(cx.zpoly.p, cx.poly[0].p, cx.poly_len[0], cx.x_poly.p, (uint32_t)m, n, s);
+        const F *srcs[4] = {cx.poly[1].p, cx.poly[2].p, cx.poly[4].p, cx.zpoly.p};
         static const int dst_slot[4] = {0, 1, 3, 4};
         Job fwd[8];
         for (int i = 0; i < 2; i++) for (int j = 0; j < 4; j++) fwd[4 * i + j] = Job{cs_buf[i][dst_slot[j]], srcs[j], i == 0 ? 1 : 3};
@@ -734,162 +791,186 @@ Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const 
         for (int i = 0; i < 2; i++) {
             const Fr zc = i == 0 ? zeta : zeta.neg();                    // zeta^cs: the value of X^|H| on the coset
             // the coefficient of X^|H| (rho of z_A, z_B; rho_w for z = w v_X + x) contributes rho zeta^cs everywhere on the coset
-            gpu::q1_coset_pointwise(cs_buf[i][5], cs_buf[i][2], cs_buf[i][0], cs_buf[i][1], cs_buf[i][3], cs_buf[i][4], rhos[1] * zc, rhos[2] * zc, rhos[0] * zc, eta_a, eta_b, eta_c, n, s);
+            gpu::q1_coset_pointwise(cs_buf[i][5], cs_buf[i][2], cs_buf[i][0], cs_buf[i][1], cs_buf[i][3], cs_buf[i][4], R.rhos[1] * zc, R.rhos[2] * zc, R.rhos[0] * zc, R.eta_a, R.eta_b, R.eta_c, n, s);
         }
         const Job inv13[2] = {{Q1, cs_buf[0][5], 1}, {Q3, cs_buf[1][5], 3}};
         gpu::ntt_batch<F>(inv13, 2, n, lg_n, true, lg_n4, s);
-        gpu::q1_combine(poly[6].p, poly[5].p, Q0, Q1, Q3, poly[3].p, inv2, inv2zeta, n, s);     // h_1 (2|H| coefficients), g_1 = remainder / X
-        poly_len[6] = 2 * n; poly_len[5] = n - 1;
+        gpu::q1_combine(cx.poly[6].p, cx.poly[5].p, Q0, Q1, Q3, cx.poly[3].p, inv2, inv2zeta, n, s);     // h_1 (2|H| coefficients), g_1 = remainder / X
+        cx.poly_len[6] = 2 * n; cx.poly_len[5] = n - 1;
     }
-    jobs.start(2, [&](Lane &ln) { mpc_commit(cx, ln, r2[1]); }, true);                          // g_1 (plain + shifted)
-    jobs.start(4, [&](Lane &ln) { mpc_commit(cx, ln, r2[2]); }, true);                          // h_1
-    jobs.join();
-    { Bytes o; for (auto &lp : r2) o.commitment_tobytes(lp.comm); fs.absorb(o.b); }
-    Fr beta = sample_outside_h();
-    timings.round2_ms = ms_since(t0); t0 = Clock::now();
+    R.jobs.start(2, [&](Lane &ln) { mpc_commit(cx, ln, R.r2[1]); }, true);                          // g_1 (plain + shifted)
+    R.jobs.start(4, [&](Lane &ln) { mpc_commit(cx, ln, R.r2[2]); }, true);                          // h_1
+    R.jobs.join();
+    { Bytes o; for (auto &lp : R.r2) o.commitment_tobytes(lp.comm); R.fs.absorb(o.b); }
+    R.beta = sample_outside_h(R.fs);
+    cx.timings.round2_ms = ms_since(R.t0); R.t0 = Clock::now();
+}
+
+void ProvingKeyImpl::prove_round3(ProofRun &R) {
+    ProverContext &cx = R.cx;
+    gpu::stream_t s = cx.stream;
+    const F *elems = gpu::domain_elements<F>(lg_n);
     // ---- third round
-    Labeled r3[2] = {{7, (long)(k - 2), false}, {8, -1, false}};
-    for (auto &lp : r3) draw_rand(lp, zk);
-    Fr vh_beta = eval_vanishing(n, beta);
-    Fr vv = vh_alpha * vh_beta, ea_vv = eta_a * vv, eb_vv = eta_b * vv, ec_vv = eta_c * vv, alpha_beta = alpha * beta;
+    for (auto &lp : R.r3) draw_rand(lp, R.zk);
+    R.vh_beta = eval_vanishing(n, R.beta);
+    const Fr vv = R.vh_alpha * R.vh_beta;
+    R.ea_vv = R.eta_a * vv; R.eb_vv = R.eta_b * vv; R.ec_vv = R.eta_c * vv; R.alpha_beta = R.alpha * R.beta;
     {   // f on K.  Its denominator (beta - row)(alpha - col) runs over pairs of ELEMENTS OF H, so 1 / den is a product of two entries of the tables v_H(alpha) / (alpha - h)
-        // (round 2's, still in ra_ev) and v_H(beta) / (beta - h) (one more product tree over H): two gathers instead of a batch inversion over K -- v_H(alpha) v_H(beta) included
-        F *outs[1] = {ra_poly.p};
+        // (round 2's, still in cx.ra_ev) and v_H(beta) / (beta - h) (one more product tree over H): two gathers instead of a batch inversion over K -- v_H(alpha) v_H(beta) included
+        F *outs[1] = {cx.ra_poly.p};
         const Fr one = Fr::one();
-        gpu::vanishing_quotient_evals(outs, &one, 1, beta, elems, (uint32_t)n, lg_n, e[0].p, e[0].n, s);
-        gpu::f_evals_from_tables(e[1].p, ix_ev[2].p, ix_ev[3].p, ix_ev[4].p, eta_a, eta_b, eta_c, ra_ev.p, ra_poly.p, d_ix_ri, d_ix_ci, k, s);
+        gpu::vanishing_quotient_evals(outs, &one, 1, R.beta, elems, (uint32_t)n, lg_n, cx.e[0].p, cx.e[0].n, s);
+        gpu::f_evals_from_tables(cx.e[1].p, ix_ev[2].p, ix_ev[3].p, ix_ev[4].p, R.eta_a, R.eta_b, R.eta_c, cx.ra_ev.p, cx.ra_poly.p, d_ix_ri, d_ix_ci, k, s);
     }
-    gpu::ntt<F>(f_poly.p, e[1].p, k, lg_k, true, s);
-    gpu::d2d(poly[7].p, f_poly.p + 1, (k - 1) * sizeof(F), s); poly_len[7] = k - 1;   // g_2 = (f - f(0)) / X
-    jobs.start(1, [&](Lane &ln) { mpc_commit(cx, ln, r3[0]); }, true);                           // g_2 (plain + shifted): under the rest of the round
+    gpu::ntt<F>(cx.f_poly.p, cx.e[1].p, k, lg_k, true, s);
+    gpu::d2d(cx.poly[7].p, cx.f_poly.p + 1, (k - 1) * sizeof(F), s); cx.poly_len[7] = k - 1;   // g_2 = (f - f(0)) / X
+    R.jobs.start(1, [&](Lane &ln) { mpc_commit(cx, ln, R.r3[0]); }, true);                           // g_2 (plain + shifted): under the rest of the round
     // h_2 = (a - b f) / v_K with a = sum eta_M v_H(alpha) v_H(beta) val_M, b = (beta - row)(alpha - col) expanded with row_col: degree <= |K| - 2,
     // so it is interpolated from ONE coset of K, where v_K is the constant g^|K| - 1 and a, b come from the key's precomputed coset values
-    gpu::ntt_scaled<F>(e[2].p, f_poly.p, k, lg_k, false, coset_tab, s);       // f on g K (the scaling by g^i rides on the transform's first pass)
-    gpu::h2_coset(e[0].p, ix_cs[0].p, ix_cs[1].p, ix_cs[2].p, ix_cs[3].p, ix_cs[4].p, ix_cs[5].p, e[2].p, alpha, beta, alpha_beta, ea_vv, eb_vv, ec_vv, coset_vk_inv, k, s);
-    gpu::ntt_scaled<F>(poly[8].p, e[0].p, k, lg_k, true, coset_tab_inv, s);   // h_2: interpolated from g K, scaled back by g^-i at the last pass's store (the coefficient of X^(|K|-1) is zero for a satisfied instance)
-    poly_len[8] = k - 1;
-    jobs.start(2, [&](Lane &ln) { mpc_commit(cx, ln, r3[1]); }, true);                           // h_2
+    gpu::ntt_scaled<F>(cx.e[2].p, cx.f_poly.p, k, lg_k, false, coset_tab, s);       // f on g K (the scaling by g^i rides on the transform's first pass)
+    gpu::h2_coset(cx.e[0].p, ix_cs[0].p, ix_cs[1].p, ix_cs[2].p, ix_cs[3].p, ix_cs[4].p, ix_cs[5].p, cx.e[2].p, R.alpha, R.beta, R.alpha_beta, R.ea_vv, R.eb_vv, R.ec_vv, coset_vk_inv, k, s);
+    gpu::ntt_scaled<F>(cx.poly[8].p, cx.e[0].p, k, lg_k, true, coset_tab_inv, s);   // h_2: interpolated from g K, scaled back by g^-i at the last pass's store (the coefficient of X^(|K|-1) is zero for a satisfied instance)
+    cx.poly_len[8] = k - 1;
+    R.jobs.start(2, [&](Lane &ln) { mpc_commit(cx, ln, R.r3[1]); }, true);                           // h_2
     // ---- evaluations.  Three of the four points are evaluations at beta, known since round 2: a lone call computes them (and the beta opening's shifted witness
     // g_1 / (X - beta)) NOW, on the main stream under round 3's commitments; only g_2(gamma) has to wait for gamma.
-    Proof pf;
-    const bool early_evals = jobs.async;
-    if (early_evals) {
-        const F *ps[3] = {poly[5].p, poly[4].p, poly[2].p};
-        const size_t ls[3] = {poly_len[5], poly_len[4], poly_len[2]};
-        const Fr at[3] = {beta, beta, beta};
+    R.early_evals = R.jobs.async;
+    if (R.early_evals) {
+        const F *ps[3] = {cx.poly[5].p, cx.poly[4].p, cx.poly[2].p};
+        const size_t ls[3] = {cx.poly_len[5], cx.poly_len[4], cx.poly_len[2]};
+        const Fr at[3] = {R.beta, R.beta, R.beta};
         Fr ev[3];
-        gpu::poly_eval_multi(ps, ls, at, 3, ev, scratch.p, scratch.n, s);           // g_1(beta), t(beta), z_b(beta)
-        pf.evals[0] = ev[0]; pf.evals[2] = ev[1]; pf.evals[3] = ev[2];
-        gpu::divide_by_linear(wit2.p, poly[5].p, poly_len[5], beta, scratch.p, scratch.n, s);
+        gpu::poly_eval_multi(ps, ls, at, 3, ev, cx.scratch.p, cx.scratch.n, s);           // g_1(beta), t(beta), z_b(beta)
+        R.pf.evals[0] = ev[0]; R.pf.evals[2] = ev[1]; R.pf.evals[3] = ev[2];
+        gpu::divide_by_linear(cx.wit2.p, cx.poly[5].p, cx.poly_len[5], R.beta, cx.scratch.p, cx.scratch.n, s);
     }
-    jobs.join();
-    { Bytes o; for (auto &lp : r3) o.commitment_tobytes(lp.comm); fs.absorb(o.b); }
-    Fr gamma = fs.rng().rand_field<Fr>();
-    timings.round3_ms = ms_since(t0); t0 = Clock::now();
-    if (early_evals) {
-        const F *ps[1] = {poly[7].p};
-        const size_t ls[1] = {poly_len[7]};
-        gpu::poly_eval_multi(ps, ls, &gamma, 1, &pf.evals[1], scratch.p, scratch.n, s);   // g_2(gamma)
+    R.jobs.join();
+    { Bytes o; for (auto &lp : R.r3) o.commitment_tobytes(lp.comm); R.fs.absorb(o.b); }
+    R.gamma = R.fs.rng().rand_field<Fr>();
+    cx.timings.round3_ms = ms_since(R.t0); R.t0 = Clock::now();
+}
+
+void ProvingKeyImpl::prove_open(ProofRun &R) {
+    ProverContext &cx = R.cx;
+    gpu::stream_t s = cx.stream;
+    if (R.early_evals) {
+        const F *ps[1] = {cx.poly[7].p};
+        const size_t ls[1] = {cx.poly_len[7]};
+        gpu::poly_eval_multi(ps, ls, &R.gamma, 1, &R.pf.evals[1], cx.scratch.p, cx.scratch.n, s);   // g_2(gamma)
     } else {
-        const F *ps[4] = {poly[5].p, poly[7].p, poly[4].p, poly[2].p};
-        const size_t ls[4] = {poly_len[5], poly_len[7], poly_len[4], poly_len[2]};
-        const Fr at[4] = {beta, gamma, beta, beta};
-        gpu::poly_eval_multi(ps, ls, at, 4, pf.evals, scratch.p, scratch.n, s);     // g_1(beta), g_2(gamma), t(beta), z_b(beta)
+        const F *ps[4] = {cx.poly[5].p, cx.poly[7].p, cx.poly[4].p, cx.poly[2].p};
+        const size_t ls[4] = {cx.poly_len[5], cx.poly_len[7], cx.poly_len[4], cx.poly_len[2]};
+        const Fr at[4] = {R.beta, R.gamma, R.beta, R.beta};
+        gpu::poly_eval_multi(ps, ls, at, 4, R.pf.evals, cx.scratch.p, cx.scratch.n, s);     // g_1(beta), g_2(gamma), t(beta), z_b(beta)
     }
-    const Fr g1_b = pf.evals[0], g2_g = pf.evals[1], t_b = pf.evals[2], zb_b = pf.evals[3];
-    { Bytes o; for (auto &v : pf.evals) o.field(v); fs.absorb(o.b); }
+    const Fr g2_g = R.pf.evals[1], t_b = R.pf.evals[2], zb_b = R.pf.evals[3];      // (g_1(beta) = evals[0] enters only through the transcript)
+    { Bytes o; for (auto &v : R.pf.evals) o.field(v); R.fs.absorb(o.b); }
     Fr ch;
-    { uint64_t lo = fs.rng().next_u64(), hi = fs.rng().next_u64(); uint32_t raw[8] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32), 0, 0, 0, 0}; ch = Fr::from_raw(raw); }
+    { uint64_t lo = R.fs.rng().next_u64(), hi = R.fs.rng().next_u64(); uint32_t raw[8] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32), 0, 0, 0, 0}; ch = Fr::from_raw(raw); }
     // ---- linear-combination coefficients (construct_linear_combinations)
-    Fr r_alpha_at_beta = (vh_alpha - vh_beta) * (alpha - beta).inverse();
-    Fr vx_beta = eval_vanishing(m, beta);
-    Fr c_za = r_alpha_at_beta * (eta_a + eta_c * zb_b), c_w = (t_b * vx_beta).neg(), c_h1 = vh_beta.neg();
-    Fr vk_gamma = eval_vanishing(k, gamma);
-    Fr bmul = gamma * g2_g + t_b * Fr::from_u64(k).inverse();
-    Fr c_row = alpha * bmul, c_col = beta * bmul, c_rc = bmul.neg(), c_h2 = vk_gamma.neg();
+    Fr r_alpha_at_beta = (R.vh_alpha - R.vh_beta) * (R.alpha - R.beta).inverse();
+    Fr vx_beta = eval_vanishing(m, R.beta);
+    Fr c_za = r_alpha_at_beta * (R.eta_a + R.eta_c * zb_b), c_w = (t_b * vx_beta).neg(), c_h1 = R.vh_beta.neg();
+    Fr vk_gamma = eval_vanishing(k, R.gamma);
+    Fr bmul = R.gamma * g2_g + t_b * Fr::from_u64(k).inverse();
+    Fr c_row = R.alpha * bmul, c_col = R.beta * bmul, c_rc = bmul.neg(), c_h2 = vk_gamma.neg();
     Fr chp[5]; chp[0] = Fr::one(); for (int i = 1; i < 5; i++) chp[i] = chp[i - 1] * ch;
     auto rand_axpy = [](Fr out[3], const Fr &sc, const KzgRand &r) { if (r.hiding) for (int i = 0; i < 3; i++) out[i] = out[i] + sc * r.b[i]; };
     auto host_divide_by_linear = [](Fr q[2], const Fr p[3], const Fr &z) { q[1] = p[2]; q[0] = p[1] + z * p[2]; };
     auto host_eval3 = [](const Fr p[3], const Fr &z) { return p[0] + z * (p[1] + z * p[2]); };
     // the two openings are independent: on the latency path they run side by side, the second one on its own buffers
-    if (jobs.async && !cx.acc_b.p) {
-        cx.acc_b.alloc(acc.n); cx.wit_b.alloc(wit.n); cx.wit2_b.alloc(wit2.n); cx.scratch_b.alloc(scratch.n);
+    if (R.jobs.async && !cx.ev_aux) {          // guarded by the LAST resource created: an allocation that throws leaves ev_aux null, and the next lone call starts over (advisor r05)
+        for (DevBuf *b : {&cx.acc_b, &cx.wit_b, &cx.wit2_b, &cx.scratch_b, &cx.scratch_c}) b->release();
+        cx.acc_b.alloc(cx.acc.n); cx.wit_b.alloc(cx.wit.n); cx.wit2_b.alloc(cx.wit2.n); cx.scratch_b.alloc(cx.scratch.n);
         cx.scratch_c.alloc(gpu::divide_by_linear_scratch(std::max(n, k) + 1)); cx.ev_aux = gpu::event_create();
     }
-    std::atomic<bool> g2_quotient_queued{false};
-    const bool two_sets = cx.acc_b.p != nullptr && jobs.async;
-    if (jobs.async) gpu::sync(s);                 // (the opening jobs read what the main stream made: everything is in place from here)
-    jobs.start(1, [&](Lane &ln) {   // open at beta: g_1 (ch^0; shifted ch^1), outer_sumcheck (ch^2), t (ch^3), z_b (ch^4)
+    const bool two_sets = cx.ev_aux != nullptr && R.jobs.async;
+    if (R.jobs.async) gpu::sync(s);                 // (the opening jobs read what the main stream made: everything is in place from here)
+    // the two jobs below hold THIS function's locals (the challenge powers, the linear-combination coefficients) by reference: if anything between their start and the join
+    // throws, they must have finished before those locals go -- this guard is declared after everything they capture, so it is destroyed first
+    struct WaitJobs { RoundJobs &j; ~WaitJobs() { j.wait_all(); } } wait_jobs{R.jobs};
+    R.jobs.start(1, [&](Lane &ln) {   // open at beta: g_1 (ch^0; shifted ch^1), outer_sumcheck (ch^2), t (ch^3), z_b (ch^4)
         gpu::stream_t ls_ = ln.stream;
         size_t plen = 3 * n;
         Fr rb[3] = {Fr::zero(), Fr::zero(), Fr::zero()};
         {
-            const F *ps[7] = {poly[5].p, poly[3].p, poly[1].p, poly[0].p, poly[6].p, poly[4].p, poly[2].p};
-            size_t ls[7] = {poly_len[5], poly_len[3], poly_len[1], poly_len[0], poly_len[6], poly_len[4], poly_len[2]};
+            const F *ps[7] = {cx.poly[5].p, cx.poly[3].p, cx.poly[1].p, cx.poly[0].p, cx.poly[6].p, cx.poly[4].p, cx.poly[2].p};
+            size_t ls[7] = {cx.poly_len[5], cx.poly_len[3], cx.poly_len[1], cx.poly_len[0], cx.poly_len[6], cx.poly_len[4], cx.poly_len[2]};
             Fr sc[7] = {chp[0], chp[2], chp[2] * c_za, chp[2] * c_w, chp[2] * c_h1, chp[3], chp[4]};
-            gpu::poly_lincomb_n(acc.p, plen, ps, ls, sc, 7, ls_);
+            gpu::poly_lincomb_n(cx.acc.p, plen, ps, ls, sc, 7, ls_);
         }
-        rand_axpy(rb, chp[0], r2[1].rand); rand_axpy(rb, chp[2] * c_za, r1[1].rand); rand_axpy(rb, chp[2] * c_w, r1[0].rand); rand_axpy(rb, chp[4], r1[2].rand);
+        rand_axpy(rb, chp[0], R.r2[1].rand); rand_axpy(rb, chp[2] * c_za, R.r1[1].rand); rand_axpy(rb, chp[2] * c_w, R.r1[0].rand); rand_axpy(rb, chp[4], R.r1[2].rand);
         // the shifted part (g_1, degree bound |H| - 2) rides in the same Pippenger instance; its quotient by X - beta may already exist (early_evals).  The second scratch half
         // keeps the two divisions of this job apart when they were queued on different streams.
-        if (!early_evals) gpu::divide_by_linear(wit2.p, poly[5].p, poly_len[5], beta, scratch.p, scratch.n, ls_);
-        gpu::divide_by_linear(wit.p, acc.p, plen, beta, scratch.p, scratch.n, ls_);
-        gpu::poly_scale(wit2.p, chp[1], poly_len[5] - 1, ls_);
-        msm_opening_prepare(cx, ln, wit.p, plen - 1, wit2.p, poly_len[5] - 1, bounds[1] - (n - 2));
+        if (!R.early_evals) gpu::divide_by_linear(cx.wit2.p, cx.poly[5].p, cx.poly_len[5], R.beta, cx.scratch.p, cx.scratch.n, ls_);
+        gpu::divide_by_linear(cx.wit.p, cx.acc.p, plen, R.beta, cx.scratch.p, cx.scratch.n, ls_);
+        gpu::poly_scale(cx.wit2.p, chp[1], cx.poly_len[5] - 1, ls_);
+        msm_opening_prepare(cx, ln, cx.wit.p, plen - 1, cx.wit2.p, cx.poly_len[5] - 1, bounds[1] - (n - 2));
         // (the blinding part of the witness is host work: under the device's digit grouping, not after the wait for its sum)
         XYZZ<Fq377> hw = XYZZ<Fq377>::inf();
-        Fr rq[2]; host_divide_by_linear(rq, rb, beta);
+        Fr rq[2]; host_divide_by_linear(rq, rb, R.beta);
         for (int i = 0; i < 2; i++) hw.add(srs->gamma_tab[i].mul(rq[i]));
-        Fr rv = host_eval3(rb, beta);
-        Fr srb[3]; for (int i = 0; i < 3; i++) srb[i] = chp[1] * r2[1].shifted_rand.b[i];
-        host_divide_by_linear(rq, srb, beta);
+        Fr rv = host_eval3(rb, R.beta);
+        Fr srb[3]; for (int i = 0; i < 3; i++) srb[i] = chp[1] * R.r2[1].shifted_rand.b[i];
+        host_divide_by_linear(rq, srb, R.beta);
         for (int i = 0; i < 2; i++) hw.add(srs->gamma_tab[i].mul(rq[i]));
-        rv = rv + host_eval3(srb, beta);
+        rv = rv + host_eval3(srb, R.beta);
         XYZZ<Fq377> w = msm_opening_finish(ln);
         w.add(hw);
-        pf.w_beta = w.to_affine(); pf.random_v_beta = rv;
+        R.pf.w_beta = w.to_affine(); R.pf.random_v_beta = rv;
     }, false);
-    jobs.start(2, [&](Lane &ln) {   // open at gamma: g_2 (ch^0; shifted ch^1), inner_sumcheck (ch^2)
+    R.jobs.start(2, [&](Lane &ln) {   // open at gamma: g_2 (ch^0; shifted ch^1), inner_sumcheck (ch^2)
         gpu::stream_t ls_ = ln.stream;
-        DevBuf &acc_ = two_sets ? cx.acc_b : acc, &wit_ = two_sets ? cx.wit_b : wit, &wit2_ = two_sets ? cx.wit2_b : wit2, &scr_ = two_sets ? cx.scratch_b : scratch;
+        DevBuf &acc_ = two_sets ? cx.acc_b : cx.acc, &wit_ = two_sets ? cx.wit_b : cx.wit, &wit2_ = two_sets ? cx.wit2_b : cx.wit2, &scr_ = two_sets ? cx.scratch_b : cx.scratch;
         size_t plen = k;
         {
-            const F *ps[8] = {poly[7].p, ix_co[2].p, ix_co[3].p, ix_co[4].p, ix_co[0].p, ix_co[1].p, ix_co[5].p, poly[8].p};
-            size_t ls[8] = {poly_len[7], k, k, k, k, k, k, poly_len[8]};
-            Fr sc[8] = {chp[0], chp[2] * ea_vv, chp[2] * eb_vv, chp[2] * ec_vv, chp[2] * c_row, chp[2] * c_col, chp[2] * c_rc, chp[2] * c_h2};
+            const F *ps[8] = {cx.poly[7].p, ix_co[2].p, ix_co[3].p, ix_co[4].p, ix_co[0].p, ix_co[1].p, ix_co[5].p, cx.poly[8].p};
+            size_t ls[8] = {cx.poly_len[7], k, k, k, k, k, k, cx.poly_len[8]};
+            Fr sc[8] = {chp[0], chp[2] * R.ea_vv, chp[2] * R.eb_vv, chp[2] * R.ec_vv, chp[2] * c_row, chp[2] * c_col, chp[2] * c_rc, chp[2] * c_h2};
             gpu::poly_lincomb_n(acc_.p, plen, ps, ls, sc, 8, ls_);
         }
-        gpu::divide_by_linear(wit_.p, acc_.p, plen, gamma, scr_.p, scr_.n, ls_);
-        if (jobs.async) {        // the shifted part g_2 / (X - gamma) is being made on the main stream by the calling thread, beside this division (two chains of a dozen short launches)
-            while (!g2_quotient_queued.load(std::memory_order_acquire)) std::this_thread::yield();
+        gpu::divide_by_linear(wit_.p, acc_.p, plen, R.gamma, scr_.p, scr_.n, ls_);
+        if (R.jobs.async) {        // the shifted part g_2 / (X - gamma) is being made on the main stream by the calling thread, beside this division (two chains of a dozen short launches)
+            while (!R.g2_quotient_queued.load(std::memory_order_acquire)) std::this_thread::yield();
             gpu::stream_wait_event(ls_, cx.ev_aux);
         } else {
-            gpu::divide_by_linear(wit2_.p, poly[7].p, poly_len[7], gamma, scr_.p, scr_.n, ls_);
-            gpu::poly_scale(wit2_.p, chp[1], poly_len[7] - 1, ls_);
+            gpu::divide_by_linear(wit2_.p, cx.poly[7].p, cx.poly_len[7], R.gamma, scr_.p, scr_.n, ls_);
+            gpu::poly_scale(wit2_.p, chp[1], cx.poly_len[7] - 1, ls_);
         }
-        msm_opening_prepare(cx, ln, wit_.p, plen - 1, wit2_.p, poly_len[7] - 1, bounds[1] - (k - 2));
+        msm_opening_prepare(cx, ln, wit_.p, plen - 1, wit2_.p, cx.poly_len[7] - 1, bounds[1] - (k - 2));
         XYZZ<Fq377> w = msm_opening_finish(ln);
-        pf.w_gamma = w.to_affine();
+        R.pf.w_gamma = w.to_affine();
     }, false);
-    if (jobs.async) {
+    if (R.jobs.async) {
         try {
-            gpu::divide_by_linear(cx.wit2_b.p, poly[7].p, poly_len[7], gamma, cx.scratch_c.p, cx.scratch_c.n, s);
-            gpu::poly_scale(cx.wit2_b.p, chp[1], poly_len[7] - 1, s);
+            gpu::divide_by_linear(cx.wit2_b.p, cx.poly[7].p, cx.poly_len[7], R.gamma, cx.scratch_c.p, cx.scratch_c.n, s);
+            gpu::poly_scale(cx.wit2_b.p, chp[1], cx.poly_len[7] - 1, s);
             gpu::event_record(cx.ev_aux, s);
-        } catch (...) { g2_quotient_queued.store(true, std::memory_order_release); throw; }      // (never leave the gamma job spinning)
-        g2_quotient_queued.store(true, std::memory_order_release);
+        } catch (...) { R.g2_quotient_queued.store(true, std::memory_order_release); throw; }      // (never leave the gamma job spinning)
+        R.g2_quotient_queued.store(true, std::memory_order_release);
     }
-    jobs.join();
-    for (int i = 0; i < 4; i++) pf.comms[i] = r1[i].comm;
-    for (int i = 0; i < 3; i++) pf.comms[4 + i] = r2[i].comm;
-    for (int i = 0; i < 2; i++) pf.comms[7 + i] = r3[i].comm;
-    timings.open_ms = ms_since(t0);
-    timings.total_ms = ms_since(t_all);
-    { std::lock_guard<std::mutex> g(ctx_mu); last_timings = timings; }
-    return pf;
+    R.jobs.join();
 }
 
-ProvingKey::~ProvingKey() { if (impl) { try { gpu::set_device(impl->device); } catch (...) {} } delete impl; }
+Proof ProvingKeyImpl::prove(ProverContext &cx, const uint8_t *host_trace, const uint8_t *msg, size_t len, const uint8_t *key, const uint8_t *zk_seed, bool throughput) {
+    gpu::set_device(device);
+    std::lock_guard<std::mutex> busy(cx.in_use);
+    cx.throughput = throughput;
+    ProofRun R(*this, cx, host_trace, msg, len, key, zk_seed);
+    prove_round1(R);
+    prove_round2(R);
+    prove_round3(R);
+    prove_open(R);
+    for (int i = 0; i < 4; i++) R.pf.comms[i] = R.r1[i].comm;
+    for (int i = 0; i < 3; i++) R.pf.comms[4 + i] = R.r2[i].comm;
+    for (int i = 0; i < 2; i++) R.pf.comms[7 + i] = R.r3[i].comm;
+    cx.timings.open_ms = ms_since(R.t0);
+    cx.timings.total_ms = ms_since(R.t_all);
+    { std::lock_guard<std::mutex> g(ctx_mu); last_timings = cx.timings; }
+    return R.pf;
+}
+
+ProvingKey::~ProvingKey() { if (impl) { DeviceScope on(impl->device); delete impl; } }
 const VerifyingKey &ProvingKey::vk() const { return impl->vk; }
 const Circuit &ProvingKey::circuit() const { return impl->circuit; }
 const ProverTimings &ProvingKey::last_timings() const { return impl->last_timings; }
@@ -1064,8 +1145,8 @@ uint64_t ProvingKey::serialize_ark_to_file(const std::string &path, bool uncompr
     struct StreamGuard { gpu::stream_t s = nullptr; ~StreamGuard() { gpu::stream_destroy(s); } } sg;
     sg.s = gpu::stream_create();
     gpu::stream_t s = sg.s;
-    struct Unlink { const std::string &p; bool armed = true; ~Unlink() { if (armed) ::remove(p.c_str()); } } partial{path};
-    FileSink o(path);
+    FileSink o(path);                                   // (throws if the file cannot be opened: nothing of ours to remove then)
+    struct Unlink { const std::string &p; bool armed = true; ~Unlink() { if (armed) ::remove(p.c_str()); } } partial{path};      // armed only once this call has created / truncated the file
     { auto v = serialize_vk_ark(K.vk, uncompressed); o.buf.put(v.data(), v.size()); }
     o.buf.u64(6);
     for (int i = 0; i < 6; i++) { o.buf.u64(0); o.buf.u8(0); }                      // Randomness::empty(): zero blinding polynomial, no shifted_rand

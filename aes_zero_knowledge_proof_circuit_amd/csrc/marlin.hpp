@@ -106,6 +106,8 @@ class ProvingKey {
 // Without the flag the tables are built when memory allows (hipMemGetInfo) and silently skipped otherwise.
 enum : unsigned { KEY_NO_TABLES = 1u };
 std::unique_ptr<ProvingKey> synthesize_keys(int circuit_kind, size_t message_len, const SrsLiterals &srs, unsigned flags = 0);
+// hold = true: every universal / Lagrange SRS built (or alive) from now on stays resident after its last key is freed; false: back to "freed with the last key"
+void srs_hold(bool hold);
 // process default of ProvingKey::contexts(): ZKAES_CONTEXTS from the environment (read once), else ZKAES_DEFAULT_CONTEXTS
 size_t default_contexts();
 // 32 bytes from the operating system (getrandom): the default zero-knowledge seed of the multi-proof entry points

@@ -116,6 +116,8 @@ def build_parser():
     ap.add_argument("--serial-probe", type=int, default=2, help="chunk-proofs proven one at a time after the timed region for un-overlapped kernel durations (0 = off)")
     ap.add_argument("--alt-proofs", type=int, default=64, help="one rank, headline mode: chunk-proofs of the %d-block alt leg measured after the timed region (0 = off)" % ALT_CHUNK)
     ap.add_argument("--latency-samples", type=int, default=5, help="one rank, headline mode: lone encrypt() calls timed per message size of the latency leg (0 = off)")
+    ap.add_argument("--no-tables", action="store_true", help="synthesize the keys without the fixed-base window tables of the SRS (ZKAES_KEY_NO_TABLES: 2.4 GB instead of 31.4 GB per process; "
+                                                             "~9 %% fewer proofs per second) -- for rehearsals of many ranks on one GPU")
     ap.add_argument("--calibrate-s", type=float, default=0.5, help="seconds of the per-box integer-rate calibration before and after the timed region (0 = off)")
     ap.add_argument("--cpu-small-samples", type=int, default=0, help="CPU-oracle samples of a one-block chunk-proof (~17 s each + 20 s of setup; off by default: the run stays under 400 s)")
     return ap
@@ -170,14 +172,15 @@ def run(args, api, dist_env=None):
     need_full = min(hi, n_full) > lo or args.warmup > 0 or args.serial_probe > 0
     need_rem = bool(rem) and hi == n_chunks and hi > lo
     pk = vk = pk_rem = vk_rem = None
+    key_flags = {"flags": api.KEY_NO_TABLES} if args.no_tables else {}
     key_setup_s = []
     if need_full:
         tk = time.perf_counter()
-        pk, vk = api.synthesize_keys(chunk_bytes)
+        pk, vk = api.synthesize_keys(chunk_bytes, **key_flags)
         key_setup_s.append(round(time.perf_counter() - tk, 2))
     if need_rem:                                              # (the second key over the same universal SRS: shares its powers and window tables)
         tk = time.perf_counter()
-        pk_rem, vk_rem = api.synthesize_keys(16 * rem)
+        pk_rem, vk_rem = api.synthesize_keys(16 * rem, **key_flags)
         key_setup_s.append(round(time.perf_counter() - tk, 2))
     for k_ in (pk, pk_rem):
         if k_ is not None and hasattr(k_, "set_contexts"):
@@ -494,7 +497,7 @@ def run(args, api, dist_env=None):
             "dtype": "u32 limbs (253-bit Fr / 377-bit Fq modular integers)",
             "data": "synthetic (numpy MT19937 bytes, seed 0x5EED; key fixed, message per rank)" if mode == "headline" else "synthetic (numpy MT19937 bytes, seed 0x5EED; one job shared by all ranks)",
             "config": {"workload": workload, "mode": mode, "blocks_total": job_blocks, "chunk_blocks": chunk, "proofs_total": n_chunks * (world if mode == "headline" else 1),
-                       "proofs_per_step_per_gpu": round((hi - lo) / args.steps, 2), "contexts_per_gpu": contexts,
+                       "proofs_per_step_per_gpu": round((hi - lo) / args.steps, 2), "contexts_per_gpu": contexts, "window_tables": not args.no_tables,
                        "parallelism": "independent chunk-proofs per rank, no data-path collective" if mode == "headline" else "chunk range per rank + one all-gather of proof bytes",
                        "circuit_model": CIRCUIT_MODEL_NOTE},
             "proofs_verified": "%d/%d" % (acc_sum, tot_sum), "wrong_ciphertext_rejected": bool(neg_sum == world),

@@ -13,7 +13,7 @@
  *   - byte buffers returned through `uint8_t**` are owned by the library: release with zkaes_bytes_free.
  *   - keys for a plaintext of 16 bytes or more use fixed-base window tables of the universal SRS (13 copies of 192-byte records of powers_of_g[0 ..= max_degree]: 31.4 GB for the
  *     reference's literals, held ONCE per process and device and shared by every key -- zkaes_pk_srs_info; skipped when the device is short of memory or with ZKAES_KEY_NO_TABLES): multi-proof calls (zkaes_encrypt_chunked / _batch) run their
- *     large MSMs (>= 500 k points) through them (13 balanced windows of 19-20 bits over ONE bucket set instead of 15 windows with their own buckets), and so does a
+ *     large MSMs (>= 100 k points) through them (13 balanced windows of 19-20 bits over ONE bucket set instead of 15 windows with their own buckets), and so does a
  *     lone zkaes_encrypt call, which additionally runs the independent commitments of each round on four MSM lanes (streams + host threads) side by side.  The
  *     SRS points are stored on BLS12-377's twisted Edwards model (7-product bucket additions): the prover's MSMs assume prime-order-subgroup bases, as KZG's are;
  *   - host threads of a multi-proof call wait for the GPU by polling with short sleeps (a fraction of a core per prover context); a lone zkaes_encrypt call
@@ -217,6 +217,10 @@ int zkaes_pk_tables_built(const zkaes_pk *pk, int *built, uint64_t *table_bytes)
  * bytes, keys sharing it now, bytes of the Lagrange-basis points (shared per |H|, |X|)}; secs (may be NULL) = {seconds THIS key's synthesis spent building the SRS
  * (~0 when it was shared), seconds of the whole synthesis}. */
 int zkaes_pk_srs_info(const zkaes_pk *pk, uint64_t out[6], double secs[2]);
+/* hold != 0: the library keeps every universal SRS (and Lagrange-basis SRS) it has built, or builds from now on, resident after the last key over it is freed -- for callers that
+ * create and free keys in turn (one key per request size) and would otherwise rebuild 31.4 GB of window tables each time; hold == 0 releases them again (device memory goes
+ * back once no key uses them).  Default: not held. */
+int zkaes_srs_hold(int hold);
 /* same sum through the precomputed-window layout the prover uses for the SRS (tables 2^(window offset j) P_i built on the fly here; one bucket set), on the
  * Weierstrass model with XYZZ buckets: correct for ANY curve points, both curves. */
 int zkaes_msm_table(int curve_id, const uint8_t *bases, const uint8_t *scalars, size_t n, int window_bits, uint8_t *out_xy, int *out_inf);

@@ -543,3 +543,44 @@ def test_bench_two_ranks_real_prover_on_one_gpu():
     assert aff[0]["last"] < aff[1]["first"]                        # two disjoint, contiguous CPU shares
     assert res["roofline"]["launches"] > 0 and res["roofline"]["proof"]["k_accumulate_launches_per_proof"] == 10
     assert took < 240, took                                         # (90 s on an idle box: two key sets + 17 proofs)
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_real_prover_on_one_gpu():
+    """the 8-rank launch path with the REAL prover (round 5 drove eight ranks only with a stub).  `python bench.py --gpus 8` starts its eight ranks itself;
+    ZKAES_BENCH_ONE_GPU=1 puts them all on device 0, gloo carries the collectives, --no-tables keeps a rank at ~10 GB (no window tables: 2.4 GB of SRS per process).
+    Exercised: the 8-way rendezvous, eight disjoint CPU shares, an UNEVEN split of ONE 196-block message (33 chunk-proofs over 8 ranks: 5 + 7 x 4) with the 4-block remainder
+    key on the last rank, the all-gather, rank 0 verifying all 33 proofs (src/lib.rs:194 is the loop that shards).  The host CPU time of the whole job goes to
+    gpurun_out/r06_bench_gpus8_one_gpu_rehearsal.json (busy cores per rank).  2-8 real GPUs stay unmeasured: this is a rehearsal of the launch path, not a scaling number."""
+    import resource
+    import subprocess
+    import time
+    env = dict(os.environ, ZKAES_BENCH_ONE_GPU="1", ZKAES_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--blocks", "196", "--steps", "2", "--warmup", "1", "--contexts", "1", "--no-cpu-baseline", "--alt-proofs", "0",
+           "--latency-samples", "0", "--no-tables", "--calibrate-s", "0"]
+    ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    took = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # ONE JSON line, from rank 0
+    res = json.loads(lines[0])
+    assert "error" not in res and res["n_gpus"] == 8 and res["scaling"] == "strong" and res["config"]["mode"] == "strong"
+    assert res["proofs_verified"] == "33/33" and res["wrong_ciphertext_rejected"] is True and res["config"]["proofs_total"] == 33 and res["value"] > 0
+    assert res["config"]["window_tables"] is False
+    aff = res["cpu_affinity_by_rank"]
+    assert len(aff) == 8 and all(a and a["cpus"] >= 1 for a in aff) and [a["local_rank"] for a in aff] == list(range(8))
+    assert all(aff[i]["last"] < aff[i + 1]["first"] for i in range(7))          # eight disjoint, contiguous CPU shares
+    cpu_s = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)
+    res["host"] = {"wall_s": round(took, 1), "cpu_s_all_ranks_and_launcher": round(cpu_s, 1), "busy_cores_per_rank_over_the_whole_run": round(cpu_s / took / 8, 2),
+                   "note": "getrusage(RUSAGE_CHILDREN) around `python bench.py --gpus 8` (eight ranks on ONE GPU over gloo): imports, key synthesis, warm-up, 33 proofs, verification by rank 0"}
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r06_bench_gpus8_one_gpu_rehearsal.json"), "w"))
+    except OSError:
+        pass
+    assert took < 400, took

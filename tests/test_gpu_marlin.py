@@ -573,3 +573,86 @@ def test_contexts_setter_and_op_lists(api, aes96):
     assert all(len(p) == 855 for p in proofs)
     lone = pk.op_lists(msg, key, throughput_path=False)
     assert sorted(lone["msm"]) == sorted(ops["msm"])               # the lone path launches the same MSMs (on four lanes)
+
+
+def test_key_lifetime_under_concurrent_calls(zko, api):
+    """VERDICT r5 next #5 (second half): lifetimes around in-flight proofs.  Four threads run multi-proof calls on ONE key while a fifth keeps changing the number of
+    prover contexts (zkaes_pk_set_contexts) and a sixth synthesizes and frees further keys over the same universal SRS (same circuit: shares the Lagrange-basis SRS too).
+    Every proof must verify, nothing may crash, and the shared SRS must still serve the first key afterwards (a freed sibling must not take it along)."""
+    import gc
+    import threading
+    pk, vk = api.synthesize_keys(16)
+    key = mt_bytes(16, 4242)
+    stop = threading.Event()
+    errors, results = [], {}
+
+    def prover(tid):
+        try:
+            out = []
+            for it in range(3):
+                msg = mt_bytes(16 * 5, 7000 + 10 * tid + it)
+                proofs = pk.encrypt_chunked(msg, key)
+                out.append((msg, proofs))
+            results[tid] = out
+        except Exception as e:                      # noqa: BLE001
+            errors.append(("prover", tid, repr(e)))
+
+    def tuner():
+        try:
+            i = 0
+            while not stop.is_set():
+                pk.set_contexts((2, 5, 3, 1, 4)[i % 5])
+                i += 1
+                stop.wait(0.002)
+        except Exception as e:                      # noqa: BLE001
+            errors.append(("tuner", repr(e)))
+
+    def sibling():
+        try:
+            while not stop.is_set():
+                k2, v2 = api.synthesize_keys(16)
+                p = api.encrypt(mt_bytes(16, 5), key, k2)
+                assert api.verify_encryption(v2, p, zko.aes_encrypt(mt_bytes(16, 5), key))
+                del k2, v2
+                gc.collect()
+        except Exception as e:                      # noqa: BLE001
+            errors.append(("sibling", repr(e)))
+
+    threads = [threading.Thread(target=prover, args=(t,)) for t in range(4)]
+    side = [threading.Thread(target=tuner), threading.Thread(target=sibling)]
+    for t in side + threads:
+        t.start()
+    for t in threads:
+        t.join()
+    stop.set()
+    for t in side:
+        t.join()
+    assert not errors, errors
+    assert sorted(results) == [0, 1, 2, 3]
+    for out in results.values():
+        for msg, proofs in out:
+            assert len(proofs) == 5
+            ct = zko.aes_encrypt(msg, key)
+            assert all(api.verify_encryption(vk, p, ct[16 * j:16 * j + 16]) for j, p in enumerate(proofs))
+    pk.set_contexts(0)
+    p = api.encrypt(mt_bytes(16, 6), key, pk)          # the first key still works: the SRS outlived its siblings
+    assert api.verify_encryption(vk, p, zko.aes_encrypt(mt_bytes(16, 6), key))
+
+
+def test_srs_hold_keeps_the_tables_resident_between_keys(api):
+    """zkaes_srs_hold (advisor r5): the cache of universal SRSs holds weak references, so a caller that creates and frees keys in turn rebuilt 31 GB of window tables per key;
+    with the hold on, the second key's synthesis builds nothing."""
+    import gc
+    gc.collect()
+    api.srs_hold(True)
+    try:
+        pk, _ = api.synthesize_keys(16)
+        del pk
+        gc.collect()
+        pk2, _ = api.synthesize_keys(32)
+        si = pk2.srs_info()
+        assert si["srs_build_s"] < 0.25 and si["copies"] == 13, si      # shared, not rebuilt (the tables take ~1.5 s), although no key was alive in between
+        del pk2
+    finally:
+        api.srs_hold(False)
+        gc.collect()
