@@ -30,6 +30,7 @@ extern "C" {
     fn zkaes_pk_serialize_ark_to_file_ex(pk: *const zkaes_pk, path: *const c_char, uncompressed: c_int, bytes_written: *mut u64) -> c_int;
     fn zkaes_pk_set_contexts(pk: *mut zkaes_pk, n: usize) -> c_int;
     fn zkaes_pk_get_contexts(pk: *const zkaes_pk, n: *mut usize) -> c_int;
+    fn zkaes_srs_hold(hold: c_int) -> c_int;
     fn zkaes_pk_srs_info(pk: *const zkaes_pk, out: *mut u64, secs: *mut f64) -> c_int;
     fn zkaes_pk_tables_built(pk: *const zkaes_pk, built: *mut c_int, table_bytes: *mut u64) -> c_int;
     fn zkaes_vk_serialize_ark(vk: *const zkaes_vk, out: *mut *mut u8, out_len: *mut usize) -> c_int;
@@ -129,6 +130,13 @@ pub fn synthesize_keys_with(plaintext_length: usize, flags: u32) -> Result<(Prov
     // circuit kind 0 = the AES circuit; the universal-SRS literals of src/lib.rs:141
     if unsafe { zkaes_synthesize_keys_ex2(0, plaintext_length, 866_944, 513, 4_062_064, flags as c_uint, &mut pk, &mut vk) } != 0 { return Err(last_error()); }
     Ok((ProvingKey(Arc::new(PkHandle(pk))), VerifyingKey(Arc::new(VkHandle(vk)))))
+}
+
+/// Keep the universal SRS (31.4 GB of window tables for the reference's literals) resident after the last key over it is dropped; `false` releases it again.
+/// For callers that create and drop keys in turn (one key per request size): without it every first key over an idle SRS rebuilds the tables (~1.5 s).
+pub fn srs_hold(hold: bool) -> Result<()> {
+    if unsafe { zkaes_srs_hold(hold as c_int) } != 0 { return Err(last_error()); }
+    Ok(())
 }
 
 /// zk_aes::encrypt (src/lib.rs:60): returns the ark-serialize bytes of the MarlinProof (`deserialize_proof(bytes)` gives the arkworks type)

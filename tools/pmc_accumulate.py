@@ -119,7 +119,13 @@ res = {
     "algorithmic_bytes_per_launch": 128 * n,
     "hbm_bytes_per_launch": hbm,
     "hbm_bytes_per_point_window": hbm / (n * nwin),
+    # the GPU box has no .git: the caller passes the commit of the code it sent (ZKAES_COMMIT=$(git rev-parse --short HEAD) in the gpurun command line); bench.py quotes it
+    "measured_at_commit": os.environ.get("ZKAES_COMMIT", "unrecorded"),
 }
+# per-SIMD VALU issue share: every VALU instruction occupies its SIMD for one quad-cycle (tools/ubench/issue_cycles.hip), SQ_INSTS_VALU counts
+# wave-instructions, GRBM_GUI_ACTIVE is summed over the 8 XCDs -> cycles of the kernel = GRBM_GUI_ACTIVE / 8, 1,024 SIMDs
+res["valu_issue_share_of_simd_cycles"] = res["counters"]["SQ_INSTS_VALU"] * 4.0 / (1024.0 * res["counters"]["GRBM_GUI_ACTIVE"] / 8.0)
+res["waves_per_simd_average"] = res["counters"]["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * res["counters"]["GRBM_GUI_ACTIVE"] / 8.0)
 dst = os.path.join("gpurun_out", "%s_pmc_k_accumulate.json" % tag)
 json.dump(res, open(dst, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -96,8 +96,9 @@ template <class F> static void run(const char *name, F launch, Stamp *d_st, int 
     fflush(stdout);
 }
 
-int main() {
+int main(int argc, char **argv) {
     const int grid = 8192, iters = 83;
+    const bool sweep = argc > 1;        // any argument: the production layout at 3 ... 208 additions per lane (how much of a SMALL MSM's accumulation is per-wave overhead?)
     const uint32_t big = 1u << 24;
     Stamp *st; AccTE<P> *sink; uint32_t *tab;
     CK(hipMalloc(&st, grid * sizeof(Stamp)));
@@ -106,6 +107,14 @@ int main() {
     CK(hipMalloc(&tab, words * 4));
     k_fill<<<(unsigned)(words / 256), 256>>>(tab, words);
     CK(hipDeviceSynchronize());
+    if (sweep) {
+        for (int it : {3, 6, 13, 26, 52, 83, 208}) {
+            char name[32]; snprintf(name, sizeof name, "s192x%d", it);
+            run(name, [&] { k_acc<48, false><<<grid, 64>>>(st, sink, tab, big - 1, it); }, st, grid, it);
+        }
+        printf("# additions per second = 8192 x 64 x iterations / time: compare the rows\n");
+        return 0;
+    }
     for (int round = 0; round < 2; round++) {
         run("l2", [&] { k_acc<48, false><<<grid, 64>>>(st, sink, tab, 4095, iters); }, st, grid, iters);
         run("s192", [&] { k_acc<48, false><<<grid, 64>>>(st, sink, tab, big - 1, iters); }, st, grid, iters);
