@@ -748,6 +748,7 @@ struct MsmWorkspace {
     uint32_t *order = nullptr, *ovf_slot = nullptr;               // per bucket: visiting order, slot in the overflow list (NO_SLOT for all but oversized buckets)
     uint32_t *ovf_bucket = nullptr, *ovf_nseg = nullptr, *ovf_off = nullptr; void *ovf_partial = nullptr; size_t cap_ovf = 0;    // overflow list + the segments' partial sums
     uint32_t *part_hist = nullptr, *part_offs = nullptr; size_t cap_part = 0;      // two-level partition: (coarse bin, workgroup) counts and their scan
+    uint32_t *canon = nullptr; size_t cap_canon = 0;                               // two-level partition: the scalars as canonical integers (8 words each), between its two passes
     uint32_t *ord_hist = nullptr, *ord_offs = nullptr;            // ORD_BINS x ORD_MAX_BLOCKS counts and their scan
     uint32_t *ctrl = nullptr;                                     // 8 control words (see k_order_hist); armed at zero between MSMs
     bool ctrl_dirty = false;                                      // an exception left the order pass half done: re-arm ctrl before the next one
@@ -803,7 +804,7 @@ MsmWorkspace *msm_workspace_create() { return new MsmWorkspace(); }
 void msm_workspace_destroy(MsmWorkspace *w) {
     if (!w) return;
     for (void *p : {(void *)w->keys_a, (void *)w->keys_b, (void *)w->vals_a, (void *)w->vals_b, (void *)w->start, (void *)w->end, (void *)w->order, (void *)w->ovf_slot,
-                    (void *)w->ovf_bucket, (void *)w->ovf_nseg, (void *)w->ovf_off, w->ovf_partial, (void *)w->part_hist, (void *)w->part_offs, (void *)w->ord_hist, (void *)w->ord_offs,
+                    (void *)w->ovf_bucket, (void *)w->ovf_nseg, (void *)w->ovf_off, w->ovf_partial, (void *)w->part_hist, (void *)w->part_offs, (void *)w->canon, (void *)w->ord_hist, (void *)w->ord_offs,
                     (void *)w->ctrl, (void *)w->deferred, (void *)w->deferred_count, w->buckets, w->seg_s, w->seg_w, w->partial, w->tmp}) dfree(p);
     if (w->h_res) (void)hipHostFree(w->h_res);
     for (auto e : w->ev) if (e) (void)hipEventDestroy(e);
@@ -1246,10 +1247,10 @@ void table_next(Affine<typename Curve::Fq> *next, const Affine<typename Curve::F
 // onesweep passes, whose stable ranking is a chain of match-any ballots per item) spent ~470 lane-instructions per (point, window) pair, 13 % of what the bucket
 // additions themselves take.  Nothing here needs a stable sort -- only "bucket-contiguous, and inside a bucket by window" (the lanes of a wave then gather from the same
 // table copy, which the round-3 partition got wrong: 5.7 % slower accumulation) -- so ranks come from LDS atomics, ~70 lane-instructions per pair:
-//   k_part_hist    : one pass over the scalars: window digits (Montgomery -> canonical, carry recoding), LDS histogram of the pairs over the COARSE bins (the high bucket
-//                    bits, <= 1024 bins); fixed tiling over a fixed grid, counts written per (bin, workgroup)
+//   k_part_hist    : one pass over the scalars: Montgomery -> canonical (stored: 8 words per scalar), window digits (carry recoding), LDS histogram of the pairs over the
+//                    COARSE bins (the high bucket bits, <= 1024 bins); fixed tiling over a fixed grid, counts written per (bin, workgroup)
 //   one scan       : every (bin, workgroup) gets its range -- no global atomics, deterministic
-//   k_part_scatter : same tiling, digits recomputed (round 6; rounds 4-5 stored 16 words per scalar and read them back): a tile's pairs are ranked by LDS atomics into bin-contiguous runs staged in LDS and written out as
+//   k_part_scatter : same tiling, digits re-derived from the canonical scalars (round 6; rounds 4-5 stored the 16 digit words per scalar): a tile's pairs are ranked by LDS atomics into bin-contiguous runs staged in LDS and written out as
 //                    (value, 13-bit key = fine bucket bits x 16 + window)
 //   k_part_fine    : one workgroup per coarse bin: LDS counts of its 8,192 (fine bucket, window) keys, in-place scan, bucket [start, end) ranges (what k_bounds used to
 //                    find), values scattered to their final place through LDS cursors
@@ -1262,12 +1263,9 @@ constexpr uint32_t PART_NBIN_MAX = 1024;                                        
 constexpr uint32_t PART_GRID = 512, PART_NONE = 0xffffffffu;
 constexpr int PART_FINE_THREADS = 1024, PART_FINE_UNROLL = 8;     // the last pass is latency-bound (load -> LDS atomic -> LDS store): many lanes per bin, several loads in flight per lane
 
-// signed window digits of one scalar: d[w] = (|digit| - 1) | neg << 31, PART_NONE for a zero digit or w >= nwin
-template <class Fr>
-__device__ __forceinline__ void part_recode(const Fr &sc, const TableLayout &L, uint32_t d[PART_MAXW]) {
-    uint32_t raw[Fr::N + 1];
-    sc.to_raw(raw);
-    raw[Fr::N] = 0;
+// signed window digits of one scalar from its canonical integer (raw[Fr::N] = 0 on entry): d[w] = (|digit| - 1) | neg << 31, PART_NONE for a zero digit or w >= nwin
+template <int NW>
+__device__ __forceinline__ void part_digits(const uint32_t (&raw)[NW + 1], const TableLayout &L, uint32_t d[PART_MAXW]) {
     uint32_t carry = 0;
 #pragma unroll
     for (int w = 0; w < PART_MAXW; w++) {
@@ -1275,7 +1273,7 @@ __device__ __forceinline__ void part_recode(const Fr &sc, const TableLayout &L, 
         if (w < L.nwin) {
             const int c = L.width(w), bit = L.offset(w), limb = bit >> 5, sh = bit & 31;
             const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
-            uint64_t two = limb <= Fr::N - 1 ? ((uint64_t)raw[limb] | ((uint64_t)raw[limb + 1] << 32)) : 0;
+            uint64_t two = limb <= NW - 1 ? ((uint64_t)raw[limb] | ((uint64_t)raw[limb + 1] << 32)) : 0;
             uint32_t v = ((uint32_t)(two >> sh) & mask) + carry;
             uint32_t neg = 0;
             carry = 0;
@@ -1302,7 +1300,7 @@ __device__ __forceinline__ void part_block_scan(uint32_t *cnt, uint32_t len, uin
 }
 template <class Fr>
 __global__ void __launch_bounds__(PART_THREADS) k_part_hist(const Fr *__restrict__ s1, uint32_t n1, const Fr *__restrict__ s2, uint32_t n2, TableLayout L, uint32_t nbin,
-                                                            uint32_t *__restrict__ hist) {
+                                                            uint32_t *__restrict__ canon, uint32_t *__restrict__ hist) {
     __shared__ uint32_t sh[PART_NBIN_MAX];
     for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) sh[b] = 0;
     __syncthreads();
@@ -1313,19 +1311,23 @@ __global__ void __launch_bounds__(PART_THREADS) k_part_hist(const Fr *__restrict
         for (int q = 0; q < PART_SPT; q++) {
             const uint32_t g = tile * PART_TILE + q * PART_THREADS + threadIdx.x;
             if (g >= n) continue;
-            uint32_t d[PART_MAXW];
-            part_recode<Fr>(g < n1 ? s1[g] : s2[g - n1], L, d);
+            uint32_t d[PART_MAXW], raw[Fr::N + 1];
+            (g < n1 ? s1[g] : s2[g - n1]).to_raw(raw);              // Montgomery -> canonical: the expensive half of the recoding (~0.5 k instructions), done ONCE per scalar
+            raw[Fr::N] = 0;
+            part_digits<Fr::N>(raw, L, d);
 #pragma unroll
             for (int w = 0; w < PART_MAXW; w++) if (d[w] != PART_NONE) atomicAdd(&sh[(d[w] & 0x7fffffffu) >> PART_FINE_BITS], 1u);
+            static_assert(Fr::N == 8, "the canonical scalar is stored as two 16-byte words");
+            uint4 *dst = reinterpret_cast<uint4 *>(canon + (size_t)g * Fr::N);
+            dst[0] = make_uint4(raw[0], raw[1], raw[2], raw[3]); dst[1] = make_uint4(raw[4], raw[5], raw[6], raw[7]);
         }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) hist[(size_t)b * gridDim.x + blockIdx.x] = sh[b];      // bin-major: the scan gives every (bin, workgroup) its range
     if (blockIdx.x == 0 && threadIdx.x == 0) hist[(size_t)nbin * gridDim.x] = 0;                                       // the scan's last entry = the number of pairs
 }
-template <class Fr>
-__global__ void __launch_bounds__(PART_THREADS) k_part_scatter(const Fr *__restrict__ s1, uint32_t n1, const Fr *__restrict__ s2, uint32_t n2, TableLayout L, uint32_t off1, uint32_t off2, uint32_t stride,
+template <int NW>
+__global__ void __launch_bounds__(PART_THREADS) k_part_scatter(const uint32_t *__restrict__ canon, uint32_t n, uint32_t n1, TableLayout L, uint32_t off1, uint32_t off2, uint32_t stride,
                                                                uint32_t nbin, const uint32_t *__restrict__ offs, uint32_t *__restrict__ out_val, uint16_t *__restrict__ out_key) {
-    const uint32_t n = n1 + n2;
     __shared__ uint32_t cursor[PART_NBIN_MAX], cnt[PART_NBIN_MAX], fill[PART_NBIN_MAX], st_val[PART_STAGE], st_key[PART_STAGE];
     __shared__ uint32_t wave_sums[PART_THREADS / 64], total;
     for (uint32_t b = threadIdx.x; b < nbin; b += PART_THREADS) cursor[b] = offs[(size_t)b * gridDim.x + blockIdx.x];
@@ -1338,10 +1340,15 @@ __global__ void __launch_bounds__(PART_THREADS) k_part_scatter(const Fr *__restr
 #pragma unroll
         for (int q = 0; q < PART_SPT; q++) {
             const uint32_t g = tile * PART_TILE + q * PART_THREADS + threadIdx.x;
-            // the digits are RECOMPUTED from the scalar (round 5 wrote them -- 16 words per scalar, 2.0 GB per proof -- in k_part_hist and read them back here: ~250 more
-            // instructions per scalar against 96 bytes of HBM traffic, on a chip that runs at its power limit)
-            if (g < n) part_recode<Fr>(g < n1 ? s1[g] : s2[g - n1], L, d[q]);
-            else {
+            // the digits are re-derived from the CANONICAL scalar k_part_hist left (8 words per scalar; rounds 4-5 stored the 16 digit words: 2.0 GB written + 2.0 GB read per
+            // proof; recomputing them from the Montgomery form here cost +1.1 % of the prover's instructions, profiles/r06_valu_by_kernel.md: the shifts and masks alone are ~100)
+            if (g < n) {
+                uint32_t raw[NW + 1];
+                const uint4 *src = reinterpret_cast<const uint4 *>(canon + (size_t)g * NW);
+                const uint4 a = src[0], b = src[1];
+                raw[0] = a.x; raw[1] = a.y; raw[2] = a.z; raw[3] = a.w; raw[4] = b.x; raw[5] = b.y; raw[6] = b.z; raw[7] = b.w; raw[NW] = 0;
+                part_digits<NW>(raw, L, d[q]);
+            } else {
 #pragma unroll
                 for (int w = 0; w < PART_MAXW; w++) d[q][w] = PART_NONE;
             }
@@ -1446,18 +1453,19 @@ static void partition_buckets(MsmWorkspace &S, const Fr *scal1, size_t n1, size_
     const int B = L.c_hi - 1;                                         // bucket bits
     const uint32_t nbin = 1u << (B - PART_FINE_BITS), G = PART_GRID;
     const size_t n = n1 + n2, nb = (size_t)1 << B, nh = (size_t)nbin * G + 1;
+    if (n > S.cap_canon) { dfree(S.canon); S.canon = (uint32_t *)dmalloc(n * Fr::N * 4); S.cap_canon = n; }
     if (nh > S.cap_part) { dfree(S.part_hist); dfree(S.part_offs); S.part_hist = (uint32_t *)dmalloc(nh * 4); S.part_offs = (uint32_t *)dmalloc(nh * 4); S.cap_part = nh; }
 #ifdef ZKAES_MEASURE
     for (int rep = (knockin() & 1) ? 0 : 1; rep < 2; rep++)
 #endif
     {
-    hipLaunchKernelGGL((k_part_hist<Fr>), dim3(G), dim3(PART_THREADS), 0, s, scal1, (uint32_t)n1, scal2, (uint32_t)n2, L, nbin, S.part_hist);
+    hipLaunchKernelGGL((k_part_hist<Fr>), dim3(G), dim3(PART_THREADS), 0, s, scal1, (uint32_t)n1, scal2, (uint32_t)n2, L, nbin, S.canon, S.part_hist);
     HIP_LAUNCH_CHECK();
     size_t tb = 0;
     HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, S.part_hist, S.part_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
     if (tb > S.cap_tmp) { dfree(S.tmp); S.tmp = dmalloc(tb); S.cap_tmp = tb; }
     HIP_CHECK(rocprim::exclusive_scan(S.tmp, tb, S.part_hist, S.part_offs, 0u, nh, rocprim::plus<uint32_t>(), s));
-    hipLaunchKernelGGL((k_part_scatter<Fr>), dim3(G), dim3(PART_THREADS), 0, s, scal1, (uint32_t)n1, scal2, (uint32_t)n2, L, (uint32_t)off1, (uint32_t)off2, (uint32_t)stride, nbin,
+    hipLaunchKernelGGL((k_part_scatter<Fr::N>), dim3(G), dim3(PART_THREADS), 0, s, (const uint32_t *)S.canon, (uint32_t)n, (uint32_t)n1, L, (uint32_t)off1, (uint32_t)off2, (uint32_t)stride, nbin,
                        (const uint32_t *)S.part_offs, S.vals_a, (uint16_t *)S.keys_a);
     HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_part_fine, dim3(nbin), dim3(PART_FINE_THREADS), 0, s, (const uint32_t *)S.part_offs, G, (const uint32_t *)S.vals_a, (const uint16_t *)S.keys_a, S.vals_b, S.start, S.end);
