@@ -370,6 +370,8 @@ __global__ void __launch_bounds__(64) k_accumulate_tail(const typename Law::Base
     const uint32_t nlist = ctrl[1];
     uint32_t total = ctrl[2];
     if (total > max_segments) total = max_segments;
+    // Edwards law (nothing is ever deferred): with no oversized bucket -- always, for uniformly distributed digits -- there is nothing to accumulate and nothing to fold
+    if constexpr (Law::edwards) { if (nlist == 0) return; }
     // workgroups whose 64 segment slots are all beyond `total` (every workgroup, for uniform digits) skip the segment work and its LDS fold
     if (blockIdx.x * blockDim.x < total) {
         __shared__ A sh[64];
@@ -413,18 +415,37 @@ __global__ void __launch_bounds__(64) k_accumulate_tail(const typename Law::Base
         // the segments of one bucket are consecutive t: the first lane of every (workgroup, bucket) run folds its run (<= 63 additions) and stores ONE
         // partial at its own slot; k_fold_overflow then visits one slot per workgroup the bucket's segments span, not one per segment
         if (t < total && (threadIdx.x == 0 || key[threadIdx.x - 1] != q)) {
-            for (uint32_t r = threadIdx.x + 1; r < 64 && key[r] == q; r++) PtOps<A>::add(acc, sh[r]);
+            for (uint32_t r = threadIdx.x + 1; r < 64 && key[r] == q; r++) {
+                if constexpr (Law::edwards) PtOps<A>::add_inline(acc, sh[r]); else PtOps<A>::add(acc, sh[r]);        // (inlined on the Edwards law: no call, no stack)
+            }
             partial[t] = acc;
         }
     }
-    if constexpr (!Law::edwards) {       // the Weierstrass law defers P = +-Q additions: whichever workgroup finishes last replays them with the complete formulas
-        __shared__ uint32_t ticket;
-        __threadfence();
-        __syncthreads();
-        if (threadIdx.x == 0) ticket = atomicAdd(deferred_count + 1, 1u);
-        __syncthreads();
-        if (ticket != gridDim.x - 1 || threadIdx.x != 0) return;
-        __threadfence();
+    // whichever workgroup finishes last (ticket counter deferred_count[1], re-armed by its taker) closes the pass: on the Weierstrass law it replays the deferred P = +-Q
+    // additions with the complete formulas (k_fold_overflow follows as its own launch); on the Edwards law it folds the overflow partials into their buckets itself --
+    // round 6: one dependent launch less behind every accumulation, and no stack in either (round 5's two kernels carried 240 B of scratch each for a call to the point
+    // addition that uniform digits never reach, and took 45-77 us to do nothing behind a lone call's accumulations, profiles/r06_lone_timeline_16.md)
+    __shared__ uint32_t ticket;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = atomicAdd(deferred_count + 1, 1u);
+    __syncthreads();
+    if (ticket != gridDim.x - 1) return;
+    __threadfence();
+    if (threadIdx.x == 0) deferred_count[1] = 0;
+    if constexpr (Law::edwards) {
+        // a bucket's partials sit one per 64-segment workgroup its segments [a, b) span, at the run's first slot
+        for (uint32_t q = threadIdx.x; q < nlist; q += blockDim.x) {
+            uint32_t a = ovf_off[q], b = ovf_off[q + 1];
+            if (b > max_segments) b = max_segments;
+            if (a >= b) continue;
+            const uint32_t k = ovf_bucket[q];
+            A acc = buckets[k];
+            for (uint32_t w = a / 64; w * 64 < b; w++) { const uint32_t i = w * 64 > a ? w * 64 : a; if (i < b) PtOps<A>::add_inline(acc, partial[i]); }
+            buckets[k] = acc;
+        }
+    } else {
+        if (threadIdx.x != 0) return;
         accumulate_fixup<P>(bases, buckets, deferred, deferred_cap, deferred_count);
     }
 }
@@ -774,6 +795,7 @@ static void ensure_scratch(MsmWorkspace &S, size_t pairs, size_t buckets, size_t
     if (!S.ev[0]) {
         for (auto &e : S.ev) HIP_CHECK(hipEventCreate(&e));
         S.deferred = (uint32_t *)dmalloc(2 * DEFERRED_CAP * 4); S.deferred_count = (uint32_t *)dmalloc(8);
+        HIP_CHECK(hipMemset(S.deferred_count, 0, 8));                 // [1] is the tail kernel's ticket: armed at zero, re-armed by the workgroup that takes the last one
         S.ord_hist = (uint32_t *)dmalloc((size_t)ORD_BINS * ORD_MAX_BLOCKS * 4); S.ord_offs = (uint32_t *)dmalloc((size_t)ORD_BINS * ORD_MAX_BLOCKS * 4);
         S.ctrl = (uint32_t *)dmalloc(32);
         HIP_CHECK(hipMemset(S.ctrl, 0, 32));
@@ -889,8 +911,8 @@ static std::vector<XYZZ<Fp<typename Law::Params>>> run_buckets(MsmWorkspace &S, 
                            (A *)S.ovf_partial + rep * S.cap_ovf, (A *)S.buckets + rep * nb, S.deferred, DEFERRED_CAP, S.deferred_count);
         HIP_LAUNCH_CHECK();
     }
-    for (int rep = 0; rep < nrep; rep++) {
-        // overflow partials -> their buckets (overflow list entries <= buckets with more than `cap` pairs <= pairs / cap)
+    if constexpr (!Law::edwards) for (int rep = 0; rep < nrep; rep++) {
+        // overflow partials -> their buckets (overflow list entries <= buckets with more than `cap` pairs <= pairs / cap); the Edwards law's tail kernel does it itself
         hipLaunchKernelGGL((k_fold_overflow<A>), dim3((max_seg + 63) / 64), dim3(64), 0, s, (A *)S.buckets + rep * nb, S.ctrl, S.ovf_bucket, S.ovf_off, max_seg, (const A *)S.ovf_partial + rep * S.cap_ovf);
         HIP_LAUNCH_CHECK();
     }

@@ -95,6 +95,21 @@ def cpu_baseline(samples_small=0, samples_chunk=3, chunk_blocks=6, budget_s=300.
     return out
 
 
+class _stdout_to_stderr:
+    """file descriptor 1 -> stderr for the duration (native libraries that print on stdout); Python's own sys.stdout is flushed either side"""
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def even_slices(lo, hi, parts):
     """`parts` contiguous shares of [lo, hi), sizes differing by at most one"""
     return [tuple(lo + x for x in sharding.split_chunks(hi - lo, i, parts)) for i in range(parts)]
@@ -138,7 +153,11 @@ def run(args, api, dist_env=None):
     if use_dist and not dist.is_initialized():
         if backend == "nccl":
             torch.cuda.set_device(device_ordinal)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_ordinal))
+            # this image's RCCL (2.26.6) prints a five-line version banner on STDOUT when its first communicator comes up; the contract is ONE JSON line on stdout, so the
+            # group is created -- and its communicator forced into being by a first barrier -- with file descriptor 1 pointing at stderr
+            with _stdout_to_stderr():
+                dist.init_process_group("nccl", device_id=torch.device("cuda", device_ordinal))
+                dist.barrier()
         else:
             dist.init_process_group(backend)
     coll_device = "cuda" if (use_dist and backend == "nccl") else None

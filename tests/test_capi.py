@@ -31,6 +31,8 @@ def test_no_cpu_fallback(api):
         api.ntt(377, bytes(64))
     with pytest.raises(api.ZkAesError, match="no HIP device"):
         api.msm(377, bytes(96), bytes(32))
+    with pytest.raises(api.ZkAesError, match="no HIP device"):
+        api.int_rate_bench(0.1)                    # the calibration probe measures a GPU or fails: it never reports a host number
 
 
 def test_product_does_not_reference_the_oracle():

@@ -295,3 +295,16 @@ def test_error_paths_release_device_memory(zko, api):
     ref = C.create_string_buffer(96)
     zko.lib().zko_api_msm(377, good, sc, C.c_size_t(1000), ref)
     assert api.msm_table(377, good, sc, 16, srs=True) == (ref.raw, False)
+
+
+def test_int_rate_bench_reports_sane_rates(api):
+    """zkaes_int_rate_bench (bench.py's per-box calibration): the Fq product stream and the hot loop over an L2-resident table, with the shader clock each ran at"""
+    r = api.int_rate_bench(0.2)
+    assert r["rounds"] >= 3
+    assert 8e12 < r["mad_per_s"] < 45e12, r                      # 24-28 T v_mad_u64_u32/s on the boxes seen so far
+    assert 3e9 < r["hot_loop_l2_additions_per_s"] < 16e9, r       # ~10 G bucket additions/s
+    assert 500 < r["fq_stream_sclk_mhz"] < 2600 and 500 < r["hot_loop_l2_sclk_mhz"] < 2600, r
+    assert 30000 < r["hot_loop_cycles_per_addition_per_wave"] < 60000, r      # 3 waves x ~13.4 k cycles per addition per SIMD
+    for bad in (0.0, -1.0, 31.0):
+        with pytest.raises(api.ZkAesError, match="seconds"):
+            api.int_rate_bench(bad)
