@@ -249,11 +249,15 @@ class ProvingKey:
             off += lens[i]
         return proofs
 
+    def free(self):
+        """release the key now (device memory: index, prover contexts, and the universal SRS if this was its last key) instead of at garbage collection"""
+        if self._p:
+            lib().zkaes_pk_free(self._p)
+            self._p = None
+
     def __del__(self):
         try:
-            if self._p:
-                lib().zkaes_pk_free(self._p)
-                self._p = None
+            self.free()
         except Exception:
             pass
 
@@ -402,6 +406,11 @@ def msm_bench_synth(n, window_bits=0, reps=3, want_point=False):
     out = C.create_string_buffer(96)
     _check(lib().zkaes_msm_bench_synth(C.c_size_t(n), int(window_bits), int(reps), C.byref(t), C.byref(a), out))
     return (t.value, a.value, out.raw) if want_point else (t.value, a.value)
+
+
+def set_default_contexts(n):
+    """zkaes_set_default_contexts: the process default of prover contexts per key (0 = back to ZKAES_CONTEXTS / 12); also what key synthesis reserves beside the window tables"""
+    _check(lib().zkaes_set_default_contexts(C.c_size_t(n)))
 
 
 def srs_hold(hold=True):

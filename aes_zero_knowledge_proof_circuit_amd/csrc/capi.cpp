@@ -109,6 +109,7 @@ int zkaes_pk_serialize_ark_to_file_ex(const zkaes_pk *pk, const char *path, int 
     });
 }
 int zkaes_pk_serialize_ark_to_file(const zkaes_pk *pk, const char *path, uint64_t *bytes_written) { return zkaes_pk_serialize_ark_to_file_ex(pk, path, 0, bytes_written); }
+int zkaes_set_default_contexts(size_t n) { return guard([&] { if (n > 64) throw std::invalid_argument("set_default_contexts: at most 64 prover contexts per key"); zk::set_default_contexts(n); }); }
 int zkaes_srs_hold(int hold) { return guard([&] { zk::srs_hold(hold != 0); }); }
 int zkaes_pk_set_contexts(zkaes_pk *pk, size_t n) {
     return guard([&] {

@@ -1517,17 +1517,21 @@ void msm_prepare_table(MsmWorkspace *ws_, const typename Curve::Fr *scal1, size_
     if ((uint64_t)nwin * stride >= (1ull << 30) || (uint64_t)n * nwin >= (1ull << 31)) throw GpuError("msm_table: index range too large");
     size_t pairs = n * (size_t)nwin;
     const size_t nb = (size_t)1 << (L.c_hi - 1);
-    S.plan_c = L.c_hi; S.plan_nwin = nwin; S.plan_pairs = pairs; S.plan_table = true; S.plan_cap = BUCKET_CAP_TABLE;
-    ensure_scratch(S, pairs, nb, BUCKET_CAP_TABLE);
+    // the per-lane cap only exists to bound the longest lane under skewed scalars; it must stay well above the MEAN bucket size or every bucket overflows into the tail kernel
+    // (uniform digits: pairs / 2^19 per bucket -- ~210 for the largest MSM of a 6-block proof, ~830 for a 28-block one over a larger SRS: round 6)
+    uint32_t cap = BUCKET_CAP_TABLE;
+    while ((uint64_t)cap < 2 * (pairs / nb) + 64) cap <<= 1;
+    S.plan_c = L.c_hi; S.plan_nwin = nwin; S.plan_pairs = pairs; S.plan_table = true; S.plan_cap = cap;
+    ensure_scratch(S, pairs, nb, cap);
     const int B = L.c_hi - 1;
     if (B > PART_FINE_BITS && (1u << (B - PART_FINE_BITS)) <= PART_NBIN_MAX && nwin <= PART_MAXW && pairs >= ((size_t)1 << 16)) {
-        partition_buckets<Fr>(S, scal1, n1, off1, scal2, n2, off2, L, stride, BUCKET_CAP_TABLE, s);
+        partition_buckets<Fr>(S, scal1, n1, off1, scal2, n2, off2, L, stride, cap, s);
         return;
     }
     // small instances and window plans outside the partition's limits: digits + one stable radix sort over the bucket bits
     if (n1) { hipLaunchKernelGGL((k_digits_table<Fr>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, scal1, (uint32_t)n1, 0u, (uint32_t)n, (uint32_t)off1, L, (uint32_t)stride, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
     if (n2) { hipLaunchKernelGGL((k_digits_table<Fr>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, scal2, (uint32_t)n2, (uint32_t)n1, (uint32_t)n, (uint32_t)off2, L, (uint32_t)stride, S.keys_a, S.vals_a); HIP_LAUNCH_CHECK(); }
-    prepare_buckets<typename Curve::FqP>(S, pairs, L.c_hi - 1, 1, L.c_hi - 1, BUCKET_CAP_TABLE, s);
+    prepare_buckets<typename Curve::FqP>(S, pairs, L.c_hi - 1, 1, L.c_hi - 1, cap, s);
 }
 template <class Curve>
 XYZZ<typename Curve::Fq> msm_table(MsmWorkspace *ws_, const Affine28<typename Curve::FqP> *tables, size_t stride, size_t off, int c, const typename Curve::Fr *scalars, size_t n, stream_t s_) {

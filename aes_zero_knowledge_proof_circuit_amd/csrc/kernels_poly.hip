@@ -349,9 +349,12 @@ __global__ void __launch_bounds__(256) k_vq_expand(VqArgs A, const F *__restrict
     F *o = k_lo == 0 ? A.out[c] : dst + (size_t)c * (A.n >> k_lo);
     for (uint32_t m = t; m < cnt; m += 256) o[j + (size_t)m * s_hi] = buf[cur][m];
 }
+// the level an expansion from level k_hi stops at: the SHORT step comes first, so that the last launch -- the one that writes n values per coset -- always runs full
+// VQ_STEP-level workgroups (lg n = 22 used to end on a two-level step: 3 * 2^20 workgroups of 256 lanes for four values each, 11.6 ms per call)
+static inline int vq_next_level(int k_hi) { const int r = k_hi % VQ_STEP; return k_hi - (r ? r : VQ_STEP); }
 size_t vanishing_quotient_scratch(int lg_n, int ncosets) {          // field elements of `scratch` vanishing_quotient_evals needs
     size_t tab = (size_t)(ncosets + 1) * (lg_n > 0 ? lg_n : 1), mids = 0;
-    for (int k = lg_n - VQ_STEP; k > 0; k -= VQ_STEP) mids += (size_t)ncosets << (lg_n - k);
+    for (int k = lg_n - VQ_STEP; k > 0; k = vq_next_level(k)) mids += (size_t)ncosets << (lg_n - k);
     return tab + mids + 8;
 }
 void vanishing_quotient_evals(F *const *out, const F *g, int ncosets, const F &a, const F *elems, uint32_t n, int lg_n, F *scratch, size_t scratch_elems, stream_t s_) {
@@ -376,7 +379,7 @@ void vanishing_quotient_evals(F *const *out, const F *g, int ncosets, const F &a
     F *mid = scratch + tab.size();
     hipLaunchKernelGGL(k_vq_top, dim3(ncosets), dim3(1024), 0, s, A, mid); HIP_LAUNCH_CHECK();
     for (int k_hi = lg_n - VQ_STEP; k_hi > 0; ) {
-        const int k_lo = k_hi > VQ_STEP ? k_hi - VQ_STEP : 0;
+        const int k_lo = vq_next_level(k_hi);
         F *dst = mid + ((size_t)ncosets << (lg_n - k_hi));
         hipLaunchKernelGGL(k_vq_expand, dim3((unsigned)((size_t)ncosets * (n >> k_hi))), dim3(256), 0, s, A, (const F *)mid, dst, k_hi, k_lo); HIP_LAUNCH_CHECK();
         mid = dst; k_hi = k_lo;

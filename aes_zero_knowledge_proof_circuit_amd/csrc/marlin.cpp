@@ -107,6 +107,9 @@ size_t default_contexts() {
     g_default_contexts.store(v);
     return v;
 }
+// n = 0: back to ZKAES_CONTEXTS / the built-in default.  The default also sizes what key synthesis leaves free beside the window tables (acquire_srs' reserve): a caller about to
+// synthesize a key whose contexts are several times larger (more blocks per proof over a larger SRS) lowers it first, or the tables are skipped for lack of room
+void set_default_contexts(size_t n) { g_default_contexts.store(n > 64 ? 64 : n); }
 // `reserve_bytes`: what the caller will still allocate beside the tables (its prover contexts): the tables are an optimisation, not a requirement -- they are skipped
 // when the device could not hold both, instead of failing key synthesis or the first multi-proof call.
 static std::shared_ptr<UniversalSrs> acquire_srs(size_t max_degree, bool want_tables, size_t reserve_bytes, gpu::stream_t stream) {

@@ -110,6 +110,7 @@ std::unique_ptr<ProvingKey> synthesize_keys(int circuit_kind, size_t message_len
 void srs_hold(bool hold);
 // process default of ProvingKey::contexts(): ZKAES_CONTEXTS from the environment (read once), else ZKAES_DEFAULT_CONTEXTS
 size_t default_contexts();
+void set_default_contexts(size_t n);       // 0 = back to the environment / built-in default; at most 64
 // 32 bytes from the operating system (getrandom): the default zero-knowledge seed of the multi-proof entry points
 void os_random_seed(uint8_t out[32]);
 

@@ -220,6 +220,10 @@ int zkaes_pk_srs_info(const zkaes_pk *pk, uint64_t out[6], double secs[2]);
 /* hold != 0: the library keeps every universal SRS (and Lagrange-basis SRS) it has built, or builds from now on, resident after the last key over it is freed -- for callers that
  * create and free keys in turn (one key per request size) and would otherwise rebuild 31.4 GB of window tables each time; hold == 0 releases them again (device memory goes
  * back once no key uses them).  Default: not held. */
+/* the PROCESS default of a key's prover contexts (what ZKAES_CONTEXTS sets at start-up; 0 = back to that; at most 64).  Besides being what keys without their own
+ * zkaes_pk_set_contexts use, it sizes the device memory key synthesis leaves free beside the window tables: lower it BEFORE synthesizing a key whose contexts are several times
+ * larger than the reference sizes' (e.g. 28 blocks per proof over a universal SRS four times the reference's literal: ~19 GB per context, 126 GB of tables). */
+int zkaes_set_default_contexts(size_t n);
 int zkaes_srs_hold(int hold);
 /* same sum through the precomputed-window layout the prover uses for the SRS (tables 2^(window offset j) P_i built on the fly here; one bucket set), on the
  * Weierstrass model with XYZZ buckets: correct for ANY curve points, both curves. */

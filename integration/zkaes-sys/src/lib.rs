@@ -31,6 +31,7 @@ extern "C" {
     fn zkaes_pk_set_contexts(pk: *mut zkaes_pk, n: usize) -> c_int;
     fn zkaes_pk_get_contexts(pk: *const zkaes_pk, n: *mut usize) -> c_int;
     fn zkaes_srs_hold(hold: c_int) -> c_int;
+    fn zkaes_set_default_contexts(n: usize) -> c_int;
     fn zkaes_pk_srs_info(pk: *const zkaes_pk, out: *mut u64, secs: *mut f64) -> c_int;
     fn zkaes_pk_tables_built(pk: *const zkaes_pk, built: *mut c_int, table_bytes: *mut u64) -> c_int;
     fn zkaes_vk_serialize_ark(vk: *const zkaes_vk, out: *mut *mut u8, out_len: *mut usize) -> c_int;
@@ -130,6 +131,12 @@ pub fn synthesize_keys_with(plaintext_length: usize, flags: u32) -> Result<(Prov
     // circuit kind 0 = the AES circuit; the universal-SRS literals of src/lib.rs:141
     if unsafe { zkaes_synthesize_keys_ex2(0, plaintext_length, 866_944, 513, 4_062_064, flags as c_uint, &mut pk, &mut vk) } != 0 { return Err(last_error()); }
     Ok((ProvingKey(Arc::new(PkHandle(pk))), VerifyingKey(Arc::new(VkHandle(vk)))))
+}
+
+/// The process default of prover contexts per key (0 = back to ZKAES_CONTEXTS / 12); lower it before synthesizing keys for much larger chunk sizes (see include/zkaes.h).
+pub fn set_default_contexts(n: usize) -> Result<()> {
+    if unsafe { zkaes_set_default_contexts(n) } != 0 { return Err(last_error()); }
+    Ok(())
 }
 
 /// Keep the universal SRS (31.4 GB of window tables for the reference's literals) resident after the last key over it is dropped; `false` releases it again.

@@ -656,3 +656,28 @@ def test_srs_hold_keeps_the_tables_resident_between_keys(api):
     finally:
         api.srs_hold(False)
         gc.collect()
+
+
+def test_twenty_eight_block_chunk_over_a_larger_universal_srs(zko, api):
+    """bench.py's `big` leg in small: a 28-block (448-byte) chunk-proof needs a universal SRS four times the reference's literal (zkaes_synthesize_keys_ex with
+    (2^22, 513, 2^24)); 28 blocks fill |H| = 2^22 to 99.9 % and |K| = 2^24 to 98.3 %.  Here without the window tables (126 GB for that SRS: the bench leg builds them in a
+    process of its own) -- per-window buckets, one context: witness bit-exact against the oracle's gate-level synthesis, proof accepted, wrong ciphertext rejected, and the
+    largest MSM (2 |K| = 33.5 M points) does not trip the per-lane cap on the way."""
+    api.set_default_contexts(1)
+    try:
+        pk, vk = api.synthesize_keys(16 * 28, srs=(1 << 22, 513, 1 << 24), flags=api.KEY_NO_TABLES)
+        info = pk.info()
+        assert int(info["h"]) == 1 << 22 and int(info["k"]) == 1 << 24
+        assert int(info["constraints"]) == 36768 + 148272 * 28 and int(info["joint_nnz"]) <= 1 << 24
+        msg, key = mt_bytes(16 * 28, 2828), mt_bytes(16, 2829)
+        cs, ct = zko.synth_aes(msg, key)
+        cs.pad_for_marlin()
+        ins, wit = cs.assignment()
+        assert pk.witness(msg, key) == ins + wit
+        proof = api.encrypt(msg, key, pk)
+        assert api.verify_encryption(vk, proof, ct)
+        bad = bytearray(ct); bad[17] ^= 4
+        assert not api.verify_encryption(vk, proof, bytes(bad))
+        pk.free()
+    finally:
+        api.set_default_contexts(0)
