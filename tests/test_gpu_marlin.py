@@ -678,6 +678,20 @@ def test_twenty_eight_block_chunk_over_a_larger_universal_srs(zko, api):
         assert api.verify_encryption(vk, proof, ct)
         bad = bytearray(ct); bad[17] ^= 4
         assert not api.verify_encryption(vk, proof, bytes(bad))
+        # byte parity at this size too: tests/golden/oracle_aes448.json is what the CPU oracle produced for this (message, key) over the same universal SRS literals
+        # (make_oracle_aes96.py 448, ~35 minutes of the build container's 8 cores): index sizes, witness, all nine prover polynomials, the proof bytes
+        import hashlib
+        import json
+        fx = json.load(open(os.path.join(GOLD, "oracle_aes448.json")))
+        assert fx["srs_literals"] == [1 << 22, 513, 1 << 24] and bytes.fromhex(fx["message"]) == msg and bytes.fromhex(fx["key"]) == key and bytes.fromhex(fx["ciphertext"]) == ct
+        assert (int(info["constraints"]), int(info["joint_nnz"])) == (fx["index"]["num_constraints"], fx["index"]["num_non_zero"])
+        assert hashlib.sha256(ins + wit).hexdigest() == fx["witness_sha256"]
+        for name, want in fx["poly_sha256"].items():
+            got = pk.debug_fetch(name)
+            assert len(got) // 32 == fx["poly_len"][name], name
+            assert hashlib.sha256(got).hexdigest() == want, name
+        assert proof.hex() == fx["proof"] and hashlib.sha256(proof).hexdigest() == fx["proof_sha256"]
+        assert api.verify_encryption(vk, bytes.fromhex(fx["proof"]), ct)
         pk.free()
     finally:
         api.set_default_contexts(0)

@@ -33,7 +33,7 @@ if bench_args is not None:
     import bench
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
-        bench.main(bench_args.split())
+        bench.main(bench_args.split() + ([] if "--big-chunk" in bench_args else ["--big-chunk", "0"]))      # (an A/B compares the headline: no `big` leg)
     line = [l for l in buf.getvalue().splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     out["blocks_per_s"] = d["value"]; out["verified"] = d["proofs_verified"]

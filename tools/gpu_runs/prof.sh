@@ -7,9 +7,9 @@
 TAG=${1:-r05}; MODE=${2:-serial}
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 O=gpurun_out/${TAG}_prof_${MODE}; mkdir -p $O
-if [ "$MODE" = batch1 ]; then ARGS="--mode batch --proofs 42 --steps 2 --warmup 1 --contexts 1 --pipeline 1 --serial-probe 0 --no-cpu-baseline --alt-proofs 0 --latency-samples 0 --calibrate-s 0"
-elif [ "$MODE" = serial ]; then ARGS="--blocks 120 --steps 2 --warmup 1 --contexts 1 --pipeline 1 --serial-probe 0 --no-cpu-baseline --alt-proofs 0 --latency-samples 0 --calibrate-s 0"
-else ARGS="--gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --alt-proofs 0 --latency-samples 0 --calibrate-s 0"; fi
+if [ "$MODE" = batch1 ]; then ARGS="--mode batch --proofs 42 --steps 2 --warmup 1 --contexts 1 --pipeline 1 --serial-probe 0 --no-cpu-baseline --alt-proofs 0 --latency-samples 0 --calibrate-s 0 --big-chunk 0"
+elif [ "$MODE" = serial ]; then ARGS="--blocks 120 --steps 2 --warmup 1 --contexts 1 --pipeline 1 --serial-probe 0 --no-cpu-baseline --alt-proofs 0 --latency-samples 0 --calibrate-s 0 --big-chunk 0"
+else ARGS="--gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --alt-proofs 0 --latency-samples 0 --calibrate-s 0 --big-chunk 0"; fi
 rm -rf $O/prof
 timeout 1500 rocprofv3 --kernel-trace --stats -d $O/prof -o $TAG -- python bench.py $ARGS > $O/bench_under_rocprof.json 2> $O/bench.err
 db=$(find $O/prof -name "*_results.db" | head -1)

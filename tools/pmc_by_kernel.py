@@ -19,10 +19,10 @@ out_dir = os.path.join("gpurun_out", "pmc_valu_" + tag)
 os.makedirs(out_dir, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
 batch = len(sys.argv) > 2 and sys.argv[2] == "batch"
-ARGS = "--blocks 120 --steps 2 --warmup 1 --contexts 1 --pipeline 1 --serial-probe 0 --no-cpu-baseline --alt-proofs 0 --latency-samples 0 --calibrate-s 0".split()
+ARGS = "--blocks 120 --steps 2 --warmup 1 --contexts 1 --pipeline 1 --serial-probe 0 --no-cpu-baseline --alt-proofs 0 --latency-samples 0 --calibrate-s 0 --big-chunk 0".split()
 PROOFS = 21          # 20 timed 6-block chunk-proofs + 1 warm-up
 if batch:
-    ARGS = "--mode batch --proofs 21 --steps 1 --warmup 1 --contexts 1 --pipeline 1 --serial-probe 0 --no-cpu-baseline --alt-proofs 0 --latency-samples 0 --calibrate-s 0".split()
+    ARGS = "--mode batch --proofs 21 --steps 1 --warmup 1 --contexts 1 --pipeline 1 --serial-probe 0 --no-cpu-baseline --alt-proofs 0 --latency-samples 0 --calibrate-s 0 --big-chunk 0".split()
     PROOFS = 22      # 21 timed single-block proofs + 1 warm-up
 cmd = ["rocprofv3", "--pmc", "SQ_INSTS_VALU", "SQ_WAVES", "--kernel-trace", "--output-format", "csv", "-d", out_dir, "-o", "valu", "--", sys.executable, "bench.py"] + ARGS
 subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1500)

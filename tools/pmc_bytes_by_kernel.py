@@ -19,7 +19,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 out_dir = os.path.join("gpurun_out", "pmc_bytes_" + tag)
 os.makedirs(out_dir, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
-ARGS = "--blocks 120 --steps 2 --warmup 1 --contexts 1 --pipeline 1 --serial-probe 0 --no-cpu-baseline --alt-proofs 0 --latency-samples 0".split()
+ARGS = "--blocks 120 --steps 2 --warmup 1 --contexts 1 --pipeline 1 --serial-probe 0 --no-cpu-baseline --alt-proofs 0 --latency-samples 0 --big-chunk 0".split()
 PROOFS = 21
 SETUP = ("k_table_next", "k_convert_bases", "k_fixed_base", "k_power_scalars", "k_fill_powers", "k_index_", "k_twiddles29", "k_lagrange", "k_stream_copy")
 
