@@ -181,6 +181,14 @@ def big_leg(args, api):
         with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 4)) as pool:
             ok = sum(pool.map(lambda j: bool(api.verify_encryption(vk, proofs[j], ct[16 * B * j:16 * B * (j + 1)])), range(len(proofs))))
         bad = bytearray(ct[:16 * B]); bad[3] ^= 1
+        # after the timing: the SAME path (window tables, multi-proof call) against the committed CPU-oracle fixture of this size, byte for byte (data under tests/golden/:
+        # the oracle's 28-block proof over these SRS literals, 33 minutes of 8 cores; tests/golden/make_oracle_aes96.py 448)
+        fx_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "oracle_aes%d.json" % (16 * B))
+        if os.path.exists(fx_path):
+            fx = json.load(open(fx_path))
+            if fx.get("srs_literals") == list(lits):
+                got = pk.encrypt_chunked(bytes.fromhex(fx["message"]), bytes.fromhex(fx["key"]), zk_seed=api.PARITY)
+                out["proof_bytes_equal_oracle_fixture"] = bool(len(got) == 1 and got[0].hex() == fx["proof"])
         si, pi = pk.srs_info(), pk.info()
         f1, _ = api.mem_info()
         out.update({"value": round(B * len(proofs) / dt, 4), "proofs": len(proofs), "proofs_verified": "%d/%d" % (ok, len(proofs)), "ms_per_proof_in_flight": round(1e3 * dt / len(proofs), 1),

@@ -695,3 +695,39 @@ def test_twenty_eight_block_chunk_over_a_larger_universal_srs(zko, api):
         pk.free()
     finally:
         api.set_default_contexts(0)
+
+
+def test_thirteen_block_chunk_matches_the_committed_oracle_fixture(api):
+    """13 blocks over a universal SRS of (2^21, 513, 2^23) -- twice the reference's literal; |H| = 2^21 is the size where the vanishing-quotient product tree takes its
+    short step first (1 + 10 levels) and the transforms of K take three passes.  WITH the window tables (58 GB): the lone path and the multi-proof table path against
+    tests/golden/oracle_aes208.json (make_oracle_aes96.py 208): witness, the nine prover polynomials, the proof bytes."""
+    import hashlib
+    import json
+    fx = json.load(open(os.path.join(GOLD, "oracle_aes208.json")))
+    free_b, _ = api.mem_info()
+    if free_b < (110 << 30):
+        pytest.skip("needs ~110 GB of free device memory (58 GB of window tables + staging)")
+    api.set_default_contexts(2)
+    try:
+        pk, vk = api.synthesize_keys(16 * 13, srs=tuple(fx["srs_literals"]))
+        info = pk.info()
+        assert (int(info["h"]), int(info["k"])) == (fx["index"]["h"], fx["index"]["k"]) == (1 << 21, 1 << 23)
+        assert (int(info["constraints"]), int(info["joint_nnz"])) == (fx["index"]["num_constraints"], fx["index"]["num_non_zero"])
+        assert pk.tables_built()[0]
+        msg, key, ct = bytes.fromhex(fx["message"]), bytes.fromhex(fx["key"]), bytes.fromhex(fx["ciphertext"])
+        z = pk.witness(msg, key)
+        assert len(z) == fx["witness_len"] and hashlib.sha256(z).hexdigest() == fx["witness_sha256"]
+        proof = api.encrypt(msg, key, pk)
+        for name, want in fx["poly_sha256"].items():
+            got = pk.debug_fetch(name)
+            assert len(got) // 32 == fx["poly_len"][name], name
+            assert hashlib.sha256(got).hexdigest() == want, name
+        assert proof.hex() == fx["proof"]
+        two = pk.encrypt_chunked(msg + msg, key, zk_seed=api.PARITY)
+        assert two[0] == proof and two[1] == proof
+        assert api.verify_encryption(vk, proof, ct)
+        bad = bytearray(ct); bad[200] ^= 0x80
+        assert not api.verify_encryption(vk, proof, bytes(bad))
+        pk.free()
+    finally:
+        api.set_default_contexts(0)

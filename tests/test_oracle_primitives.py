@@ -76,7 +76,7 @@ def test_committed_oracle_fixtures_are_about_the_inputs_they_claim(zko, vectors)
     big = json.load(open(os.path.join(gold, "oracle_aes448.json")))       # 28 blocks over a universal SRS of (2^22, 513, 2^24): NOT the reference's literal (bench.py's `big` leg)
     assert big["blocks"] == 28 and big["srs_literals"] == [1 << 22, 513, 1 << 24] and (big["index"]["h"], big["index"]["k"]) == (1 << 22, 1 << 24)
     assert big["index"]["num_constraints"] == 36768 + 148272 * 28
-    for name in ("oracle_aes64.json", "oracle_aes96.json", "oracle_aes448.json"):
+    for name in ("oracle_aes64.json", "oracle_aes96.json", "oracle_aes208.json", "oracle_aes448.json"):
         f = json.load(open(os.path.join(gold, name)))
         proof = bytes.fromhex(f["proof"])
         assert hashlib.sha256(proof).hexdigest() == f["proof_sha256"] and len(proof) in (855, 859)
