@@ -8,7 +8,7 @@
 //   2. k_order_*     : visiting order of the buckets by descending size (counting sort, deterministic) + the list of oversized buckets
 //   3. k_accumulate  : ONE LANE PER BUCKET, the dominant kernel (integer-ALU bound).  EdwardsLaw (BLS12-377 SRS paths): extended twisted Edwards accumulator, 7-product
 //                      unified additions of gathered 192-byte Niels28 records (te28.cuh); WeierLaw (arbitrary points, BLS12-381): XYZZ accumulator, 10-product mixed
-//                      additions with the P = +-Q case deferred.  k_accumulate_tail: overflow segments of oversized buckets; k_fold_overflow folds them into their buckets
+//                      additions with the P = +-Q case deferred.  k_accumulate_tail: overflow segments of oversized buckets, folded into their buckets by its last workgroup (Edwards) or by k_fold_overflow (Weierstrass)
 //   4. reduction     : Edwards: k_reduce_l1_pair (8-bucket lane-interleaved segments, two lanes per segment) -> k_reduce_rc (row / column sums on DPP quads) ->
 //                      k_reduce_terms (six unweighted terms per set) -> the weighted tail on the host (or k_reduce_combine); Weierstrass: k_reduce_l1 / l2 -> k_sum_tree -> k_reduce_window
 //   5. host          : table mode: nothing (one bucket set); per-window mode: Horner over the <= 37 window sums (c doublings each)
@@ -355,7 +355,8 @@ __device__ void accumulate_fixup(const Affine28<P> *__restrict__ bases, Acc28<P>
 
 // overflow segment t of list entry q (bucket k = ovf_bucket[q]) covers sorted positions [start[k] + (j+1) CAP, min(start[k] + (j+2) CAP, end[k])), j = t - ovf_off[q]
 // ONE tail launch per MSM: the overflow segments, then -- Weierstrass law only, in whichever workgroup finishes last (ticket counter deferred_count[1]) -- the replay of
-// the deferred degenerate additions of this kernel and of k_accumulate.  The overflow partials are folded into their buckets by k_fold_overflow, launched behind this kernel.
+// the deferred degenerate additions of this kernel and of k_accumulate.  The overflow partials are folded into their buckets by k_fold_overflow, launched behind this kernel (Weierstrass), or by
+// this kernel's last workgroup itself (Edwards, round 6: the same ticket).
 // For uniformly distributed digits there are no segments and no deferred pairs: every lane exits after one load.
 template <class Law>
 __global__ void __launch_bounds__(64) k_accumulate_tail(const typename Law::Base *__restrict__ bases, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ start,
