@@ -246,7 +246,7 @@ struct ProverContext {
     DevBuf za_ev, zb_ev, x_poly, x_tmp, x_evals, tmp_n, ra_ev, ra_poly, zpoly, t_partial;
     DevBuf poly[9];                    // w z_a z_b mask t g_1 h_1 g_2 h_2
     size_t poly_len[9] = {0};
-    DevBuf e[5], big_tmp, f_poly, acc, wit, wit2, scratch;
+    DevBuf e[5], f_poly, acc, wit, wit2, scratch;
     ProverTimings timings;
     // MSM lanes: lane 0 = (stream, msm_ws) above; lanes 1..4 (own stream + MSM scratch, created on first use) let a LONE encrypt() call run the independent
     // commitments of a round side by side, each started as soon as ITS polynomial exists (latency path only: with several proofs in flight the chip is already full)
@@ -272,7 +272,7 @@ struct ProverContext {
         gpu::dfree(d_trace); gpu::dfree(d_z); gpu::dfree(d_msg); gpu::dfree(d_key);
         for (auto p : d_cls) gpu::dfree(p);
         gpu::dfree(d_rng);
-        for (DevBuf *b : {&za_ev, &zb_ev, &x_poly, &x_tmp, &x_evals, &tmp_n, &ra_ev, &ra_poly, &zpoly, &t_partial, &big_tmp, &f_poly, &acc, &wit, &wit2, &scratch}) b->release();
+        for (DevBuf *b : {&za_ev, &zb_ev, &x_poly, &x_tmp, &x_evals, &tmp_n, &ra_ev, &ra_poly, &zpoly, &t_partial, &f_poly, &acc, &wit, &wit2, &scratch}) b->release();
         for (auto &b : poly) b.release();
         for (auto &b : e) b.release();
         for (DevBuf *b : {&acc_b, &wit_b, &wit2_b, &scratch_b, &scratch_c}) b->release();
@@ -361,7 +361,7 @@ class ProvingKeyImpl {
         for (int i = 0; i < 9; i++) cx.poly[i].alloc(caps[i]);
         size_t big = std::max(n4, k2);
         for (auto &b : cx.e) b.alloc(big);
-        cx.big_tmp.alloc(big); cx.f_poly.alloc(k);
+        cx.f_poly.alloc(k);
         cx.acc.alloc(std::max(3 * n, k) + 1); cx.wit.alloc(std::max(3 * n, k) + 1); cx.wit2.alloc(std::max(n, k) + 1); cx.scratch.alloc(std::max(8 + 3 * gpu::poly_eval_scratch(n + 1) + gpu::poly_eval_scratch(k), gpu::divide_by_linear_scratch(std::max(3 * n, k) + 1)));
     }
 
@@ -563,9 +563,9 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &lit
     {
         const bool want_tables = lg_k >= 20 && !(flags & KEY_NO_TABLES);
         // what this key's callers may still allocate beside the tables: the workspaces of the effective number of prover contexts (alloc_workspace: ~18 |H| + 6 |K| +
-        // 6 max(4 |H|, 2 |K|) field elements, plus the MSM scratch of the largest opening -- 13 windows x 16 B per pair: ~1.2 / 5 GB for the 1- / 6-block key)
+        // 5 max(4 |H|, 2 |K|) field elements, plus the MSM scratch of the largest opening -- 13 windows x 16 B per pair: ~1.2 / 5 GB for the 1- / 6-block key)
         const size_t big = std::max(4 * n, 2 * k);
-        const size_t per_context = (18 * n + 6 * k + 6 * big) * sizeof(F) + 13 * big * 16 + ((size_t)256 << 20);
+        const size_t per_context = (18 * n + 6 * k + 5 * big) * sizeof(F) + 13 * big * 16 + ((size_t)256 << 20);
         auto t_srs = Clock::now();
         srs = acquire_srs(max_degree, want_tables, default_contexts() * per_context, stream);
         setup_srs_s = ms_since(t_srs) / 1e3;
