@@ -350,7 +350,7 @@ class ProvingKeyImpl {
     }
     void alloc_workspace(ProverContext &cx) {
         const Circuit &c = circuit;
-        size_t n4 = next_pow2(3 * n + 1), k2 = 2 * k;
+        size_t n4 = next_pow2(3 * n + 1);
         cx.d_trace = (uint8_t *)gpu::dmalloc(c.trace_bytes + 64); cx.d_z = (uint8_t *)gpu::dmalloc(c.num_variables() + 64);
         cx.d_msg = (uint8_t *)gpu::dmalloc(std::max<size_t>(message_len, 16)); cx.d_key = (uint8_t *)gpu::dmalloc(16);
         for (auto &p : cx.d_cls) p = (int8_t *)gpu::dmalloc(n + 64);
@@ -359,7 +359,9 @@ class ProvingKeyImpl {
         cx.zpoly.alloc(n + 1); cx.t_partial.alloc(t_nseg + 1);
         size_t caps[9] = {n + 1, n + 1, n + 1, 3 * n, n, n, 3 * n, k, k + 1};
         for (int i = 0; i < 9; i++) cx.poly[i].alloc(caps[i]);
-        size_t big = std::max(n4, k2);
+        // e[0..4]: round 2 takes four |H|-sized slots of each (4|H|-domain cosets), round 3 takes |K| of e[0..2]; the transforms run in place behind their first pass
+        // (round 6: these were max(4|H|, 2|K|) -- twice what any user touches; with the dropped big_tmp 8 GB less across the bench's twelve contexts)
+        size_t big = std::max(n4, k);
         for (auto &b : cx.e) b.alloc(big);
         cx.f_poly.alloc(k);
         cx.acc.alloc(std::max(3 * n, k) + 1); cx.wit.alloc(std::max(3 * n, k) + 1); cx.wit2.alloc(std::max(n, k) + 1); cx.scratch.alloc(std::max(8 + 3 * gpu::poly_eval_scratch(n + 1) + gpu::poly_eval_scratch(k), gpu::divide_by_linear_scratch(std::max(3 * n, k) + 1)));
@@ -563,9 +565,9 @@ void ProvingKeyImpl::setup(int kind, size_t message_len_, const SrsLiterals &lit
     {
         const bool want_tables = lg_k >= 20 && !(flags & KEY_NO_TABLES);
         // what this key's callers may still allocate beside the tables: the workspaces of the effective number of prover contexts (alloc_workspace: ~18 |H| + 6 |K| +
-        // 5 max(4 |H|, 2 |K|) field elements, plus the MSM scratch of the largest opening -- 13 windows x 16 B per pair: ~1.2 / 5 GB for the 1- / 6-block key)
-        const size_t big = std::max(4 * n, 2 * k);
-        const size_t per_context = (18 * n + 6 * k + 5 * big) * sizeof(F) + 13 * big * 16 + ((size_t)256 << 20);
+        // 5 max(4 |H|, |K|) field elements, plus the MSM scratch of the largest opening -- 13 windows x 16 B per pair: ~1.2 / 5 GB for the 1- / 6-block key)
+        const size_t big = std::max(4 * n, 2 * k), ebuf = std::max(4 * n, k);
+        const size_t per_context = (18 * n + 6 * k + 5 * ebuf) * sizeof(F) + 13 * big * 16 + ((size_t)256 << 20);
         auto t_srs = Clock::now();
         srs = acquire_srs(max_degree, want_tables, default_contexts() * per_context, stream);
         setup_srs_s = ms_since(t_srs) / 1e3;
