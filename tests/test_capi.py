@@ -42,3 +42,14 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".cuh", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle/" not in text and "import oracle" not in text and "from oracle" not in text and "zko" not in text, os.path.join(dirpath, f)
+
+
+def test_process_wide_settings_validate_without_a_device(api):
+    """zkaes_set_default_contexts / zkaes_srs_hold only set process defaults (no device needed): the bound of 64 contexts per key is enforced at the boundary with a message,
+    0 restores the built-in default, and holding / releasing the SRS cache with nothing in it is a no-op"""
+    with pytest.raises(api.ZkAesError, match="at most 64"):
+        api.set_default_contexts(65)
+    api.set_default_contexts(3)
+    api.set_default_contexts(0)
+    api.srs_hold(True)
+    api.srs_hold(False)
